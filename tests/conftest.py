@@ -1,0 +1,38 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name)) as z:
+        return {k: z[k] for k in z.files}
+
+
+def rel_err(a, b):
+    """max|a-b| / max|b| -- the parity figure quoted everywhere (bar: 1e-4 in fp32)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = max(float(np.abs(b).max()), 1e-30)
+    return float(np.abs(a - b).max()) / scale
+
+
+GATT_CASES = ["b2c3n16", "b2c1n64", "b2c72n64", "b2c3n307"]
+
+
+@pytest.fixture(params=GATT_CASES)
+def gatt_case(request):
+    g = load_golden(f"gatt_{request.param}.npz")
+    c = load_golden(f"gacn_{request.param}.npz")
+    return request.param, g, c

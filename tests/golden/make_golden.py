@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE.
+
+Run in the build container only (it has /root/reference; the GPU box does not):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference is imported from /root/reference/src, fed seeded synthetic
+inputs, and its outputs / autograd gradients are stored as small .npz files.
+Nothing of the reference's source travels: the fixtures hold data only.
+
+Fixtures:
+  gatt_*.npz   GraphAttention fwd+bwd   (attention.py:12-39)
+  gacn_*.npz   GACN fwd+bwd             (msgat.py:17-31)
+  meam_*.npz   MEAM fwd+bwd with its full state_dict (msgat.py:103-134)
+  msgat72_n32.npz  msgat72 fwd + HuberLoss(50) + all grads (msgat.py:166-229, loss.py:51-52)
+  adj_n12.npz  sym-normalised adjacency from a csv edge list (data_loader.py:49-66)
+  slices_*.npz TimeSeriesSlice / normalize (data_loader.py:92-120)
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference/src")
+
+from models.attention import GraphAttention  # noqa: E402
+from models.msgat import GACN, MEAM, msgat72  # noqa: E402
+from loss import HuberLoss  # noqa: E402
+import data_loader as ref_dl  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(4)
+
+
+def synthetic_adjacency(n, n_edges, seed):
+    """N nodes, E distinct undirected non-self edges, then D^-1/2 (A+I) D^-1/2."""
+    rng = np.random.default_rng(seed)
+    a = np.eye(n, dtype=np.float64)
+    got = 0
+    while got < n_edges:
+        s, d = rng.integers(0, n, size=2)
+        if s == d or a[s, d] != 0:
+            continue
+        a[s, d] = a[d, s] = 1.0
+        got += 1
+    r = 1.0 / np.sqrt(a.sum(1))
+    return (r[:, None] * a * r[None, :]).astype(np.float32)
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name)
+    np.savez(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def gatt_case(tag, B, C, N, T, n_edges, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, C, N, T)).astype(np.float32)
+    adj = synthetic_adjacency(N, n_edges, seed + 1)
+    Wg = (rng.standard_normal((T, T)) * (2.0 / (T + T)) ** 0.5).astype(np.float32)
+    alpha = rng.uniform(-C ** -0.5, C ** -0.5, size=C).astype(np.float32)
+    dy = rng.standard_normal((B, C, N, T)).astype(np.float32)
+
+    m = GraphAttention(C, T)
+    with torch.no_grad():
+        m.Wg.copy_(t(Wg))
+        m.alpha.copy_(t(alpha))
+    xt = t(x).requires_grad_(True)
+    y = m(xt, t(adj))
+    y.backward(t(dy))
+    save(f"gatt_{tag}.npz", x=x, adj=adj, Wg=Wg, alpha=alpha, dy=dy,
+         y=y, dx=xt.grad, dWg=m.Wg.grad, dalpha=m.alpha.grad)
+
+    # GACN on the same inputs
+    O = 24
+    W = (rng.standard_normal((O, C)) * (2.0 / (O + C)) ** 0.5).astype(np.float32)
+    dz = rng.standard_normal((B, O, N, T)).astype(np.float32)
+    g = GACN(C, O, T)
+    with torch.no_grad():
+        g.gatt.Wg.copy_(t(Wg))
+        g.gatt.alpha.copy_(t(alpha))
+        g.W.copy_(t(W))
+    xt = t(x).requires_grad_(True)
+    z = g(xt, t(adj))
+    z.backward(t(dz))
+    # x/adj/Wg/alpha are shared with gatt_{tag}.npz and not stored twice
+    save(f"gacn_{tag}.npz", W=W, dz=dz, z=z, dx=xt.grad, dWg=g.gatt.Wg.grad,
+         dalpha=g.gatt.alpha.grad, dW=g.W.grad)
+
+
+def meam_case(tag, cin, cout, N, B, seed):
+    torch.manual_seed(seed)
+    T = 12
+    m = MEAM(cin, cout, n_nodes=N, n_timesteps=T, dilations=[1, 2])
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.ndim >= 2:
+                torch.nn.init.xavier_normal_(p)
+            else:
+                torch.nn.init.uniform_(p, -p.size(0) ** -0.5, p.size(0) ** -0.5)
+    adj = synthetic_adjacency(N, N, seed + 1)
+    x = torch.randn(B, cin, N, T, requires_grad=True)
+    dout = torch.randn(B, cout, N, T)
+    out = m(x, t(adj))
+    out.backward(dout)
+    arrays = {f"p.{k}": v for k, v in m.state_dict().items()}
+    arrays.update({f"g.{k}": p.grad for k, p in m.named_parameters()})
+    save(f"meam_{tag}.npz", x=x, adj=adj, dout=dout, out=out, dx=x.grad, **arrays)
+
+
+def msgat_case(seed):
+    torch.manual_seed(seed)
+    N, B, R, C, T = 32, 2, 3, 3, 12
+    adj = synthetic_adjacency(N, N, seed + 1)
+    net = msgat72(n_components=R, in_channels=C, in_timesteps=T, out_timesteps=T, use_te=True, adj=t(adj))
+    X = torch.randn(B, R, C, N, T)
+    H = torch.randint(0, 24, (B,))
+    D = torch.randint(0, 7, (B,))
+    Y = torch.randn(B, N, T) * 60.0  # large enough that both Huber branches are taken at delta=50
+    pred = net(X, H, D)
+    loss = HuberLoss(50.0)(pred, Y)
+    loss.backward()
+    arrays = {f"p.{k}": v for k, v in net.state_dict().items()}
+    arrays.update({f"g.{k}": p.grad for k, p in net.named_parameters() if p.grad is not None})
+    save("msgat72_n32.npz", X=X, H=H, D=D, Y=Y, pred=pred, loss=loss, **arrays)
+
+
+def adjacency_case():
+    """Runs the reference's private csv -> adjacency routine on a temp edge list."""
+    n = 12
+    edges = [(0, 1), (1, 2), (2, 3), (3, 0), (4, 5), (5, 6), (7, 8), (8, 9), (9, 10), (10, 7), (2, 7), (11, 0), (1, 0)]
+    with tempfile.NamedTemporaryFile("w", suffix=".csv", delete=False) as f:
+        f.write("from,to,cost\n")
+        for s, d in edges:
+            f.write(f"{s},{d},1.0\n")
+        path = f.name
+
+    class Stub:
+        pass
+
+    stub = Stub()
+    stub.num_nodes, stub.adj_file = n, path
+    adj = ref_dl.DataLoaderForMSGAT._DataLoaderForMSGAT__load_adj(stub)
+    os.unlink(path)
+    save("adj_n12.npz", n=np.int64(n), edges=np.asarray(edges, dtype=np.int64), adj=adj)
+
+
+def slices_case(seed):
+    """normalize + TimeSeriesSlice on a small synthetic series (data_loader.py:92-120)."""
+    rng = np.random.default_rng(seed)
+    tau, q, hours = 12, 12, [1, 2, 24]
+    total, N, C = 24 * 12 * 3, 5, 2
+    raw = (rng.standard_normal((total, N, C)) * 10 + 50).astype(np.float32)  # npz layout [T_total,N,C]
+    data = torch.from_numpy(raw).float().transpose(0, -1)  # data_loader.py:71 -> [C,N,T_total]
+    in_timesteps = tau * max(hours)
+    length = data.size(-1) - in_timesteps - q + 1
+    split1 = int(0.6 * length)
+    norm = ref_dl.normalize(data, split=in_timesteps + split1)
+    interval = [in_timesteps, in_timesteps + split1]
+    ds = ref_dl.TimeSeriesSlice(norm, data[0], interval, hours, q, tau)
+    idx = [0, 1, 7, len(ds) - 1]
+    items = [ds[i] for i in idx]
+    save("slices_small.npz", raw=raw, hours=np.asarray(hours), tau=np.int64(tau), q=np.int64(q),
+         norm=norm, interval=np.asarray(interval), length=np.int64(len(ds)), idx=np.asarray(idx),
+         x=torch.stack([it[0] for it in items]), h=torch.stack([it[1] for it in items]),
+         d=torch.stack([it[2] for it in items]), y=torch.stack([it[3] for it in items]))
+
+
+if __name__ == "__main__":
+    gatt_case("b2c3n16", 2, 3, 16, 12, 20, 100)
+    gatt_case("b2c1n64", 2, 1, 64, 12, 70, 200)
+    gatt_case("b2c72n64", 2, 72, 64, 12, 70, 300)
+    gatt_case("b2c3n307", 2, 3, 307, 12, 340, 400)
+    meam_case("3to72_n32", 3, 72, 32, 2, 500)
+    meam_case("72to72_n32", 72, 72, 32, 2, 600)
+    msgat_case(700)
+    adjacency_case()
+    slices_case(800)

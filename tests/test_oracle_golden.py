@@ -1,0 +1,96 @@
+"""Pins the CPU oracle (oracle/) to the golden vectors produced by the reference.
+
+CPU only.  Tolerances: the fp32 dense torch restatement must match the reference
+(also fp32 torch) to 2e-6 relative; the numpy oracle run in float64 must match the
+reference's fp32 results to 2e-5 relative (the reference's own rounding).
+"""
+import numpy as np
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import dense_torch, gat_oracle
+
+
+def test_numpy_forward_backward_matches_reference(gatt_case):
+    _, g, c = gatt_case
+    f64 = lambda k, d=g: d[k].astype(np.float64)  # noqa: E731
+    y = gat_oracle.gatt_forward(f64("x"), f64("adj"), f64("Wg"), f64("alpha"))
+    assert rel_err(y, g["y"]) < 2e-5
+    dx, dWg, dalpha = gat_oracle.gatt_backward(f64("x"), f64("adj"), f64("Wg"), f64("alpha"), f64("dy"))
+    assert rel_err(dx, g["dx"]) < 2e-5
+    assert rel_err(dWg, g["dWg"]) < 2e-5
+    assert rel_err(dalpha, g["dalpha"]) < 2e-5
+
+    z = gat_oracle.gacn_forward(f64("x"), f64("adj"), f64("Wg"), f64("alpha"), f64("W", c))
+    assert rel_err(z, c["z"]) < 2e-5
+    dx, dWg, dalpha, dW = gat_oracle.gacn_backward(
+        f64("x"), f64("adj"), f64("Wg"), f64("alpha"), f64("W", c), f64("dz", c))
+    assert rel_err(dx, c["dx"]) < 2e-5
+    assert rel_err(dWg, c["dWg"]) < 2e-5
+    assert rel_err(dalpha, c["dalpha"]) < 2e-5
+    assert rel_err(dW, c["dW"]) < 2e-5
+
+
+def test_numpy_oracle_in_float32_is_within_bar(gatt_case):
+    """The oracle run in the reference's own arithmetic type stays inside the 1e-4 bar."""
+    _, g, c = gatt_case
+    y = gat_oracle.gatt_forward(g["x"], g["adj"], g["Wg"], g["alpha"])
+    assert y.dtype == np.float32
+    assert rel_err(y, g["y"]) < 1e-5
+    dx, dWg, dalpha, dW = gat_oracle.gacn_backward(g["x"], g["adj"], g["Wg"], g["alpha"], c["W"], c["dz"])
+    for got, want in ((dx, c["dx"]), (dWg, c["dWg"]), (dalpha, c["dalpha"]), (dW, c["dW"])):
+        assert rel_err(got, want) < 1e-4
+
+
+def test_dense_torch_matches_reference(gatt_case):
+    _, g, c = gatt_case
+    t = lambda a: torch.from_numpy(a)  # noqa: E731
+    x = t(g["x"]).requires_grad_(True)
+    Wg = t(g["Wg"]).requires_grad_(True)
+    alpha = t(g["alpha"]).requires_grad_(True)
+    y = dense_torch.graph_attention_dense(x, t(g["adj"]), Wg, alpha)
+    y.backward(t(g["dy"]))
+    assert rel_err(y.detach(), g["y"]) < 2e-6
+    assert rel_err(x.grad, g["dx"]) < 2e-6
+    assert rel_err(Wg.grad, g["dWg"]) < 5e-6
+    assert rel_err(alpha.grad, g["dalpha"]) < 5e-6
+
+    x = t(g["x"]).requires_grad_(True)
+    W = t(c["W"]).requires_grad_(True)
+    z = dense_torch.gacn_dense(x, t(g["adj"]), t(g["Wg"]), t(g["alpha"]), W)
+    z.backward(t(c["dz"]))
+    assert rel_err(z.detach(), c["z"]) < 2e-6
+    assert rel_err(x.grad, c["dx"]) < 2e-6
+    assert rel_err(W.grad, c["dW"]) < 5e-6
+
+
+def test_lse_matches_dense_softmax_denominator():
+    g = load_golden("gatt_b2c3n16.npz")
+    x = g["x"].astype(np.float64)
+    lse = gat_oracle.gatt_lse(x, g["Wg"].astype(np.float64), g["alpha"].astype(np.float64))
+    q = np.einsum("bcnt,c->bnt", x, g["alpha"].astype(np.float64))
+    S = (q @ g["Wg"].astype(np.float64)) @ q.transpose(0, 2, 1)
+    assert np.allclose(np.exp(S - lse[..., None]).sum(-1), 1.0, atol=1e-12)
+
+
+def test_masked_rows_do_not_sum_to_one():
+    """the mask is applied AFTER the full-row softmax."""
+    g = load_golden("gatt_b2c3n16.npz")
+    _, cache = gat_oracle.gatt_forward(g["x"], g["adj"], g["Wg"], g["alpha"], return_cache=True)
+    assert np.allclose(cache["P"].sum(-1), 1.0, atol=1e-5)
+    assert cache["E"].sum(-1).max() < 0.9
+
+
+def test_adjacency_matches_reference_loader():
+    a = load_golden("adj_n12.npz")
+    adj = gat_oracle.sym_norm_adjacency(int(a["n"]), a["edges"])
+    assert np.allclose(adj, a["adj"], atol=1e-7)
+    assert np.allclose(adj, adj.T)
+
+
+def test_huber_matches_reference():
+    m = load_golden("msgat72_n32.npz")
+    got = gat_oracle.huber_loss(m["pred"].astype(np.float64), m["Y"].astype(np.float64), 50.0)
+    assert abs(got - float(m["loss"])) < 1e-4 * abs(float(m["loss"]))
+    got_t = dense_torch.huber(torch.from_numpy(m["pred"]), torch.from_numpy(m["Y"]), 50.0)
+    assert abs(float(got_t) - float(m["loss"])) < 1e-5 * abs(float(m["loss"]))
