@@ -1,0 +1,178 @@
+/*
+ * msgat_hip.h -- C ABI of libmsgat_hip.so: the MI355X (gfx950) implementation of the
+ * MS-GAT graph-attention hot path.
+ *
+ * The reference (luokn/ms-gat) has no FFI: its hot path is a sequence of PyTorch eager
+ * ops.  Each entry point below names the reference lines it replaces (paths under
+ * /root/reference/).  INTEGRATION.md shows the ctypes binding a maintainer adds to call
+ * them from `GraphAttention.forward` / `GACN.forward`.
+ *
+ * Conventions
+ *   - plain C, PODs only: raw device pointers, ints, a hipStream_t passed as void*.
+ *   - every device entry point only ENQUEUES kernels on `stream` and returns; it never
+ *     allocates, frees, synchronises or touches global mutable state (re-entrant; safe
+ *     under hipGraph capture).  All buffers, including the tensors saved for backward
+ *     and the workspace, are owned by the caller.
+ *   - return value: 0 (MSGAT_OK) or a negative MSGAT_ERR_* code; hipError_t e from a
+ *     launch is reported as MSGAT_ERR_HIP_BASE - e.  No exceptions cross the ABI.
+ *   - all floating point is IEEE fp32; tensors are dense, contiguous, row-major.
+ *
+ * Vocabulary
+ *   relation r in [0,R)  one independent parameter set (alpha_r, Wg_r, W_r).  The
+ *                        reference evaluates R = n_components such sets over one shared
+ *                        adjacency (msgat.py:191-199,204); a single GACN call has R = 1.
+ *   group    g in [0,G)  one (relation, sample) pair, G = R*Bg, g = r*Bg + b.  A group is
+ *                        one [N,N] attention problem (attention is per sample,
+ *                        attention.py:34).
+ *   signals  x[G,C,N,T]  the reference's [batch, channels, nodes, timesteps] layout
+ *                        (attention.py:21), relations stacked on the batch axis.
+ *   graph                CSR + CSC of the non-zeros of the [N,N] adjacency
+ *                        (data_loader.py:59-66 builds it dense; msgat.py:190 holds it).
+ */
+#ifndef MSGAT_HIP_H
+#define MSGAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSGAT_ABI_VERSION 1
+
+enum {
+  MSGAT_OK = 0,
+  MSGAT_ERR_NULL = -1,        /* a required pointer is NULL                         */
+  MSGAT_ERR_SHAPE = -2,       /* a dimension is <= 0 or inconsistent                 */
+  MSGAT_ERR_UNSUPPORTED = -3, /* T not in {4,8,12,16}, C/Co beyond the built limits  */
+  MSGAT_ERR_WORKSPACE = -4,   /* workspace smaller than msgat_bwd_workspace_bytes()  */
+  MSGAT_ERR_GRAPH = -5,       /* malformed CSR/CSC                                   */
+  MSGAT_ERR_HIP_BASE = -1000  /* -1000 - hipError_t                                  */
+};
+
+/* How a GACN call orders aggregation and channel projection (they commute: the
+ * aggregation acts on the node axis, W on the channel axis). */
+enum {
+  MSGAT_MODE_PLAIN = 0,   /* Co == 0: GraphAttention only (attention.py:32-36)               */
+  MSGAT_MODE_AGG_FIRST = 1, /* C <= Co: aggregate C channels, then project (msgat.py order)  */
+  MSGAT_MODE_PROJ_FIRST = 2 /* C >  Co: project to Co channels, then aggregate (3x less gather) */
+};
+
+/* Device-resident sparse adjacency.  Built on the host by msgat_graph_build() and copied
+ * to the device by the caller. */
+typedef struct msgat_graph {
+  int32_t n_nodes;
+  int32_t nnz;
+  const int32_t* rowptr; /* [N+1]  CSR row starts                                   */
+  const int32_t* col;    /* [nnz]  column of each CSR edge                          */
+  const float* val;      /* [nnz]  adjacency weight of each CSR edge                */
+  const int32_t* erow;   /* [nnz]  row of each CSR edge (COO companion of col)      */
+  const int32_t* colptr; /* [N+1]  CSC column starts                                */
+  const int32_t* crow;   /* [nnz]  row of each CSC entry                            */
+  const int32_t* cperm;  /* [nnz]  CSC position -> CSR edge index                   */
+} msgat_graph_t;
+
+typedef struct msgat_shape {
+  int32_t R;  /* relations (parameter sets)                      */
+  int32_t Bg; /* groups per relation; G = R*Bg                    */
+  int32_t C;  /* input channels                                   */
+  int32_t Co; /* output channels of W; 0 = no projection (PLAIN)  */
+  int32_t N;  /* nodes                                            */
+  int32_t T;  /* timesteps (the score contraction axis)           */
+} msgat_shape_t;
+
+/* Forward buffers.  `need_bwd` != 0 makes the call fill everything backward needs. */
+typedef struct msgat_fwd {
+  const float* x;     /* in  [G,C,N,T]                                                    */
+  const float* alpha; /* in  [R,C]        attention.py:30                                 */
+  const float* Wg;    /* in  [R,T,T]      attention.py:29                                 */
+  const float* W;     /* in  [R,Co,C]     msgat.py:23 (NULL iff Co == 0)                  */
+  float* z;           /* out [G,Co,N,T]   (PLAIN: [G,C,N,T])                              */
+  float* q;           /* out [G,N,T]      q = k = sum_c alpha_c x_c   (attention.py:33)   */
+  float* kW;          /* out [G,N,T]      k @ Wg                      (attention.py:34)   */
+  float* lse;         /* out [G,N]        row log-sum-exp of the scores in log2 units:
+                             log2 sum_m 2^(S[n,m] log2 e); natural log = lse * ln 2        */
+  float* pq;          /* out [G,N,T]      softmax(S) @ q, only written when need_bwd      */
+  float* E;           /* out [G,nnz]      softmax(S)*adj at the edges (attention.py:36)   */
+  float* u;           /* out AGG_FIRST: y [G,C,N,T] when need_bwd; PROJ_FIRST: W x [G,Co,N,T];
+                             PLAIN: unused (may be NULL)                                  */
+  int32_t need_bwd;
+} msgat_fwd_t;
+
+typedef struct msgat_bwd {
+  /* forward inputs and what forward saved */
+  const float* x;
+  const float* alpha;
+  const float* Wg;
+  const float* W;
+  const float* q;
+  const float* kW;
+  const float* lse;
+  const float* pq;
+  const float* E;
+  const float* u;
+  /* incoming gradient, contiguous, same shape as z */
+  const float* dz;
+  /* gradients out (overwritten, not accumulated) */
+  float* dx;     /* [G,C,N,T]                       */
+  float* dalpha; /* [R,C]                           */
+  float* dWg;    /* [R,T,T]                         */
+  float* dW;     /* [R,Co,C]   (NULL iff Co == 0)   */
+  /* scratch, >= msgat_bwd_workspace_bytes() bytes, 256-byte aligned */
+  void* workspace;
+  size_t workspace_bytes;
+} msgat_bwd_t;
+
+/* ---- library ------------------------------------------------------------------- */
+int msgat_abi_version(void);
+const char* msgat_status_string(int status);
+/* MSGAT_MODE_* the library uses for (C, Co); the caller sizes `u` from it. */
+int msgat_gacn_mode(int32_t C, int32_t Co);
+
+/* ---- host: dense adjacency -> CSR/CSC ---------------------------------------------
+ * Replaces the dense mask `att * adjacency` of attention.py:36 by its non-zeros.
+ * `adj` is a HOST pointer to the row-major [n,n] fp32 matrix with leading dimension ld.
+ * An entry is an edge iff it is != 0 (NaN counts as an edge). */
+int msgat_graph_count(const float* adj, int32_t n, int64_t ld, int32_t* nnz_out);
+int msgat_graph_build(const float* adj, int32_t n, int64_t ld, int32_t nnz,
+                      int32_t* rowptr, int32_t* col, float* val, int32_t* erow,
+                      int32_t* colptr, int32_t* crow, int32_t* cperm);
+/* Host-side structural check of a (host-resident) graph. */
+int msgat_graph_validate(const msgat_graph_t* host_graph);
+
+/* ---- device: fused entry points --------------------------------------------------
+ * msgat_gacn_forward replaces attention.py:33-36 (+ msgat.py:27-28 when Co > 0).
+ * msgat_gacn_backward replaces the autograd of those lines (adj gets no gradient,
+ * msgat.py:190). */
+int msgat_gacn_forward(const msgat_shape_t* shape, const msgat_graph_t* graph,
+                       const msgat_fwd_t* io, void* stream);
+size_t msgat_bwd_workspace_bytes(const msgat_shape_t* shape, int32_t nnz);
+int msgat_gacn_backward(const msgat_shape_t* shape, const msgat_graph_t* graph,
+                        const msgat_bwd_t* io, void* stream);
+
+/* ---- device: the individual stages (exposed for tests, profiling and bench.py) ----
+ * Each is what the fused entry points enqueue, in order. */
+
+/* attention.py:33 (and msgat.py:27 when projecting first): q = sum_c alpha_c x_c and,
+ * if u != NULL, u[g,o] = sum_c W[r,o,c] x[g,c]. */
+int msgat_stage_project(const msgat_shape_t* shape, const float* x, const float* alpha,
+                        const float* W, float* q, float* u, void* stream);
+/* attention.py:34 + the edge part of :36: kW = q Wg, lse = row log-sum-exp over ALL N
+ * columns of kW q^T (log2 units), pq = softmax @ q (optional), E = softmax * adj at the edges. */
+int msgat_stage_scores(const msgat_shape_t* shape, const msgat_graph_t* graph,
+                       const float* q, const float* Wg, float* kW, float* lse, float* pq,
+                       float* E, void* stream);
+/* attention.py:36: v[g,c,n,:] = sum_{e in row n} E[g,e] u[g,c,col_e,:] over Cu channels. */
+int msgat_stage_aggregate(const msgat_shape_t* shape, const msgat_graph_t* graph,
+                          int32_t Cu, const float* u, const float* E, float* v, void* stream);
+/* attention.py:36 + msgat.py:27-28 for C <= Co: y = aggregate(x) (stored if y != NULL),
+ * z[g,o] = sum_c W[r,o,c] y[g,c]. */
+int msgat_stage_aggregate_project(const msgat_shape_t* shape, const msgat_graph_t* graph,
+                                  const float* x, const float* E, const float* W, float* y,
+                                  float* z, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSGAT_HIP_H */

@@ -1,0 +1,98 @@
+"""ctypes binding of libmsgat_hip.so -- the only door between Python and the HIP kernels.
+
+The structures and prototypes mirror include/msgat_hip.h one to one.  There is no CPU
+fallback anywhere in this package: if the library is missing, `lib()` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libmsgat_hip.so")
+
+MSGAT_OK = 0
+MODE_PLAIN, MODE_AGG_FIRST, MODE_PROJ_FIRST = 0, 1, 2
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int32)
+
+
+class Graph(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_int32), ("nnz", C.c_int32),
+        ("rowptr", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p), ("erow", C.c_void_p),
+        ("colptr", C.c_void_p), ("crow", C.c_void_p), ("cperm", C.c_void_p),
+    ]
+
+
+class Shape(C.Structure):
+    _fields_ = [("R", C.c_int32), ("Bg", C.c_int32), ("C", C.c_int32), ("Co", C.c_int32),
+                ("N", C.c_int32), ("T", C.c_int32)]
+
+
+class Fwd(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x", "alpha", "Wg", "W", "z", "q", "kW", "lse", "pq", "E", "u")] + [
+        ("need_bwd", C.c_int32)]
+
+
+class Bwd(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "x", "alpha", "Wg", "W", "q", "kW", "lse", "pq", "E", "u", "dz", "dx", "dalpha", "dWg", "dW",
+        "workspace")] + [("workspace_bytes", C.c_size_t)]
+
+
+_PROTOTYPES = {
+    "msgat_abi_version": (C.c_int, []),
+    "msgat_status_string": (C.c_char_p, [C.c_int]),
+    "msgat_gacn_mode": (C.c_int, [C.c_int32, C.c_int32]),
+    "msgat_graph_count": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, c_int_p]),
+    "msgat_graph_build": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32] + [C.c_void_p] * 7),
+    "msgat_graph_validate": (C.c_int, [C.POINTER(Graph)]),
+    "msgat_gacn_forward": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph), C.POINTER(Fwd), C.c_void_p]),
+    "msgat_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Shape), C.c_int32]),
+    "msgat_gacn_backward": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph), C.POINTER(Bwd), C.c_void_p]),
+    "msgat_stage_project": (C.c_int, [C.POINTER(Shape)] + [C.c_void_p] * 6),
+    "msgat_stage_scores": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)] + [C.c_void_p] * 7),
+    "msgat_stage_aggregate": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph), C.c_int32] + [C.c_void_p] * 4),
+    "msgat_stage_aggregate_project": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)] + [C.c_void_p] * 6),
+}
+
+_lock = threading.Lock()
+_handle = None
+
+
+class MsgatError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """The loaded library; raises if it has not been built (no fallback path exists)."""
+    global _handle
+    if _handle is not None:
+        return _handle
+    with _lock:
+        if _handle is None:
+            if not os.path.exists(LIB_PATH):
+                raise MsgatError(
+                    f"{LIB_PATH} is missing: build it with `python -m ms_gat_amd.build` "
+                    "(hipcc --offload-arch=gfx950). ms_gat_amd has no CPU or eager fallback.")
+            h = C.CDLL(LIB_PATH)
+            for name, (res, args) in _PROTOTYPES.items():
+                fn = getattr(h, name)  # AttributeError here = header/library mismatch
+                fn.restype, fn.argtypes = res, args
+            if h.msgat_abi_version() != 1:
+                raise MsgatError("libmsgat_hip.so ABI version mismatch; rebuild")
+            _handle = h
+    return _handle
+
+
+def check(status: int, what: str) -> None:
+    if status != MSGAT_OK:
+        msg = lib().msgat_status_string(status)
+        raise MsgatError(f"{what} failed: {msg.decode() if msg else status} (status {status})")
+
+
+def exported_symbols():
+    return sorted(_PROTOTYPES)

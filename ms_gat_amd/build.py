@@ -1,0 +1,85 @@
+"""Builds libmsgat_hip.so (gfx950 only) in-tree with hipcc.
+
+    python -m ms_gat_amd.build          # incremental
+    python -m ms_gat_amd.build --force  # rebuild everything
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting
+.so travels to the GPU box with the repo snapshot (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+OBJDIR = os.path.join(ROOT, "build", "obj")
+LIB = os.path.join(PKG, "libmsgat_hip.so")
+
+SOURCES = ["api.hip", "project.hip", "scores.hip", "aggregate.hip", "reduce.hip", "graph_host.cpp"]
+HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(INCLUDE, "msgat_hip.h")]
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", f"--offload-arch={ARCH}",
+         "-I" + INCLUDE, "-I" + CSRC]
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libmsgat_hip.so cannot be built")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(hipcc: str, src: str, obj: str, extra) -> None:
+    cmd = [hipcc, *FLAGS, *extra, "-c", src, "-o", obj]
+    if src.endswith(".cpp"):
+        cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "-Wall", "-I" + INCLUDE, "-x", "c++", "-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {os.path.basename(src)}:\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+
+
+def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
+    """Compile every HIP source for gfx950 and link libmsgat_hip.so; returns its path."""
+    hipcc = _hipcc()
+    os.makedirs(OBJDIR, exist_ok=True)
+    jobs, objs = [], []
+    for name in SOURCES:
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(OBJDIR, name.rsplit(".", 1)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src, *HEADERS, os.path.abspath(__file__)]):
+            jobs.append((src, obj))
+    if jobs:
+        if verbose:
+            print(f"[ms_gat_amd.build] hipcc --offload-arch={ARCH}: {', '.join(os.path.basename(s) for s, _ in jobs)}",
+                  flush=True)
+        with cf.ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            for f in [ex.submit(_compile, hipcc, s, o, list(extra_flags)) for s, o in jobs]:
+                f.result()
+    if jobs or force or _stale(LIB, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"[ms_gat_amd.build] linked {LIB}", flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

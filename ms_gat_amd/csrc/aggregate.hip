@@ -1,0 +1,283 @@
+// The sparse side of the attention: neighbour aggregation over the CSR/CSC edges.
+//
+//   forward    v[g,c,n,:] = sum_{e in row n} E[g,e] u[g,c,col_e,:]          attention.py:36
+//   backward   du[g,c,m,:] = sum_{e into m}  E[g,e] dv[g,c,row_e,:]          (same kernel on the CSC)
+//              dE[g,e]     = sum_{c,t} dv[g,c,row_e,t] u[g,c,col_e,t]        (SDDMM)
+//
+// Layout.  The reference's [B,C,N,T] layout makes one (group, channel) pair a contiguous
+// [N,T] fp32 slab of N*48 bytes (42 KB at PEMSD7's N = 883).  A whole slab fits in the
+// CU's 160 KB LDS, so a block streams its slab(s) in with perfectly coalesced 16-B loads
+// (HBM sees every byte of u exactly once), gathers neighbour rows from LDS, and streams
+// the result out coalesced.  Slabs that do not fit (N > ~3400) fall back to a
+// gather-from-L2 kernel.  Either way the kernel is HBM-bound: algorithmic bytes =
+// read u once + write v once.
+#include "common.hpp"
+
+namespace msgat {
+
+// ---- LDS-slab aggregate ---------------------------------------------------------------------
+template <int T4>
+__global__ __launch_bounds__(kBlock) void k_agg_lds(
+    const int* __restrict__ ptr, const int* __restrict__ idx, const int* __restrict__ perm,
+    const float4* __restrict__ u4, const float* __restrict__ E, const float* __restrict__ addvec,
+    const float4* __restrict__ extra4, float4* __restrict__ v4, int Bg, int Cu, int N, int nnz,
+    int CH) {
+  extern __shared__ float4 slab[];  // [ch][N][T4]
+  const int g = blockIdx.y;
+  const int r = g / Bg;
+  const int c0 = blockIdx.x * CH;
+  const int ch = min(CH, Cu - c0);
+  const int NT4 = N * T4;
+  const size_t base = ((size_t)g * Cu + c0) * NT4;
+  const int total = ch * NT4;
+
+  for (int i = threadIdx.x; i < total; i += kBlock) slab[i] = u4[base + i];
+  __syncthreads();
+
+  const float* Eg = E + (size_t)g * nnz;
+  for (int c = 0; c < ch; ++c) {
+    const float4* sl = slab + c * NT4;
+    const float av = (addvec != nullptr) ? addvec[r * Cu + c0 + c] : 0.f;
+    for (int s = threadIdx.x; s < NT4; s += kBlock) {
+      const int n = s / T4;
+      const int j = s - n * T4;
+      float4 acc = f4zero();
+      const int e1 = ptr[n + 1];
+      for (int e = ptr[n]; e < e1; ++e) {
+        const float w = Eg[perm != nullptr ? perm[e] : e];
+        f4fma(w, sl[idx[e] * T4 + j], acc);
+      }
+      if (addvec != nullptr) f4fma(av, extra4[(size_t)g * NT4 + s], acc);
+      v4[base + (size_t)c * NT4 + s] = acc;
+    }
+  }
+}
+
+// ---- gather-from-L2 aggregate (slab too large for LDS) ------------------------------------------
+template <int T4>
+__global__ __launch_bounds__(kBlock) void k_agg_glb(
+    const int* __restrict__ ptr, const int* __restrict__ idx, const int* __restrict__ perm,
+    const float4* __restrict__ u4, const float* __restrict__ E, const float* __restrict__ addvec,
+    const float4* __restrict__ extra4, float4* __restrict__ v4, int Bg, int Cu, int N, int nnz) {
+  const int g = blockIdx.z;
+  const int r = g / Bg;
+  const int c = blockIdx.y;
+  const int NT4 = N * T4;
+  const int s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= NT4) return;
+  const int n = s / T4;
+  const int j = s - n * T4;
+  const float4* sl = u4 + ((size_t)g * Cu + c) * NT4;
+  const float* Eg = E + (size_t)g * nnz;
+  float4 acc = f4zero();
+  const int e1 = ptr[n + 1];
+  for (int e = ptr[n]; e < e1; ++e) {
+    const float w = Eg[perm != nullptr ? perm[e] : e];
+    f4fma(w, sl[(size_t)idx[e] * T4 + j], acc);
+  }
+  if (addvec != nullptr) f4fma(addvec[r * Cu + c], extra4[(size_t)g * NT4 + s], acc);
+  v4[((size_t)g * Cu + c) * NT4 + s] = acc;
+}
+
+template <int T4>
+static int launch_aggregate_t(const int* ptr, const int* idx, const int* perm, int nnz,
+                              const float* u, const float* E, const float* addvec,
+                              const float* extra, float* v, int G, int Bg, int Cu, int N,
+                              hipStream_t s) {
+  const int T = 4 * T4;
+  const int CH = slab_channels(N, T, Cu, kLdsBudget);
+  if (CH >= 1) {
+    const size_t lds = (size_t)CH * N * T * sizeof(float);
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_lds<T4>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
+    }
+    dim3 grid(cdiv(Cu, CH), G);
+    hipLaunchKernelGGL(k_agg_lds<T4>, grid, dim3(kBlock), lds, s, ptr, idx, perm, (const float4*)u, E,
+                       addvec, (const float4*)extra, (float4*)v, Bg, Cu, N, nnz, CH);
+  } else {
+    dim3 grid(cdiv(N * T4, kBlock), Cu, G);
+    hipLaunchKernelGGL(k_agg_glb<T4>, grid, dim3(kBlock), 0, s, ptr, idx, perm, (const float4*)u, E,
+                       addvec, (const float4*)extra, (float4*)v, Bg, Cu, N, nnz);
+  }
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
+}
+
+int launch_aggregate(const int* ptr, const int* idx, const int* perm, int nnz, const float* u,
+                     const float* E, const float* addvec, const float* extra, float* v, int G,
+                     int Bg, int Cu, int N, int T, hipStream_t s) {
+  switch (T) {
+    case 4: return launch_aggregate_t<1>(ptr, idx, perm, nnz, u, E, addvec, extra, v, G, Bg, Cu, N, s);
+    case 8: return launch_aggregate_t<2>(ptr, idx, perm, nnz, u, E, addvec, extra, v, G, Bg, Cu, N, s);
+    case 12: return launch_aggregate_t<3>(ptr, idx, perm, nnz, u, E, addvec, extra, v, G, Bg, Cu, N, s);
+    case 16: return launch_aggregate_t<4>(ptr, idx, perm, nnz, u, E, addvec, extra, v, G, Bg, Cu, N, s);
+  }
+  return MSGAT_ERR_UNSUPPORTED;
+}
+
+// ---- aggregate, then project (C <= Co: the reference's own order, msgat.py:26-28) -------------------
+// One lane owns one (node, 4 timesteps) slot: for each input channel it gathers the
+// neighbour rows (x is small here -- C is 1 or 3 in the first MEAM -- so it lives in L2),
+// optionally stores y for the backward pass, and folds it into OT output channels.
+template <int T4, int OT>
+__global__ __launch_bounds__(kBlock) void k_agg_proj(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float4* __restrict__ x4,
+    const float* __restrict__ E, const float* __restrict__ W, float4* __restrict__ y4,
+    float4* __restrict__ z4, int Bg, int C, int Co, int N, int nnz) {
+  extern __shared__ float Wl[];  // [C][OT]
+  const int g = blockIdx.y;
+  const int r = g / Bg;
+  const int o0 = blockIdx.z * OT;
+  for (int i = threadIdx.x; i < C * OT; i += kBlock) {
+    const int c = i / OT, oo = i - c * OT, o = o0 + oo;
+    Wl[i] = (o < Co) ? W[((size_t)r * Co + o) * C + c] : 0.f;
+  }
+  __syncthreads();
+  const int NT4 = N * T4;
+  const int s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= NT4) return;
+  const int n = s / T4;
+  const int j = s - n * T4;
+  const float* Eg = E + (size_t)g * nnz;
+  const int e0 = rowptr[n], e1 = rowptr[n + 1];
+
+  float4 acc[OT];
+#pragma unroll
+  for (int oo = 0; oo < OT; ++oo) acc[oo] = f4zero();
+  for (int c = 0; c < C; ++c) {
+    const float4* sl = x4 + ((size_t)g * C + c) * NT4;
+    float4 y = f4zero();
+    for (int e = e0; e < e1; ++e) f4fma(Eg[e], sl[(size_t)col[e] * T4 + j], y);
+    if (y4 != nullptr && blockIdx.z == 0) y4[((size_t)g * C + c) * NT4 + s] = y;
+    const float4* wrow = reinterpret_cast<const float4*>(Wl + c * OT);
+#pragma unroll
+    for (int o4 = 0; o4 < OT / 4; ++o4) {
+      const float4 w = wrow[o4];
+      f4fma(w.x, y, acc[4 * o4 + 0]);
+      f4fma(w.y, y, acc[4 * o4 + 1]);
+      f4fma(w.z, y, acc[4 * o4 + 2]);
+      f4fma(w.w, y, acc[4 * o4 + 3]);
+    }
+  }
+#pragma unroll
+  for (int oo = 0; oo < OT; ++oo) {
+    const int o = o0 + oo;
+    if (o < Co) z4[((size_t)g * Co + o) * NT4 + s] = acc[oo];
+  }
+}
+
+template <int T4, int OT>
+static int launch_agg_proj_t(const msgat_graph_t& gr, const float* x, const float* E, const float* W,
+                             float* y, float* z, int G, int Bg, int C, int Co, int N,
+                             hipStream_t s) {
+  dim3 grid(cdiv(N * T4, kBlock), G, cdiv(Co, OT));
+  const size_t lds = (size_t)C * OT * sizeof(float);
+  hipLaunchKernelGGL((k_agg_proj<T4, OT>), grid, dim3(kBlock), lds, s, gr.rowptr, gr.col,
+                     (const float4*)x, E, W, (float4*)y, (float4*)z, Bg, C, Co, N, gr.nnz);
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
+}
+
+template <int T4>
+static int launch_agg_proj_o(const msgat_graph_t& gr, const float* x, const float* E, const float* W,
+                             float* y, float* z, int G, int Bg, int C, int Co, int N,
+                             hipStream_t s) {
+  if (Co % 24 == 0) return launch_agg_proj_t<T4, 24>(gr, x, E, W, y, z, G, Bg, C, Co, N, s);
+  if (Co % 32 == 0) return launch_agg_proj_t<T4, 32>(gr, x, E, W, y, z, G, Bg, C, Co, N, s);
+  if (Co % 16 == 0) return launch_agg_proj_t<T4, 16>(gr, x, E, W, y, z, G, Bg, C, Co, N, s);
+  if (Co <= 4) return launch_agg_proj_t<T4, 4>(gr, x, E, W, y, z, G, Bg, C, Co, N, s);
+  return launch_agg_proj_t<T4, 8>(gr, x, E, W, y, z, G, Bg, C, Co, N, s);
+}
+
+int launch_aggregate_project(const msgat_graph_t& gr, const float* x, const float* E,
+                             const float* W, float* y, float* z, int G, int Bg, int C, int Co,
+                             int N, int T, hipStream_t s) {
+  switch (T) {
+    case 4: return launch_agg_proj_o<1>(gr, x, E, W, y, z, G, Bg, C, Co, N, s);
+    case 8: return launch_agg_proj_o<2>(gr, x, E, W, y, z, G, Bg, C, Co, N, s);
+    case 12: return launch_agg_proj_o<3>(gr, x, E, W, y, z, G, Bg, C, Co, N, s);
+    case 16: return launch_agg_proj_o<4>(gr, x, E, W, y, z, G, Bg, C, Co, N, s);
+  }
+  return MSGAT_ERR_UNSUPPORTED;
+}
+
+// ---- SDDMM: dE partials per channel chunk ---------------------------------------------------------
+// One lane per CSR edge (n -> m): <dv[c,n,:], u[c,m,:]> summed over the chunk's channels.
+// u rows are the random side (gathered from the LDS slab); dv rows follow the edge order,
+// which is row-sorted, so neighbouring lanes read the same or adjacent rows.
+template <int T4, bool USE_LDS>
+__global__ __launch_bounds__(kBlock) void k_sddmm(
+    const int* __restrict__ erow, const int* __restrict__ col, const float4* __restrict__ u4,
+    const float4* __restrict__ dv4, float* __restrict__ dEp, int Cu, int N, int nnz, int CH,
+    int nchunks) {
+  extern __shared__ float4 slab[];
+  const int g = blockIdx.z;
+  const int k = blockIdx.y;
+  const int c0 = k * CH;
+  const int ch = min(CH, Cu - c0);
+  const int NT4 = N * T4;
+  const size_t base = ((size_t)g * Cu + c0) * NT4;
+  if (USE_LDS) {
+    const int total = ch * NT4;
+    for (int i = threadIdx.x; i < total; i += kBlock) slab[i] = u4[base + i];
+    __syncthreads();
+  }
+  float* out = dEp + ((size_t)g * nchunks + k) * nnz;
+  for (int e = blockIdx.x * kBlock + threadIdx.x; e < nnz; e += gridDim.x * kBlock) {
+    const int n = erow[e], m = col[e];
+    float acc = 0.f;
+    for (int c = 0; c < ch; ++c) {
+      const float4* a = dv4 + base + (size_t)c * NT4 + (size_t)n * T4;
+      const float4* b = USE_LDS ? (slab + c * NT4 + m * T4) : (u4 + base + (size_t)c * NT4 + (size_t)m * T4);
+#pragma unroll
+      for (int j = 0; j < T4; ++j) acc = f4dot(a[j], b[j], acc);
+    }
+    out[e] = acc;
+  }
+}
+
+int sddmm_chunks(int Cu, int N, int T) {
+  const int CH = slab_channels(N, T, Cu, kLdsBudget);
+  return CH >= 1 ? cdiv(Cu, CH) : 1;
+}
+
+template <int T4>
+static int launch_sddmm_t(const msgat_graph_t& gr, const float* u, const float* dv, float* dEp,
+                          int G, int Cu, int N, hipStream_t s) {
+  const int T = 4 * T4;
+  const int CH = slab_channels(N, T, Cu, kLdsBudget);
+  if (CH >= 1) {
+    const size_t lds = (size_t)CH * N * T * sizeof(float);
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm<T4, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
+    }
+    const int nchunks = cdiv(Cu, CH);
+    dim3 grid(1, nchunks, G);
+    hipLaunchKernelGGL((k_sddmm<T4, true>), grid, dim3(kBlock), lds, s, gr.erow, gr.col,
+                       (const float4*)u, (const float4*)dv, dEp, Cu, N, gr.nnz, CH, nchunks);
+  } else {
+    dim3 grid(min(cdiv(gr.nnz, kBlock), 1024), 1, G);
+    hipLaunchKernelGGL((k_sddmm<T4, false>), grid, dim3(kBlock), 0, s, gr.erow, gr.col,
+                       (const float4*)u, (const float4*)dv, dEp, Cu, N, gr.nnz, Cu, 1);
+  }
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
+}
+
+int launch_sddmm(const msgat_graph_t& gr, const float* u, const float* dv, float* dEp, int G,
+                 int Cu, int N, int T, hipStream_t s) {
+  if (gr.nnz == 0) return MSGAT_OK;
+  switch (T) {
+    case 4: return launch_sddmm_t<1>(gr, u, dv, dEp, G, Cu, N, s);
+    case 8: return launch_sddmm_t<2>(gr, u, dv, dEp, G, Cu, N, s);
+    case 12: return launch_sddmm_t<3>(gr, u, dv, dEp, G, Cu, N, s);
+    case 16: return launch_sddmm_t<4>(gr, u, dv, dEp, G, Cu, N, s);
+  }
+  return MSGAT_ERR_UNSUPPORTED;
+}
+
+}  // namespace msgat

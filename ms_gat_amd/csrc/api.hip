@@ -1,0 +1,255 @@
+// extern "C" entry points of libmsgat_hip.so (see include/msgat_hip.h).
+// Argument checks happen on the host before anything is enqueued: a bad shape must come
+// back as a status code, never as a faulting kernel.
+#include "common.hpp"
+
+using namespace msgat;
+
+namespace {
+
+int check_shape(const msgat_shape_t* sh) {
+  if (!sh) return MSGAT_ERR_NULL;
+  if (sh->R <= 0 || sh->Bg <= 0 || sh->C <= 0 || sh->Co < 0 || sh->N <= 0 || sh->T <= 0) return MSGAT_ERR_SHAPE;
+  if (!t_supported(sh->T)) return MSGAT_ERR_UNSUPPORTED;
+  if (sh->C > kMaxC || sh->Co > kMaxC) return MSGAT_ERR_UNSUPPORTED;
+  if ((int64_t)sh->R * sh->Bg > 65535) return MSGAT_ERR_UNSUPPORTED;  // groups ride on gridDim.y/z
+  if ((int64_t)sh->N * sh->T > (1 << 28)) return MSGAT_ERR_UNSUPPORTED;
+  return MSGAT_OK;
+}
+
+int check_graph(const msgat_shape_t* sh, const msgat_graph_t* gr) {
+  if (!gr) return MSGAT_ERR_NULL;
+  if (gr->n_nodes != sh->N || gr->nnz < 0) return MSGAT_ERR_SHAPE;
+  if (!gr->rowptr || !gr->colptr) return MSGAT_ERR_NULL;
+  if (gr->nnz > 0 && (!gr->col || !gr->val || !gr->erow || !gr->crow || !gr->cperm)) return MSGAT_ERR_NULL;
+  return MSGAT_OK;
+}
+
+inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// backward workspace layout, shared by the size query and the run
+struct BwdPlan {
+  int mode, G, Cu, nch;
+  size_t off_dEp, off_gE, off_delta, off_dkW, off_dq, off_dv, off_dwg, off_cp, total;
+};
+
+BwdPlan plan_bwd(const msgat_shape_t& sh, int nnz) {
+  BwdPlan p{};
+  p.mode = msgat_gacn_mode(sh.C, sh.Co);
+  p.G = sh.R * sh.Bg;
+  p.Cu = (p.mode == MSGAT_MODE_PROJ_FIRST) ? sh.Co : sh.C;
+  p.nch = sddmm_chunks(p.Cu, sh.N, sh.T);
+  const size_t G = p.G, N = sh.N, T = sh.T, P = N * T;
+  size_t off = 0;
+  auto take = [&](size_t floats) {
+    const size_t o = off;
+    off += align256(floats * sizeof(float));
+    return o;
+  };
+  p.off_dEp = take(G * p.nch * (size_t)nnz);
+  p.off_gE = take(G * (size_t)nnz);
+  p.off_delta = take(G * N);
+  p.off_dkW = take(G * P);
+  p.off_dq = take(G * P);
+  // AGG_FIRST: dy = W^T dz [G,C,P];  PROJ_FIRST: du = E^T dz [G,Co,P];  PLAIN: none
+  p.off_dv = take(p.mode == MSGAT_MODE_PLAIN ? 0 : G * (size_t)p.Cu * P);
+  p.off_dwg = take(dwg_partial_floats(p.G, sh.N, sh.T));
+  size_t cp = 0;
+  if (p.mode == MSGAT_MODE_PLAIN) {
+    cp = chanpair_partial_floats(p.G, 1, sh.C, (int)P);
+  } else if (p.mode == MSGAT_MODE_AGG_FIRST) {
+    cp = chanpair_partial_floats(p.G, sh.Co, sh.C, (int)P);
+    const size_t cp2 = chanpair_partial_floats(p.G, 1, sh.C, (int)P);
+    if (cp2 > cp) cp = cp2;
+  } else {
+    cp = chanpair_partial_floats(p.G, sh.Co + 1, sh.C, (int)P);
+  }
+  p.off_cp = take(cp);
+  p.total = off;
+  return p;
+}
+
+}  // namespace
+
+extern "C" int msgat_abi_version(void) { return MSGAT_ABI_VERSION; }
+
+extern "C" const char* msgat_status_string(int status) {
+  switch (status) {
+    case MSGAT_OK: return "ok";
+    case MSGAT_ERR_NULL: return "required pointer is NULL";
+    case MSGAT_ERR_SHAPE: return "bad or inconsistent dimension";
+    case MSGAT_ERR_UNSUPPORTED: return "unsupported size (T must be 4/8/12/16, channels <= 256)";
+    case MSGAT_ERR_WORKSPACE: return "workspace too small";
+    case MSGAT_ERR_GRAPH: return "malformed CSR/CSC graph";
+  }
+  if (status <= MSGAT_ERR_HIP_BASE) return hipGetErrorString((hipError_t)(MSGAT_ERR_HIP_BASE - status));
+  return "unknown status";
+}
+
+extern "C" int msgat_gacn_mode(int32_t C, int32_t Co) {
+  if (Co <= 0) return MSGAT_MODE_PLAIN;
+  return (C > Co) ? MSGAT_MODE_PROJ_FIRST : MSGAT_MODE_AGG_FIRST;
+}
+
+// ---- stages -------------------------------------------------------------------------------------
+extern "C" int msgat_stage_project(const msgat_shape_t* sh, const float* x, const float* alpha,
+                                   const float* W, float* q, float* u, void* stream) {
+  int st = check_shape(sh);
+  if (st) return st;
+  if (!x || !alpha || !q) return MSGAT_ERR_NULL;
+  const int G = sh->R * sh->Bg, P = sh->N * sh->T;
+  hipStream_t s = (hipStream_t)stream;
+  if (u == nullptr) return launch_qonly(x, alpha, q, G, sh->Bg, sh->C, P, s);
+  if (!W || sh->Co <= 0) return MSGAT_ERR_NULL;
+  return launch_project(x, W, 0, alpha, nullptr, nullptr, u, q, G, sh->Bg, sh->C, sh->Co, P, s);
+}
+
+extern "C" int msgat_stage_scores(const msgat_shape_t* sh, const msgat_graph_t* gr, const float* q,
+                                  const float* Wg, float* kW, float* lse, float* pq, float* E,
+                                  void* stream) {
+  int st = check_shape(sh);
+  if (st) return st;
+  st = check_graph(sh, gr);
+  if (st) return st;
+  if (!q || !Wg || !kW || !lse) return MSGAT_ERR_NULL;
+  if (gr->nnz > 0 && !E) return MSGAT_ERR_NULL;
+  return launch_scores(*gr, q, Wg, kW, lse, pq, E, sh->R * sh->Bg, sh->Bg, sh->N, sh->T, (hipStream_t)stream);
+}
+
+extern "C" int msgat_stage_aggregate(const msgat_shape_t* sh, const msgat_graph_t* gr, int32_t Cu,
+                                     const float* u, const float* E, float* v, void* stream) {
+  int st = check_shape(sh);
+  if (st) return st;
+  st = check_graph(sh, gr);
+  if (st) return st;
+  if (!u || !v || (gr->nnz > 0 && !E)) return MSGAT_ERR_NULL;
+  if (Cu <= 0 || Cu > kMaxC) return MSGAT_ERR_SHAPE;
+  return launch_aggregate(gr->rowptr, gr->col, nullptr, gr->nnz, u, E, nullptr, nullptr, v, sh->R * sh->Bg,
+                          sh->Bg, Cu, sh->N, sh->T, (hipStream_t)stream);
+}
+
+extern "C" int msgat_stage_aggregate_project(const msgat_shape_t* sh, const msgat_graph_t* gr,
+                                             const float* x, const float* E, const float* W, float* y,
+                                             float* z, void* stream) {
+  int st = check_shape(sh);
+  if (st) return st;
+  st = check_graph(sh, gr);
+  if (st) return st;
+  if (!x || !W || !z || (gr->nnz > 0 && !E)) return MSGAT_ERR_NULL;
+  if (sh->Co <= 0) return MSGAT_ERR_SHAPE;
+  return launch_aggregate_project(*gr, x, E, W, y, z, sh->R * sh->Bg, sh->Bg, sh->C, sh->Co, sh->N, sh->T,
+                                  (hipStream_t)stream);
+}
+
+// ---- fused forward ---------------------------------------------------------------------------------
+extern "C" int msgat_gacn_forward(const msgat_shape_t* sh, const msgat_graph_t* gr,
+                                  const msgat_fwd_t* io, void* stream) {
+  int st = check_shape(sh);
+  if (st) return st;
+  st = check_graph(sh, gr);
+  if (st) return st;
+  if (!io) return MSGAT_ERR_NULL;
+  if (!io->x || !io->alpha || !io->Wg || !io->z || !io->q || !io->kW || !io->lse) return MSGAT_ERR_NULL;
+  if (gr->nnz > 0 && !io->E) return MSGAT_ERR_NULL;
+  const int mode = msgat_gacn_mode(sh->C, sh->Co);
+  if (mode != MSGAT_MODE_PLAIN && !io->W) return MSGAT_ERR_NULL;
+  if (mode == MSGAT_MODE_PROJ_FIRST && !io->u) return MSGAT_ERR_NULL;
+  if (io->need_bwd && !io->pq) return MSGAT_ERR_NULL;
+  if (io->need_bwd && mode == MSGAT_MODE_AGG_FIRST && !io->u) return MSGAT_ERR_NULL;
+
+  hipStream_t s = (hipStream_t)stream;
+  const int G = sh->R * sh->Bg, P = sh->N * sh->T;
+  float* pq = io->need_bwd ? io->pq : nullptr;
+
+  if (mode == MSGAT_MODE_PROJ_FIRST)
+    st = launch_project(io->x, io->W, 0, io->alpha, nullptr, nullptr, io->u, io->q, G, sh->Bg, sh->C, sh->Co, P, s);
+  else
+    st = launch_qonly(io->x, io->alpha, io->q, G, sh->Bg, sh->C, P, s);
+  if (st) return st;
+
+  st = launch_scores(*gr, io->q, io->Wg, io->kW, io->lse, pq, io->E, G, sh->Bg, sh->N, sh->T, s);
+  if (st) return st;
+
+  switch (mode) {
+    case MSGAT_MODE_PLAIN:
+      return launch_aggregate(gr->rowptr, gr->col, nullptr, gr->nnz, io->x, io->E, nullptr, nullptr, io->z, G,
+                              sh->Bg, sh->C, sh->N, sh->T, s);
+    case MSGAT_MODE_AGG_FIRST:
+      return launch_aggregate_project(*gr, io->x, io->E, io->W, io->need_bwd ? io->u : nullptr, io->z, G,
+                                      sh->Bg, sh->C, sh->Co, sh->N, sh->T, s);
+    default:
+      return launch_aggregate(gr->rowptr, gr->col, nullptr, gr->nnz, io->u, io->E, nullptr, nullptr, io->z, G,
+                              sh->Bg, sh->Co, sh->N, sh->T, s);
+  }
+}
+
+// ---- fused backward --------------------------------------------------------------------------------
+extern "C" size_t msgat_bwd_workspace_bytes(const msgat_shape_t* sh, int32_t nnz) {
+  if (check_shape(sh) != MSGAT_OK || nnz < 0) return 0;
+  return plan_bwd(*sh, nnz).total;
+}
+
+extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t* gr,
+                                   const msgat_bwd_t* io, void* stream) {
+  int st = check_shape(sh);
+  if (st) return st;
+  st = check_graph(sh, gr);
+  if (st) return st;
+  if (!io) return MSGAT_ERR_NULL;
+  if (!io->x || !io->alpha || !io->Wg || !io->q || !io->kW || !io->lse || !io->pq || !io->dz ||
+      !io->dx || !io->dalpha || !io->dWg || !io->workspace)
+    return MSGAT_ERR_NULL;
+  if (gr->nnz > 0 && !io->E) return MSGAT_ERR_NULL;
+  const BwdPlan p = plan_bwd(*sh, gr->nnz);
+  if (p.mode != MSGAT_MODE_PLAIN && (!io->W || !io->dW || !io->u)) return MSGAT_ERR_NULL;
+  if (io->workspace_bytes < p.total) return MSGAT_ERR_WORKSPACE;
+  if (((uintptr_t)io->workspace & 255) != 0) return MSGAT_ERR_WORKSPACE;
+
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = (char*)io->workspace;
+  float* dEp = (float*)(ws + p.off_dEp);
+  float* gE = (float*)(ws + p.off_gE);
+  float* delta = (float*)(ws + p.off_delta);
+  float* dkW = (float*)(ws + p.off_dkW);
+  float* dq = (float*)(ws + p.off_dq);
+  float* dvb = (float*)(ws + p.off_dv);
+  float* dwgp = (float*)(ws + p.off_dwg);
+  float* cpp = (float*)(ws + p.off_cp);
+  const int G = p.G, Bg = sh->Bg, C = sh->C, Co = sh->Co, N = sh->N, T = sh->T, P = N * T;
+
+  // features the attention acted on (u) and the gradient arriving at its output (dv)
+  const float* u = (p.mode == MSGAT_MODE_PROJ_FIRST) ? io->u : io->x;
+  const float* dv = io->dz;
+  if (p.mode == MSGAT_MODE_AGG_FIRST) {
+    // z = W y:  dy = W^T dz,  dW = dz y^T
+    st = launch_project(io->dz, io->W, 1, nullptr, nullptr, nullptr, dvb, nullptr, G, Bg, Co, C, P, s);
+    if (st) return st;
+    st = launch_chanpair(io->dz, nullptr, io->u, cpp, io->dW, Co * C, nullptr, 0, G, Bg, Co, C, P, s);
+    if (st) return st;
+    dv = dvb;
+  }
+
+  st = launch_sddmm(*gr, u, dv, dEp, G, p.Cu, N, T, s);
+  if (st) return st;
+  st = launch_bwd_edge(*gr, dEp, p.nch, io->E, io->q, io->pq, io->Wg, gE, delta, dkW, dq, G, Bg, N, T, s);
+  if (st) return st;
+  st = launch_bwd_dense_col(*gr, io->q, io->kW, io->lse, delta, gE, dq, G, N, T, s);
+  if (st) return st;
+  st = launch_dwg(io->q, dkW, dwgp, io->dWg, G, Bg, N, T, s);
+  if (st) return st;
+
+  if (p.mode == MSGAT_MODE_PROJ_FIRST) {
+    // du = E^T dz;  dx = W^T du + alpha (x) dq;  dW = du x^T;  dalpha = dq . x
+    st = launch_aggregate(gr->colptr, gr->crow, gr->cperm, gr->nnz, dv, io->E, nullptr, nullptr, dvb, G, Bg,
+                          Co, N, T, s);
+    if (st) return st;
+    st = launch_project(dvb, io->W, 1, nullptr, io->alpha, dq, io->dx, nullptr, G, Bg, Co, C, P, s);
+    if (st) return st;
+    return launch_chanpair(dvb, dq, io->x, cpp, io->dW, Co * C, io->dalpha, C, G, Bg, Co + 1, C, P, s);
+  }
+  // PLAIN / AGG_FIRST:  dx = E^T dv + alpha (x) dq;  dalpha = dq . x
+  st = launch_aggregate(gr->colptr, gr->crow, gr->cperm, gr->nnz, dv, io->E, io->alpha, dq, io->dx, G, Bg, C,
+                        N, T, s);
+  if (st) return st;
+  return launch_chanpair(nullptr, dq, io->x, cpp, nullptr, 0, io->dalpha, C, G, Bg, 1, C, P, s);
+}

@@ -1,0 +1,94 @@
+// Shared helpers for the gfx950 kernels of libmsgat_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "msgat_hip.h"
+
+#define MSGAT_CHECK_LAUNCH()                                   \
+  do {                                                         \
+    hipError_t e__ = hipGetLastError();                        \
+    if (e__ != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e__; \
+  } while (0)
+
+namespace msgat {
+
+constexpr int kWave = 64;          // gfx950 wavefront
+constexpr int kBlock = 256;        // 4 waves, one per SIMD
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr int kMaxT = 16;          // timesteps supported: 4, 8, 12, 16
+constexpr int kMaxC = 256;         // channels supported per side
+constexpr int kLdsBudget = 64 * 1024;  // per-block LDS the slab kernels aim for (>= 2 blocks/CU)
+constexpr int kLdsMax = 160 * 1024;
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void f4fma(float a, const float4& x, float4& acc) {
+  acc.x = fmaf(a, x.x, acc.x);
+  acc.y = fmaf(a, x.y, acc.y);
+  acc.z = fmaf(a, x.z, acc.z);
+  acc.w = fmaf(a, x.w, acc.w);
+}
+__device__ __forceinline__ float f4dot(const float4& a, const float4& b, float acc) {
+  acc = fmaf(a.x, b.x, acc);
+  acc = fmaf(a.y, b.y, acc);
+  acc = fmaf(a.z, b.z, acc);
+  acc = fmaf(a.w, b.w, acc);
+  return acc;
+}
+// v_exp_f32: 2^x, 1 ulp, no denormal results (flushes to 0 below 2^-126) -- what the
+// softmax needs; exp2f() from the device library adds range scaling we do not want.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+
+inline bool t_supported(int T) { return T == 4 || T == 8 || T == 12 || T == 16; }
+
+// how many channels of an [N,T] fp32 slab fit the per-block LDS budget
+inline int slab_channels(int N, int T, int Cu, int budget_bytes) {
+  const int64_t slab = (int64_t)N * T * 4;
+  int ch = (int)(budget_bytes / slab);
+  if (ch < 1) ch = (slab <= kLdsMax - 1024) ? 1 : 0;  // 0 => slab does not fit LDS at all
+  if (ch > Cu) ch = Cu;
+  return ch;
+}
+
+// ---- kernel launchers (defined in the .hip files) ---------------------------------
+int launch_qonly(const float* x, const float* alpha, float* q, int G, int Bg, int C, int P,
+                 hipStream_t s);
+// out[g,co,p] = sum_ci M(r; ci->co) in[g,ci,p] (+ addvec[r,co]*extra[g,p]);  q[g,p] = sum_ci qvec[r,ci] in[g,ci,p]
+int launch_project(const float* in, const float* M, int m_in_major, const float* qvec,
+                   const float* addvec, const float* extra, float* out, float* q, int G, int Bg,
+                   int Ci, int Co, int P, hipStream_t s);
+int launch_scores(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW, float* lse,
+                  float* pq, float* E, int G, int Bg, int N, int T, hipStream_t s);
+// v[g,c,n,:] = sum_{e in ptr[n]..ptr[n+1]} E[g, perm?perm[e]:e] u[g,c,idx[e],:] (+ addvec[r,c]*extra[g,n,:])
+int launch_aggregate(const int* ptr, const int* idx, const int* perm, int nnz, const float* u,
+                     const float* E, const float* addvec, const float* extra, float* v, int G,
+                     int Bg, int Cu, int N, int T, hipStream_t s);
+int launch_aggregate_project(const msgat_graph_t& gr, const float* x, const float* E,
+                             const float* W, float* y, float* z, int G, int Bg, int C, int Co,
+                             int N, int T, hipStream_t s);
+// dEp[g,k,e] = sum over channel chunk k of <dv[g,c,erow[e],:], u[g,c,col[e],:]>
+int sddmm_chunks(int Cu, int N, int T);
+int launch_sddmm(const msgat_graph_t& gr, const float* u, const float* dv, float* dEp, int G,
+                 int Cu, int N, int T, hipStream_t s);
+int launch_bwd_edge(const msgat_graph_t& gr, const float* dEp, int nchunks, const float* E,
+                    const float* q, const float* pq, const float* Wg, float* gE, float* delta,
+                    float* dkW, float* dq, int G, int Bg, int N, int T, hipStream_t s);
+int launch_bwd_dense_col(const msgat_graph_t& gr, const float* q, const float* kW,
+                         const float* lse, const float* delta, const float* gE, float* dq, int G,
+                         int N, int T, hipStream_t s);
+// dWg[r,t,s] = sum_{g in r, n} q[g,n,t] dkW[g,n,s]
+size_t dwg_partial_floats(int G, int N, int T);
+int launch_dwg(const float* q, const float* dkW, float* part, float* dWg, int G, int Bg, int N,
+               int T, hipStream_t s);
+// out[r,a,c] = sum_{g in r, p} A(g,a,p) B[g,c,p];  channel a == Ca-1 comes from Aextra[g,p] when given
+size_t chanpair_partial_floats(int G, int Ca, int Cb, int P);
+int launch_chanpair(const float* A, const float* Aextra, const float* B, float* part, float* dst0,
+                    int n0, float* dst1, int n1, int G, int Bg, int Ca, int Cb, int P,
+                    hipStream_t s);
+
+}  // namespace msgat

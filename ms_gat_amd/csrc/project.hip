@@ -1,0 +1,128 @@
+// Per-node channel mixing: the dense, streaming side of the hot path.
+//
+//   q[g,p]     = sum_c alpha[r,c] x[g,c,p]                 attention.py:33 (q == k)
+//   u[g,o,p]   = sum_c W[r,o,c]  x[g,c,p]                  msgat.py:27, applied BEFORE the
+//                                                          aggregation when C > Co
+//   dx[g,c,p]  = sum_o W[r,o,c] du[g,o,p] + alpha[r,c] dq[g,p]   (backward of both)
+//
+// p runs over the flat [N*T] axis of one (group, channel) slab, which is contiguous in
+// the reference's [B,C,N,T] layout, so a lane owns 4 consecutive positions (one 16-B
+// load per channel) and the channel loop streams the slabs: HBM-bound, x is read once.
+#include "common.hpp"
+
+namespace msgat {
+
+// ---- q only (AGG_FIRST / PLAIN) ------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_qonly(const float4* __restrict__ x4,
+                                                  const float* __restrict__ alpha,
+                                                  float4* __restrict__ q4, int Bg, int C, int P4) {
+  const int g = blockIdx.y;
+  const int r = g / Bg;
+  const int p4 = blockIdx.x * kBlock + threadIdx.x;
+  if (p4 >= P4) return;
+  const float4* src = x4 + (size_t)g * C * P4 + p4;
+  float4 acc = f4zero();
+  for (int c = 0; c < C; ++c) f4fma(alpha[r * C + c], src[(size_t)c * P4], acc);
+  q4[(size_t)g * P4 + p4] = acc;
+}
+
+int launch_qonly(const float* x, const float* alpha, float* q, int G, int Bg, int C, int P,
+                 hipStream_t s) {
+  const int P4 = P / 4;
+  dim3 grid(cdiv(P4, kBlock), G);
+  hipLaunchKernelGGL(k_qonly, grid, dim3(kBlock), 0, s, (const float4*)x, alpha, (float4*)q, Bg, C, P4);
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
+}
+
+// ---- general channel projection --------------------------------------------------------
+// One block = 256 lanes x 4 positions of one group, OT output channels (blockIdx.z picks
+// the tile).  The [Ci x OT] slice of the matrix sits in LDS and is read as wave-uniform
+// broadcasts (one ds_read_b128 feeds 4 output channels x 4 positions = 16 FMAs).
+template <int OT>
+__global__ __launch_bounds__(kBlock) void k_project(
+    const float4* __restrict__ in4, const float* __restrict__ M, int m_in_major,
+    const float* __restrict__ qvec, const float* __restrict__ addvec,
+    const float4* __restrict__ extra4, float4* __restrict__ out4, float4* __restrict__ q4, int Bg,
+    int Ci, int Co, int P4) {
+  extern __shared__ float lds[];
+  float* Ml = lds;            // [Ci][OT]
+  float* ql = lds + Ci * OT;  // [Ci]
+  const int g = blockIdx.y;
+  const int r = g / Bg;
+  const int o0 = blockIdx.z * OT;
+  const bool do_q = (qvec != nullptr) && (blockIdx.z == 0);
+
+  for (int i = threadIdx.x; i < Ci * OT; i += kBlock) {
+    const int ci = i / OT, oo = i - ci * OT, o = o0 + oo;
+    float w = 0.f;
+    if (o < Co) w = m_in_major ? M[((size_t)r * Ci + ci) * Co + o] : M[((size_t)r * Co + o) * Ci + ci];
+    Ml[i] = w;
+  }
+  for (int i = threadIdx.x; i < Ci; i += kBlock) ql[i] = do_q ? qvec[r * Ci + i] : 0.f;
+  __syncthreads();
+
+  const int p4 = blockIdx.x * kBlock + threadIdx.x;
+  if (p4 >= P4) return;
+
+  float4 acc[OT];
+#pragma unroll
+  for (int oo = 0; oo < OT; ++oo) acc[oo] = f4zero();
+  float4 qa = f4zero();
+  const float4* src = in4 + (size_t)g * Ci * P4 + p4;
+
+#pragma unroll 4
+  for (int ci = 0; ci < Ci; ++ci) {
+    const float4 xv = src[(size_t)ci * P4];
+    const float4* wrow = reinterpret_cast<const float4*>(Ml + ci * OT);
+#pragma unroll
+    for (int o4 = 0; o4 < OT / 4; ++o4) {
+      const float4 w = wrow[o4];
+      f4fma(w.x, xv, acc[4 * o4 + 0]);
+      f4fma(w.y, xv, acc[4 * o4 + 1]);
+      f4fma(w.z, xv, acc[4 * o4 + 2]);
+      f4fma(w.w, xv, acc[4 * o4 + 3]);
+    }
+    f4fma(ql[ci], xv, qa);
+  }
+
+  float4 ex = f4zero();
+  if (addvec != nullptr) ex = extra4[(size_t)g * P4 + p4];
+#pragma unroll
+  for (int oo = 0; oo < OT; ++oo) {
+    const int o = o0 + oo;
+    if (o < Co) {
+      float4 v = acc[oo];
+      if (addvec != nullptr) f4fma(addvec[r * Co + o], ex, v);
+      out4[((size_t)g * Co + o) * P4 + p4] = v;
+    }
+  }
+  if (do_q) q4[(size_t)g * P4 + p4] = qa;
+}
+
+template <int OT>
+static int launch_project_t(const float* in, const float* M, int m_in_major, const float* qvec,
+                            const float* addvec, const float* extra, float* out, float* q, int G,
+                            int Bg, int Ci, int Co, int P4, hipStream_t s) {
+  dim3 grid(cdiv(P4, kBlock), G, cdiv(Co, OT));
+  const size_t lds = (size_t)(Ci * OT + Ci) * sizeof(float);
+  hipLaunchKernelGGL(k_project<OT>, grid, dim3(kBlock), lds, s, (const float4*)in, M, m_in_major,
+                     qvec, addvec, (const float4*)extra, (float4*)out, (float4*)q, Bg, Ci, Co, P4);
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
+}
+
+int launch_project(const float* in, const float* M, int m_in_major, const float* qvec,
+                   const float* addvec, const float* extra, float* out, float* q, int G, int Bg,
+                   int Ci, int Co, int P, hipStream_t s) {
+  const int P4 = P / 4;
+  // widest tile that divides the work evenly; 24 and 32 cover the reference's widths
+  // (Co = 16/24/32 forward, C = 48/72/96 backward)
+  if (Co % 24 == 0) return launch_project_t<24>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, s);
+  if (Co % 32 == 0) return launch_project_t<32>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, s);
+  if (Co % 16 == 0) return launch_project_t<16>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, s);
+  if (Co <= 4) return launch_project_t<4>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, s);
+  return launch_project_t<8>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, s);
+}
+
+}  // namespace msgat

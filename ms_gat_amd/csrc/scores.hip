@@ -1,0 +1,424 @@
+// The dense side of the attention: everything that needs ALL N columns of a row.
+//
+// attention.py:34 takes softmax over the full [N] row of S = (k Wg) q^T and only then
+// (attention.py:36) multiplies by the adjacency, so the normaliser of every edge
+// coefficient is a sum over all N columns.  Nothing N x N is ever written here:
+//
+//   forward   kW = q Wg;  lse[n] = log sum_m exp(kW[n].q[m])   (online max/sum, flash style)
+//             pq[n] = sum_m softmax(S)[n,m] q[m]               (only when training)
+//             E[e]  = exp(kW[row_e].q[col_e] - lse[row_e]) * adj_e      (edges only)
+//   backward  dq[m] -= sum_n softmax(S)[n,m] delta[n] kW[n]    (the dense column term)
+//
+// K = T = 12 dot products feed an exp, so everything stays fp32 (bf16 MFMA would break
+// the 1e-4 bar); the kernels are bound by fp32 FMA + v_exp_f32 issue, not by HBM.
+#include "common.hpp"
+
+namespace msgat {
+
+constexpr int kRT = 64;    // rows (or columns) per block = one lane each
+constexpr int kNS = 4;     // the 4 waves of a block split the reduction axis
+constexpr int kMC = 256;   // columns of q staged in LDS per step
+constexpr int kSub = 8;    // columns per online-softmax update
+
+template <int T, bool WITH_PQ>
+__global__ __launch_bounds__(kBlock) void k_scores(
+    const float* __restrict__ q, const float* __restrict__ Wg, const int* __restrict__ rowptr,
+    const int* __restrict__ col, const float* __restrict__ val, const int* __restrict__ erow,
+    float* __restrict__ kW, float* __restrict__ lse, float* __restrict__ pq, float* __restrict__ E,
+    int Bg, int N, int nnz) {
+  constexpr int T4 = T / 4;
+  __shared__ float4 qs4[kMC * T4];
+  __shared__ float red[kNS][kRT][T + 2];
+  __shared__ float kw2s[kRT][T];
+  __shared__ float lse2s[kRT];
+
+  const int g = blockIdx.y;
+  const int r = g / Bg;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int split = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n0 = blockIdx.x * kRT;
+  const int n = n0 + lane;
+  const bool valid = n < N;
+  const float* qg = q + (size_t)g * N * T;
+
+  // this lane's row: q[n] and kW[n] = q[n] Wg
+  float qr[T];
+#pragma unroll
+  for (int t4 = 0; t4 < T4; ++t4) {
+    float4 v = f4zero();
+    if (valid) v = reinterpret_cast<const float4*>(qg + (size_t)n * T)[t4];
+    qr[4 * t4 + 0] = v.x; qr[4 * t4 + 1] = v.y; qr[4 * t4 + 2] = v.z; qr[4 * t4 + 3] = v.w;
+  }
+  float kw2[T];
+  const float* wg = Wg + (size_t)r * T * T;
+#pragma unroll
+  for (int s = 0; s < T; ++s) {
+    float a = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) a = fmaf(qr[t], wg[t * T + s], a);
+    kw2[s] = a;
+  }
+  if (split == 0 && valid) {
+    float4* dst = reinterpret_cast<float4*>(kW + ((size_t)g * N + n) * T);
+#pragma unroll
+    for (int t4 = 0; t4 < T4; ++t4) dst[t4] = make_float4(kw2[4 * t4], kw2[4 * t4 + 1], kw2[4 * t4 + 2], kw2[4 * t4 + 3]);
+  }
+#pragma unroll
+  for (int s = 0; s < T; ++s) kw2[s] *= kLog2e;  // scores in log2 units: exp(x) = 2^(x log2 e)
+
+  float m = -INFINITY, l = 0.f;
+  float racc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) racc[t] = 0.f;
+
+  for (int c0 = 0; c0 < N; c0 += kMC) {
+    const int cols = min(kMC, N - c0);
+    __syncthreads();
+    {
+      const float4* src = reinterpret_cast<const float4*>(qg + (size_t)c0 * T);
+      for (int i = threadIdx.x; i < cols * T4; i += kBlock) qs4[i] = src[i];
+    }
+    __syncthreads();
+    for (int j = split * kSub; j < cols; j += kNS * kSub) {
+      float s[kSub];
+      float cm = -INFINITY;
+#pragma unroll
+      for (int jj = 0; jj < kSub; ++jj) {
+        float a = -INFINITY;
+        if (j + jj < cols) {  // wave-uniform
+          const float4* qc = &qs4[(j + jj) * T4];
+          a = 0.f;
+#pragma unroll
+          for (int t4 = 0; t4 < T4; ++t4) {
+            const float4 v = qc[t4];
+            a = fmaf(kw2[4 * t4 + 0], v.x, a);
+            a = fmaf(kw2[4 * t4 + 1], v.y, a);
+            a = fmaf(kw2[4 * t4 + 2], v.z, a);
+            a = fmaf(kw2[4 * t4 + 3], v.w, a);
+          }
+        }
+        s[jj] = a;
+        cm = fmaxf(cm, a);
+      }
+      const float mn = fmaxf(m, cm);
+      const float sc = fast_exp2(m - mn);  // m == -inf on the first update -> 0
+      m = mn;
+      l *= sc;
+      if (WITH_PQ) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) racc[t] *= sc;
+      }
+#pragma unroll
+      for (int jj = 0; jj < kSub; ++jj) {
+        if (j + jj < cols) {
+          const float p = fast_exp2(s[jj] - mn);
+          l += p;
+          if (WITH_PQ) {
+            const float4* qc = &qs4[(j + jj) * T4];
+#pragma unroll
+            for (int t4 = 0; t4 < T4; ++t4) {
+              const float4 v = qc[t4];
+              racc[4 * t4 + 0] = fmaf(p, v.x, racc[4 * t4 + 0]);
+              racc[4 * t4 + 1] = fmaf(p, v.y, racc[4 * t4 + 1]);
+              racc[4 * t4 + 2] = fmaf(p, v.z, racc[4 * t4 + 2]);
+              racc[4 * t4 + 3] = fmaf(p, v.w, racc[4 * t4 + 3]);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // merge the 4 column splits of each row
+#pragma unroll
+  for (int t = 0; t < T; ++t) red[split][lane][t] = racc[t];
+  red[split][lane][T] = m;
+  red[split][lane][T + 1] = l;
+  __syncthreads();
+  if (split == 0) {
+    float M = red[0][lane][T];
+#pragma unroll
+    for (int i = 1; i < kNS; ++i) M = fmaxf(M, red[i][lane][T]);
+    float L = 0.f;
+    float R[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) R[t] = 0.f;
+#pragma unroll
+    for (int i = 0; i < kNS; ++i) {
+      const float w = fast_exp2(red[i][lane][T] - M);  // a split that saw no column has m = -inf -> 0
+      L = fmaf(w, red[i][lane][T + 1], L);
+      if (WITH_PQ) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) R[t] = fmaf(w, red[i][lane][t], R[t]);
+      }
+    }
+    const float lse2 = M + fast_log2(L);
+    lse2s[lane] = lse2;
+#pragma unroll
+    for (int t = 0; t < T; ++t) kw2s[lane][t] = kw2[t];
+    if (valid) {
+      lse[(size_t)g * N + n] = lse2;  // kept in log2 units so backward re-creates the exponent bit for bit
+      if (WITH_PQ) {
+        const float inv = 1.0f / L;
+        float4* dst = reinterpret_cast<float4*>(pq + ((size_t)g * N + n) * T);
+#pragma unroll
+        for (int t4 = 0; t4 < T4; ++t4)
+          dst[t4] = make_float4(R[4 * t4] * inv, R[4 * t4 + 1] * inv, R[4 * t4 + 2] * inv, R[4 * t4 + 3] * inv);
+      }
+    }
+  }
+  __syncthreads();
+
+  // edge coefficients of this block's rows: one lane per CSR edge, coalesced over e
+  const int e0 = rowptr[n0];
+  const int e1 = rowptr[min(n0 + kRT, N)];
+  for (int e = e0 + threadIdx.x; e < e1; e += kBlock) {
+    const int nl = erow[e] - n0;
+    const float4* qm = reinterpret_cast<const float4*>(qg + (size_t)col[e] * T);
+    float a = 0.f;
+#pragma unroll
+    for (int t4 = 0; t4 < T4; ++t4) {
+      const float4 v = qm[t4];
+      a = fmaf(kw2s[nl][4 * t4 + 0], v.x, a);
+      a = fmaf(kw2s[nl][4 * t4 + 1], v.y, a);
+      a = fmaf(kw2s[nl][4 * t4 + 2], v.z, a);
+      a = fmaf(kw2s[nl][4 * t4 + 3], v.w, a);
+    }
+    E[(size_t)g * nnz + e] = fast_exp2(a - lse2s[nl]) * val[e];
+  }
+}
+
+template <int T>
+static int launch_scores_t(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW,
+                           float* lse, float* pq, float* E, int G, int Bg, int N, hipStream_t s) {
+  dim3 grid(cdiv(N, kRT), G);
+  if (pq != nullptr)
+    hipLaunchKernelGGL((k_scores<T, true>), grid, dim3(kBlock), 0, s, q, Wg, gr.rowptr, gr.col, gr.val,
+                       gr.erow, kW, lse, pq, E, Bg, N, gr.nnz);
+  else
+    hipLaunchKernelGGL((k_scores<T, false>), grid, dim3(kBlock), 0, s, q, Wg, gr.rowptr, gr.col, gr.val,
+                       gr.erow, kW, lse, pq, E, Bg, N, gr.nnz);
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
+}
+
+int launch_scores(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW, float* lse,
+                  float* pq, float* E, int G, int Bg, int N, int T, hipStream_t s) {
+  switch (T) {
+    case 4: return launch_scores_t<4>(gr, q, Wg, kW, lse, pq, E, G, Bg, N, s);
+    case 8: return launch_scores_t<8>(gr, q, Wg, kW, lse, pq, E, G, Bg, N, s);
+    case 12: return launch_scores_t<12>(gr, q, Wg, kW, lse, pq, E, G, Bg, N, s);
+    case 16: return launch_scores_t<16>(gr, q, Wg, kW, lse, pq, E, G, Bg, N, s);
+  }
+  return MSGAT_ERR_UNSUPPORTED;
+}
+
+// ---- backward: per-row edge pass ---------------------------------------------------------
+// dE_e = sum of the per-chunk partials; g_e = E_e dE_e; delta_n = sum_e g_e;
+// dkW[n] = sum_e g_e (q[col_e] - pq[n]);  dq[n] = dkW[n] Wg^T  (row-local part of dq)
+template <int T>
+__global__ __launch_bounds__(kBlock) void k_bwd_edge(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dEp,
+    int nchunks, const float* __restrict__ E, const float* __restrict__ q,
+    const float* __restrict__ pq, const float* __restrict__ Wg, float* __restrict__ gE,
+    float* __restrict__ delta, float* __restrict__ dkW, float* __restrict__ dq, int Bg, int N,
+    int nnz) {
+  constexpr int T4 = T / 4;
+  const int g = blockIdx.y;
+  const int r = g / Bg;
+  const int n = blockIdx.x * kBlock + threadIdx.x;
+  if (n >= N) return;
+  float d = 0.f;
+  float dk[T], pr[T];
+#pragma unroll
+  for (int t4 = 0; t4 < T4; ++t4) {
+    const float4 v = reinterpret_cast<const float4*>(pq + ((size_t)g * N + n) * T)[t4];
+    pr[4 * t4 + 0] = v.x; pr[4 * t4 + 1] = v.y; pr[4 * t4 + 2] = v.z; pr[4 * t4 + 3] = v.w;
+    dk[4 * t4 + 0] = 0.f; dk[4 * t4 + 1] = 0.f; dk[4 * t4 + 2] = 0.f; dk[4 * t4 + 3] = 0.f;
+  }
+  // dkW[n] = sum_e g_e q[col_e] - delta_n pq[n] = sum_e g_e (q[col_e] - pq[n]): subtracting
+  // first keeps a saturated (one-hot) row exact -- pq[n] then equals q[col_e] bit for bit
+  for (int e = rowptr[n]; e < rowptr[n + 1]; ++e) {
+    float dE = 0.f;
+    for (int k = 0; k < nchunks; ++k) dE += dEp[((size_t)g * nchunks + k) * nnz + e];
+    const float ge = E[(size_t)g * nnz + e] * dE;
+    gE[(size_t)g * nnz + e] = ge;
+    d += ge;
+    const float4* qm = reinterpret_cast<const float4*>(q + ((size_t)g * N + col[e]) * T);
+#pragma unroll
+    for (int t4 = 0; t4 < T4; ++t4) {
+      const float4 v = qm[t4];
+      dk[4 * t4 + 0] = fmaf(ge, v.x - pr[4 * t4 + 0], dk[4 * t4 + 0]);
+      dk[4 * t4 + 1] = fmaf(ge, v.y - pr[4 * t4 + 1], dk[4 * t4 + 1]);
+      dk[4 * t4 + 2] = fmaf(ge, v.z - pr[4 * t4 + 2], dk[4 * t4 + 2]);
+      dk[4 * t4 + 3] = fmaf(ge, v.w - pr[4 * t4 + 3], dk[4 * t4 + 3]);
+    }
+  }
+  float4* dkdst = reinterpret_cast<float4*>(dkW + ((size_t)g * N + n) * T);
+#pragma unroll
+  for (int t4 = 0; t4 < T4; ++t4) dkdst[t4] = make_float4(dk[4 * t4], dk[4 * t4 + 1], dk[4 * t4 + 2], dk[4 * t4 + 3]);
+  delta[(size_t)g * N + n] = d;
+  const float* wg = Wg + (size_t)r * T * T;
+  float out[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    float a = 0.f;
+#pragma unroll
+    for (int s = 0; s < T; ++s) a = fmaf(dk[s], wg[t * T + s], a);
+    out[t] = a;
+  }
+  float4* dqdst = reinterpret_cast<float4*>(dq + ((size_t)g * N + n) * T);
+#pragma unroll
+  for (int t4 = 0; t4 < T4; ++t4) dqdst[t4] = make_float4(out[4 * t4], out[4 * t4 + 1], out[4 * t4 + 2], out[4 * t4 + 3]);
+}
+
+int launch_bwd_edge(const msgat_graph_t& gr, const float* dEp, int nchunks, const float* E,
+                    const float* q, const float* pq, const float* Wg, float* gE, float* delta,
+                    float* dkW, float* dq, int G, int Bg, int N, int T, hipStream_t s) {
+  dim3 grid(cdiv(N, kBlock), G);
+#define MSGAT_EDGE(TT)                                                                            \
+  hipLaunchKernelGGL(k_bwd_edge<TT>, grid, dim3(kBlock), 0, s, gr.rowptr, gr.col, dEp, nchunks, E, q, \
+                     pq, Wg, gE, delta, dkW, dq, Bg, N, gr.nnz)
+  switch (T) {
+    case 4: MSGAT_EDGE(4); break;
+    case 8: MSGAT_EDGE(8); break;
+    case 12: MSGAT_EDGE(12); break;
+    case 16: MSGAT_EDGE(16); break;
+    default: return MSGAT_ERR_UNSUPPORTED;
+  }
+#undef MSGAT_EDGE
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
+}
+
+// ---- backward: dense column pass -----------------------------------------------------------
+// One lane per column m; rows stream through LDS as records [kW2(T) | delta*kW(T) | lse2].
+//   dq[m] += sum_{e into m} g_e kW[row_e]  -  sum_n exp(kW[n].q[m] - lse[n]) delta[n] kW[n]
+constexpr int kRC = 128;  // rows staged per step
+
+template <int T>
+__global__ __launch_bounds__(kBlock) void k_bwd_dense_col(
+    const float* __restrict__ q, const float* __restrict__ kW, const float* __restrict__ lse,
+    const float* __restrict__ delta, const float* __restrict__ gE, const int* __restrict__ colptr,
+    const int* __restrict__ crow, const int* __restrict__ cperm, float* __restrict__ dq, int N,
+    int nnz) {
+  constexpr int T4 = T / 4;
+  constexpr int REC4 = 2 * T4 + 1;  // float4s per row record
+  __shared__ float4 rec4[kRC * REC4];
+  __shared__ float red[kNS][kRT][T];
+
+  const int g = blockIdx.y;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int split = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int mcol = blockIdx.x * kRT + lane;
+  const bool valid = mcol < N;
+  const float* qg = q + (size_t)g * N * T;
+  const float* kWg = kW + (size_t)g * N * T;
+
+  float qc[T];
+#pragma unroll
+  for (int t4 = 0; t4 < T4; ++t4) {
+    float4 v = f4zero();
+    if (valid) v = reinterpret_cast<const float4*>(qg + (size_t)mcol * T)[t4];
+    qc[4 * t4 + 0] = v.x; qc[4 * t4 + 1] = v.y; qc[4 * t4 + 2] = v.z; qc[4 * t4 + 3] = v.w;
+  }
+  float acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = 0.f;
+
+  for (int r0 = 0; r0 < N; r0 += kRC) {
+    const int rows = min(kRC, N - r0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows; i += kBlock) {
+      const int nr = r0 + i;
+      const float4* kr = reinterpret_cast<const float4*>(kWg + (size_t)nr * T);
+      const float d = delta[(size_t)g * N + nr];
+#pragma unroll
+      for (int t4 = 0; t4 < T4; ++t4) {
+        const float4 v = kr[t4];
+        rec4[i * REC4 + t4] = make_float4(v.x * kLog2e, v.y * kLog2e, v.z * kLog2e, v.w * kLog2e);
+        rec4[i * REC4 + T4 + t4] = make_float4(v.x * d, v.y * d, v.z * d, v.w * d);
+      }
+      rec4[i * REC4 + 2 * T4] = make_float4(lse[(size_t)g * N + nr], 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    for (int row = split; row < rows; row += kNS) {
+      const float4* rec = &rec4[row * REC4];
+      // same operands in the same fma order as k_scores: the score is re-created bit for
+      // bit, so exp2(s - lse2) equals the forward's softmax value (rows that are one-hot on
+      // an edge cancel against the sparse term; a 1e-4 slip in the exponent would not)
+      float s = 0.f;
+#pragma unroll
+      for (int t4 = 0; t4 < T4; ++t4) {
+        const float4 v = rec[t4];
+        s = fmaf(v.x, qc[4 * t4 + 0], s);
+        s = fmaf(v.y, qc[4 * t4 + 1], s);
+        s = fmaf(v.z, qc[4 * t4 + 2], s);
+        s = fmaf(v.w, qc[4 * t4 + 3], s);
+      }
+      const float p = fast_exp2(s - rec[2 * T4].x);
+#pragma unroll
+      for (int t4 = 0; t4 < T4; ++t4) {
+        const float4 v = rec[T4 + t4];
+        acc[4 * t4 + 0] = fmaf(p, v.x, acc[4 * t4 + 0]);
+        acc[4 * t4 + 1] = fmaf(p, v.y, acc[4 * t4 + 1]);
+        acc[4 * t4 + 2] = fmaf(p, v.z, acc[4 * t4 + 2]);
+        acc[4 * t4 + 3] = fmaf(p, v.w, acc[4 * t4 + 3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) red[split][lane][t] = acc[t];
+  __syncthreads();
+  if (split != 0 || !valid) return;
+
+  float tot[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) tot[t] = (red[0][lane][t] + red[1][lane][t]) + (red[2][lane][t] + red[3][lane][t]);
+  float sp[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) sp[t] = 0.f;
+  for (int k = colptr[mcol]; k < colptr[mcol + 1]; ++k) {
+    const float ge = gE[(size_t)g * nnz + cperm[k]];
+    const float4* kr = reinterpret_cast<const float4*>(kWg + (size_t)crow[k] * T);
+#pragma unroll
+    for (int t4 = 0; t4 < T4; ++t4) {
+      const float4 v = kr[t4];
+      sp[4 * t4 + 0] = fmaf(ge, v.x, sp[4 * t4 + 0]);
+      sp[4 * t4 + 1] = fmaf(ge, v.y, sp[4 * t4 + 1]);
+      sp[4 * t4 + 2] = fmaf(ge, v.z, sp[4 * t4 + 2]);
+      sp[4 * t4 + 3] = fmaf(ge, v.w, sp[4 * t4 + 3]);
+    }
+  }
+  float4* dst = reinterpret_cast<float4*>(dq + ((size_t)g * N + mcol) * T);
+#pragma unroll
+  for (int t4 = 0; t4 < T4; ++t4) {
+    float4 v = dst[t4];
+    v.x += sp[4 * t4 + 0] - tot[4 * t4 + 0];
+    v.y += sp[4 * t4 + 1] - tot[4 * t4 + 1];
+    v.z += sp[4 * t4 + 2] - tot[4 * t4 + 2];
+    v.w += sp[4 * t4 + 3] - tot[4 * t4 + 3];
+    dst[t4] = v;
+  }
+}
+
+int launch_bwd_dense_col(const msgat_graph_t& gr, const float* q, const float* kW,
+                         const float* lse, const float* delta, const float* gE, float* dq, int G,
+                         int N, int T, hipStream_t s) {
+  dim3 grid(cdiv(N, kRT), G);
+#define MSGAT_DCOL(TT)                                                                              \
+  hipLaunchKernelGGL(k_bwd_dense_col<TT>, grid, dim3(kBlock), 0, s, q, kW, lse, delta, gE, gr.colptr, \
+                     gr.crow, gr.cperm, dq, N, gr.nnz)
+  switch (T) {
+    case 4: MSGAT_DCOL(4); break;
+    case 8: MSGAT_DCOL(8); break;
+    case 12: MSGAT_DCOL(12); break;
+    case 16: MSGAT_DCOL(16); break;
+    default: return MSGAT_ERR_UNSUPPORTED;
+  }
+#undef MSGAT_DCOL
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
+}
+
+}  // namespace msgat

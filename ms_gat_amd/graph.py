@@ -1,0 +1,142 @@
+"""Sensor-graph adjacency: the sym-normalised dense matrix the reference uses and the
+CSR/CSC form the HIP kernels walk.
+
+Reference: /root/reference/src/data_loader.py:49-66 builds `D^-1/2 (A + I) D^-1/2` from a
+csv edge list; src/models/msgat.py:190 keeps it as a frozen parameter `adj`;
+src/models/attention.py:36 applies it as a dense mask.  Only its non-zeros matter to that
+product, so `SparseGraph` holds them (built by the native host routine
+`msgat_graph_build`, include/msgat_hip.h).
+"""
+from __future__ import annotations
+
+import collections
+import ctypes as C
+import weakref
+from typing import Iterable, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def sym_norm_adjacency(n_nodes: int, edges: Iterable[Tuple[int, int]]) -> torch.Tensor:
+    """`D^-1/2 (A + I) D^-1/2` as a dense fp32 [N,N] tensor (data_loader.py:59-66).
+
+    `edges` are undirected (src, dst) pairs; duplicates and self pairs collapse to a
+    single unit entry, as the assignment `A[s, d] = A[d, s] = 1` does in the reference.
+    """
+    a = torch.eye(n_nodes, dtype=torch.float32)
+    e = torch.as_tensor(np.asarray(list(edges), dtype=np.int64).reshape(-1, 2))
+    if e.numel():
+        a[e[:, 0], e[:, 1]] = 1.0
+        a[e[:, 1], e[:, 0]] = 1.0
+    d = a.sum(dim=1).rsqrt()
+    return d[:, None] * a * d[None, :]
+
+
+def random_edges(n_nodes: int, n_edges: int, seed: int = 0) -> np.ndarray:
+    """`n_edges` distinct undirected non-self edges, uniform over node pairs."""
+    max_edges = n_nodes * (n_nodes - 1) // 2
+    if n_edges > max_edges:
+        raise ValueError(f"{n_edges} edges requested, a simple graph on {n_nodes} nodes has {max_edges}")
+    rng = np.random.default_rng(seed)
+    seen, out = set(), []
+    while len(out) < n_edges:
+        s, d = (int(v) for v in rng.integers(0, n_nodes, size=2))
+        if s == d:
+            continue
+        key = (s, d) if s < d else (d, s)
+        if key in seen:
+            continue
+        seen.add(key)
+        out.append((s, d))
+    return np.asarray(out, dtype=np.int64).reshape(-1, 2)
+
+
+def synthetic_adjacency(n_nodes: int, n_edges: int, seed: int = 0) -> torch.Tensor:
+    """PEMS-like synthetic sensor graph (no PEMS files ship with the reference)."""
+    return sym_norm_adjacency(n_nodes, random_edges(n_nodes, n_edges, seed))
+
+
+class SparseGraph:
+    """CSR + CSC of a dense adjacency, host arrays plus (lazily) device copies."""
+
+    def __init__(self, adjacency: torch.Tensor):
+        if adjacency.dim() != 2 or adjacency.size(0) != adjacency.size(1):
+            raise ValueError(f"adjacency must be [N,N], got {tuple(adjacency.shape)}")
+        a = adjacency.detach().to(device="cpu", dtype=torch.float32).contiguous()
+        n = a.size(0)
+        L = _lib.lib()
+        nnz = C.c_int32(0)
+        _lib.check(L.msgat_graph_count(a.data_ptr(), n, n, C.byref(nnz)), "msgat_graph_count")
+        self.n_nodes, self.nnz = n, int(nnz.value)
+        m = max(self.nnz, 1)
+        self.rowptr = torch.zeros(n + 1, dtype=torch.int32)
+        self.colptr = torch.zeros(n + 1, dtype=torch.int32)
+        self.col = torch.zeros(m, dtype=torch.int32)
+        self.val = torch.zeros(m, dtype=torch.float32)
+        self.erow = torch.zeros(m, dtype=torch.int32)
+        self.crow = torch.zeros(m, dtype=torch.int32)
+        self.cperm = torch.zeros(m, dtype=torch.int32)
+        _lib.check(L.msgat_graph_build(a.data_ptr(), n, n, self.nnz, self.rowptr.data_ptr(), self.col.data_ptr(),
+                                       self.val.data_ptr(), self.erow.data_ptr(), self.colptr.data_ptr(),
+                                       self.crow.data_ptr(), self.cperm.data_ptr()), "msgat_graph_build")
+        self._dev = {}
+
+    _FIELDS = ("rowptr", "col", "val", "erow", "colptr", "crow", "cperm")
+
+    def _struct(self, tensors) -> _lib.Graph:
+        g = _lib.Graph()
+        g.n_nodes, g.nnz = self.n_nodes, self.nnz
+        for name in self._FIELDS:
+            setattr(g, name, tensors[name].data_ptr())
+        return g
+
+    def host_struct(self) -> _lib.Graph:
+        return self._struct({k: getattr(self, k) for k in self._FIELDS})
+
+    def validate(self) -> None:
+        hs = self.host_struct()
+        _lib.check(_lib.lib().msgat_graph_validate(C.byref(hs)), "msgat_graph_validate")
+
+    def on(self, device: torch.device):
+        """(ctypes struct of device pointers, tensors kept alive) for `device`."""
+        key = str(device)
+        if key not in self._dev:
+            tensors = {k: getattr(self, k).to(device) for k in self._FIELDS}
+            self._dev[key] = (self._struct(tensors), tensors)
+        return self._dev[key]
+
+    def dense(self) -> torch.Tensor:
+        a = torch.zeros(self.n_nodes, self.n_nodes)
+        if self.nnz:
+            a[self.erow[: self.nnz].long(), self.col[: self.nnz].long()] = self.val[: self.nnz]
+        return a
+
+
+# The adjacency is a frozen parameter (msgat.py:190): one CSR build per tensor version.
+_CACHE: "collections.OrderedDict[tuple, tuple]" = collections.OrderedDict()
+_CACHE_MAX = 16
+
+
+def graph_of(adjacency: torch.Tensor) -> SparseGraph:
+    """Cached `SparseGraph` of a dense adjacency tensor.
+
+    Keyed on (storage address, shape, device, version).  A hit on the very same tensor
+    object is free; a hit through a different object (a view, or a new tensor the allocator
+    placed at a recycled address) is confirmed by comparing contents before it is trusted.
+    """
+    key = (adjacency.data_ptr(), tuple(adjacency.shape), str(adjacency.device), adjacency._version)
+    hit = _CACHE.get(key)
+    if hit is not None:
+        g, ref, snapshot = hit
+        if ref() is adjacency or torch.equal(snapshot, adjacency.detach()):
+            _CACHE.move_to_end(key)
+            return g
+    g = SparseGraph(adjacency)
+    _CACHE[key] = (g, weakref.ref(adjacency), adjacency.detach().clone())
+    _CACHE.move_to_end(key)
+    while len(_CACHE) > _CACHE_MAX:
+        _CACHE.popitem(last=False)
+    return g

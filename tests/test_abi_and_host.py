@@ -1,0 +1,167 @@
+"""CPU-side checks: the C-ABI library builds, loads and exports every symbol
+include/msgat_hip.h declares; the native host graph builder; the loud refusal of CPU
+tensors.  No device compute is called here.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from oracle import gat_oracle
+
+
+@pytest.fixture(scope="session", autouse=True)
+def built_library():
+    from ms_gat_amd import build
+    return build.build(verbose=False)
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "msgat_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(msgat_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ms_gat_amd import _lib
+    names = _declared_functions()
+    assert len(names) >= 12
+    h = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(h, n), f"{n} declared in include/msgat_hip.h but not exported"
+    assert sorted(_lib.exported_symbols()) == names, "ctypes prototypes and header disagree"
+    assert _lib.lib().msgat_abi_version() == 1
+
+
+def test_struct_layouts_match_the_header():
+    from ms_gat_amd import _lib
+    assert C.sizeof(_lib.Shape) == 6 * 4
+    assert C.sizeof(_lib.Graph) == 8 + 7 * 8
+    assert C.sizeof(_lib.Fwd) == 11 * 8 + 8       # 11 pointers + int32 (padded)
+    assert C.sizeof(_lib.Bwd) == 16 * 8 + 8
+
+
+def test_mode_selection_and_status_strings():
+    from ms_gat_amd import _lib
+    L = _lib.lib()
+    assert L.msgat_gacn_mode(3, 0) == _lib.MODE_PLAIN
+    assert L.msgat_gacn_mode(1, 24) == _lib.MODE_AGG_FIRST
+    assert L.msgat_gacn_mode(24, 24) == _lib.MODE_AGG_FIRST
+    assert L.msgat_gacn_mode(72, 24) == _lib.MODE_PROJ_FIRST
+    assert L.msgat_status_string(0) == b"ok"
+    assert b"workspace" in L.msgat_status_string(-4)
+
+
+def test_bad_arguments_come_back_as_status_codes():
+    """Argument errors must be reported before anything is enqueued (no GPU needed)."""
+    from ms_gat_amd import _lib
+    L = _lib.lib()
+    shape = _lib.Shape(1, 2, 3, 24, 16, 12)
+    assert L.msgat_gacn_forward(C.byref(shape), None, None, None) == -1          # NULL graph
+    bad_t = _lib.Shape(1, 2, 3, 24, 16, 10)
+    g = _lib.Graph()
+    g.n_nodes = 16
+    assert L.msgat_gacn_forward(C.byref(bad_t), C.byref(g), None, None) == -3    # T = 10 unsupported
+    assert L.msgat_gacn_forward(C.byref(_lib.Shape(0, 2, 3, 24, 16, 12)), C.byref(g), None, None) == -2
+    g.n_nodes = 15
+    assert L.msgat_gacn_forward(C.byref(shape), C.byref(g), None, None) == -2    # graph/shape mismatch
+    assert L.msgat_bwd_workspace_bytes(C.byref(bad_t), 10) == 0
+    assert L.msgat_bwd_workspace_bytes(C.byref(shape), 40) > 0
+    with pytest.raises(_lib.MsgatError):
+        _lib.check(-4, "x")
+
+
+def _numpy_csr(adj):
+    rows, cols = np.nonzero(adj)
+    return rows, cols, adj[rows, cols]
+
+
+@pytest.mark.parametrize("n,e,seed", [(1, 0, 0), (7, 5, 1), (64, 70, 2), (307, 340, 3), (883, 866, 4)])
+def test_native_csr_csc_build_matches_numpy(n, e, seed):
+    import ms_gat_amd
+    adj = ms_gat_amd.synthetic_adjacency(n, e, seed)
+    g = ms_gat_amd.SparseGraph(adj)
+    g.validate()
+    rows, cols, vals = _numpy_csr(adj.numpy())
+    assert g.nnz == len(rows) == n + 2 * e
+    assert np.array_equal(g.erow[: g.nnz].numpy(), rows)
+    assert np.array_equal(g.col[: g.nnz].numpy(), cols)
+    assert np.array_equal(g.val[: g.nnz].numpy(), vals)
+    assert np.array_equal(g.rowptr.numpy(), np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n))]))
+    # CSC: entries sorted by column then row, cperm maps back into the CSR order
+    order = np.lexsort((rows, cols))
+    assert np.array_equal(g.cperm[: g.nnz].numpy(), order)
+    assert np.array_equal(g.crow[: g.nnz].numpy(), rows[order])
+    assert np.array_equal(g.colptr.numpy(), np.concatenate([[0], np.cumsum(np.bincount(cols, minlength=n))]))
+    assert torch.equal(g.dense(), adj)
+
+
+def test_csr_build_on_asymmetric_weighted_matrix_with_empty_rows():
+    import ms_gat_amd
+    rng = np.random.default_rng(5)
+    a = (rng.random((23, 23)) < 0.15) * rng.standard_normal((23, 23))
+    a[4, :] = 0
+    a[:, 9] = 0
+    g = ms_gat_amd.SparseGraph(torch.from_numpy(a.astype(np.float32)))
+    g.validate()
+    assert torch.equal(g.dense(), torch.from_numpy(a.astype(np.float32)))
+    assert g.rowptr[4] == g.rowptr[5] and g.colptr[9] == g.colptr[10]
+
+
+def test_graph_validate_rejects_corruption():
+    import ms_gat_amd
+    from ms_gat_amd import _lib
+    g = ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(20, 25, 0))
+    g.col[3] = 99
+    with pytest.raises(_lib.MsgatError):
+        g.validate()
+
+
+def test_sym_norm_adjacency_matches_reference_and_oracle():
+    import ms_gat_amd
+    a = load_golden("adj_n12.npz")
+    ours = ms_gat_amd.sym_norm_adjacency(int(a["n"]), a["edges"]).numpy()
+    assert np.allclose(ours, a["adj"], atol=1e-7)
+    e = ms_gat_amd.random_edges(50, 80, seed=3)
+    assert len({tuple(sorted(p)) for p in e.tolist()}) == 80 and all(s != d for s, d in e.tolist())
+    assert np.allclose(ms_gat_amd.sym_norm_adjacency(50, e).numpy(), gat_oracle.sym_norm_adjacency(50, e), atol=1e-7)
+
+
+def test_graph_cache_hits_same_tensor_and_detects_recycled_storage():
+    import ms_gat_amd
+    from ms_gat_amd import graph
+    a = ms_gat_amd.synthetic_adjacency(30, 30, 0)
+    g1 = graph.graph_of(a)
+    assert graph.graph_of(a) is g1
+    assert graph.graph_of(a.view(30, 30)) is g1          # a view of the same storage: contents equal
+    a.add_(0.0)                                          # version bump -> rebuilt
+    assert graph.graph_of(a) is not g1
+    b = a.clone()
+    g2 = graph.graph_of(b)
+    b.data.copy_(ms_gat_amd.synthetic_adjacency(30, 31, 1))  # same storage & version, new contents
+    assert graph.graph_of(b.data.view(30, 30)) is not g2
+
+
+def test_cpu_tensors_are_refused_not_silently_computed():
+    import ms_gat_amd
+    from ms_gat_amd._lib import MsgatError
+    m = ms_gat_amd.GACN(3, 24, 12)
+    assert sorted(k for k, _ in m.named_parameters()) == ["W", "gatt.Wg", "gatt.alpha"]
+    assert tuple(m.W.shape) == (24, 3) and tuple(m.gatt.Wg.shape) == (12, 12) and tuple(m.gatt.alpha.shape) == (3,)
+    with pytest.raises(MsgatError):
+        m(torch.randn(1, 3, 8, 12), torch.eye(8))
+
+
+def test_product_package_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under ms_gat_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "ms_gat_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "dense_torch" not in text and "gat_oracle" not in text, f

@@ -1,0 +1,362 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden vectors and the oracle.
+
+Bar (BASELINE.json north_star): 1e-4 relative in fp32, measured as max|a-b| / max|b|
+per tensor (`rel_err` in conftest.py).  Every test here needs a real MI355X.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import dense_torch, gat_oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _cuda(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(_dev())
+
+
+def run_ours(x, adj, Wg, alpha, W, dz):
+    """One fwd+bwd through ms_gat_amd.ops.gacn with R stacked relations.
+    x [G,C,N,T]; Wg [R,T,T]; alpha [R,C]; W [R,Co,C] or None; dz like the output."""
+    import ms_gat_amd
+    xt = _cuda(x).requires_grad_(True)
+    Wgt = _cuda(Wg).requires_grad_(True)
+    at = _cuda(alpha).requires_grad_(True)
+    Wt = None if W is None else _cuda(W).requires_grad_(True)
+    z = ms_gat_amd.gacn(xt, at, Wgt, Wt, _cuda(adj))
+    z.backward(_cuda(dz))
+    torch.cuda.synchronize()
+    out = dict(z=z.detach().cpu().numpy(), dx=xt.grad.cpu().numpy(), dWg=Wgt.grad.cpu().numpy(),
+               dalpha=at.grad.cpu().numpy())
+    if Wt is not None:
+        out["dW"] = Wt.grad.cpu().numpy()
+    return out
+
+
+def oracle_f64(x, adj, Wg, alpha, W, dz):
+    """numpy float64 oracle, relation by relation."""
+    R = Wg.shape[0]
+    Bg = x.shape[0] // R
+    f = lambda a: np.asarray(a, dtype=np.float64)  # noqa: E731
+    zs, dxs, dWgs, das, dWs = [], [], [], [], []
+    for r in range(R):
+        sl = slice(r * Bg, (r + 1) * Bg)
+        if W is None:
+            zs.append(gat_oracle.gatt_forward(f(x[sl]), f(adj), f(Wg[r]), f(alpha[r])))
+            dx, dWg, da = gat_oracle.gatt_backward(f(x[sl]), f(adj), f(Wg[r]), f(alpha[r]), f(dz[sl]))
+        else:
+            zs.append(gat_oracle.gacn_forward(f(x[sl]), f(adj), f(Wg[r]), f(alpha[r]), f(W[r])))
+            dx, dWg, da, dW = gat_oracle.gacn_backward(f(x[sl]), f(adj), f(Wg[r]), f(alpha[r]), f(W[r]), f(dz[sl]))
+            dWs.append(dW)
+        dxs.append(dx), dWgs.append(dWg), das.append(da)
+    out = dict(z=np.concatenate(zs), dx=np.concatenate(dxs), dWg=np.stack(dWgs), dalpha=np.stack(das))
+    if W is not None:
+        out["dW"] = np.stack(dWs)
+    return out
+
+
+def assert_close(got, want, tol=TOL, what="", floor=0.0):
+    """`floor` is an absolute scale for tensors whose exact value is 0 (inputs are O(1))."""
+    for k in want:
+        e = rel_err(got[k], want[k])
+        if floor > 0.0:
+            e = min(e, float(np.abs(np.asarray(got[k], dtype=np.float64) - want[k]).max()) / floor)
+        assert e < tol, f"{what} {k}: rel err {e:.3e} >= {tol}"
+
+
+def random_problem(R, Bg, C, Co, N, T, n_edges, seed, x_scale=1.0):
+    import ms_gat_amd
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal((R * Bg, C, N, T)) * x_scale).astype(np.float32)
+    adj = ms_gat_amd.synthetic_adjacency(N, n_edges, seed + 1).numpy()
+    Wg = (rng.standard_normal((R, T, T)) * (1.0 / T) ** 0.5).astype(np.float32)
+    alpha = rng.uniform(-C ** -0.5, C ** -0.5, size=(R, C)).astype(np.float32)
+    W = None if Co == 0 else (rng.standard_normal((R, Co, C)) * (2.0 / (Co + C)) ** 0.5).astype(np.float32)
+    dz = rng.standard_normal((R * Bg, Co if Co else C, N, T)).astype(np.float32)
+    return x, adj, Wg, alpha, W, dz
+
+
+# ---------------------------------------------------------------------------------------
+# golden vectors produced by the reference (tests/golden/make_golden.py)
+# ---------------------------------------------------------------------------------------
+def test_graph_attention_matches_reference_golden(gatt_case):
+    tag, g, _ = gatt_case
+    got = run_ours(g["x"], g["adj"], g["Wg"][None], g["alpha"][None], None, g["dy"])
+    want = dict(z=g["y"], dx=g["dx"], dWg=g["dWg"][None], dalpha=g["dalpha"][None])
+    assert_close(got, want, what=f"GraphAttention[{tag}]")
+
+
+def test_gacn_matches_reference_golden(gatt_case):
+    tag, g, c = gatt_case
+    got = run_ours(g["x"], g["adj"], g["Wg"][None], g["alpha"][None], c["W"][None], c["dz"])
+    want = dict(z=c["z"], dx=c["dx"], dWg=c["dWg"][None], dalpha=c["dalpha"][None], dW=c["dW"][None])
+    assert_close(got, want, what=f"GACN[{tag}]")
+
+
+def test_modules_are_drop_in_for_the_reference_golden():
+    """nn.Module boundary: same ctor args, parameter names and forward signature."""
+    import ms_gat_amd
+    g, c = load_golden("gatt_b2c3n16.npz"), load_golden("gacn_b2c3n16.npz")
+    m = ms_gat_amd.GACN(3, 24, 12).to(_dev())
+    missing = m.load_state_dict({"gatt.Wg": _cuda(g["Wg"]), "gatt.alpha": _cuda(g["alpha"]), "W": _cuda(c["W"])})
+    assert not missing.missing_keys and not missing.unexpected_keys
+    x = _cuda(g["x"]).requires_grad_(True)
+    z = m(x, _cuda(g["adj"]))
+    z.backward(_cuda(c["dz"]))
+    assert rel_err(z.detach().cpu(), c["z"]) < TOL
+    assert rel_err(x.grad.cpu(), c["dx"]) < TOL
+    assert rel_err(m.W.grad.cpu(), c["dW"]) < TOL
+    assert rel_err(m.gatt.Wg.grad.cpu(), c["dWg"]) < TOL
+    assert rel_err(m.gatt.alpha.grad.cpu(), c["dalpha"]) < TOL
+
+    a = ms_gat_amd.GraphAttention(3, 12).to(_dev())
+    a.load_state_dict({"Wg": _cuda(g["Wg"]), "alpha": _cuda(g["alpha"])})
+    with torch.no_grad():
+        y = a(_cuda(g["x"]), _cuda(g["adj"]))
+    assert rel_err(y.cpu(), g["y"]) < TOL
+
+
+# ---------------------------------------------------------------------------------------
+# oracle comparisons on seeded inputs: modes, stacked relations, odd sizes
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("R,Bg,C,Co,N,T,E", [
+    (1, 2, 3, 0, 50, 12, 60),      # PLAIN
+    (3, 2, 1, 24, 70, 12, 80),     # AGG_FIRST, stacked relations, C=1 (PEMSD7 first MEAM)
+    (3, 2, 72, 24, 65, 12, 80),    # PROJ_FIRST, stacked (second MEAM of msgat72)
+    (2, 1, 48, 16, 33, 12, 40),    # msgat48 widths
+    (1, 2, 96, 32, 40, 12, 50),    # msgat96 widths
+    (1, 1, 5, 3, 17, 12, 20),      # odd channel counts, PROJ_FIRST with Co < 4
+    (1, 1, 7, 40, 19, 12, 25),     # AGG_FIRST with Co that needs the generic 8-wide tile
+    (1, 2, 6, 6, 64, 4, 70),       # T = 4, N a multiple of the row tile
+    (1, 1, 9, 4, 130, 8, 140),     # T = 8
+    (2, 1, 4, 8, 257, 16, 300),    # T = 16, N just over a tile boundary
+    (1, 1, 2, 0, 1, 12, 0),        # a single node: only the self loop
+])
+def test_against_numpy_oracle(R, Bg, C, Co, N, T, E):
+    prob = random_problem(R, Bg, C, Co, N, T, E, seed=R * 1000 + C * 10 + N)
+    # a single node has softmax == 1 exactly, so dWg is exactly 0: compare on the O(1) input scale
+    assert_close(run_ours(*prob), oracle_f64(*prob), what=f"R{R} Bg{Bg} C{C} Co{Co} N{N} T{T}",
+                 floor=1.0 if N == 1 else 0.0)
+
+
+def _ref32_cpu(x, adj, Wg, alpha, W, dz):
+    """The reference's own fp32 op sequence (R = 1) on the CPU, as a yardstick."""
+    t = lambda a: torch.from_numpy(a).requires_grad_(True)  # noqa: E731
+    xt, Wgt, at, Wt = t(x), t(Wg[0]), t(alpha[0]), t(W[0])
+    z = dense_torch.gacn_dense(xt, torch.from_numpy(adj), Wgt, at, Wt)
+    z.backward(torch.from_numpy(dz))
+    return dict(z=z.detach().numpy(), dx=xt.grad.numpy(), dWg=Wgt.grad.numpy()[None],
+                dalpha=at.grad.numpy()[None], dW=Wt.grad.numpy()[None])
+
+
+def test_large_scores_need_the_running_max():
+    """Scores up to ~1e2: exp() overflows fp32 without max subtraction, rows are partly
+    saturated.  Yardstick: the reference's own fp32 op sequence -- we may not be worse than
+    3x its distance from the float64 oracle (or the usual 1e-4, whichever is larger)."""
+    prob = random_problem(1, 2, 3, 24, 90, 12, 100, seed=5, x_scale=6.0)
+    got, want, ref32 = run_ours(*prob), oracle_f64(*prob), _ref32_cpu(*prob)
+    assert all(np.isfinite(v).all() for v in got.values())
+    for k in want:
+        bar = max(TOL, 3.0 * rel_err(ref32[k], want[k]))
+        assert rel_err(got[k], want[k]) < bar, (k, rel_err(got[k], want[k]), bar)
+
+
+def test_fully_saturated_softmax_stays_finite_and_accurate():
+    """Scores ~1e3: every softmax row is one-hot in fp32 and the true dWg / dalpha / most of dq
+    are ~1e-12 (differences of O(1e3) terms that cancel).  Outputs and the O(1) gradients
+    (z, dx, dW) must meet the usual bar; the cancelling ones are held to 1e-5 of the
+    magnitude of the terms that cancel (the float64 oracle supplies that magnitude)."""
+    prob = random_problem(1, 2, 3, 24, 90, 12, 100, seed=5, x_scale=25.0)
+    x, adj, Wg, alpha, W, dz = prob
+    got, want = run_ours(*prob), oracle_f64(*prob)
+    assert all(np.isfinite(v).all() for v in got.values())
+    for k in ("z", "dx", "dW"):
+        assert rel_err(got[k], want[k]) < TOL, (k, rel_err(got[k], want[k]))
+    f = lambda a: np.asarray(a, dtype=np.float64)  # noqa: E731
+    _, c = gat_oracle.gatt_forward(f(x), f(adj), f(Wg[0]), f(alpha[0]), return_cache=True)
+    dy = np.einsum("oc,bont->bcnt", f(W[0]), f(dz))
+    g = np.abs(c["P"] * f(adj) * np.einsum("bcnt,bcmt->bnm", dy, f(x)))
+    dS_mag = g + g.sum(-1, keepdims=True) * c["P"]            # |g| + |delta| P: the two sides that cancel
+    dkW_mag = dS_mag @ np.abs(c["q"])
+    dq_mag = dS_mag.transpose(0, 2, 1) @ np.abs(c["kW"]) + dkW_mag @ np.abs(f(Wg[0])).T
+    scale = dict(dWg=np.einsum("bnt,bns->ts", np.abs(c["q"]), dkW_mag).max(),
+                 dalpha=np.einsum("bnt,bcnt->c", dq_mag, np.abs(f(x))).max())
+    for k in ("dWg", "dalpha"):
+        err = np.abs(f(got[k]) - want[k]).max()
+        assert err < 1e-5 * scale[k], (k, err, scale[k])
+
+
+def test_arbitrary_adjacency_with_empty_rows_and_asymmetry():
+    """The boundary takes any [N,N] tensor, not just sym-normalised graphs."""
+    rng = np.random.default_rng(11)
+    N = 45
+    adj = (rng.random((N, N)) < 0.08).astype(np.float32) * rng.standard_normal((N, N)).astype(np.float32)
+    adj[3, :] = 0.0   # node with no in-row edges
+    adj[:, 7] = 0.0   # node nobody aggregates from
+    x, _, Wg, alpha, W, dz = random_problem(1, 2, 4, 24, N, 12, 10, seed=12)
+    assert_close(run_ours(x, adj, Wg, alpha, W, dz), oracle_f64(x, adj, Wg, alpha, W, dz), what="arbitrary adj")
+    x, _, Wg, alpha, W, dz = random_problem(1, 2, 30, 8, N, 12, 10, seed=13)
+    assert_close(run_ours(x, adj, Wg, alpha, W, dz), oracle_f64(x, adj, Wg, alpha, W, dz), what="arbitrary adj P")
+
+
+def test_all_zero_adjacency_gives_zero_output_and_zero_grads():
+    import ms_gat_amd
+    x, _, Wg, alpha, W, dz = random_problem(1, 1, 3, 24, 20, 12, 5, seed=14)
+    adj = np.zeros((20, 20), dtype=np.float32)
+    got = run_ours(x, adj, Wg, alpha, W, dz)
+    for k, v in got.items():
+        assert np.all(v == 0), k
+    assert ms_gat_amd.SparseGraph(torch.from_numpy(adj)).nnz == 0
+
+
+def test_dense_adjacency_rows_sum_to_one():
+    """With adj == 1 everywhere the masked softmax is the full softmax: aggregating a
+    feature that is constant over nodes returns it unchanged (row sums are exactly 1)."""
+    import ms_gat_amd
+    N, C, T = 40, 3, 12
+    rng = np.random.default_rng(3)
+    base = rng.standard_normal((1, C, 1, T)).astype(np.float32)
+    x = np.ascontiguousarray(np.repeat(base, N, axis=2))
+    adj = np.ones((N, N), dtype=np.float32)
+    Wg = rng.standard_normal((1, T, T)).astype(np.float32)
+    alpha = rng.standard_normal((1, C)).astype(np.float32)
+    with torch.no_grad():
+        y = ms_gat_amd.graph_attention(_cuda(x), _cuda(alpha), _cuda(Wg), _cuda(adj)).cpu().numpy()
+    assert rel_err(y, x) < 1e-5
+
+
+def test_stage_outputs_lse_and_edge_coefficients():
+    """Checks the saved intermediates the C ABI documents: q, kW, lse (log2 units), pq, E."""
+    import ctypes as C
+    import ms_gat_amd
+    from ms_gat_amd import _lib
+    prob = random_problem(2, 2, 3, 0, 77, 12, 90, seed=21)
+    x, adj, Wg, alpha = prob[:4]
+    G, Cc, N, T = x.shape
+    g = ms_gat_amd.SparseGraph(torch.from_numpy(adj))
+    gs, _keep = g.on(_dev())
+    shape = _lib.Shape(2, 2, Cc, 0, N, T)
+    xt, at, Wgt = _cuda(x), _cuda(alpha), _cuda(Wg)
+    q = torch.empty(G, N, T, device=_dev())
+    kW, pq = torch.empty_like(q), torch.empty_like(q)
+    lse = torch.empty(G, N, device=_dev())
+    E = torch.empty(G, g.nnz, device=_dev())
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.check(L.msgat_stage_project(C.byref(shape), xt.data_ptr(), at.data_ptr(), None, q.data_ptr(), None, s), "project")
+    _lib.check(L.msgat_stage_scores(C.byref(shape), C.byref(gs), q.data_ptr(), Wgt.data_ptr(), kW.data_ptr(),
+                                    lse.data_ptr(), pq.data_ptr(), E.data_ptr(), s), "scores")
+    torch.cuda.synchronize()
+    rows, cols = g.erow[: g.nnz].long().numpy(), g.col[: g.nnz].long().numpy()
+    for r in range(2):
+        sl = slice(2 * r, 2 * r + 2)
+        x64 = x[sl].astype(np.float64)
+        _, cache = gat_oracle.gatt_forward(x64, adj.astype(np.float64), Wg[r].astype(np.float64),
+                                           alpha[r].astype(np.float64), return_cache=True)
+        assert rel_err(q[sl].cpu(), cache["q"]) < 1e-5
+        assert rel_err(kW[sl].cpu(), cache["kW"]) < 1e-5
+        want_lse = gat_oracle.gatt_lse(x64, Wg[r].astype(np.float64), alpha[r].astype(np.float64))
+        assert np.abs(lse[sl].cpu().numpy() * np.log(2.0) - want_lse).max() < 1e-4  # stored in log2 units
+        assert rel_err(pq[sl].cpu(), cache["P"] @ cache["q"]) < TOL
+        assert rel_err(E[sl].cpu(), cache["E"][:, rows, cols]) < TOL
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE.json sizes: dense oracle on the same GPU + size-independent properties
+# ---------------------------------------------------------------------------------------
+def _dense_oracle_gpu(x, adj, Wg, alpha, W, dz):
+    """oracle/dense_torch.py (the reference's op sequence) run with autograd on the GPU."""
+    R = Wg.shape[0]
+    Bg = x.shape[0] // R
+    outs = dict(z=[], dx=[], dWg=[], dalpha=[], dW=[])
+    adj_t = _cuda(adj)
+    for r in range(R):
+        xt = _cuda(x[r * Bg:(r + 1) * Bg]).requires_grad_(True)
+        Wgt, at, Wt = (_cuda(v[r]).requires_grad_(True) for v in (Wg, alpha, W))
+        z = dense_torch.gacn_dense(xt, adj_t, Wgt, at, Wt)
+        z.backward(_cuda(dz[r * Bg:(r + 1) * Bg]))
+        for k, v in (("z", z.detach()), ("dx", xt.grad), ("dWg", Wgt.grad), ("dalpha", at.grad), ("dW", Wt.grad)):
+            outs[k].append(v.cpu().numpy())
+    return dict(z=np.concatenate(outs["z"]), dx=np.concatenate(outs["dx"]), dWg=np.stack(outs["dWg"]),
+                dalpha=np.stack(outs["dalpha"]), dW=np.stack(outs["dW"]))
+
+
+@pytest.mark.parametrize("C,Bg", [(1, 32), (72, 32)])
+def test_pemsd7_full_size_against_dense_eager(C, Bg):
+    """configs[2]: PEMSD7-like N=883, B=32, R=3, C in {1, 72} -> Co=24."""
+    prob = random_problem(3, Bg, C, 24, 883, 12, 866, seed=70 + C)
+    got = run_ours(*prob)
+    want = _dense_oracle_gpu(*prob)
+    assert_close(got, want, what=f"PEMSD7 C={C}")
+
+
+def test_pemsd4_b64_full_size_against_dense_eager():
+    """configs[1]: PEMSD4-like N=307, B=64, single relation."""
+    for C in (3, 72):
+        prob = random_problem(1, 64, C, 24, 307, 12, 340, seed=40 + C)
+        assert_close(run_ours(*prob), _dense_oracle_gpu(*prob), what=f"PEMSD4 C={C}")
+
+
+def test_full_size_linearity_in_W_and_in_cotangent():
+    """Size-independent properties at N=883, B=32, C=72: z is linear in W; every gradient
+    is linear in dz."""
+    import ms_gat_amd
+    x, adj, Wg, alpha, W, dz = random_problem(1, 32, 72, 24, 883, 12, 866, seed=99)
+    rng = np.random.default_rng(100)
+    W2 = rng.standard_normal(W.shape).astype(np.float32) * 0.1
+    g = ms_gat_amd.SparseGraph(torch.from_numpy(adj))
+    xt, at, Wgt = _cuda(x), _cuda(alpha), _cuda(Wg)
+    with torch.no_grad():
+        z1 = ms_gat_amd.gacn(xt, at, Wgt, _cuda(W), g)
+        z2 = ms_gat_amd.gacn(xt, at, Wgt, _cuda(W2), g)
+        z12 = ms_gat_amd.gacn(xt, at, Wgt, _cuda(W + W2), g)
+    assert rel_err((z1 + z2).cpu(), z12.cpu()) < 1e-5
+    a = run_ours(x, adj, Wg, alpha, W, dz)
+    b = run_ours(x, adj, Wg, alpha, W, 2.0 * dz)
+    for k in ("dx", "dWg", "dalpha", "dW"):
+        assert rel_err(2.0 * a[k], b[k]) < 1e-5, k
+
+
+def test_stress_graph_uses_the_large_n_path():
+    """N large enough that an [N,T] slab does not fit LDS: gather-from-L2 kernels."""
+    prob = random_problem(1, 1, 3, 24, 4000, 12, 8000, seed=61)
+    got = run_ours(*prob)
+    want = _dense_oracle_gpu(*prob)
+    assert_close(got, want, what="N=4000 AGG_FIRST")
+    prob = random_problem(1, 1, 40, 8, 3500, 12, 7000, seed=62)
+    assert_close(run_ours(*prob), _dense_oracle_gpu(*prob), what="N=3500 PROJ_FIRST")
+
+
+def test_mid_size_graph_uses_a_large_lds_slab():
+    """64 KB < N*T*4 <= 159 KB: one slab per block with the raised dynamic-LDS limit."""
+    prob = random_problem(1, 2, 12, 4, 2000, 12, 4000, seed=63)
+    assert_close(run_ours(*prob), _dense_oracle_gpu(*prob), what="N=2000 PROJ_FIRST")
+    prob = random_problem(1, 2, 3, 0, 2000, 12, 4000, seed=64)
+    x, adj, Wg, alpha, _, dz = prob
+    want = oracle_f64(x, adj, Wg, alpha, None, dz)
+    assert_close(run_ours(*prob), want, what="N=2000 PLAIN")
+
+
+def test_results_are_bitwise_reproducible():
+    """No float atomics anywhere: two runs give identical bits."""
+    prob = random_problem(2, 4, 72, 24, 307, 12, 340, seed=77)
+    a, b = run_ours(*prob), run_ours(*prob)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_cpu_tensors_are_refused_not_silently_computed():
+    import ms_gat_amd
+    from ms_gat_amd._lib import MsgatError
+    m = ms_gat_amd.GraphAttention(3, 12)
+    with pytest.raises(MsgatError):
+        m(torch.randn(1, 3, 8, 12), torch.eye(8))
