@@ -74,8 +74,9 @@ class HotPath:
             x = layer_norm_t(torch.randn(R, B, cin, N, T, generator=gx))  # msgat.py:122: GACN sees LayerNorm output
             self.xs.append(x.to(device).requires_grad_(True))
             self.dzs.append(torch.randn(R, B, wl["Co"], N, T, generator=gx).to(device))
+        from ms_gat_amd import parallel
         self.params = [p for m in self.layers for p in m.parameters()]
-        self.flat = torch.zeros(sum(p.numel() for p in self.params), device=device)
+        self.sync = parallel.FlatGradAllReduce(self.params)
 
     def step(self, world):
         for m, x, dz in zip(self.layers, self.xs, self.dzs):
@@ -85,9 +86,7 @@ class HotPath:
             z = m(x, self.graph)
             z.backward(dz)
         if world > 1:  # one flat bucket: the payload is KBs, the collective is latency-bound
-            torch.cat([p.grad.reshape(-1) for p in self.params], out=self.flat)
-            dist.all_reduce(self.flat)
-            self.flat.div_(world)
+            self.sync(weight=float(self.wl["B"]))
 
     def forward_only(self):
         with torch.no_grad():

@@ -172,6 +172,21 @@ int msgat_stage_aggregate_project(const msgat_shape_t* shape, const msgat_graph_
                                   const float* x, const float* E, const float* W, float* y,
                                   float* z, void* stream);
 
+/* Backward building blocks (also what msgat_gacn_backward enqueues).
+ * msgat_stage_mix:      out[g,co,p] = sum_ci M[r,..] in[g,ci,p] (+ addvec[r,co] extra[g,p]);
+ *                       M is [R,Co,Ci] (m_in_major = 0) or [R,Ci,Co] (m_in_major = 1, i.e. W^T applied).
+ *                       P = N*T positions.  dy = W^T dz and dx = W^T du + alpha (x) dq use it.
+ * msgat_stage_contract: dst[r,a,c] = sum_{g in r, p} A[g,a,p] B[g,c,p]; if Aextra != NULL it supplies
+ *                       row a = Ca-1 (shape [G,P]) and A holds the other Ca-1 rows.  The first n0
+ *                       outputs of a relation go to dst0, the next n1 to dst1 (dW and dalpha).
+ *                       `partials` needs msgat_contract_partial_floats() floats. */
+int msgat_stage_mix(const msgat_shape_t* shape, int32_t Ci, int32_t Co, const float* in, const float* M,
+                    int32_t m_in_major, const float* addvec, const float* extra, float* out, void* stream);
+size_t msgat_contract_partial_floats(const msgat_shape_t* shape, int32_t Ca, int32_t Cb);
+int msgat_stage_contract(const msgat_shape_t* shape, int32_t Ca, int32_t Cb, const float* A,
+                         const float* Aextra, const float* B, float* partials, float* dst0, int32_t n0,
+                         float* dst1, int32_t n1, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,11 @@ _PROTOTYPES = {
     "msgat_stage_scores": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)] + [C.c_void_p] * 7),
     "msgat_stage_aggregate": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph), C.c_int32] + [C.c_void_p] * 4),
     "msgat_stage_aggregate_project": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)] + [C.c_void_p] * 6),
+    "msgat_stage_mix": (C.c_int, [C.POINTER(Shape), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "msgat_contract_partial_floats": (C.c_size_t, [C.POINTER(Shape), C.c_int32, C.c_int32]),
+    "msgat_stage_contract": (C.c_int, [C.POINTER(Shape), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
 }
 
 _lock = threading.Lock()

@@ -16,10 +16,35 @@
 namespace msgat {
 
 // ---- LDS-slab aggregate ---------------------------------------------------------------------
+// 1024 lanes per block: the gather phase is a chain of dependent loads (row extent -> edge
+// index/weight -> LDS row), so it is latency-, not bandwidth-limited; 16 waves per block and two
+// blocks per CU keep the CU's 32 wave slots full while one block streams its slab in or out.
+constexpr int kAggBlock = 1024;
+
+// up to 4 edges per trip: the index/weight loads of a trip are independent and issue together
+template <int T4, typename RowPtr>
+__device__ __forceinline__ float4 gather_row(const int* __restrict__ idx, const float* __restrict__ Eg,
+                                             int e0, int e1, RowPtr rows, int j) {
+  float4 acc = f4zero();
+  for (int e = e0; e < e1; e += 4) {
+    int m[4];
+    float w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ee = min(e + k, e1 - 1);
+      m[k] = idx[ee];
+      w[k] = (e + k < e1) ? Eg[ee] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) f4fma(w[k], rows[(size_t)m[k] * T4 + j], acc);
+  }
+  return acc;
+}
+
 template <int T4>
-__global__ __launch_bounds__(kBlock) void k_agg_lds(
-    const int* __restrict__ ptr, const int* __restrict__ idx, const int* __restrict__ perm,
-    const float4* __restrict__ u4, const float* __restrict__ E, const float* __restrict__ addvec,
+__global__ __launch_bounds__(kAggBlock) void k_agg_lds(
+    const int* __restrict__ ptr, const int* __restrict__ idx, const float4* __restrict__ u4,
+    const float* __restrict__ E, const float* __restrict__ addvec,
     const float4* __restrict__ extra4, float4* __restrict__ v4, int Bg, int Cu, int N, int nnz,
     int CH) {
   extern __shared__ float4 slab[];  // [ch][N][T4]
@@ -31,23 +56,19 @@ __global__ __launch_bounds__(kBlock) void k_agg_lds(
   const size_t base = ((size_t)g * Cu + c0) * NT4;
   const int total = ch * NT4;
 
-  for (int i = threadIdx.x; i < total; i += kBlock) slab[i] = u4[base + i];
+  for (int i = threadIdx.x; i < total; i += kAggBlock) slab[i] = u4[base + i];
   __syncthreads();
 
   const float* Eg = E + (size_t)g * nnz;
-  for (int c = 0; c < ch; ++c) {
-    const float4* sl = slab + c * NT4;
-    const float av = (addvec != nullptr) ? addvec[r * Cu + c0 + c] : 0.f;
-    for (int s = threadIdx.x; s < NT4; s += kBlock) {
-      const int n = s / T4;
-      const int j = s - n * T4;
-      float4 acc = f4zero();
-      const int e1 = ptr[n + 1];
-      for (int e = ptr[n]; e < e1; ++e) {
-        const float w = Eg[perm != nullptr ? perm[e] : e];
-        f4fma(w, sl[idx[e] * T4 + j], acc);
-      }
-      if (addvec != nullptr) f4fma(av, extra4[(size_t)g * NT4 + s], acc);
+  for (int s = threadIdx.x; s < NT4; s += kAggBlock) {
+    const int n = s / T4;
+    const int j = s - n * T4;
+    const int e0 = ptr[n], e1 = ptr[n + 1];
+    float4 ex = f4zero();
+    if (addvec != nullptr) ex = extra4[(size_t)g * NT4 + s];
+    for (int c = 0; c < ch; ++c) {
+      float4 acc = gather_row<T4>(idx, Eg, e0, e1, slab + c * NT4, j);
+      if (addvec != nullptr) f4fma(addvec[r * Cu + c0 + c], ex, acc);
       v4[base + (size_t)c * NT4 + s] = acc;
     }
   }
@@ -56,8 +77,8 @@ __global__ __launch_bounds__(kBlock) void k_agg_lds(
 // ---- gather-from-L2 aggregate (slab too large for LDS) ------------------------------------------
 template <int T4>
 __global__ __launch_bounds__(kBlock) void k_agg_glb(
-    const int* __restrict__ ptr, const int* __restrict__ idx, const int* __restrict__ perm,
-    const float4* __restrict__ u4, const float* __restrict__ E, const float* __restrict__ addvec,
+    const int* __restrict__ ptr, const int* __restrict__ idx, const float4* __restrict__ u4,
+    const float* __restrict__ E, const float* __restrict__ addvec,
     const float4* __restrict__ extra4, float4* __restrict__ v4, int Bg, int Cu, int N, int nnz) {
   const int g = blockIdx.z;
   const int r = g / Bg;
@@ -68,22 +89,15 @@ __global__ __launch_bounds__(kBlock) void k_agg_glb(
   const int n = s / T4;
   const int j = s - n * T4;
   const float4* sl = u4 + ((size_t)g * Cu + c) * NT4;
-  const float* Eg = E + (size_t)g * nnz;
-  float4 acc = f4zero();
-  const int e1 = ptr[n + 1];
-  for (int e = ptr[n]; e < e1; ++e) {
-    const float w = Eg[perm != nullptr ? perm[e] : e];
-    f4fma(w, sl[(size_t)idx[e] * T4 + j], acc);
-  }
+  float4 acc = gather_row<T4>(idx, E + (size_t)g * nnz, ptr[n], ptr[n + 1], sl, j);
   if (addvec != nullptr) f4fma(addvec[r * Cu + c], extra4[(size_t)g * NT4 + s], acc);
   v4[((size_t)g * Cu + c) * NT4 + s] = acc;
 }
 
 template <int T4>
-static int launch_aggregate_t(const int* ptr, const int* idx, const int* perm, int nnz,
-                              const float* u, const float* E, const float* addvec,
-                              const float* extra, float* v, int G, int Bg, int Cu, int N,
-                              hipStream_t s) {
+static int launch_aggregate_t(const int* ptr, const int* idx, int nnz, const float* u, const float* E,
+                              const float* addvec, const float* extra, float* v, int G, int Bg, int Cu,
+                              int N, hipStream_t s) {
   const int T = 4 * T4;
   const int CH = slab_channels(N, T, Cu, kLdsBudget);
   if (CH >= 1) {
@@ -94,27 +108,44 @@ static int launch_aggregate_t(const int* ptr, const int* idx, const int* perm, i
       if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
     }
     dim3 grid(cdiv(Cu, CH), G);
-    hipLaunchKernelGGL(k_agg_lds<T4>, grid, dim3(kBlock), lds, s, ptr, idx, perm, (const float4*)u, E,
-                       addvec, (const float4*)extra, (float4*)v, Bg, Cu, N, nnz, CH);
+    hipLaunchKernelGGL(k_agg_lds<T4>, grid, dim3(kAggBlock), lds, s, ptr, idx, (const float4*)u, E, addvec,
+                       (const float4*)extra, (float4*)v, Bg, Cu, N, nnz, CH);
   } else {
     dim3 grid(cdiv(N * T4, kBlock), Cu, G);
-    hipLaunchKernelGGL(k_agg_glb<T4>, grid, dim3(kBlock), 0, s, ptr, idx, perm, (const float4*)u, E,
-                       addvec, (const float4*)extra, (float4*)v, Bg, Cu, N, nnz);
+    hipLaunchKernelGGL(k_agg_glb<T4>, grid, dim3(kBlock), 0, s, ptr, idx, (const float4*)u, E, addvec,
+                       (const float4*)extra, (float4*)v, Bg, Cu, N, nnz);
   }
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
 
-int launch_aggregate(const int* ptr, const int* idx, const int* perm, int nnz, const float* u,
-                     const float* E, const float* addvec, const float* extra, float* v, int G,
-                     int Bg, int Cu, int N, int T, hipStream_t s) {
+int launch_aggregate(const int* ptr, const int* idx, int nnz, const float* u, const float* E,
+                     const float* addvec, const float* extra, float* v, int G, int Bg, int Cu, int N,
+                     int T, hipStream_t s) {
   switch (T) {
-    case 4: return launch_aggregate_t<1>(ptr, idx, perm, nnz, u, E, addvec, extra, v, G, Bg, Cu, N, s);
-    case 8: return launch_aggregate_t<2>(ptr, idx, perm, nnz, u, E, addvec, extra, v, G, Bg, Cu, N, s);
-    case 12: return launch_aggregate_t<3>(ptr, idx, perm, nnz, u, E, addvec, extra, v, G, Bg, Cu, N, s);
-    case 16: return launch_aggregate_t<4>(ptr, idx, perm, nnz, u, E, addvec, extra, v, G, Bg, Cu, N, s);
+    case 4: return launch_aggregate_t<1>(ptr, idx, nnz, u, E, addvec, extra, v, G, Bg, Cu, N, s);
+    case 8: return launch_aggregate_t<2>(ptr, idx, nnz, u, E, addvec, extra, v, G, Bg, Cu, N, s);
+    case 12: return launch_aggregate_t<3>(ptr, idx, nnz, u, E, addvec, extra, v, G, Bg, Cu, N, s);
+    case 16: return launch_aggregate_t<4>(ptr, idx, nnz, u, E, addvec, extra, v, G, Bg, Cu, N, s);
   }
   return MSGAT_ERR_UNSUPPORTED;
+}
+
+// E in CSC order for the transposed aggregate of the backward pass: Ec[g,k] = E[g, cperm[k]]
+__global__ __launch_bounds__(kBlock) void k_permute_edges(const float* __restrict__ E,
+                                                          const int* __restrict__ cperm,
+                                                          float* __restrict__ Ec, int nnz) {
+  const int g = blockIdx.y;
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k < nnz) Ec[(size_t)g * nnz + k] = E[(size_t)g * nnz + cperm[k]];
+}
+
+int launch_permute_edges(const float* E, const int* cperm, float* Ec, int G, int nnz, hipStream_t s) {
+  if (nnz == 0) return MSGAT_OK;
+  dim3 grid(cdiv(nnz, kBlock), G);
+  hipLaunchKernelGGL(k_permute_edges, grid, dim3(kBlock), 0, s, E, cperm, Ec, nnz);
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
 }
 
 // ---- aggregate, then project (C <= Co: the reference's own order, msgat.py:26-28) -------------------
@@ -148,8 +179,7 @@ __global__ __launch_bounds__(kBlock) void k_agg_proj(
   for (int oo = 0; oo < OT; ++oo) acc[oo] = f4zero();
   for (int c = 0; c < C; ++c) {
     const float4* sl = x4 + ((size_t)g * C + c) * NT4;
-    float4 y = f4zero();
-    for (int e = e0; e < e1; ++e) f4fma(Eg[e], sl[(size_t)col[e] * T4 + j], y);
+    float4 y = gather_row<T4>(col, Eg, e0, e1, sl, j);
     if (y4 != nullptr && blockIdx.z == 0) y4[((size_t)g * C + c) * NT4 + s] = y;
     const float4* wrow = reinterpret_cast<const float4*>(Wl + c * OT);
 #pragma unroll

@@ -30,7 +30,7 @@ inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 // backward workspace layout, shared by the size query and the run
 struct BwdPlan {
   int mode, G, Cu, nch;
-  size_t off_dEp, off_gE, off_delta, off_dkW, off_dq, off_dv, off_dwg, off_cp, total;
+  size_t off_dEp, off_gE, off_Ec, off_delta, off_dkW, off_dq, off_dv, off_dwg, off_cp, total;
 };
 
 BwdPlan plan_bwd(const msgat_shape_t& sh, int nnz) {
@@ -48,6 +48,7 @@ BwdPlan plan_bwd(const msgat_shape_t& sh, int nnz) {
   };
   p.off_dEp = take(G * p.nch * (size_t)nnz);
   p.off_gE = take(G * (size_t)nnz);
+  p.off_Ec = take(G * (size_t)nnz);
   p.off_delta = take(G * N);
   p.off_dkW = take(G * P);
   p.off_dq = take(G * P);
@@ -124,7 +125,7 @@ extern "C" int msgat_stage_aggregate(const msgat_shape_t* sh, const msgat_graph_
   if (st) return st;
   if (!u || !v || (gr->nnz > 0 && !E)) return MSGAT_ERR_NULL;
   if (Cu <= 0 || Cu > kMaxC) return MSGAT_ERR_SHAPE;
-  return launch_aggregate(gr->rowptr, gr->col, nullptr, gr->nnz, u, E, nullptr, nullptr, v, sh->R * sh->Bg,
+  return launch_aggregate(gr->rowptr, gr->col, gr->nnz, u, E, nullptr, nullptr, v, sh->R * sh->Bg,
                           sh->Bg, Cu, sh->N, sh->T, (hipStream_t)stream);
 }
 
@@ -139,6 +140,33 @@ extern "C" int msgat_stage_aggregate_project(const msgat_shape_t* sh, const msga
   if (sh->Co <= 0) return MSGAT_ERR_SHAPE;
   return launch_aggregate_project(*gr, x, E, W, y, z, sh->R * sh->Bg, sh->Bg, sh->C, sh->Co, sh->N, sh->T,
                                   (hipStream_t)stream);
+}
+
+extern "C" int msgat_stage_mix(const msgat_shape_t* sh, int32_t Ci, int32_t Co, const float* in,
+                               const float* M, int32_t m_in_major, const float* addvec, const float* extra,
+                               float* out, void* stream) {
+  int st = check_shape(sh);
+  if (st) return st;
+  if (!in || !M || !out || (addvec && !extra)) return MSGAT_ERR_NULL;
+  if (Ci <= 0 || Co <= 0 || Ci > kMaxC || Co > kMaxC) return MSGAT_ERR_SHAPE;
+  return launch_project(in, M, m_in_major, nullptr, addvec, extra, out, nullptr, sh->R * sh->Bg, sh->Bg, Ci, Co,
+                        sh->N * sh->T, (hipStream_t)stream);
+}
+
+extern "C" size_t msgat_contract_partial_floats(const msgat_shape_t* sh, int32_t Ca, int32_t Cb) {
+  if (check_shape(sh) != MSGAT_OK || Ca <= 0 || Cb <= 0) return 0;
+  return chanpair_partial_floats(sh->R * sh->Bg, Ca, Cb, sh->N * sh->T);
+}
+
+extern "C" int msgat_stage_contract(const msgat_shape_t* sh, int32_t Ca, int32_t Cb, const float* A,
+                                    const float* Aextra, const float* B, float* partials, float* dst0,
+                                    int32_t n0, float* dst1, int32_t n1, void* stream) {
+  int st = check_shape(sh);
+  if (st) return st;
+  if (!B || !partials || (!A && !(Aextra && Ca == 1))) return MSGAT_ERR_NULL;
+  if (Ca <= 0 || Cb <= 0 || Ca > kMaxC + 1 || Cb > kMaxC || n0 < 0 || n1 < 0 || n0 + n1 > Ca * Cb) return MSGAT_ERR_SHAPE;
+  return launch_chanpair(A, Aextra, B, partials, dst0, n0, dst1, n1, sh->R * sh->Bg, sh->Bg, Ca, Cb,
+                         sh->N * sh->T, (hipStream_t)stream);
 }
 
 // ---- fused forward ---------------------------------------------------------------------------------
@@ -172,13 +200,13 @@ extern "C" int msgat_gacn_forward(const msgat_shape_t* sh, const msgat_graph_t* 
 
   switch (mode) {
     case MSGAT_MODE_PLAIN:
-      return launch_aggregate(gr->rowptr, gr->col, nullptr, gr->nnz, io->x, io->E, nullptr, nullptr, io->z, G,
+      return launch_aggregate(gr->rowptr, gr->col, gr->nnz, io->x, io->E, nullptr, nullptr, io->z, G,
                               sh->Bg, sh->C, sh->N, sh->T, s);
     case MSGAT_MODE_AGG_FIRST:
       return launch_aggregate_project(*gr, io->x, io->E, io->W, io->need_bwd ? io->u : nullptr, io->z, G,
                                       sh->Bg, sh->C, sh->Co, sh->N, sh->T, s);
     default:
-      return launch_aggregate(gr->rowptr, gr->col, nullptr, gr->nnz, io->u, io->E, nullptr, nullptr, io->z, G,
+      return launch_aggregate(gr->rowptr, gr->col, gr->nnz, io->u, io->E, nullptr, nullptr, io->z, G,
                               sh->Bg, sh->Co, sh->N, sh->T, s);
   }
 }
@@ -209,6 +237,7 @@ extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t*
   char* ws = (char*)io->workspace;
   float* dEp = (float*)(ws + p.off_dEp);
   float* gE = (float*)(ws + p.off_gE);
+  float* Ec = (float*)(ws + p.off_Ec);
   float* delta = (float*)(ws + p.off_delta);
   float* dkW = (float*)(ws + p.off_dkW);
   float* dq = (float*)(ws + p.off_dq);
@@ -238,18 +267,18 @@ extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t*
   st = launch_dwg(io->q, dkW, dwgp, io->dWg, G, Bg, N, T, s);
   if (st) return st;
 
+  st = launch_permute_edges(io->E, gr->cperm, Ec, G, gr->nnz, s);
+  if (st) return st;
   if (p.mode == MSGAT_MODE_PROJ_FIRST) {
     // du = E^T dz;  dx = W^T du + alpha (x) dq;  dW = du x^T;  dalpha = dq . x
-    st = launch_aggregate(gr->colptr, gr->crow, gr->cperm, gr->nnz, dv, io->E, nullptr, nullptr, dvb, G, Bg,
-                          Co, N, T, s);
+    st = launch_aggregate(gr->colptr, gr->crow, gr->nnz, dv, Ec, nullptr, nullptr, dvb, G, Bg, Co, N, T, s);
     if (st) return st;
     st = launch_project(dvb, io->W, 1, nullptr, io->alpha, dq, io->dx, nullptr, G, Bg, Co, C, P, s);
     if (st) return st;
     return launch_chanpair(dvb, dq, io->x, cpp, io->dW, Co * C, io->dalpha, C, G, Bg, Co + 1, C, P, s);
   }
   // PLAIN / AGG_FIRST:  dx = E^T dv + alpha (x) dq;  dalpha = dq . x
-  st = launch_aggregate(gr->colptr, gr->crow, gr->cperm, gr->nnz, dv, io->E, io->alpha, dq, io->dx, G, Bg, C,
-                        N, T, s);
+  st = launch_aggregate(gr->colptr, gr->crow, gr->nnz, dv, Ec, io->alpha, dq, io->dx, G, Bg, C, N, T, s);
   if (st) return st;
   return launch_chanpair(nullptr, dq, io->x, cpp, nullptr, 0, io->dalpha, C, G, Bg, 1, C, P, s);
 }

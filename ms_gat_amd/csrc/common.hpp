@@ -22,7 +22,7 @@ constexpr int kMaxC = 256;         // channels supported per side
 constexpr int kLdsBudget = 64 * 1024;  // per-block LDS the slab kernels aim for (>= 2 blocks/CU)
 constexpr int kLdsMax = 160 * 1024;
 
-static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -62,12 +62,22 @@ int launch_qonly(const float* x, const float* alpha, float* q, int G, int Bg, in
 int launch_project(const float* in, const float* M, int m_in_major, const float* qvec,
                    const float* addvec, const float* extra, float* out, float* q, int G, int Bg,
                    int Ci, int Co, int P, hipStream_t s);
+// MFMA forms (mfma.hip); launch_project / launch_chanpair dispatch to them
+size_t project_mfma_lds_bytes(int Ci, int Co, bool has_extra);
+int launch_project_mfma(const float* in, const float* M, int m_in_major, const float* qvec,
+                        const float* addvec, const float* extra, float* out, float* q, int G, int Bg,
+                        int Ci, int Co, int P, hipStream_t s);
+int chanpair_mfma_spans(int P);
+int launch_chanpair_mfma(const float* A, const float* Aextra, const float* B, float* part, int G,
+                         int Ca, int Cb, int P, hipStream_t s);
 int launch_scores(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW, float* lse,
                   float* pq, float* E, int G, int Bg, int N, int T, hipStream_t s);
-// v[g,c,n,:] = sum_{e in ptr[n]..ptr[n+1]} E[g, perm?perm[e]:e] u[g,c,idx[e],:] (+ addvec[r,c]*extra[g,n,:])
-int launch_aggregate(const int* ptr, const int* idx, const int* perm, int nnz, const float* u,
-                     const float* E, const float* addvec, const float* extra, float* v, int G,
-                     int Bg, int Cu, int N, int T, hipStream_t s);
+// v[g,c,n,:] = sum_{e in ptr[n]..ptr[n+1]} E[g,e] u[g,c,idx[e],:] (+ addvec[r,c]*extra[g,n,:])
+int launch_aggregate(const int* ptr, const int* idx, int nnz, const float* u, const float* E,
+                     const float* addvec, const float* extra, float* v, int G, int Bg, int Cu, int N,
+                     int T, hipStream_t s);
+// Ec[g,k] = E[g, cperm[k]]: edge coefficients in CSC order for the transposed aggregate
+int launch_permute_edges(const float* E, const int* cperm, float* Ec, int G, int nnz, hipStream_t s);
 int launch_aggregate_project(const msgat_graph_t& gr, const float* x, const float* E,
                              const float* W, float* y, float* z, int G, int Bg, int C, int Co,
                              int N, int T, hipStream_t s);

@@ -1,0 +1,376 @@
+// The two GEMM-shaped pieces of the hot path on the matrix cores (exact fp32 MFMA,
+// v_mfma_f32_16x16x4_f32: bit-for-bit an fmaf chain, so the 1e-4 bar is untouched).
+//
+//   k_project_mfma   out[g,co,p] = sum_ci M(co,ci) in[g,ci,p] (+ addvec[co] extra[g,p]),  q = alpha . in
+//                    forward: u = W x (msgat.py:27 applied before the aggregation), q (attention.py:33)
+//                    backward: dy = W^T dz, dx = W^T du + alpha (x) dq
+//   k_chanpair_mfma  part[a,c] = sum_p A[g,a,p] B[g,c,p]   (dW = du x^T, dalpha = dq . x, dW = dz y^T)
+//
+// Both stream their operands from HBM in the reference's [B,C,N,T] layout (a (group, channel)
+// slab is contiguous over p = n*T + t) and are HBM-bound by design.  What limits such a kernel
+// on CDNA4 is bytes in flight per SIMD, so the small 16x16 tile (4 accumulator registers) is used:
+// it keeps 3-4 waves per SIMD resident, each with 8 x 1 KiB loads outstanding.
+//   - projection: positions ride on the MFMA's N axis.  Lane (j = lane & 15, kq = lane >> 4)
+//     loads one float4 = 4 consecutive positions of channel 4k + kq; its 4 components feed 4
+//     independent 16x16 tiles, so one 16-B load per lane drives 4 MFMAs per 16 output channels
+//     and the 4 result tiles re-assemble into float4 stores.  The matrix is the A operand (LDS).
+//   - contraction: positions ride on K and channels on the lanes, the worst case for global
+//     loads, so 16-position tiles of all rows are staged through a per-wave LDS buffer in
+//     64-B row pieces (see k_chanpair_mfma).
+#include "common.hpp"
+
+namespace msgat {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 zero4() {
+  f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  return z;
+}
+
+// ---------------------------------------------------------------------------------------------
+// projection
+// ---------------------------------------------------------------------------------------------
+constexpr int kKC = 8;  // k-steps (groups of 4 input channels) per register buffer
+
+__host__ __device__ static inline int proj_kpad(int Kx) {
+  const int K4 = (Kx + 3) & ~3;
+  return K4 + 2;  // Kpad/2 odd: the 16 rows x 2 k-quarters of a half-wave fragment read hit 32 banks
+}
+
+// MG = output-channel tiles (of 16) held in accumulators per pass over the input channels.
+// The k-loop keeps kKC loads in flight per wave in a register ring: slot i is re-issued for k-step
+// k + kKC right after k-step k consumed it.  Every load is unconditional (addresses are clamped,
+// padding is neutralised by zero matrix entries): a load inside a branch makes hipcc fall back
+// to s_waitcnt vmcnt(0), which serialises the prefetch against the MFMAs.
+template <int MG, bool DO_Q>
+__global__ __launch_bounds__(kBlock) void k_project_mfma(
+    const float4* __restrict__ in4, const float* __restrict__ M, int m_in_major,
+    const float* __restrict__ qvec, const float* __restrict__ addvec,
+    const float4* __restrict__ extra4, float4* __restrict__ out4, float4* __restrict__ q4, int Bg,
+    int Ci, int Co, int P4) {
+  extern __shared__ float lds[];
+  const bool has_extra = addvec != nullptr;
+  const int Kx = Ci + (has_extra ? 1 : 0);  // the extra "channel" carries addvec (x) extra
+  const int K4 = (Kx + 3) >> 2;             // k-steps
+  const int Kpad = proj_kpad(Kx);
+  const int Mt = cdiv(Co, 16);
+  const int Mrows = cdiv(Mt, MG) * MG * 16;  // rows padded to whole passes (zeros)
+  float* Wl = lds;                           // [Mrows][Kpad]
+  float* ql = lds + Mrows * Kpad;            // [4*K4]
+  const int g = blockIdx.y;
+  const int r = g / Bg;
+
+  for (int i = threadIdx.x; i < Mrows * Kpad; i += kBlock) {
+    const int co = i / Kpad, k = i - co * Kpad;
+    float w = 0.f;
+    if (co < Co) {
+      if (k < Ci) w = m_in_major ? M[((size_t)r * Ci + k) * Co + co] : M[((size_t)r * Co + co) * Ci + k];
+      else if (k == Ci && has_extra) w = addvec[r * Co + co];
+    }
+    Wl[i] = w;
+  }
+  if (DO_Q)
+    for (int i = threadIdx.x; i < 4 * K4; i += kBlock) ql[i] = (i < Ci) ? qvec[r * Ci + i] : 0.f;
+  __syncthreads();
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = lane & 15, kq = lane >> 4;
+  const int p4 = (blockIdx.x * 4 + wave) * 16 + j;
+  const bool pvalid = p4 < P4;
+  const int p4c = min(p4, P4 - 1);  // out-of-range lanes re-read the last position; their stores are masked
+  const float4* src = in4 + (size_t)g * Ci * P4 + p4c;
+  const float4* ex = has_extra ? extra4 + (size_t)g * P4 + p4c : src;
+
+  // channel 4*kk + kq of this lane's 4 positions; padding channels alias a real one (their matrix
+  // column is zero) -- never a branch
+  auto loadB = [&](int kk) -> float4 {
+    const int ci = 4 * min(kk, K4 - 1) + kq;
+    const float4* p = (ci < Ci) ? src + (size_t)ci * P4 : ((ci == Ci) ? ex : src);
+    return *p;
+  };
+
+  float4 qa = f4zero();
+  for (int m0 = 0; m0 < Mt; m0 += MG) {
+    f32x4 acc[MG][4];
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[mg][i] = zero4();
+    const float* wrow = Wl + (m0 * 16 + j) * Kpad + kq;  // A fragment: row co = tile*16 + j, column 4k + kq
+    float4 ring[kKC];
+#pragma unroll
+    for (int i = 0; i < kKC; ++i) ring[i] = loadB(i);
+    auto step = [&](int kk, const float4& b) {
+#pragma unroll
+      for (int mg = 0; mg < MG; ++mg) {
+        const float a = wrow[mg * 16 * Kpad + 4 * kk];
+        acc[mg][0] = mfma16(a, b.x, acc[mg][0]);
+        acc[mg][1] = mfma16(a, b.y, acc[mg][1]);
+        acc[mg][2] = mfma16(a, b.z, acc[mg][2]);
+        acc[mg][3] = mfma16(a, b.w, acc[mg][3]);
+      }
+      if (DO_Q && m0 == 0) f4fma(ql[4 * kk + kq], b, qa);
+    };
+    // whole chunks: one straight-line basic block per trip, so hipcc emits counted vmcnt waits
+    int k0 = 0;
+    for (; k0 + kKC <= K4; k0 += kKC) {
+#pragma unroll
+      for (int i = 0; i < kKC; ++i) {
+        step(k0 + i, ring[i]);
+        ring[i] = loadB(k0 + i + kKC);
+      }
+    }
+    // tail (< kKC k-steps, already in the ring): wave-uniform branches, no loads inside
+#pragma unroll
+    for (int i = 0; i < kKC; ++i)
+      if (k0 + i < K4) step(k0 + i, ring[i]);
+    // D tile i: column = lane & 15 <-> position 4*p4 + i;  row = 4*(lane >> 4) + reg
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int co = (m0 + mg) * 16 + 4 * kq + reg;
+        if (co < Co && pvalid)
+          out4[((size_t)g * Co + co) * P4 + p4] =
+              make_float4(acc[mg][0][reg], acc[mg][1][reg], acc[mg][2][reg], acc[mg][3][reg]);
+      }
+  }
+  if (DO_Q) {  // the four lane quarters hold the 4k + kq channels' share of q
+    qa.x += __shfl_xor(qa.x, 16); qa.y += __shfl_xor(qa.y, 16); qa.z += __shfl_xor(qa.z, 16); qa.w += __shfl_xor(qa.w, 16);
+    qa.x += __shfl_xor(qa.x, 32); qa.y += __shfl_xor(qa.y, 32); qa.z += __shfl_xor(qa.z, 32); qa.w += __shfl_xor(qa.w, 32);
+    if (kq == 0 && pvalid) q4[(size_t)g * P4 + p4] = qa;
+  }
+}
+
+static int proj_passes_mg(int Co, int* mg_out) {
+  const int Mt = cdiv(Co, 16);
+  const int passes = cdiv(Mt, 5);  // all output tiles in one pass when they fit 5 x 16 accumulator registers
+  *mg_out = cdiv(Mt, passes);
+  return passes;
+}
+
+size_t project_mfma_lds_bytes(int Ci, int Co, bool has_extra) {
+  const int Kx = Ci + (has_extra ? 1 : 0);
+  int MG;
+  const int passes = proj_passes_mg(Co, &MG);
+  return (size_t)(passes * MG * 16 * proj_kpad(Kx) + 4 * ((Kx + 3) / 4)) * sizeof(float);
+}
+
+template <int MG>
+static int launch_project_mg(const float* in, const float* M, int m_in_major, const float* qvec,
+                             const float* addvec, const float* extra, float* out, float* q, int G, int Bg,
+                             int Ci, int Co, int P4, hipStream_t s) {
+  const size_t lds = project_mfma_lds_bytes(Ci, Co, addvec != nullptr);
+  dim3 grid(cdiv(P4, 64), G);
+  if (qvec != nullptr)
+    hipLaunchKernelGGL((k_project_mfma<MG, true>), grid, dim3(kBlock), lds, s, (const float4*)in, M, m_in_major,
+                       qvec, addvec, (const float4*)extra, (float4*)out, (float4*)q, Bg, Ci, Co, P4);
+  else
+    hipLaunchKernelGGL((k_project_mfma<MG, false>), grid, dim3(kBlock), lds, s, (const float4*)in, M,
+                       m_in_major, qvec, addvec, (const float4*)extra, (float4*)out, (float4*)q, Bg, Ci, Co, P4);
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
+}
+
+int launch_project_mfma(const float* in, const float* M, int m_in_major, const float* qvec,
+                        const float* addvec, const float* extra, float* out, float* q, int G, int Bg,
+                        int Ci, int Co, int P, hipStream_t s) {
+  const int P4 = P / 4;
+  int MG;
+  proj_passes_mg(Co, &MG);
+  switch (MG) {
+    case 1: return launch_project_mg<1>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, s);
+    case 2: return launch_project_mg<2>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, s);
+    case 3: return launch_project_mg<3>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, s);
+    case 4: return launch_project_mg<4>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, s);
+    default: return launch_project_mg<5>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, s);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// channel-pair contraction over positions
+// ---------------------------------------------------------------------------------------------
+// part[a,c] = sum_p A[a,p] B[c,p]: positions are the MFMA's K axis, channels ride on the lanes, so
+// an operand fragment is "one word per channel row" -- the worst possible global access.  Each
+// wave therefore stages 16-position tiles of all its Ca + Cb rows through its own LDS buffer:
+//   - global side: 4 adjacent lanes fetch the 4 16-B chunks of one row (64 contiguous bytes),
+//     16 rows per wave-instruction, every byte of A and B read once;
+//   - LDS side: chunk q of row r is stored at slot 4r + (q ^ ((r >> 2) & 3)); a fragment read is
+//     one ds_read_b32 per lane (row = lane & 15, word = lane >> 4 of the chunk), 2-way banked;
+//   - a chunk holds 4 positions = one MFMA k-step.
+// The next tile is prefetched into registers while the current one is multiplied, so one LDS
+// buffer per wave suffices and the main loop has no barrier; the only barrier is the one before
+// the 4 waves' accumulators are summed (fixed order) into the block's partial.
+constexpr int kSpan = 1024;     // positions per block = one partial
+constexpr int kWaveSpan = 256;  // positions per wave
+constexpr int kTile = 16;       // positions per staged tile
+
+template <int MA, int NB>
+__global__ __launch_bounds__(kBlock) void k_chanpair_mfma(
+    const float* __restrict__ A, const float* __restrict__ Aextra, const float* __restrict__ B,
+    float* __restrict__ part, int Ca, int Cb, int P, int nspan, int nzb, int wave_f4) {
+  extern __shared__ float4 lds4[];
+  constexpr int NK = ((MA + NB) * 16 * 4 + 63) / 64;  // staging loads per lane per tile (upper bound)
+  const int g = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = lane & 15, kq = lane >> 4;
+  const int sp = blockIdx.x;  // the block's span of positions
+  // blockIdx.z walks the [MA*16 x NB*16] blocks of a channel matrix larger than one block
+  const int a0 = (blockIdx.z / nzb) * (MA * 16);
+  const int c0 = (blockIdx.z % nzb) * (NB * 16);
+  const int ca = min(MA * 16, Ca - a0), cb = min(NB * 16, Cb - c0);
+  const int rows = ca + cb;  // rows [0,ca) = A channels, [ca,rows) = B channels, row `rows` = zeros
+  const int pbeg = min(P, sp * kSpan + wave * kWaveSpan);
+  const int pend = min(P, pbeg + kWaveSpan);
+  const int ntile = cdiv(pend - pbeg, kTile);  // 0 for a wave past the end: it contributes zeros
+  const int CaMain = (Aextra != nullptr) ? Ca - 1 : Ca;
+
+  float4* buf = lds4 + (size_t)wave * wave_f4;
+  constexpr int kZeroRow = NK * 16;  // first row past the NK*64 staging slots
+  if (lane < 4) buf[kZeroRow * 4 + lane] = f4zero();
+
+  // staging plan of this lane: slot L = lane + 64k <-> (row L>>2, chunk (L&3) ^ ((row>>2)&3)).
+  // Slots past the last row alias row 0 for the load (always a valid address: no load sits in a
+  // branch, see k_project_mfma) and are simply not written to LDS.
+  const float* src[NK];
+  int qpos[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int L = lane + 64 * k;
+    const int row = (L >> 2) < rows ? (L >> 2) : 0;
+    const int q = (L & 3) ^ ((row >> 2) & 3);
+    const float* p;
+    if (row < ca) {
+      const int a = a0 + row;
+      p = (a < CaMain) ? A + ((size_t)g * CaMain + a) * P : Aextra + (size_t)g * P;
+    } else {
+      p = B + ((size_t)g * Cb + (c0 + row - ca)) * P;
+    }
+    src[k] = p;
+    qpos[k] = 4 * q;
+  }
+  const int plast = P - 4;  // P % 4 == 0: the last whole float4 of a row
+  auto fetch = [&](int t, float4 (&regs)[NK]) {
+    const int p0 = pbeg + t * kTile;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int p = p0 + qpos[k];
+      const float4 v = *reinterpret_cast<const float4*>(src[k] + min(p, plast));
+      regs[k] = (p < pend) ? v : f4zero();  // select, not a branch
+    }
+  };
+  auto stash = [&](const float4 (&regs)[NK]) {  // slots past the last row are scratch (never read)
+#pragma unroll
+    for (int k = 0; k < NK; ++k) buf[lane + 64 * k] = regs[k];
+  };
+
+  // fragment words of this lane: word kq of chunk qq of its row (the zero row when the channel is absent)
+  const float* bufw = reinterpret_cast<const float*>(buf);
+  int aw[MA][4], bw[NB][4];
+#pragma unroll
+  for (int ma = 0; ma < MA; ++ma) {
+    const int row = (ma * 16 + j < ca) ? ma * 16 + j : kZeroRow;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) aw[ma][qq] = (row * 4 + (qq ^ ((row >> 2) & 3))) * 4 + kq;
+  }
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int row = (nb * 16 + j < cb) ? ca + nb * 16 + j : kZeroRow;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) bw[nb][qq] = (row * 4 + (qq ^ ((row >> 2) & 3))) * 4 + kq;
+  }
+
+  f32x4 acc[MA][NB];
+#pragma unroll
+  for (int ma = 0; ma < MA; ++ma)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[ma][nb] = zero4();
+
+  float4 regs[NK];
+  if (ntile > 0) {
+    fetch(0, regs);
+    stash(regs);
+  }
+  for (int t = 0; t < ntile; ++t) {
+    // next tile in flight while this one is multiplied; unconditional (the last trip re-reads its
+    // own tile) so the loop body stays one basic block with counted waits
+    fetch(min(t + 1, ntile - 1), regs);
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      float av[MA], bv[NB];
+#pragma unroll
+      for (int ma = 0; ma < MA; ++ma) av[ma] = bufw[aw[ma][qq]];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) bv[nb] = bufw[bw[nb][qq]];
+#pragma unroll
+      for (int ma = 0; ma < MA; ++ma)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[ma][nb] = mfma16(av[ma], bv[nb], acc[ma][nb]);
+    }
+    stash(regs);  // same wave, in-order LDS: the reads above are done
+  }
+
+  // sum the 4 waves' accumulators in a fixed order: element e = ((ma*NB + nb)*4 + reg)*64 + lane
+  float* red = reinterpret_cast<float*>(buf);
+#pragma unroll
+  for (int ma = 0; ma < MA; ++ma)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) red[((ma * NB + nb) * 4 + reg) * 64 + lane] = acc[ma][nb][reg];
+  __syncthreads();
+  const float* all = reinterpret_cast<const float*>(lds4);
+  const int wstride = wave_f4 * 4;
+  float* out = part + ((size_t)g * nspan + sp) * ((size_t)Ca * Cb);
+  for (int e = threadIdx.x; e < MA * NB * 256; e += kBlock) {
+    const float v = (all[e] + all[wstride + e]) + (all[2 * wstride + e] + all[3 * wstride + e]);
+    const int el = e & 63, reg = (e >> 6) & 3, tile = e >> 8;
+    const int ma = tile / NB, nb = tile - ma * NB;
+    const int a = a0 + ma * 16 + 4 * (el >> 4) + reg;  // D row = 4*(lane >> 4) + reg
+    const int c = c0 + nb * 16 + (el & 15);            // D column = lane & 15
+    if (a < Ca && c < Cb) out[(size_t)a * Cb + c] = v;
+  }
+}
+
+int chanpair_mfma_spans(int P) { return cdiv(P, kSpan); }
+
+template <int MA, int NB>
+static int launch_chanpair_t(const float* A, const float* Aextra, const float* B, float* part, int G,
+                             int Ca, int Cb, int P, hipStream_t s) {
+  const int nspan = cdiv(P, kSpan);
+  const int nza = cdiv(Ca, MA * 16), nzb = cdiv(Cb, NB * 16);
+  const int rows_max = min(MA * 16, Ca) + min(NB * 16, Cb);
+  // per wave: NK*64 staging slots + the zero row, reused for the MA*NB*256-float reduction
+  constexpr int NK = ((MA + NB) * 16 * 4 + 63) / 64;
+  const int wave_f4 = max(NK * 64 + 4, MA * NB * 64);
+  (void)rows_max;
+  const size_t lds = (size_t)4 * wave_f4 * sizeof(float4);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chanpair_mfma<MA, NB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
+  }
+  dim3 grid(nspan, G, nza * nzb);
+  hipLaunchKernelGGL((k_chanpair_mfma<MA, NB>), grid, dim3(kBlock), lds, s, A, Aextra, B, part, Ca, Cb, P,
+                     nspan, nzb, wave_f4);
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
+}
+
+int launch_chanpair_mfma(const float* A, const float* Aextra, const float* B, float* part, int G,
+                         int Ca, int Cb, int P, hipStream_t s) {
+  const int MA = min(cdiv(Ca, 16), 3), NB = min(cdiv(Cb, 16), 6);
+#define MSGAT_CP(ma, nb) \
+  if (MA == ma && NB == nb) return launch_chanpair_t<ma, nb>(A, Aextra, B, part, G, Ca, Cb, P, s);
+  MSGAT_CP(1, 1) MSGAT_CP(1, 2) MSGAT_CP(1, 3) MSGAT_CP(1, 4) MSGAT_CP(1, 5) MSGAT_CP(1, 6)
+  MSGAT_CP(2, 1) MSGAT_CP(2, 2) MSGAT_CP(2, 3) MSGAT_CP(2, 4) MSGAT_CP(2, 5) MSGAT_CP(2, 6)
+  MSGAT_CP(3, 1) MSGAT_CP(3, 2) MSGAT_CP(3, 3) MSGAT_CP(3, 4) MSGAT_CP(3, 5) MSGAT_CP(3, 6)
+#undef MSGAT_CP
+  return MSGAT_ERR_UNSUPPORTED;
+}
+
+}  // namespace msgat

@@ -115,8 +115,11 @@ static int launch_project_t(const float* in, const float* M, int m_in_major, con
 int launch_project(const float* in, const float* M, int m_in_major, const float* qvec,
                    const float* addvec, const float* extra, float* out, float* q, int G, int Bg,
                    int Ci, int Co, int P, hipStream_t s) {
+  // matrix cores whenever there are enough output channels to fill a tile and the matrix fits LDS
+  if (Co >= 8 && project_mfma_lds_bytes(Ci, Co, addvec != nullptr) <= 64 * 1024)
+    return launch_project_mfma(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P, s);
   const int P4 = P / 4;
-  // widest tile that divides the work evenly; 24 and 32 cover the reference's widths
+  // VALU fallback (few outputs or a very large matrix): widest tile that divides the work evenly; 24 and 32 cover the reference's widths
   // (Co = 16/24/32 forward, C = 48/72/96 backward)
   if (Co % 24 == 0) return launch_project_t<24>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, s);
   if (Co % 32 == 0) return launch_project_t<32>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, s);

@@ -140,6 +140,8 @@ def test_modules_are_drop_in_for_the_reference_golden():
     (1, 1, 9, 4, 130, 8, 140),     # T = 8
     (2, 1, 4, 8, 257, 16, 300),    # T = 16, N just over a tile boundary
     (1, 1, 2, 0, 1, 12, 0),        # a single node: only the self loop
+    (1, 1, 200, 180, 20, 12, 25),  # matrix too large for the MFMA kernel's LDS: VALU projection, blocked dW
+    (1, 2, 33, 40, 21, 12, 25),    # AGG_FIRST with > 32 channels on both sides
 ])
 def test_against_numpy_oracle(R, Bg, C, Co, N, T, E):
     prob = random_problem(R, Bg, C, Co, N, T, E, seed=R * 1000 + C * 10 + N)

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Times the individual stage kernels of libmsgat_hip.so with HIP events (GPU box only).
+
+    python tools/kbench.py [--workload pemsd7] [--reps 20] [--only mix,contract,...]
+
+Prints one line per stage: microseconds per launch and algorithmic GB/s.  Used to iterate on a
+single kernel without the autograd plumbing around it.
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ms_gat_amd  # noqa: E402
+from ms_gat_amd import _lib  # noqa: E402
+
+WL = {"pemsd7": dict(N=883, E=866, B=32, R=3, C=72, Co=24, T=12),
+      "pemsd4": dict(N=307, E=340, B=64, R=1, C=72, Co=24, T=12),
+      "stress": dict(N=8192, E=65536, B=8, R=4, C=72, Co=24, T=12)}
+
+
+def timeit(fn, reps):
+    for _ in range(3):
+        fn()
+    s = torch.cuda.current_stream()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record(s)
+    for _ in range(reps):
+        fn()
+    t1.record(s)
+    t1.synchronize()
+    return t0.elapsed_time(t1) * 1e-3 / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="pemsd7")
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    w = WL[a.workload]
+    N, T, R, B, Cc, Co = w["N"], w["T"], w["R"], w["B"], w["C"], w["Co"]
+    G, P = R * B, N * T
+    dev = torch.device("cuda:0")
+    L = _lib.lib()
+    graph = ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(N, w["E"], 0))
+    gs, _keep = graph.on(dev)
+    nnz = graph.nnz
+    st = torch.cuda.current_stream().cuda_stream
+    rnd = lambda *s: torch.randn(*s, device=dev)  # noqa: E731
+    x, u, dz = rnd(G, Cc, N, T), rnd(G, Co, N, T), rnd(G, Co, N, T)
+    alpha, Wg, W = rnd(R, Cc) * 0.1, rnd(R, T, T) * 0.3, rnd(R, Co, Cc) * 0.1
+    q, kW, pq, dq = rnd(G, N, T), rnd(G, N, T), rnd(G, N, T), rnd(G, N, T)
+    lse, E = rnd(G, N), torch.rand(G, max(nnz, 1), device=dev)
+    out_u, out_x = torch.empty_like(u), torch.empty_like(x)
+    shape = _lib.Shape(R, B, Cc, Co, N, T)
+    sp = C.byref(shape)
+    gp = C.byref(gs)
+    ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    stages = {}
+
+    def reg(name, nbytes, fn):
+        stages[name] = (nbytes, fn)
+
+    reg("project_fwd  x->u,q", 4 * G * P * (Cc + Co + 1),
+        lambda: _lib.check(L.msgat_stage_project(sp, ptr(x), ptr(alpha), ptr(W), ptr(q), ptr(out_u), st), "p"))
+    reg("scores       q->kW,lse,pq,E", 4 * G * P * 4,
+        lambda: _lib.check(L.msgat_stage_scores(sp, gp, ptr(q), ptr(Wg), ptr(kW), ptr(lse), ptr(pq), ptr(E), st), "s"))
+    reg("scores_nopq  q->kW,lse,E", 4 * G * P * 3,
+        lambda: _lib.check(L.msgat_stage_scores(sp, gp, ptr(q), ptr(Wg), ptr(kW), ptr(lse), None, ptr(E), st), "s"))
+    reg("aggregate    u->z (Cu=Co)", 8 * G * Co * P,
+        lambda: _lib.check(L.msgat_stage_aggregate(sp, gp, Co, ptr(u), ptr(E), ptr(out_u), st), "a"))
+    reg("mix_bwd      du,dq->dx", 4 * G * P * (Co + 1 + Cc),
+        lambda: _lib.check(L.msgat_stage_mix(sp, Co, Cc, ptr(u), ptr(W), 1, ptr(alpha), ptr(dq), ptr(out_x), st), "m"))
+    nfl = L.msgat_contract_partial_floats(sp, Co + 1, Cc)
+    part = torch.empty(nfl, device=dev)
+    dW, da = torch.empty(R, Co, Cc, device=dev), torch.empty(R, Cc, device=dev)
+    reg("contract     du,dq,x->dW,dalpha", 4 * G * P * (Co + 1 + Cc),
+        lambda: _lib.check(L.msgat_stage_contract(sp, Co + 1, Cc, ptr(u), ptr(dq), ptr(x), ptr(part), ptr(dW),
+                                                  Co * Cc, ptr(da), Cc, st), "c"))
+    only = [s for s in a.only.split(",") if s]
+    for name, (nbytes, fn) in stages.items():
+        if only and not any(o in name for o in only):
+            continue
+        sec = timeit(fn, a.reps)
+        print(f"{name:36s} {sec * 1e6:9.1f} us   {nbytes / sec / 1e9:8.1f} GB/s  ({nbytes / 1e6:.0f} MB)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
