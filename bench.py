@@ -141,6 +141,25 @@ def time_aggregate_kernel(hp, reps=20):
     return sec, bytes_
 
 
+def recorded_traffic(workload):
+    """HBM bytes per launch of k_agg_lds from the PMC passes committed under profiles/ (FETCH_SIZE and
+    WRITE_SIZE collected separately, gfx950 x2 correction on the fetch side; see profiles/*/hbm_traffic.json).
+    PMC counters cannot be collected from inside this process, so the newest committed record is quoted."""
+    import glob
+    if workload != "pemsd7":
+        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                k = json.load(f)["kernels"]
+            for name, v in k.items():
+                if "k_agg_lds" in name:
+                    return int(v["hbm_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,7 +225,7 @@ def main():
         out["roofline"] = {
             "kernel": "k_agg_lds (attention-aggregate, second GACN depth)", "bound": "hbm",
             "achieved": round(nbytes / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": recorded_traffic(args.workload),
             "us_per_launch": round(sec * 1e6, 2), "algorithmic_bytes": nbytes,
         }
     if rank == 0 and world == 1 and not args.no_baselines:

@@ -24,7 +24,8 @@ LIB = os.path.join(PKG, "libmsgat_hip.so")
 SOURCES = ["api.hip", "project.hip", "mfma.hip", "scores.hip", "aggregate.hip", "reduce.hip", "graph_host.cpp"]
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(INCLUDE, "msgat_hip.h")]
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", f"--offload-arch={ARCH}",
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize",
+         f"--offload-arch={ARCH}",
          "-I" + INCLUDE, "-I" + CSRC]
 
 

@@ -15,93 +15,123 @@
 
 namespace msgat {
 
-constexpr int kRT = 64;    // rows (or columns) per block = one lane each
-constexpr int kNS = 4;     // the 4 waves of a block split the reduction axis
-constexpr int kMC = 256;   // columns of q staged in LDS per step
-constexpr int kSub = 8;    // columns per online-softmax update
+constexpr int kRL = 2;          // rows (or columns) per lane: packed fp32 math + half the LDS broadcasts
+constexpr int kRT = 64 * kRL;   // rows (or columns) per block
+constexpr int kNS = 8;          // the 8 waves of a block split the reduction axis (VALU-bound: needs waves)
+constexpr int kSBlock = 64 * kNS;  // lanes per block of the dense kernels
+constexpr int kMC = 256;        // columns of q staged in LDS per step
+constexpr int kSub = 8;         // columns per online-softmax update
 
+// Two independent rows per lane as a pair of scalars.  Deliberately NOT a packed vector type:
+// v_pk_fma_f32 issues at half rate on gfx950 (no throughput gain) and made hipcc route the LDS
+// broadcasts through v_readfirstlane + SGPR operands, 12 extra instructions per column.
+struct v2f {
+  float x, y;
+  __device__ __forceinline__ v2f& operator*=(const v2f& o) { x *= o.x; y *= o.y; return *this; }
+  __device__ __forceinline__ v2f& operator+=(const v2f& o) { x += o.x; y += o.y; return *this; }
+};
+__device__ __forceinline__ v2f operator-(const v2f& a, const v2f& b) { return v2f{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ v2f splat(float a) { return v2f{a, a}; }
+__device__ __forceinline__ v2f fma2(const v2f& a, const v2f& b, const v2f& c) { return v2f{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+__device__ __forceinline__ v2f max2(const v2f& a, const v2f& b) { return v2f{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
+__device__ __forceinline__ v2f exp2v(const v2f& a) { return v2f{fast_exp2(a.x), fast_exp2(a.y)}; }
+
+// Lane l of every wave owns rows n0 + l and n0 + 64 + l (the two halves of a v2f); wave w
+// takes columns j = 8w .. 8w+7 (mod 32) of each staged tile.  Per column: 3 LDS broadcasts of
+// q[m], then 2 x 12 v_fma_f32 for the two scores and (training) 2 x 12 more for pq.
 template <int T, bool WITH_PQ>
-__global__ __launch_bounds__(kBlock) void k_scores(
+__global__ __launch_bounds__(kSBlock) void k_scores(
     const float* __restrict__ q, const float* __restrict__ Wg, const int* __restrict__ rowptr,
     const int* __restrict__ col, const float* __restrict__ val, const int* __restrict__ erow,
     float* __restrict__ kW, float* __restrict__ lse, float* __restrict__ pq, float* __restrict__ E,
     int Bg, int N, int nnz) {
   constexpr int T4 = T / 4;
-  __shared__ float4 qs4[kMC * T4];
-  __shared__ float red[kNS][kRT][T + 2];
+  constexpr int kMG = 4;                                   // splits merged per phase
+  constexpr int RED = kMG * kRT * (T + 2);                 // floats for the split merge
+  constexpr int STAGE = kMC * T;                           // floats for a column tile
+  __shared__ float4 pool4[(RED > STAGE ? RED : STAGE) / 4];  // column tile, then merge scratch
   __shared__ float kw2s[kRT][T];
   __shared__ float lse2s[kRT];
+  float4* qs4 = pool4;
+  float* red = reinterpret_cast<float*>(pool4);            // [kMG][kRT][T+2]
 
   const int g = blockIdx.y;
   const int r = g / Bg;
   const int lane = threadIdx.x & (kWave - 1);
   const int split = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n0 = blockIdx.x * kRT;
-  const int n = n0 + lane;
-  const bool valid = n < N;
   const float* qg = q + (size_t)g * N * T;
-
-  // this lane's row: q[n] and kW[n] = q[n] Wg
-  float qr[T];
-#pragma unroll
-  for (int t4 = 0; t4 < T4; ++t4) {
-    float4 v = f4zero();
-    if (valid) v = reinterpret_cast<const float4*>(qg + (size_t)n * T)[t4];
-    qr[4 * t4 + 0] = v.x; qr[4 * t4 + 1] = v.y; qr[4 * t4 + 2] = v.z; qr[4 * t4 + 3] = v.w;
-  }
-  float kw2[T];
   const float* wg = Wg + (size_t)r * T * T;
-#pragma unroll
-  for (int s = 0; s < T; ++s) {
-    float a = 0.f;
-#pragma unroll
-    for (int t = 0; t < T; ++t) a = fmaf(qr[t], wg[t * T + s], a);
-    kw2[s] = a;
-  }
-  if (split == 0 && valid) {
-    float4* dst = reinterpret_cast<float4*>(kW + ((size_t)g * N + n) * T);
-#pragma unroll
-    for (int t4 = 0; t4 < T4; ++t4) dst[t4] = make_float4(kw2[4 * t4], kw2[4 * t4 + 1], kw2[4 * t4 + 2], kw2[4 * t4 + 3]);
-  }
-#pragma unroll
-  for (int s = 0; s < T; ++s) kw2[s] *= kLog2e;  // scores in log2 units: exp(x) = 2^(x log2 e)
 
-  float m = -INFINITY, l = 0.f;
-  float racc[T];
+  // the lane's two rows: q[n] and kW[n] = q[n] Wg (stored unscaled, used scaled by log2 e)
+  v2f kw2[T];
 #pragma unroll
-  for (int t = 0; t < T; ++t) racc[t] = 0.f;
+  for (int h = 0; h < kRL; ++h) {
+    const int n = n0 + h * 64 + lane;
+    const bool valid = n < N;
+    float qr[T];
+#pragma unroll
+    for (int t4 = 0; t4 < T4; ++t4) {
+      float4 v = f4zero();
+      if (valid) v = reinterpret_cast<const float4*>(qg + (size_t)n * T)[t4];
+      qr[4 * t4 + 0] = v.x; qr[4 * t4 + 1] = v.y; qr[4 * t4 + 2] = v.z; qr[4 * t4 + 3] = v.w;
+    }
+    float kw[T];
+#pragma unroll
+    for (int s = 0; s < T; ++s) {
+      float a = 0.f;
+#pragma unroll
+      for (int t = 0; t < T; ++t) a = fmaf(qr[t], wg[t * T + s], a);
+      kw[s] = a;
+    }
+    if (split == 0 && valid) {
+      float4* dst = reinterpret_cast<float4*>(kW + ((size_t)g * N + n) * T);
+#pragma unroll
+      for (int t4 = 0; t4 < T4; ++t4) dst[t4] = make_float4(kw[4 * t4], kw[4 * t4 + 1], kw[4 * t4 + 2], kw[4 * t4 + 3]);
+    }
+#pragma unroll
+    for (int s = 0; s < T; ++s) {  // scores in log2 units: exp(x) = 2^(x log2 e)
+      if (h == 0) kw2[s].x = kw[s] * kLog2e; else kw2[s].y = kw[s] * kLog2e;
+    }
+  }
+
+  v2f m = splat(-INFINITY), l = splat(0.f);
+  v2f racc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) racc[t] = splat(0.f);
 
   for (int c0 = 0; c0 < N; c0 += kMC) {
     const int cols = min(kMC, N - c0);
     __syncthreads();
     {
       const float4* src = reinterpret_cast<const float4*>(qg + (size_t)c0 * T);
-      for (int i = threadIdx.x; i < cols * T4; i += kBlock) qs4[i] = src[i];
+      for (int i = threadIdx.x; i < cols * T4; i += kSBlock) qs4[i] = src[i];
     }
     __syncthreads();
     for (int j = split * kSub; j < cols; j += kNS * kSub) {
-      float s[kSub];
-      float cm = -INFINITY;
+      v2f s[kSub];
+      v2f cm = splat(-INFINITY);
 #pragma unroll
       for (int jj = 0; jj < kSub; ++jj) {
-        float a = -INFINITY;
+        v2f a = splat(-INFINITY);
         if (j + jj < cols) {  // wave-uniform
           const float4* qc = &qs4[(j + jj) * T4];
-          a = 0.f;
+          a = splat(0.f);
+          // the fma order (t ascending, acc last) is what k_bwd_dense_col reproduces bit for bit
 #pragma unroll
           for (int t4 = 0; t4 < T4; ++t4) {
             const float4 v = qc[t4];
-            a = fmaf(kw2[4 * t4 + 0], v.x, a);
-            a = fmaf(kw2[4 * t4 + 1], v.y, a);
-            a = fmaf(kw2[4 * t4 + 2], v.z, a);
-            a = fmaf(kw2[4 * t4 + 3], v.w, a);
+            a = fma2(kw2[4 * t4 + 0], splat(v.x), a);
+            a = fma2(kw2[4 * t4 + 1], splat(v.y), a);
+            a = fma2(kw2[4 * t4 + 2], splat(v.z), a);
+            a = fma2(kw2[4 * t4 + 3], splat(v.w), a);
           }
         }
         s[jj] = a;
-        cm = fmaxf(cm, a);
+        cm = max2(cm, a);
       }
-      const float mn = fmaxf(m, cm);
-      const float sc = fast_exp2(m - mn);  // m == -inf on the first update -> 0
+      const v2f mn = max2(m, cm);
+      const v2f sc = exp2v(m - mn);  // m == -inf on the first update -> 0
       m = mn;
       l *= sc;
       if (WITH_PQ) {
@@ -111,17 +141,17 @@ __global__ __launch_bounds__(kBlock) void k_scores(
 #pragma unroll
       for (int jj = 0; jj < kSub; ++jj) {
         if (j + jj < cols) {
-          const float p = fast_exp2(s[jj] - mn);
+          const v2f p = exp2v(s[jj] - mn);
           l += p;
           if (WITH_PQ) {
             const float4* qc = &qs4[(j + jj) * T4];
 #pragma unroll
             for (int t4 = 0; t4 < T4; ++t4) {
               const float4 v = qc[t4];
-              racc[4 * t4 + 0] = fmaf(p, v.x, racc[4 * t4 + 0]);
-              racc[4 * t4 + 1] = fmaf(p, v.y, racc[4 * t4 + 1]);
-              racc[4 * t4 + 2] = fmaf(p, v.z, racc[4 * t4 + 2]);
-              racc[4 * t4 + 3] = fmaf(p, v.w, racc[4 * t4 + 3]);
+              racc[4 * t4 + 0] = fma2(p, splat(v.x), racc[4 * t4 + 0]);
+              racc[4 * t4 + 1] = fma2(p, splat(v.y), racc[4 * t4 + 1]);
+              racc[4 * t4 + 2] = fma2(p, splat(v.z), racc[4 * t4 + 2]);
+              racc[4 * t4 + 3] = fma2(p, splat(v.w), racc[4 * t4 + 3]);
             }
           }
         }
@@ -129,34 +159,54 @@ __global__ __launch_bounds__(kBlock) void k_scores(
     }
   }
 
-  // merge the 4 column splits of each row
+  // merge the column splits of each row, kMG splits per phase through the (now dead) column tile
+  float M = -INFINITY, L = 0.f;
+  float R[T];
 #pragma unroll
-  for (int t = 0; t < T; ++t) red[split][lane][t] = racc[t];
-  red[split][lane][T] = m;
-  red[split][lane][T + 1] = l;
-  __syncthreads();
-  if (split == 0) {
-    float M = red[0][lane][T];
+  for (int t = 0; t < T; ++t) R[t] = 0.f;
+  for (int ph = 0; ph < kNS / kMG; ++ph) {
+    __syncthreads();
+    if (split / kMG == ph) {
 #pragma unroll
-    for (int i = 1; i < kNS; ++i) M = fmaxf(M, red[i][lane][T]);
-    float L = 0.f;
-    float R[T];
+      for (int h = 0; h < kRL; ++h) {
+        float* dst = red + ((size_t)(split % kMG) * kRT + h * 64 + lane) * (T + 2);
 #pragma unroll
-    for (int t = 0; t < T; ++t) R[t] = 0.f;
-#pragma unroll
-    for (int i = 0; i < kNS; ++i) {
-      const float w = fast_exp2(red[i][lane][T] - M);  // a split that saw no column has m = -inf -> 0
-      L = fmaf(w, red[i][lane][T + 1], L);
-      if (WITH_PQ) {
-#pragma unroll
-        for (int t = 0; t < T; ++t) R[t] = fmaf(w, red[i][lane][t], R[t]);
+        for (int t = 0; t < T; ++t) dst[t] = h == 0 ? racc[t].x : racc[t].y;
+        dst[T] = h == 0 ? m.x : m.y;
+        dst[T + 1] = h == 0 ? l.x : l.y;
       }
     }
-    const float lse2 = M + fast_log2(L);
-    lse2s[lane] = lse2;
+    __syncthreads();
+    if (threadIdx.x < kRT) {
+      const float* r0 = red + (size_t)threadIdx.x * (T + 2);
+      constexpr int SS = kRT * (T + 2);  // stride between splits
+      float Mn = M;
 #pragma unroll
-    for (int t = 0; t < T; ++t) kw2s[lane][t] = kw2[t];
-    if (valid) {
+      for (int i = 0; i < kMG; ++i) Mn = fmaxf(Mn, r0[i * SS + T]);
+      const float w0 = fast_exp2(M - Mn);  // first phase: M = -inf -> 0 (a row always has >= 1 column)
+      L *= w0;
+      if (WITH_PQ) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) R[t] *= w0;
+      }
+      M = Mn;
+#pragma unroll
+      for (int i = 0; i < kMG; ++i) {
+        const float w = fast_exp2(r0[i * SS + T] - M);  // a split that saw no column has m = -inf -> 0
+        L = fmaf(w, r0[i * SS + T + 1], L);
+        if (WITH_PQ) {
+#pragma unroll
+          for (int t = 0; t < T; ++t) R[t] = fmaf(w, r0[i * SS + t], R[t]);
+        }
+      }
+    }
+  }
+  if (threadIdx.x < kRT) {
+    const int row = threadIdx.x;
+    const int n = n0 + row;
+    const float lse2 = M + fast_log2(L);
+    lse2s[row] = lse2;
+    if (n < N) {
       lse[(size_t)g * N + n] = lse2;  // kept in log2 units so backward re-creates the exponent bit for bit
       if (WITH_PQ) {
         const float inv = 1.0f / L;
@@ -167,12 +217,19 @@ __global__ __launch_bounds__(kBlock) void k_scores(
       }
     }
   }
+  if (split == 0) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      kw2s[lane][t] = kw2[t].x;
+      kw2s[64 + lane][t] = kw2[t].y;
+    }
+  }
   __syncthreads();
 
   // edge coefficients of this block's rows: one lane per CSR edge, coalesced over e
   const int e0 = rowptr[n0];
   const int e1 = rowptr[min(n0 + kRT, N)];
-  for (int e = e0 + threadIdx.x; e < e1; e += kBlock) {
+  for (int e = e0 + threadIdx.x; e < e1; e += kSBlock) {
     const int nl = erow[e] - n0;
     const float4* qm = reinterpret_cast<const float4*>(qg + (size_t)col[e] * T);
     float a = 0.f;
@@ -193,10 +250,10 @@ static int launch_scores_t(const msgat_graph_t& gr, const float* q, const float*
                            float* lse, float* pq, float* E, int G, int Bg, int N, hipStream_t s) {
   dim3 grid(cdiv(N, kRT), G);
   if (pq != nullptr)
-    hipLaunchKernelGGL((k_scores<T, true>), grid, dim3(kBlock), 0, s, q, Wg, gr.rowptr, gr.col, gr.val,
+    hipLaunchKernelGGL((k_scores<T, true>), grid, dim3(kSBlock), 0, s, q, Wg, gr.rowptr, gr.col, gr.val,
                        gr.erow, kW, lse, pq, E, Bg, N, gr.nnz);
   else
-    hipLaunchKernelGGL((k_scores<T, false>), grid, dim3(kBlock), 0, s, q, Wg, gr.rowptr, gr.col, gr.val,
+    hipLaunchKernelGGL((k_scores<T, false>), grid, dim3(kSBlock), 0, s, q, Wg, gr.rowptr, gr.col, gr.val,
                        gr.erow, kW, lse, pq, E, Bg, N, gr.nnz);
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
@@ -297,39 +354,47 @@ int launch_bwd_edge(const msgat_graph_t& gr, const float* dEp, int nchunks, cons
 constexpr int kRC = 128;  // rows staged per step
 
 template <int T>
-__global__ __launch_bounds__(kBlock) void k_bwd_dense_col(
+__global__ __launch_bounds__(kSBlock) void k_bwd_dense_col(
     const float* __restrict__ q, const float* __restrict__ kW, const float* __restrict__ lse,
     const float* __restrict__ delta, const float* __restrict__ gE, const int* __restrict__ colptr,
     const int* __restrict__ crow, const int* __restrict__ cperm, float* __restrict__ dq, int N,
     int nnz) {
   constexpr int T4 = T / 4;
   constexpr int REC4 = 2 * T4 + 1;  // float4s per row record
-  __shared__ float4 rec4[kRC * REC4];
-  __shared__ float red[kNS][kRT][T];
+  constexpr int RED = kNS * kRT * T;
+  constexpr int STAGE = kRC * REC4 * 4;
+  __shared__ float4 pool4[(RED > STAGE ? RED : STAGE) / 4];  // row records, then merge scratch
+  float4* rec4 = pool4;
+  float* red = reinterpret_cast<float*>(pool4);              // [kNS][kRT][T]
 
   const int g = blockIdx.y;
   const int lane = threadIdx.x & (kWave - 1);
   const int split = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int mcol = blockIdx.x * kRT + lane;
-  const bool valid = mcol < N;
+  const int m0 = blockIdx.x * kRT;
   const float* qg = q + (size_t)g * N * T;
   const float* kWg = kW + (size_t)g * N * T;
 
-  float qc[T];
+  // the lane's two columns m0 + lane and m0 + 64 + lane
+  v2f qc[T];
 #pragma unroll
-  for (int t4 = 0; t4 < T4; ++t4) {
-    float4 v = f4zero();
-    if (valid) v = reinterpret_cast<const float4*>(qg + (size_t)mcol * T)[t4];
-    qc[4 * t4 + 0] = v.x; qc[4 * t4 + 1] = v.y; qc[4 * t4 + 2] = v.z; qc[4 * t4 + 3] = v.w;
+  for (int h = 0; h < kRL; ++h) {
+    const int mcol = m0 + h * 64 + lane;
+#pragma unroll
+    for (int t4 = 0; t4 < T4; ++t4) {
+      float4 v = f4zero();
+      if (mcol < N) v = reinterpret_cast<const float4*>(qg + (size_t)mcol * T)[t4];
+      if (h == 0) { qc[4 * t4].x = v.x; qc[4 * t4 + 1].x = v.y; qc[4 * t4 + 2].x = v.z; qc[4 * t4 + 3].x = v.w; }
+      else        { qc[4 * t4].y = v.x; qc[4 * t4 + 1].y = v.y; qc[4 * t4 + 2].y = v.z; qc[4 * t4 + 3].y = v.w; }
+    }
   }
-  float acc[T];
+  v2f acc[T];
 #pragma unroll
-  for (int t = 0; t < T; ++t) acc[t] = 0.f;
+  for (int t = 0; t < T; ++t) acc[t] = splat(0.f);
 
   for (int r0 = 0; r0 < N; r0 += kRC) {
     const int rows = min(kRC, N - r0);
     __syncthreads();
-    for (int i = threadIdx.x; i < rows; i += kBlock) {
+    for (int i = threadIdx.x; i < rows; i += kSBlock) {
       const int nr = r0 + i;
       const float4* kr = reinterpret_cast<const float4*>(kWg + (size_t)nr * T);
       const float d = delta[(size_t)g * N + nr];
@@ -347,34 +412,48 @@ __global__ __launch_bounds__(kBlock) void k_bwd_dense_col(
       // same operands in the same fma order as k_scores: the score is re-created bit for
       // bit, so exp2(s - lse2) equals the forward's softmax value (rows that are one-hot on
       // an edge cancel against the sparse term; a 1e-4 slip in the exponent would not)
-      float s = 0.f;
+      v2f s = splat(0.f);
 #pragma unroll
       for (int t4 = 0; t4 < T4; ++t4) {
         const float4 v = rec[t4];
-        s = fmaf(v.x, qc[4 * t4 + 0], s);
-        s = fmaf(v.y, qc[4 * t4 + 1], s);
-        s = fmaf(v.z, qc[4 * t4 + 2], s);
-        s = fmaf(v.w, qc[4 * t4 + 3], s);
+        s = fma2(splat(v.x), qc[4 * t4 + 0], s);
+        s = fma2(splat(v.y), qc[4 * t4 + 1], s);
+        s = fma2(splat(v.z), qc[4 * t4 + 2], s);
+        s = fma2(splat(v.w), qc[4 * t4 + 3], s);
       }
-      const float p = fast_exp2(s - rec[2 * T4].x);
+      const v2f p = exp2v(s - splat(rec[2 * T4].x));
 #pragma unroll
       for (int t4 = 0; t4 < T4; ++t4) {
         const float4 v = rec[T4 + t4];
-        acc[4 * t4 + 0] = fmaf(p, v.x, acc[4 * t4 + 0]);
-        acc[4 * t4 + 1] = fmaf(p, v.y, acc[4 * t4 + 1]);
-        acc[4 * t4 + 2] = fmaf(p, v.z, acc[4 * t4 + 2]);
-        acc[4 * t4 + 3] = fmaf(p, v.w, acc[4 * t4 + 3]);
+        acc[4 * t4 + 0] = fma2(p, splat(v.x), acc[4 * t4 + 0]);
+        acc[4 * t4 + 1] = fma2(p, splat(v.y), acc[4 * t4 + 1]);
+        acc[4 * t4 + 2] = fma2(p, splat(v.z), acc[4 * t4 + 2]);
+        acc[4 * t4 + 3] = fma2(p, splat(v.w), acc[4 * t4 + 3]);
       }
     }
   }
-#pragma unroll
-  for (int t = 0; t < T; ++t) red[split][lane][t] = acc[t];
   __syncthreads();
-  if (split != 0 || !valid) return;
+#pragma unroll
+  for (int h = 0; h < kRL; ++h) {
+    float* dst = red + ((size_t)split * kRT + h * 64 + lane) * T;
+#pragma unroll
+    for (int t = 0; t < T; ++t) dst[t] = h == 0 ? acc[t].x : acc[t].y;
+  }
+  __syncthreads();
+  if (threadIdx.x >= kRT) return;
+  const int mcol = m0 + threadIdx.x;
+  if (mcol >= N) return;
 
+  const float* r0p = red + (size_t)threadIdx.x * T;
+  constexpr int SS = kRT * T;
   float tot[T];
 #pragma unroll
-  for (int t = 0; t < T; ++t) tot[t] = (red[0][lane][t] + red[1][lane][t]) + (red[2][lane][t] + red[3][lane][t]);
+  for (int t = 0; t < T; ++t) {
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < kNS; ++i) a += r0p[i * SS + t];  // fixed order
+    tot[t] = a;
+  }
   float sp[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) sp[t] = 0.f;
@@ -407,7 +486,7 @@ int launch_bwd_dense_col(const msgat_graph_t& gr, const float* q, const float* k
                          int N, int T, hipStream_t s) {
   dim3 grid(cdiv(N, kRT), G);
 #define MSGAT_DCOL(TT)                                                                              \
-  hipLaunchKernelGGL(k_bwd_dense_col<TT>, grid, dim3(kBlock), 0, s, q, kW, lse, delta, gE, gr.colptr, \
+  hipLaunchKernelGGL(k_bwd_dense_col<TT>, grid, dim3(kSBlock), 0, s, q, kW, lse, delta, gE, gr.colptr, \
                      gr.crow, gr.cperm, dq, N, gr.nnz)
   switch (T) {
     case 4: MSGAT_DCOL(4); break;
