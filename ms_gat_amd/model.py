@@ -1,0 +1,242 @@
+"""The callers of the hot path: MS-GAT's blocks around `GACN`, with the reference's
+`state_dict` layout so checkpoints interchange.
+
+Reference: /root/reference/src/models/msgat.py (GACN :17, TACN :57, CACN :83, MEAM :103,
+TPC :137, MSGAT :166, factories :220-229), attention.py (TemporalAttention :42,
+ChannelAttention :72), embeddings.py (TimeEmbedding :12).  Only the graph branch runs in
+the HIP library; the temporal / channel branches, LayerNorms and convolutions are dense
+PyTorch-ROCm ops here (SURVEY.md section 8f lists them as the next rows, not this round's).
+
+Parameter names and shapes are the reference's (`tpcs.{r}.tgacns.{l}.gacn.gatt.Wg`, ...):
+`tests/test_model_cpu.py` checks every key and shape against a reference checkpoint.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence
+
+import torch
+from torch import nn
+
+from .attention import GACN
+
+
+class TemporalAttention(nn.Module):
+    """[T,T] attention from rank-10 node projections (attention.py:58-66).  signals [B,C,N,T]."""
+
+    rank = 10
+
+    def __init__(self, n_channels: int, n_nodes: int):
+        super().__init__()
+        self.n_channels, self.n_nodes = n_channels, n_nodes
+        self.Wt1 = nn.Parameter(torch.empty(self.rank, n_nodes))
+        self.Wt2 = nn.Parameter(torch.empty(self.rank, n_nodes))
+        self.alpha = nn.Parameter(torch.empty(n_channels))
+
+    def forward(self, signals: torch.Tensor) -> torch.Tensor:
+        mixed = torch.tensordot(signals, self.alpha, dims=([1], [0]))   # [B,N,T]: channel-weighted sum
+        per_t = mixed.transpose(1, 2)                                    # [B,T,N]
+        left = per_t @ self.Wt1.t()                                      # [B,T,10]
+        right = per_t @ self.Wt2.t()                                     # [B,T,10]
+        att = torch.softmax(left @ right.transpose(1, 2), dim=-1)        # [B,T,T], rows = output step
+        return signals @ att.transpose(1, 2).unsqueeze(1)                # out[..,t] = sum_i att[t,i] x[..,i]
+
+    def extra_repr(self) -> str:
+        return f"n_channels={self.n_channels}, n_nodes={self.n_nodes}"
+
+
+class ChannelAttention(nn.Module):
+    """[C,C] attention from node-weighted signals (attention.py:88-94).  signals [B,C,N,T]."""
+
+    def __init__(self, n_nodes: int, n_timesteps: int):
+        super().__init__()
+        self.n_nodes, self.n_timesteps = n_nodes, n_timesteps
+        self.Wc = nn.Parameter(torch.empty(n_timesteps, n_timesteps))
+        self.alpha = nn.Parameter(torch.empty(n_nodes))
+
+    def forward(self, signals: torch.Tensor) -> torch.Tensor:
+        B, C, N, T = signals.shape
+        pooled = torch.tensordot(signals, self.alpha, dims=([2], [0]))   # [B,C,T]: node-weighted sum
+        att = torch.softmax(pooled @ self.Wc @ pooled.transpose(1, 2), dim=-1)   # [B,C,C]
+        return (att @ signals.reshape(B, C, N * T)).view(B, C, N, T)
+
+    def extra_repr(self) -> str:
+        return f"n_nodes={self.n_nodes}, n_timesteps={self.n_timesteps}"
+
+
+class TrimRight(nn.Module):
+    """Drops the last `n` steps of the time axis: makes a padded dilated conv causal (msgat.py:34-54)."""
+
+    def __init__(self, n: int):
+        super().__init__()
+        self.n = n
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return x[..., : x.size(-1) - self.n]
+
+    def extra_repr(self) -> str:
+        return f"n={self.n}"
+
+
+class TACN(nn.Module):
+    """Temporal attention, then a stack of causal dilated [1,2] convolutions (msgat.py:57-80)."""
+
+    def __init__(self, in_channels: int, out_channels: int, n_nodes: int, dilations: Sequence[int]):
+        super().__init__()
+        self.in_channels, self.out_channels, self.n_nodes, self.dilations = (
+            in_channels, out_channels, n_nodes, list(dilations))
+        layers: List[nn.Module] = [TemporalAttention(in_channels, n_nodes)]   # seq.0
+        width = in_channels
+        for d in self.dilations:                                              # seq.1, seq.3, ... hold weights
+            layers.append(nn.Conv2d(width, out_channels, kernel_size=(1, 2), padding=(0, d), dilation=(1, d)))
+            layers.append(TrimRight(d))
+            width = out_channels
+        self.seq = nn.Sequential(*layers)
+
+    def forward(self, signals: torch.Tensor) -> torch.Tensor:
+        return self.seq(signals)
+
+
+class CACN(nn.Module):
+    """Channel attention, then a 1x1 convolution (msgat.py:83-100)."""
+
+    def __init__(self, in_channels: int, out_channels: int, n_nodes: int, n_timesteps: int):
+        super().__init__()
+        self.in_channels, self.out_channels, self.n_nodes, self.n_timesteps = (
+            in_channels, out_channels, n_nodes, n_timesteps)
+        self.seq = nn.Sequential(ChannelAttention(n_nodes, n_timesteps), nn.Conv2d(in_channels, out_channels, 1))
+
+    def forward(self, signals: torch.Tensor) -> torch.Tensor:
+        return self.seq(signals)
+
+
+class MEAM(nn.Module):
+    """LayerNorm -> {channel, temporal, graph} branches -> concat + 1x1 residual -> ReLU (msgat.py:103-134).
+
+    The graph branch is the hot path: `self.gacn(normed, adjacency)` (msgat.py:127)."""
+
+    def __init__(self, in_channels: int, out_channels: int, n_nodes: int, n_timesteps: int,
+                 dilations: Sequence[int]):
+        if out_channels % 3:
+            raise ValueError("out_channels must be divisible by the 3 branches")
+        super().__init__()
+        self.in_channels, self.out_channels, self.n_nodes, self.n_timesteps, self.dilations = (
+            in_channels, out_channels, n_nodes, n_timesteps, list(dilations))
+        branch = out_channels // 3
+        self.ln = nn.LayerNorm([n_timesteps])
+        self.res = nn.Conv2d(in_channels, out_channels, kernel_size=1)
+        self.cacn = CACN(in_channels, branch, n_nodes=n_nodes, n_timesteps=n_timesteps)
+        self.tacn = TACN(in_channels, branch, n_nodes=n_nodes, dilations=dilations)
+        self.gacn = GACN(in_channels, branch, n_timesteps=n_timesteps)
+
+    def forward(self, signals: torch.Tensor, adjacency) -> torch.Tensor:
+        normed = self.ln(signals)
+        branches = torch.cat([self.cacn(normed), self.tacn(normed), self.gacn(normed, adjacency)], dim=1)
+        return torch.relu(branches + self.res(signals))
+
+
+class TPC(nn.Module):
+    """One component: a stack of MEAMs, LayerNorm, and a [1,C] convolution mapping T_in -> T_out (msgat.py:137-163)."""
+
+    def __init__(self, channels: Sequence[int], n_nodes: int, in_timesteps: int, out_timesteps: int,
+                 dilations: Sequence[Sequence[int]]):
+        super().__init__()
+        self.channels, self.n_nodes, self.in_timesteps, self.out_timesteps, self.dilations = (
+            list(channels), n_nodes, in_timesteps, out_timesteps, [list(d) for d in dilations])
+        self.tgacns = nn.ModuleList(
+            MEAM(channels[i], channels[i + 1], n_nodes=n_nodes, n_timesteps=in_timesteps, dilations=d)
+            for i, d in enumerate(dilations))
+        self.ln = nn.LayerNorm([in_timesteps])
+        self.fc = nn.Conv2d(in_timesteps, out_timesteps, kernel_size=(1, channels[-1]))
+
+    def forward(self, signals: torch.Tensor, adjacency) -> torch.Tensor:
+        for block in self.tgacns:
+            signals = block(signals, adjacency)
+        out = self.fc(self.ln(signals).transpose(1, 3))       # [B,T_out,N,1]
+        return out.squeeze(-1).transpose(1, 2)                # [B,N,T_out]
+
+
+class TimeEmbedding(nn.Module):
+    """Hour-of-day + day-of-week gate [B,R,N,T_out] (embeddings.py:12-39)."""
+
+    def __init__(self, n_components: int, n_nodes: int, n_timesteps: int):
+        super().__init__()
+        self.n_components, self.n_nodes, self.n_timesteps = n_components, n_nodes, n_timesteps
+        width = n_components * n_nodes * n_timesteps
+        self.d_ebd = nn.Embedding(7, width)
+        self.h_ebd = nn.Embedding(24, width)
+
+    def forward(self, H: torch.Tensor, D: torch.Tensor) -> torch.Tensor:
+        gate = self.h_ebd(H) + self.d_ebd(D)
+        return gate.view(-1, self.n_components, self.n_nodes, self.n_timesteps)
+
+
+class MSGAT(nn.Module):
+    """X [B,R,C,N,T], H [B], D [B] -> [B,N,T_out]  (msgat.py:166-217).
+
+    `use_te=False` uses the learned static gate `W [R,N,T_out]` that the reference declares
+    (msgat.py:189) but cannot reach (its forward reads `self.te` unconditionally, msgat.py:203).
+    """
+
+    def __init__(self, components: Sequence[Dict], in_timesteps: int, out_timesteps: int, use_te: bool,
+                 adj: torch.Tensor):
+        super().__init__()
+        n_nodes = len(adj)
+        if use_te:
+            self.te = TimeEmbedding(len(components), n_nodes, out_timesteps)
+        else:
+            self.te = None
+            self.W = nn.Parameter(torch.empty(len(components), n_nodes, out_timesteps))
+        self.adj = nn.Parameter(adj.detach().clone().float(), requires_grad=False)
+        self.tpcs = nn.ModuleList(
+            TPC(channels=c["channels"], n_nodes=n_nodes, in_timesteps=in_timesteps, out_timesteps=out_timesteps,
+                dilations=c["dilations"]) for c in components)
+        self.reset_parameters()
+
+    def forward(self, X: torch.Tensor, H: torch.Tensor, D: torch.Tensor) -> torch.Tensor:
+        gates = self.te(H, D).unbind(1) if self.te is not None else self.W.unbind(0)
+        out = None
+        for tpc, x, gate in zip(self.tpcs, X.unbind(1), gates):
+            term = tpc(x, self.adj) * gate
+            out = term if out is None else out + term
+        return out
+
+    def reset_parameters(self) -> None:
+        """xavier_normal_ for >= 2-D, U(-size0^-1/2, +size0^-1/2) for 1-D, every trainable tensor (msgat.py:206-217)."""
+        with torch.no_grad():
+            for p in self.parameters():
+                if not p.requires_grad:
+                    continue
+                if p.dim() >= 2:
+                    nn.init.xavier_normal_(p)
+                else:
+                    bound = p.size(0) ** -0.5
+                    p.uniform_(-bound, bound)
+
+
+_WIDTHS = {  # msgat.py:220-229
+    "ms-gat48": dict(hidden=48, dilations=[[1, 2], [2, 4]]),
+    "ms-gat72": dict(hidden=72, dilations=[[1, 2], [2, 4]]),
+    "ms-gat96": dict(hidden=96, dilations=[[1, 1, 2, 2], [4, 4]]),
+}
+_WIDTHS["ms-gat"] = _WIDTHS["ms-gat72"]  # main.py:17
+
+
+def build_msgat(name: str, n_components: int, in_channels: int, **kwargs) -> MSGAT:
+    cfg = _WIDTHS[name]
+    comp = {"channels": [in_channels, cfg["hidden"], cfg["hidden"]], "dilations": cfg["dilations"]}
+    return MSGAT([comp] * n_components, **kwargs)
+
+
+def msgat48(n_components: int, in_channels: int, **kwargs) -> MSGAT:
+    return build_msgat("ms-gat48", n_components, in_channels, **kwargs)
+
+
+def msgat72(n_components: int, in_channels: int, **kwargs) -> MSGAT:
+    return build_msgat("ms-gat72", n_components, in_channels, **kwargs)
+
+
+def msgat96(n_components: int, in_channels: int, **kwargs) -> MSGAT:
+    return build_msgat("ms-gat96", n_components, in_channels, **kwargs)
+
+
+models = {name: (lambda n=name: (lambda **kw: build_msgat(n, **kw)))() for name in _WIDTHS}

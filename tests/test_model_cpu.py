@@ -1,0 +1,157 @@
+"""CPU checks of the callers around the hot path: checkpoint layout, dense branches, data slicing,
+loss / metrics, and the engine loop (with a CPU stand-in model -- the real model needs the GPU)."""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from conftest import load_golden, rel_err
+
+
+def _ref_state(name):
+    g = load_golden(name)
+    return g, {k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("p.")}
+
+
+def test_msgat72_state_dict_matches_reference_checkpoint_layout():
+    from ms_gat_amd import model
+    g, ref = _ref_state("msgat72_n32.npz")
+    net = model.msgat72(n_components=3, in_channels=3, in_timesteps=12, out_timesteps=12, use_te=True,
+                        adj=torch.from_numpy(g["p.adj"]))
+    ours = net.state_dict()
+    assert list(ours.keys()) == list(ref.keys())            # same names in the same order
+    for k in ref:
+        assert tuple(ours[k].shape) == tuple(ref[k].shape), k
+    assert not net.adj.requires_grad and "adj" in ours      # frozen parameter, still in the checkpoint
+    missing = net.load_state_dict(ref)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    assert sum(p.numel() for p in net.parameters() if p.requires_grad) == sum(
+        v.numel() for k, v in ref.items() if k != "adj")
+
+
+@pytest.mark.parametrize("name,widths", [("ms-gat48", 48), ("ms-gat", 72), ("ms-gat96", 96)])
+def test_factories_and_init_scheme(name, widths):
+    from ms_gat_amd import model
+    torch.manual_seed(0)
+    net = model.build_msgat(name, n_components=2, in_channels=1, in_timesteps=12, out_timesteps=12, use_te=True,
+                            adj=torch.eye(20))
+    assert net.tpcs[0].tgacns[1].gacn.W.shape == (widths // 3, widths)
+    assert len(net.tpcs[0].tgacns) == 2
+    for n, p in net.named_parameters():                      # msgat.py:206-217
+        if p.dim() == 1:
+            assert p.abs().max() <= p.size(0) ** -0.5 + 1e-6, n
+    w = net.te.h_ebd.weight
+    assert abs(float(w.std()) - (2.0 / (w.size(0) + w.size(1))) ** 0.5) < 0.1 * float(w.std())
+
+
+def test_use_te_false_uses_the_static_gate():
+    from ms_gat_amd import model
+    net = model.msgat48(n_components=2, in_channels=1, in_timesteps=12, out_timesteps=12, use_te=False,
+                        adj=torch.eye(8))
+    assert net.te is None and tuple(net.W.shape) == (2, 8, 12)
+    assert "W" in net.state_dict() and not any(k.startswith("te.") for k in net.state_dict())
+
+
+def test_dense_branches_match_reference_meam_intermediates():
+    """TACN + CACN + residual are plain PyTorch: feed them the reference MEAM's weights and check
+    the part of the MEAM output they own (first 2/3 of the channels before the ReLU is not
+    observable, so compare the whole block with the graph branch taken from the oracle)."""
+    from ms_gat_amd import model
+    from oracle import dense_torch
+    for tag, cin in (("3to72_n32", 3), ("72to72_n32", 72)):
+        g, ref = _ref_state(f"meam_{tag}.npz")
+        m = model.MEAM(cin, 72, n_nodes=32, n_timesteps=12, dilations=[1, 2])
+        m.load_state_dict(ref)
+        x, adj = torch.from_numpy(g["x"]), torch.from_numpy(g["adj"])
+        normed = m.ln(x)
+        graph = dense_torch.gacn_dense(normed, adj, m.gacn.gatt.Wg, m.gacn.gatt.alpha, m.gacn.W)  # oracle, CPU
+        out = torch.relu(torch.cat([m.cacn(normed), m.tacn(normed), graph], dim=1) + m.res(x))
+        assert rel_err(out.detach(), g["out"]) < 1e-5, tag
+
+
+def test_periodic_windows_and_zscore_match_reference_slices():
+    from ms_gat_amd import data
+    g = load_golden("slices_small.npz")
+    raw = torch.from_numpy(g["raw"]).float().transpose(0, -1)
+    hours, tau, q = g["hours"].tolist(), int(g["tau"]), int(g["q"])
+    intervals, train_end = data.split_intervals(raw.size(-1), hours, q, tau)
+    assert list(intervals[0]) == g["interval"].tolist()
+    normed = data.zscore(raw, split=train_end)
+    assert torch.allclose(normed, torch.from_numpy(g["norm"]), atol=1e-6)
+    ds = data.PeriodicWindows(normed, raw[0], intervals[0], hours, q, tau)
+    assert len(ds) == int(g["length"])
+    for k, i in enumerate(g["idx"].tolist()):
+        x, h, d, y = ds[i]
+        assert torch.equal(x, torch.from_numpy(g["x"][k]))
+        assert int(h) == int(g["h"][k]) and int(d) == int(g["d"][k])
+        assert torch.equal(y, torch.from_numpy(g["y"][k]))
+    # the three splits tile the forecast origins 60/20/20 without overlap
+    assert intervals[0][1] == intervals[1][0] and intervals[1][1] == intervals[2][0]
+
+
+def test_synthetic_pems_batches_have_the_model_input_shapes():
+    from ms_gat_amd import data
+    ds = data.SyntheticPEMS(n_nodes=20, n_edges=25, n_channels=3, in_hours=[1, 2, 24], batch_size=4, days=4)
+    x, h, d, y = next(iter(ds.training))
+    assert tuple(x.shape) == (4, 3, 3, 20, 12) and tuple(y.shape) == (4, 20, 12)
+    assert h.dtype == torch.int64 and int(h.max()) < 24 and int(d.max()) < 7
+    assert torch.allclose(ds.adj, ds.adj.t())
+
+
+def test_huber_and_metrics_match_reference_definitions():
+    from ms_gat_amd import engine
+    m = load_golden("msgat72_n32.npz")
+    pred, y = torch.from_numpy(m["pred"]), torch.from_numpy(m["Y"])
+    assert abs(float(engine.huber_loss(pred, y, 50.0)) - float(m["loss"])) < 1e-5 * abs(float(m["loss"]))
+    met = engine.Metrics()
+    met.update(pred, y)
+    met.update(pred * 0.5, y)
+    n = 2 * y.numel()
+    ae = (pred - y).abs().sum() + (0.5 * pred - y).abs().sum()
+    mask = y > 0
+    ape = 100 * (((pred - y)[mask] / y[mask]).abs().sum() + ((0.5 * pred - y)[mask] / y[mask]).abs().sum())
+    se = ((pred - y) ** 2).sum() + ((0.5 * pred - y) ** 2).sum()
+    assert abs(met.MAE - float(ae) / n) < 1e-4 * met.MAE
+    assert abs(met.MAPE - float(ape) / n) < 1e-4 * met.MAPE       # divides by ALL entries, as metrics.py:31
+    assert abs(met.RMSE - (float(se) / n) ** 0.5) < 1e-4 * met.RMSE
+
+
+class _TinyModel(nn.Module):
+    """Stand-in with the MSGAT call signature model(X, H, D) -> [B,N,T]."""
+
+    def __init__(self, R, C, T):
+        super().__init__()
+        self.mix = nn.Conv2d(R * C, 1, 1)
+        self.h = nn.Embedding(24, 1)
+
+    def forward(self, X, H, D):
+        B, R, C, N, T = X.shape
+        return self.mix(X.reshape(B, R * C, N, T)).squeeze(1) + self.h(H).view(B, 1, 1)
+
+
+def test_trainer_loop_checkpoint_and_evaluator_roundtrip(tmp_path):
+    from ms_gat_amd import data, engine
+    torch.manual_seed(0)
+    ds = data.SyntheticPEMS(n_nodes=6, n_edges=6, n_channels=2, in_hours=[1, 2], batch_size=16, days=3)
+    model = _TinyModel(2, 2, 12)
+    tr = engine.Trainer(model, loss_delta=50.0, out_dir=str(tmp_path))
+    tr.max_epochs, tr.min_epochs = 3, 1
+    tr.fit((ds.training, ds.validation))
+    assert tr.epoch == 4 and tr.best["epoch"] >= 2
+    log = (tmp_path / "run.log").read_text().strip().splitlines()
+    assert len(log) == 6 and "[Train   ]" in log[0] and "epoch=1,loss=" in log[0] and "RMSE=" in log[1]
+    ck = torch.load(tr.best["ckpt"], weights_only=False)
+    assert set(ck) == {"best", "epoch", "model", "optimizer", "scheduler", "grad_scaler"}   # engine.py:136-143
+
+    model2 = _TinyModel(2, 2, 12)
+    ev = engine.Evaluator(model2, 50.0, str(tmp_path / "eval"), tr.best["ckpt"])
+    for a, b in zip(model2.state_dict().values(), ck["model"].values()):
+        assert torch.equal(a, b)
+    loss = ev.eval(ds.evaluation)
+    assert np.isfinite(loss) and "[Evaluate]" in (tmp_path / "eval" / "run.log").read_text()
+
+    tr2 = engine.Trainer(_TinyModel(2, 2, 12), 50.0, str(tmp_path / "resume"))
+    tr2.load(tr.best["ckpt"])
+    assert tr2.epoch == ck["epoch"] + 1 and tr2.best["loss"] == ck["best"]["loss"]
+    # DataParallel-style prefixes written by the reference (main.py:54) are accepted
+    assert list(engine.strip_data_parallel_prefix({"module.a": 1, "module.b": 2})) == ["a", "b"]
