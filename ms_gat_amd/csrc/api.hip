@@ -14,6 +14,8 @@ int check_shape(const msgat_shape_t* sh) {
   if (sh->C > kMaxC || sh->Co > kMaxC) return MSGAT_ERR_UNSUPPORTED;
   if ((int64_t)sh->R * sh->Bg > 65535) return MSGAT_ERR_UNSUPPORTED;  // groups ride on gridDim.y/z
   if ((int64_t)sh->N * sh->T > (1 << 28)) return MSGAT_ERR_UNSUPPORTED;
+  // one group's [C,N,T] block is indexed with 32-bit element offsets
+  if ((int64_t)(sh->C > sh->Co ? sh->C : sh->Co + 1) * sh->N * sh->T >= (1ll << 31)) return MSGAT_ERR_UNSUPPORTED;
   return MSGAT_OK;
 }
 
@@ -57,13 +59,13 @@ BwdPlan plan_bwd(const msgat_shape_t& sh, int nnz) {
   p.off_dwg = take(dwg_partial_floats(p.G, sh.N, sh.T));
   size_t cp = 0;
   if (p.mode == MSGAT_MODE_PLAIN) {
-    cp = chanpair_partial_floats(p.G, 1, sh.C, (int)P);
+    cp = chanpair_partial_floats(p.G, sh.Bg, 1, sh.C);
   } else if (p.mode == MSGAT_MODE_AGG_FIRST) {
-    cp = chanpair_partial_floats(p.G, sh.Co, sh.C, (int)P);
-    const size_t cp2 = chanpair_partial_floats(p.G, 1, sh.C, (int)P);
+    cp = chanpair_partial_floats(p.G, sh.Bg, sh.Co, sh.C);
+    const size_t cp2 = chanpair_partial_floats(p.G, sh.Bg, 1, sh.C);
     if (cp2 > cp) cp = cp2;
   } else {
-    cp = chanpair_partial_floats(p.G, sh.Co + 1, sh.C, (int)P);
+    cp = chanpair_partial_floats(p.G, sh.Bg, sh.Co + 1, sh.C);
   }
   p.off_cp = take(cp);
   p.total = off;
@@ -155,7 +157,7 @@ extern "C" int msgat_stage_mix(const msgat_shape_t* sh, int32_t Ci, int32_t Co, 
 
 extern "C" size_t msgat_contract_partial_floats(const msgat_shape_t* sh, int32_t Ca, int32_t Cb) {
   if (check_shape(sh) != MSGAT_OK || Ca <= 0 || Cb <= 0) return 0;
-  return chanpair_partial_floats(sh->R * sh->Bg, Ca, Cb, sh->N * sh->T);
+  return chanpair_partial_floats(sh->R * sh->Bg, sh->Bg, Ca, Cb);
 }
 
 extern "C" int msgat_stage_contract(const msgat_shape_t* sh, int32_t Ca, int32_t Cb, const float* A,

@@ -67,9 +67,9 @@ size_t project_mfma_lds_bytes(int Ci, int Co, bool has_extra);
 int launch_project_mfma(const float* in, const float* M, int m_in_major, const float* qvec,
                         const float* addvec, const float* extra, float* out, float* q, int G, int Bg,
                         int Ci, int Co, int P, hipStream_t s);
-int chanpair_mfma_spans(int P);
-int launch_chanpair_mfma(const float* A, const float* Aextra, const float* B, float* part, int G,
-                         int Ca, int Cb, int P, hipStream_t s);
+int chanpair_mfma_blocks(int R);  // blocks (= partials) per relation
+int launch_chanpair_mfma(const float* A, const float* Aextra, const float* B, float* part, int R, int Bg,
+                         int Ca, int Cb, int P, int nblk, hipStream_t s);
 int launch_scores(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW, float* lse,
                   float* pq, float* E, int G, int Bg, int N, int T, hipStream_t s);
 // v[g,c,n,:] = sum_{e in ptr[n]..ptr[n+1]} E[g,e] u[g,c,idx[e],:] (+ addvec[r,c]*extra[g,n,:])
@@ -96,7 +96,7 @@ size_t dwg_partial_floats(int G, int N, int T);
 int launch_dwg(const float* q, const float* dkW, float* part, float* dWg, int G, int Bg, int N,
                int T, hipStream_t s);
 // out[r,a,c] = sum_{g in r, p} A(g,a,p) B[g,c,p];  channel a == Ca-1 comes from Aextra[g,p] when given
-size_t chanpair_partial_floats(int G, int Ca, int Cb, int P);
+size_t chanpair_partial_floats(int G, int Bg, int Ca, int Cb);
 int launch_chanpair(const float* A, const float* Aextra, const float* B, float* part, float* dst0,
                     int n0, float* dst1, int n1, int G, int Bg, int Ca, int Cb, int P,
                     hipStream_t s);

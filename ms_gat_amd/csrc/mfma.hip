@@ -15,8 +15,8 @@
 //     independent 16x16 tiles, so one 16-B load per lane drives 4 MFMAs per 16 output channels
 //     and the 4 result tiles re-assemble into float4 stores.  The matrix is the A operand (LDS).
 //   - contraction: positions ride on K and channels on the lanes, the worst case for global
-//     loads, so 16-position tiles of all rows are staged through a per-wave LDS buffer in
-//     64-B row pieces (see k_chanpair_mfma).
+//     loads, so 256-position tiles of all rows are staged through LDS in 1-KiB row pieces by a
+//     persistent split-K kernel (see k_chanpair_mfma).
 #include "common.hpp"
 
 namespace msgat {
@@ -194,94 +194,137 @@ int launch_project_mfma(const float* in, const float* M, int m_in_major, const f
 // ---------------------------------------------------------------------------------------------
 // channel-pair contraction over positions
 // ---------------------------------------------------------------------------------------------
-// part[a,c] = sum_p A[a,p] B[c,p]: positions are the MFMA's K axis, channels ride on the lanes, so
-// an operand fragment is "one word per channel row" -- the worst possible global access.  Each
-// wave therefore stages 16-position tiles of all its Ca + Cb rows through its own LDS buffer:
-//   - global side: 4 adjacent lanes fetch the 4 16-B chunks of one row (64 contiguous bytes),
-//     16 rows per wave-instruction, every byte of A and B read once;
-//   - LDS side: chunk q of row r is stored at slot 4r + (q ^ ((r >> 2) & 3)); a fragment read is
-//     one ds_read_b32 per lane (row = lane & 15, word = lane >> 4 of the chunk), 2-way banked;
-//   - a chunk holds 4 positions = one MFMA k-step.
-// The next tile is prefetched into registers while the current one is multiplied, so one LDS
-// buffer per wave suffices and the main loop has no barrier; the only barrier is the one before
-// the 4 waves' accumulators are summed (fixed order) into the block's partial.
-constexpr int kSpan = 1024;     // positions per block = one partial
-constexpr int kWaveSpan = 256;  // positions per wave
-constexpr int kTile = 16;       // positions per staged tile
+// part[a,c] = sum_{g in r} sum_p A[g,a,p] B[g,c,p]: positions are the MFMA's K axis, channels ride
+// on the lanes, so an operand fragment is "one word per channel row" -- the worst possible global
+// access.  A block (8 waves, one block per CU) therefore stages 256-position tiles of all its
+// Ca + Cb rows through LDS:
+//   - global side: one wave-instruction reads 1 KiB contiguous of ONE row.  A row of the [N,T]
+//     slab starts at an arbitrary 16-B offset (N*T*4 is not a multiple of 128), so every piece
+//     straddles one extra 128-B line: 1-KiB pieces cost 9 lines per 8, 64-B pieces 2 per 1
+//     (measured with 64-B pieces: 2.5 TB/s).  Every byte of A and B is read once.
+//   - LDS side: rows are padded by 16 B so the 16 rows x 4 words of a fragment read
+//     (ds_read_b32, row = lane & 15, word = lane >> 4 of a 16-B chunk) are 2-way banked;
+//   - wave w multiplies positions [32w, 32w+32) of the tile: 8 k-steps of 4 positions.
+// Persistent split-K: the tiles of a relation (its Bg groups back to back) form one stream and each
+// block owns a contiguous run of it, so the load pipeline (two tiles in flight per wave, in two
+// register sets) never drains between groups and there is ONE reduction per block: the 8 waves'
+// accumulators are summed in a fixed order into the block's partial (no atomics).  In-kernel
+// stamps showed the alternative -- one block per (group, 1024 positions) -- spending 45% of a
+// block in its exposed prologue, first-tile wait and reduction.
+
+// Diagnostic build only (tools/contract_stamps.hip): s_memtime stamps of the phases of one block.
+#ifdef MSGAT_STAMPS
+__device__ unsigned long long g_stamps[8 * 4096];
+#define MSGAT_STAMP(i)                                                                             \
+  do {                                                                                             \
+    if (threadIdx.x == 0 && blockIdx.z == 0) {                                                     \
+      const unsigned b = blockIdx.y * gridDim.x + blockIdx.x;                                      \
+      if (b < 4096) {                                                                              \
+        g_stamps[b * 8 + (i)] = __builtin_amdgcn_s_memtime();                                      \
+        if ((i) == 0) g_stamps[b * 8 + 6] = __builtin_amdgcn_s_memrealtime();                      \
+        if ((i) == 5) g_stamps[b * 8 + 7] = __builtin_amdgcn_s_memrealtime();                      \
+      }                                                                                            \
+    }                                                                                              \
+  } while (0)
+#else
+#define MSGAT_STAMP(i)
+#endif
+
+// Workgroup barrier for LDS hand-offs that leaves global loads in flight: __syncthreads() makes
+// hipcc drain vmcnt(0) first, which would serialise the register prefetch against the barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int kCpWaves = 8;
+constexpr int kCpBlock = 64 * kCpWaves;
+constexpr int kTile = 32 * kCpWaves;   // positions per staged tile: 32 (8 k-steps) per wave
+constexpr int kLPR = kTile / 4;        // lanes per row piece (64: one row per wave-instruction)
+constexpr int kRPI = 64 / kLPR;        // rows per wave-instruction
+constexpr int kRowF4 = kTile / 4 + 1;  // float4s per LDS row (piece + 16 B pad)
 
 template <int MA, int NB>
-__global__ __launch_bounds__(kBlock) void k_chanpair_mfma(
+__global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
     const float* __restrict__ A, const float* __restrict__ Aextra, const float* __restrict__ B,
-    float* __restrict__ part, int Ca, int Cb, int P, int nspan, int nzb, int wave_f4) {
+    float* __restrict__ part, int Ca, int Cb, int P, int Bg, int nzb) {
   extern __shared__ float4 lds4[];
-  constexpr int NK = ((MA + NB) * 16 * 4 + 63) / 64;  // staging loads per lane per tile (upper bound)
-  const int g = blockIdx.y;
+  constexpr int RPW = ((MA + NB) * 16 + kCpWaves * kRPI - 1) / (kCpWaves * kRPI);  // load instructions per wave per tile
+  const int r = blockIdx.y;
+  const int nblk = gridDim.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = lane & 15, kq = lane >> 4;
-  const int sp = blockIdx.x;  // the block's span of positions
   // blockIdx.z walks the [MA*16 x NB*16] blocks of a channel matrix larger than one block
   const int a0 = (blockIdx.z / nzb) * (MA * 16);
   const int c0 = (blockIdx.z % nzb) * (NB * 16);
   const int ca = min(MA * 16, Ca - a0), cb = min(NB * 16, Cb - c0);
-  const int rows = ca + cb;  // rows [0,ca) = A channels, [ca,rows) = B channels, row `rows` = zeros
-  const int pbeg = min(P, sp * kSpan + wave * kWaveSpan);
-  const int pend = min(P, pbeg + kWaveSpan);
-  const int ntile = cdiv(pend - pbeg, kTile);  // 0 for a wave past the end: it contributes zeros
+  const int rows = ca + cb;  // rows [0,ca) = A channels, [ca,rows) = B channels
+  constexpr int kZeroRow = (MA + NB) * 16;  // an all-zero row for absent channels
   const int CaMain = (Aextra != nullptr) ? Ca - 1 : Ca;
+  // this block's run of the relation's tile stream
+  const int tpg = cdiv(P, kTile);  // tiles per group (the last one is partial)
+  const long long ntot = (long long)Bg * tpg;
+  const int t0 = (int)(ntot * blockIdx.x / nblk), t1 = (int)(ntot * (blockIdx.x + 1) / nblk);
+  const int ntile = t1 - t0;
 
-  float4* buf = lds4 + (size_t)wave * wave_f4;
-  constexpr int kZeroRow = NK * 16;  // first row past the NK*64 staging slots
-  if (lane < 4) buf[kZeroRow * 4 + lane] = f4zero();
+  MSGAT_STAMP(0);
+  if (threadIdx.x < kRowF4) lds4[kZeroRow * kRowF4 + threadIdx.x] = f4zero();
 
-  // staging plan of this lane: slot L = lane + 64k <-> (row L>>2, chunk (L&3) ^ ((row>>2)&3)).
-  // Slots past the last row alias row 0 for the load (always a valid address: no load sits in a
-  // branch, see k_project_mfma) and are simply not written to LDS.
-  const float* src[NK];
-  int qpos[NK];
+  // staging plan: instruction k of this wave covers rows (wave + kCpWaves*k)*kRPI + (lane / kLPR); a
+  // lane fetches float4 (lane % kLPR) of the tile.  Rows past the last one alias row 0 (always a
+  // valid address: no load sits in a branch, see k_project_mfma) and land in scratch rows nobody reads.
+  const int lrow = lane / kLPR, lcol = lane % kLPR;
+  const float* src[RPW];  // row pointer for group 0 of the relation
+  int gstride[RPW];       // elements between consecutive groups of that row
 #pragma unroll
-  for (int k = 0; k < NK; ++k) {
-    const int L = lane + 64 * k;
-    const int row = (L >> 2) < rows ? (L >> 2) : 0;
-    const int q = (L & 3) ^ ((row >> 2) & 3);
+  for (int k = 0; k < RPW; ++k) {
+    const int rr = (wave + kCpWaves * k) * kRPI + lrow;
+    const int row = rr < rows ? rr : 0;
+    const size_t g0 = (size_t)r * Bg;
     const float* p;
     if (row < ca) {
       const int a = a0 + row;
-      p = (a < CaMain) ? A + ((size_t)g * CaMain + a) * P : Aextra + (size_t)g * P;
+      if (a < CaMain) { p = A + (g0 * CaMain + a) * P; gstride[k] = CaMain * P; }
+      else            { p = Aextra + g0 * P;           gstride[k] = P; }
     } else {
-      p = B + ((size_t)g * Cb + (c0 + row - ca)) * P;
+      p = B + (g0 * Cb + (c0 + row - ca)) * P;
+      gstride[k] = Cb * P;
     }
-    src[k] = p;
-    qpos[k] = 4 * q;
+    src[k] = p + 4 * lcol;
   }
-  const int plast = P - 4;  // P % 4 == 0: the last whole float4 of a row
-  auto fetch = [&](int t, float4 (&regs)[NK]) {
-    const int p0 = pbeg + t * kTile;
+  const int plast = P - 4 - 4 * lcol;  // clamp so that the float4 stays inside the row (P % 4 == 0)
+  auto fetch = [&](int t, float4 (&regs)[RPW]) {  // t relative to t0, clamped to the run
+    const int tau = t0 + min(t, ntile - 1);
+    const int b = tau / tpg;
+    const int p0 = (tau - b * tpg) * kTile;
+    const float keep = (p0 + 4 * lcol < P) ? 1.f : 0.f;
+    const int poff = min(p0, plast);
 #pragma unroll
-    for (int k = 0; k < NK; ++k) {
-      const int p = p0 + qpos[k];
-      const float4 v = *reinterpret_cast<const float4*>(src[k] + min(p, plast));
-      regs[k] = (p < pend) ? v : f4zero();  // select, not a branch
+    for (int k = 0; k < RPW; ++k) {
+      // tail positions are zeroed by a multiply, not a select: hipcc sinks a load that only feeds a
+      // select into a branch, and a load inside a branch costs the counted vmcnt waits (the
+      // clamped address re-reads finite in-row data, so x * 0 is exact)
+      const float4 v = *reinterpret_cast<const float4*>(src[k] + (size_t)b * gstride[k] + poff);
+      regs[k] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
     }
   };
-  auto stash = [&](const float4 (&regs)[NK]) {  // slots past the last row are scratch (never read)
+  auto stash = [&](const float4 (&regs)[RPW]) {
 #pragma unroll
-    for (int k = 0; k < NK; ++k) buf[lane + 64 * k] = regs[k];
+    for (int k = 0; k < RPW; ++k) {
+      const int rr = (wave + kCpWaves * k) * kRPI + lrow;
+      if (rr < kZeroRow) lds4[rr * kRowF4 + lcol] = regs[k];
+    }
   };
 
-  // fragment words of this lane: word kq of chunk qq of its row (the zero row when the channel is absent)
-  const float* bufw = reinterpret_cast<const float*>(buf);
-  int aw[MA][4], bw[NB][4];
+  // fragment words of this lane: word kq of chunk (8*wave + qq) of its row
+  const float* ldsw = reinterpret_cast<const float*>(lds4);
+  int aw[MA], bw[NB];
 #pragma unroll
   for (int ma = 0; ma < MA; ++ma) {
     const int row = (ma * 16 + j < ca) ? ma * 16 + j : kZeroRow;
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) aw[ma][qq] = (row * 4 + (qq ^ ((row >> 2) & 3))) * 4 + kq;
+    aw[ma] = row * (kRowF4 * 4) + 32 * wave + kq;
   }
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int row = (nb * 16 + j < cb) ? ca + nb * 16 + j : kZeroRow;
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) bw[nb][qq] = (row * 4 + (qq ^ ((row >> 2) & 3))) * 4 + kq;
+    bw[nb] = row * (kRowF4 * 4) + 32 * wave + kq;
   }
 
   f32x4 acc[MA][NB];
@@ -290,32 +333,48 @@ __global__ __launch_bounds__(kBlock) void k_chanpair_mfma(
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[ma][nb] = zero4();
 
-  float4 regs[NK];
-  if (ntile > 0) {
-    fetch(0, regs);
-    stash(regs);
-  }
-  for (int t = 0; t < ntile; ++t) {
-    // next tile in flight while this one is multiplied; unconditional (the last trip re-reads its
-    // own tile) so the loop body stays one basic block with counted waits
-    fetch(min(t + 1, ntile - 1), regs);
+  auto multiply = [&]() {
 #pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
+    for (int qq = 0; qq < 8; ++qq) {
       float av[MA], bv[NB];
 #pragma unroll
-      for (int ma = 0; ma < MA; ++ma) av[ma] = bufw[aw[ma][qq]];
+      for (int ma = 0; ma < MA; ++ma) av[ma] = ldsw[aw[ma] + 4 * qq];
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) bv[nb] = bufw[bw[nb][qq]];
+      for (int nb = 0; nb < NB; ++nb) bv[nb] = ldsw[bw[nb] + 4 * qq];
 #pragma unroll
       for (int ma = 0; ma < MA; ++ma)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[ma][nb] = mfma16(av[ma], bv[nb], acc[ma][nb]);
     }
-    stash(regs);  // same wave, in-order LDS: the reads above are done
+  };
+  // two tiles in flight per wave (two register sets): while tile t is multiplied the loads of
+  // t+1 and t+2 are outstanding.  All fetches are unconditional (clamped tile index) to keep
+  // hipcc's vmcnt waits counted.
+  if (ntile > 0) {
+    float4 ra[RPW], rb[RPW];
+    fetch(0, ra);
+    fetch(1, rb);
+    MSGAT_STAMP(1);
+    for (int t = 0; t < ntile; t += 2) {
+      lds_barrier();  // every wave is done reading the previous tile
+      stash(ra);
+      lds_barrier();
+      if (t == 0) MSGAT_STAMP(2);
+      fetch(t + 2, ra);
+      multiply();
+      if (t == 0) MSGAT_STAMP(3);
+      lds_barrier();
+      stash(rb);
+      lds_barrier();
+      fetch(t + 3, rb);
+      if (t + 1 < ntile) multiply();  // wave-uniform; LDS reads and MFMAs only
+    }
   }
 
-  // sum the 4 waves' accumulators in a fixed order: element e = ((ma*NB + nb)*4 + reg)*64 + lane
-  float* red = reinterpret_cast<float*>(buf);
+  // sum the 8 waves' accumulators in a fixed order: element e = ((ma*NB + nb)*4 + reg)*64 + lane
+  MSGAT_STAMP(4);
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(lds4) + (size_t)wave * (MA * NB * 256);
 #pragma unroll
   for (int ma = 0; ma < MA; ++ma)
 #pragma unroll
@@ -324,48 +383,51 @@ __global__ __launch_bounds__(kBlock) void k_chanpair_mfma(
       for (int reg = 0; reg < 4; ++reg) red[((ma * NB + nb) * 4 + reg) * 64 + lane] = acc[ma][nb][reg];
   __syncthreads();
   const float* all = reinterpret_cast<const float*>(lds4);
-  const int wstride = wave_f4 * 4;
-  float* out = part + ((size_t)g * nspan + sp) * ((size_t)Ca * Cb);
-  for (int e = threadIdx.x; e < MA * NB * 256; e += kBlock) {
-    const float v = (all[e] + all[wstride + e]) + (all[2 * wstride + e] + all[3 * wstride + e]);
+  float* out = part + ((size_t)r * nblk + blockIdx.x) * ((size_t)Ca * Cb);
+  for (int e = threadIdx.x; e < MA * NB * 256; e += kCpBlock) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < kCpWaves; ++w) v += all[w * (MA * NB * 256) + e];
     const int el = e & 63, reg = (e >> 6) & 3, tile = e >> 8;
     const int ma = tile / NB, nb = tile - ma * NB;
     const int a = a0 + ma * 16 + 4 * (el >> 4) + reg;  // D row = 4*(lane >> 4) + reg
     const int c = c0 + nb * 16 + (el & 15);            // D column = lane & 15
     if (a < Ca && c < Cb) out[(size_t)a * Cb + c] = v;
   }
+  MSGAT_STAMP(5);
 }
 
-int chanpair_mfma_spans(int P) { return cdiv(P, kSpan); }
+// blocks per relation: one block per CU in total (the kernel is built for one resident block per CU)
+int chanpair_mfma_blocks(int R) {
+  int dev = 0, ncu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+    ncu = 256;  // MI355X
+  return max(1, ncu / R);
+}
 
 template <int MA, int NB>
-static int launch_chanpair_t(const float* A, const float* Aextra, const float* B, float* part, int G,
-                             int Ca, int Cb, int P, hipStream_t s) {
-  const int nspan = cdiv(P, kSpan);
+static int launch_chanpair_t(const float* A, const float* Aextra, const float* B, float* part, int R, int Bg,
+                             int Ca, int Cb, int P, int nblk, hipStream_t s) {
   const int nza = cdiv(Ca, MA * 16), nzb = cdiv(Cb, NB * 16);
-  const int rows_max = min(MA * 16, Ca) + min(NB * 16, Cb);
-  // per wave: NK*64 staging slots + the zero row, reused for the MA*NB*256-float reduction
-  constexpr int NK = ((MA + NB) * 16 * 4 + 63) / 64;
-  const int wave_f4 = max(NK * 64 + 4, MA * NB * 64);
-  (void)rows_max;
-  const size_t lds = (size_t)4 * wave_f4 * sizeof(float4);
+  // tile rows + the zero row, reused for the 8 x MA*NB*256-float reduction
+  const size_t lds = sizeof(float4) * (size_t)max(((MA + NB) * 16 + 1) * kRowF4, kCpWaves * MA * NB * 64);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chanpair_mfma<MA, NB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
   }
-  dim3 grid(nspan, G, nza * nzb);
-  hipLaunchKernelGGL((k_chanpair_mfma<MA, NB>), grid, dim3(kBlock), lds, s, A, Aextra, B, part, Ca, Cb, P,
-                     nspan, nzb, wave_f4);
+  dim3 grid(nblk, R, nza * nzb);
+  hipLaunchKernelGGL((k_chanpair_mfma<MA, NB>), grid, dim3(kCpBlock), lds, s, A, Aextra, B, part, Ca, Cb, P, Bg,
+                     nzb);
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
 
-int launch_chanpair_mfma(const float* A, const float* Aextra, const float* B, float* part, int G,
-                         int Ca, int Cb, int P, hipStream_t s) {
+int launch_chanpair_mfma(const float* A, const float* Aextra, const float* B, float* part, int R, int Bg,
+                         int Ca, int Cb, int P, int nblk, hipStream_t s) {
   const int MA = min(cdiv(Ca, 16), 3), NB = min(cdiv(Cb, 16), 6);
 #define MSGAT_CP(ma, nb) \
-  if (MA == ma && NB == nb) return launch_chanpair_t<ma, nb>(A, Aextra, B, part, G, Ca, Cb, P, s);
+  if (MA == ma && NB == nb) return launch_chanpair_t<ma, nb>(A, Aextra, B, part, R, Bg, Ca, Cb, P, nblk, s);
   MSGAT_CP(1, 1) MSGAT_CP(1, 2) MSGAT_CP(1, 3) MSGAT_CP(1, 4) MSGAT_CP(1, 5) MSGAT_CP(1, 6)
   MSGAT_CP(2, 1) MSGAT_CP(2, 2) MSGAT_CP(2, 3) MSGAT_CP(2, 4) MSGAT_CP(2, 5) MSGAT_CP(2, 6)
   MSGAT_CP(3, 1) MSGAT_CP(3, 2) MSGAT_CP(3, 3) MSGAT_CP(3, 4) MSGAT_CP(3, 5) MSGAT_CP(3, 6)

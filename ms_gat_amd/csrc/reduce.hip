@@ -103,18 +103,21 @@ int launch_dwg(const float* q, const float* dkW, float* part, float* dWg, int G,
 }
 
 // ---- channel-pair contraction over positions --------------------------------------------------------
-// k_chanpair_mfma (mfma.hip) leaves one [Ca x Cb] partial per 1024-position span; the fixed-order
-// sum over a relation's groups and spans happens here.
-size_t chanpair_partial_floats(int G, int Ca, int Cb, int P) {
-  return (size_t)G * chanpair_mfma_spans(P) * Ca * Cb;
+// k_chanpair_mfma (mfma.hip) leaves one [Ca x Cb] partial per block of its persistent grid; the
+// fixed-order sum over a relation's blocks happens here.
+size_t chanpair_partial_floats(int G, int Bg, int Ca, int Cb) {
+  const int R = G / Bg;
+  return (size_t)R * chanpair_mfma_blocks(R) * Ca * Cb;
 }
 
 int launch_chanpair(const float* A, const float* Aextra, const float* B, float* part, float* dst0,
                     int n0, float* dst1, int n1, int G, int Bg, int Ca, int Cb, int P,
                     hipStream_t s) {
-  const int st = launch_chanpair_mfma(A, Aextra, B, part, G, Ca, Cb, P, s);
+  const int R = G / Bg;
+  const int nblk = chanpair_mfma_blocks(R);
+  const int st = launch_chanpair_mfma(A, Aextra, B, part, R, Bg, Ca, Cb, P, nblk, s);
   if (st) return st;
-  return launch_reduce_partials(part, G / Bg, Bg * chanpair_mfma_spans(P), Ca * Cb, dst0, n0, dst1, n1, s);
+  return launch_reduce_partials(part, R, nblk, Ca * Cb, dst0, n0, dst1, n1, s);
 }
 
 }  // namespace msgat
