@@ -55,6 +55,26 @@ inline int slab_channels(int N, int T, int Cu, int budget_bytes) {
   return ch;
 }
 
+// Diagnostic builds only (tools/*_stamps.hip compile a kernel file with -DMSGAT_STAMPS): s_memtime
+// stamps of the phases of a block, written to a buffer nothing else reads.  The product library is
+// built without the macro and contains no stamp.
+#ifdef MSGAT_STAMPS
+__device__ unsigned long long g_stamps[8 * 4096];
+#define MSGAT_STAMP(i)                                                                             \
+  do {                                                                                             \
+    if (threadIdx.x == 0 && blockIdx.z == 0) {                                                     \
+      const unsigned b__ = blockIdx.y * gridDim.x + blockIdx.x;                                    \
+      if (b__ < 4096) {                                                                            \
+        g_stamps[b__ * 8 + (i)] = __builtin_amdgcn_s_memtime();                                    \
+        if ((i) == 0) g_stamps[b__ * 8 + 6] = __builtin_amdgcn_s_memrealtime();                    \
+        if ((i) == 5) g_stamps[b__ * 8 + 7] = __builtin_amdgcn_s_memrealtime();                    \
+      }                                                                                            \
+    }                                                                                              \
+  } while (0)
+#else
+#define MSGAT_STAMP(i)
+#endif
+
 // ---- kernel launchers (defined in the .hip files) ---------------------------------
 int launch_qonly(const float* x, const float* alpha, float* q, int G, int Bg, int C, int P,
                  hipStream_t s);

@@ -212,24 +212,6 @@ int launch_project_mfma(const float* in, const float* M, int m_in_major, const f
 // stamps showed the alternative -- one block per (group, 1024 positions) -- spending 45% of a
 // block in its exposed prologue, first-tile wait and reduction.
 
-// Diagnostic build only (tools/contract_stamps.hip): s_memtime stamps of the phases of one block.
-#ifdef MSGAT_STAMPS
-__device__ unsigned long long g_stamps[8 * 4096];
-#define MSGAT_STAMP(i)                                                                             \
-  do {                                                                                             \
-    if (threadIdx.x == 0 && blockIdx.z == 0) {                                                     \
-      const unsigned b = blockIdx.y * gridDim.x + blockIdx.x;                                      \
-      if (b < 4096) {                                                                              \
-        g_stamps[b * 8 + (i)] = __builtin_amdgcn_s_memtime();                                      \
-        if ((i) == 0) g_stamps[b * 8 + 6] = __builtin_amdgcn_s_memrealtime();                      \
-        if ((i) == 5) g_stamps[b * 8 + 7] = __builtin_amdgcn_s_memrealtime();                      \
-      }                                                                                            \
-    }                                                                                              \
-  } while (0)
-#else
-#define MSGAT_STAMP(i)
-#endif
-
 // Workgroup barrier for LDS hand-offs that leaves global loads in flight: __syncthreads() makes
 // hipcc drain vmcnt(0) first, which would serialise the register prefetch against the barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
