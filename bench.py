@@ -255,18 +255,19 @@ def main():
         cores = min(len(os.sched_getaffinity(0)), 16)  # the GPU box gives one GPU a 16-core share
         torch.set_num_threads(cores)
         cpu = torch.device("cpu")
-        Bs = max(1, min(wl["B"], 4))
+        Bs = wl["B"] if wl["N"] <= 1024 else max(1, wl["B"] // 8)  # bounded: ~10-20 s of host time
         dense_reference_step(hp, cpu, Bs)  # warm-up
         t0 = time.perf_counter()
         n = 0
-        while n < 2 or (time.perf_counter() - t0 < 10.0 and n < 20):
+        while n < 3 or (time.perf_counter() - t0 < 12.0 and n < 40):
             dense_reference_step(hp, cpu, Bs)
             n += 1
         dt = (time.perf_counter() - t0) / n
         out["cpu_baseline"] = {
             "value": round(Bs / dt, 3), "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": (f"{n} fwd+bwd passes of oracle/dense_torch.py (the reference's dense op sequence) on "
-                       f"{Bs} of the {wl['B']} samples per relation, same graph/relations/widths, {cores} torch threads"),
+                       f"{Bs} of the {wl['B']} samples per relation, all {wl['R']} relations and both GACN depths, "
+                       f"same graph and widths, {cores} torch threads"),
         }
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -270,14 +270,34 @@ int launch_scores(const msgat_graph_t& gr, const float* q, const float* Wg, floa
   return MSGAT_ERR_UNSUPPORTED;
 }
 
-// ---- backward: per-row edge pass ---------------------------------------------------------
-// dE_e = sum of the per-chunk partials; g_e = E_e dE_e; delta_n = sum_e g_e;
-// dkW[n] = sum_e g_e (q[col_e] - pq[n]);  dq[n] = dkW[n] Wg^T  (row-local part of dq)
+// ---- backward: edge and row passes ---------------------------------------------------------
+// k_edge_grad (one lane per edge, coalesced over e):  dE_e = sum of the per-chunk SDDMM partials,
+//   g_e = E_e dE_e.
+// k_bwd_row (one lane per row): delta_n = sum_e g_e;  dkW[n] = sum_e g_e (q[col_e] - pq[n]);
+//   dq[n] = dkW[n] Wg^T  (the row-local part of dq).
+__global__ __launch_bounds__(kBlock) void k_edge_grad(const float* __restrict__ dEp, int nchunks,
+                                                      const float* __restrict__ E,
+                                                      float* __restrict__ gE, int nnz) {
+  const int g = blockIdx.y;
+  const int e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= nnz) return;
+  const float* p = dEp + (size_t)g * nchunks * nnz + e;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int k = 0;
+  for (; k + 4 <= nchunks; k += 4) {  // 4 independent loads in flight; fixed summation order
+    a0 += p[(size_t)(k + 0) * nnz];
+    a1 += p[(size_t)(k + 1) * nnz];
+    a2 += p[(size_t)(k + 2) * nnz];
+    a3 += p[(size_t)(k + 3) * nnz];
+  }
+  for (; k < nchunks; ++k) a0 += p[(size_t)k * nnz];
+  gE[(size_t)g * nnz + e] = E[(size_t)g * nnz + e] * ((a0 + a1) + (a2 + a3));
+}
+
 template <int T>
-__global__ __launch_bounds__(kBlock) void k_bwd_edge(
-    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dEp,
-    int nchunks, const float* __restrict__ E, const float* __restrict__ q,
-    const float* __restrict__ pq, const float* __restrict__ Wg, float* __restrict__ gE,
+__global__ __launch_bounds__(kBlock) void k_bwd_row(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ gE,
+    const float* __restrict__ q, const float* __restrict__ pq, const float* __restrict__ Wg,
     float* __restrict__ delta, float* __restrict__ dkW, float* __restrict__ dq, int Bg, int N,
     int nnz) {
   constexpr int T4 = T / 4;
@@ -294,21 +314,30 @@ __global__ __launch_bounds__(kBlock) void k_bwd_edge(
     dk[4 * t4 + 0] = 0.f; dk[4 * t4 + 1] = 0.f; dk[4 * t4 + 2] = 0.f; dk[4 * t4 + 3] = 0.f;
   }
   // dkW[n] = sum_e g_e q[col_e] - delta_n pq[n] = sum_e g_e (q[col_e] - pq[n]): subtracting
-  // first keeps a saturated (one-hot) row exact -- pq[n] then equals q[col_e] bit for bit
-  for (int e = rowptr[n]; e < rowptr[n + 1]; ++e) {
-    float dE = 0.f;
-    for (int k = 0; k < nchunks; ++k) dE += dEp[((size_t)g * nchunks + k) * nnz + e];
-    const float ge = E[(size_t)g * nnz + e] * dE;
-    gE[(size_t)g * nnz + e] = ge;
-    d += ge;
-    const float4* qm = reinterpret_cast<const float4*>(q + ((size_t)g * N + col[e]) * T);
+  // first keeps a saturated (one-hot) row exact -- pq[n] then equals q[col_e] bit for bit.
+  // Two edges per trip: their index / weight loads are independent and issue together.
+  const float* gEg = gE + (size_t)g * nnz;
+  const float* qg = q + (size_t)g * N * T;
+  const int e1 = rowptr[n + 1];
+  for (int e = rowptr[n]; e < e1; e += 2) {
+    const int eb = min(e + 1, e1 - 1);
+    const float ga = gEg[e];
+    const float gb = (e + 1 < e1) ? gEg[eb] : 0.f;
+    const float4* qa = reinterpret_cast<const float4*>(qg + (size_t)col[e] * T);
+    const float4* qb = reinterpret_cast<const float4*>(qg + (size_t)col[eb] * T);
+    d += ga;
+    d += gb;
 #pragma unroll
     for (int t4 = 0; t4 < T4; ++t4) {
-      const float4 v = qm[t4];
-      dk[4 * t4 + 0] = fmaf(ge, v.x - pr[4 * t4 + 0], dk[4 * t4 + 0]);
-      dk[4 * t4 + 1] = fmaf(ge, v.y - pr[4 * t4 + 1], dk[4 * t4 + 1]);
-      dk[4 * t4 + 2] = fmaf(ge, v.z - pr[4 * t4 + 2], dk[4 * t4 + 2]);
-      dk[4 * t4 + 3] = fmaf(ge, v.w - pr[4 * t4 + 3], dk[4 * t4 + 3]);
+      const float4 va = qa[t4], vb = qb[t4];
+      dk[4 * t4 + 0] = fmaf(ga, va.x - pr[4 * t4 + 0], dk[4 * t4 + 0]);
+      dk[4 * t4 + 1] = fmaf(ga, va.y - pr[4 * t4 + 1], dk[4 * t4 + 1]);
+      dk[4 * t4 + 2] = fmaf(ga, va.z - pr[4 * t4 + 2], dk[4 * t4 + 2]);
+      dk[4 * t4 + 3] = fmaf(ga, va.w - pr[4 * t4 + 3], dk[4 * t4 + 3]);
+      dk[4 * t4 + 0] = fmaf(gb, vb.x - pr[4 * t4 + 0], dk[4 * t4 + 0]);
+      dk[4 * t4 + 1] = fmaf(gb, vb.y - pr[4 * t4 + 1], dk[4 * t4 + 1]);
+      dk[4 * t4 + 2] = fmaf(gb, vb.z - pr[4 * t4 + 2], dk[4 * t4 + 2]);
+      dk[4 * t4 + 3] = fmaf(gb, vb.w - pr[4 * t4 + 3], dk[4 * t4 + 3]);
     }
   }
   float4* dkdst = reinterpret_cast<float4*>(dkW + ((size_t)g * N + n) * T);
@@ -332,18 +361,23 @@ __global__ __launch_bounds__(kBlock) void k_bwd_edge(
 int launch_bwd_edge(const msgat_graph_t& gr, const float* dEp, int nchunks, const float* E,
                     const float* q, const float* pq, const float* Wg, float* gE, float* delta,
                     float* dkW, float* dq, int G, int Bg, int N, int T, hipStream_t s) {
+  if (gr.nnz > 0) {
+    dim3 ge(cdiv(gr.nnz, kBlock), G);
+    hipLaunchKernelGGL(k_edge_grad, ge, dim3(kBlock), 0, s, dEp, nchunks, E, gE, gr.nnz);
+    MSGAT_CHECK_LAUNCH();
+  }
   dim3 grid(cdiv(N, kBlock), G);
-#define MSGAT_EDGE(TT)                                                                            \
-  hipLaunchKernelGGL(k_bwd_edge<TT>, grid, dim3(kBlock), 0, s, gr.rowptr, gr.col, dEp, nchunks, E, q, \
-                     pq, Wg, gE, delta, dkW, dq, Bg, N, gr.nnz)
+#define MSGAT_ROW(TT)                                                                               \
+  hipLaunchKernelGGL(k_bwd_row<TT>, grid, dim3(kBlock), 0, s, gr.rowptr, gr.col, gE, q, pq, Wg, delta, \
+                     dkW, dq, Bg, N, gr.nnz)
   switch (T) {
-    case 4: MSGAT_EDGE(4); break;
-    case 8: MSGAT_EDGE(8); break;
-    case 12: MSGAT_EDGE(12); break;
-    case 16: MSGAT_EDGE(16); break;
+    case 4: MSGAT_ROW(4); break;
+    case 8: MSGAT_ROW(8); break;
+    case 12: MSGAT_ROW(12); break;
+    case 16: MSGAT_ROW(16); break;
     default: return MSGAT_ERR_UNSUPPORTED;
   }
-#undef MSGAT_EDGE
+#undef MSGAT_ROW
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
