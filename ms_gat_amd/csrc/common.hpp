@@ -60,13 +60,18 @@ inline int slab_channels(int N, int T, int Cu, int budget_bytes) {
 // built without the macro and contains no stamp.
 #ifdef MSGAT_STAMPS
 __device__ unsigned long long g_stamps[8 * 4096];
+__device__ unsigned g_hwid[4096];  // (XCC_ID << 16) | HW_ID of the block's first wave
 #define MSGAT_STAMP(i)                                                                             \
   do {                                                                                             \
     if (threadIdx.x == 0 && blockIdx.z == 0) {                                                     \
       const unsigned b__ = blockIdx.y * gridDim.x + blockIdx.x;                                    \
       if (b__ < 4096) {                                                                            \
         g_stamps[b__ * 8 + (i)] = __builtin_amdgcn_s_memtime();                                    \
-        if ((i) == 0) g_stamps[b__ * 8 + 6] = __builtin_amdgcn_s_memrealtime();                    \
+        if ((i) == 0) {                                                                            \
+          g_stamps[b__ * 8 + 6] = __builtin_amdgcn_s_memrealtime();                                \
+          g_hwid[b__] = (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 16) |      \
+                        (__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (15 << 11)) & 0xffff);    \
+        }                                                                                          \
         if ((i) == 5) g_stamps[b__ * 8 + 7] = __builtin_amdgcn_s_memrealtime();                    \
       }                                                                                            \
     }                                                                                              \

@@ -1,0 +1,388 @@
+// The dense side of the attention: everything that needs ALL N columns of a row.
+//
+// attention.py:34 takes softmax over the full [N] row of S = (k Wg) q^T and only then
+// (attention.py:36) multiplies by the adjacency, so the normaliser of every edge
+// coefficient is a sum over all N columns.  Nothing N x N is ever written here:
+//
+//   forward   kW = q Wg;  lse[n] = log2 sum_m 2^(kW2[n].q[m])     (online max/sum, flash style)
+//             pq[n] = sum_m softmax(S)[n,m] q[m]                   (only when training)
+//             E[e]  = 2^(kW2[row_e].q[col_e] - lse[row_e]) * adj_e (edges only)
+//   backward  dq[m] -= sum_n softmax(S)[n,m] delta[n] kW[n]        (the dense column term)
+//
+// These kernels read [G,N,T] and are bound by fp32 issue, not HBM.  BOTH matrix products of a
+// 16x16 tile run on the matrix core as exact-fp32 v_mfma_f32_16x16x4_f32 (bf16 is not an option:
+// the scores feed an exp and the parity bar is 1e-4):
+//   1. scores   S = own . streamed^T      K = T     -> T/4 MFMAs (3 at T = 12)
+//   2. payload  acc += P . payload        K = 16    -> 4 MFMAs, the accumulator of (1), after the
+//      exp, IS the B operand of (2) with no data movement (its k index is just permuted, and the A
+//      operand is read from LDS in the matching order)
+// and the VALU is left with 4 exp + ~25 bookkeeping instructions per tile.  An all-VALU version of
+// these loops issued ~32 instructions per (row, column) pair and ran at ~75 us; a version with (1)
+// on MFMA and (2) on the VALU was paced by LDS broadcast traffic (in-kernel stamps).
+//
+// 16x16x4 layouts: A[i][k]: lane (i = lane & 15, k = lane >> 4); B[k][j]: lane (j = lane & 15,
+// k = lane >> 4); D[4*quad + r][j] in register r of lane (j = lane & 15, quad = lane >> 4).
+// The MFMA is a k-ordered fmaf chain starting from C, the same order as the VALU chain that
+// computes the edge scores, so edge pass and backward agree on every score bit for bit.
+#include "common.hpp"
+
+namespace msgat {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+constexpr int kDWaves = 4;             // the whole grid must be resident at once: leftover blocks run as a second round
+constexpr int kDBlock = 64 * kDWaves;
+constexpr int kDRows = 16 * kDWaves;   // own rows (forward) / columns (backward) per block
+constexpr int kDMC = 128;              // streamed columns (forward) / rows (backward) staged per step
+constexpr int kPS = 20;                // floats per staged payload row: T <= 16 values, zero padded;
+                                       // 20 makes the payload fragment read bank-conflict free
+constexpr float kDefer = 8.f;          // re-base the running max only when a score exceeds it by 2^8
+
+// Every block of these grids does the same work and the whole grid is resident at once, but the
+// dispatcher packs workgroups onto a CU until a resource runs out (in-kernel stamps: some CUs held
+// 8 blocks, others 3, and the kernel ran 1.7x longer than its median block).  Asking for unused
+// dynamic LDS caps the blocks per CU at ceil(blocks / CUs), which forces an even spread.
+static size_t balance_pad_bytes(int nblocks, size_t static_lds) {
+  int dev = 0, ncu = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+    ncu = 256;  // MI355X
+  const int per_cu = cdiv(nblocks, ncu);
+  const size_t share = (size_t)kLdsMax / per_cu;  // LDS a block may occupy so that exactly per_cu fit
+  if (share <= static_lds + 1024) return 0;        // already limited by its own LDS
+  size_t pad = share - static_lds - 512;
+  if (pad > 64 * 1024 - 256) pad = 64 * 1024 - 256;  // stay under the default dynamic-LDS limit
+  return pad & ~(size_t)255;
+}
+
+// ---- forward -----------------------------------------------------------------------------------------
+// Wave w owns rows n0 + 16w .. +15 (B operand of the score product: their kW2) and streams all
+// columns.  Score tile D[i = column][j = row]: lane (row j, quad) holds its row against columns
+// m0 + 4*quad + r.  Payload tile D2[i = timestep s][j = row] += q[m][s] P[row][m].
+template <int T, bool WITH_PQ>
+__global__ __launch_bounds__(kDBlock) void k_scores(
+    const float* __restrict__ q, const float* __restrict__ Wg, const int* __restrict__ rowptr,
+    const int* __restrict__ col, const float* __restrict__ val, const int* __restrict__ erow,
+    float* __restrict__ kW, float* __restrict__ lse, float* __restrict__ pq, float* __restrict__ E,
+    int Bg, int N, int nnz) {
+  constexpr int T4 = T / 4;
+  __shared__ float4 qs4[kDMC * kPS / 4];  // staged columns: [column][q(T) | zeros]
+  __shared__ float kw2s[kDRows][T];       // the block's rows, log2-scaled, for the edge pass
+  __shared__ float lse2s[kDRows];
+  const float* qsw = reinterpret_cast<const float*>(qs4);
+
+  const int g = blockIdx.y;
+  const int r = g / Bg;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = lane & 15, quad = lane >> 4;
+  const int n0 = blockIdx.x * kDRows;
+  const int n = n0 + 16 * wave + j;  // this lane's row (shared by its 4 quads)
+  const bool valid = n < N;
+  const float* qg = q + (size_t)g * N * T;
+  const float* wg = Wg + (size_t)r * T * T;
+
+  MSGAT_STAMP(0);
+  // B fragment of the row: kW2[n][4*kk + quad]; kW itself is stored unscaled
+  float bfrag[T4];
+  {
+    float qr[T];
+#pragma unroll
+    for (int t4 = 0; t4 < T4; ++t4) {
+      float4 v = f4zero();
+      if (valid) v = reinterpret_cast<const float4*>(qg + (size_t)n * T)[t4];
+      qr[4 * t4 + 0] = v.x; qr[4 * t4 + 1] = v.y; qr[4 * t4 + 2] = v.z; qr[4 * t4 + 3] = v.w;
+    }
+#pragma unroll
+    for (int kk = 0; kk < T4; ++kk) {
+      const int s = 4 * kk + quad;
+      float a = 0.f;
+#pragma unroll
+      for (int t = 0; t < T; ++t) a = fmaf(qr[t], wg[t * T + s], a);
+      if (valid) kW[((size_t)g * N + n) * T + s] = a;
+      bfrag[kk] = a * kLog2e;  // scores in log2 units: exp(x) = 2^(x log2 e)
+      kw2s[16 * wave + j][s] = bfrag[kk];
+    }
+  }
+
+  MSGAT_STAMP(1);
+  float m = -3.0e38f;  // running max of the row, identical in its 4 quads; finite floor, not -inf
+  float lsum = 0.f;    // this quad's share of sum_m 2^(S - m)
+  f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = da, dc = da, dd = da;  // payload accumulators (four independent chains)
+
+  // Staging is double-buffered through registers: the loads of chunk c+1 are issued before chunk c
+  // is multiplied and land in LDS after it.  All blocks of the grid are resident at once, so a
+  // block's own critical path -- not throughput -- set the kernel time while every chunk began
+  // with an exposed global-load round trip.
+  constexpr int kF4 = kPS / 4;                                   // float4s per staged column
+  constexpr int kSt = (kDMC * kF4 + kDBlock - 1) / kDBlock;       // staging float4s per lane per chunk
+  float4 pre[kSt];
+  auto prefetch = [&](int c0) {
+    const int cols = min(kDMC, N - c0);
+#pragma unroll
+    for (int k = 0; k < kSt; ++k) {
+      const int i = threadIdx.x + k * kDBlock;
+      const int c = i / kF4, f = i - c * kF4;
+      const bool live = (c < cols) && (f < T4);
+      const float4 v = reinterpret_cast<const float4*>(qg + (size_t)(c0 + (live ? c : 0)) * T)[live ? f : 0];
+      const float keep = live ? 1.f : 0.f;  // multiply, not select: keeps the load out of a branch
+      pre[k] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
+    }
+  };
+  prefetch(0);
+  for (int c0 = 0; c0 < N; c0 += kDMC) {
+    const int cols = min(kDMC, N - c0);
+    const int cols16 = (cols + 15) & ~15;
+    __syncthreads();  // every wave is done with the previous chunk
+#pragma unroll
+    for (int k = 0; k < kSt; ++k) {
+      const int i = threadIdx.x + k * kDBlock;
+      if (i < kDMC * kF4) qs4[i] = pre[k];
+    }
+    __syncthreads();
+    prefetch(min(c0 + kDMC, max(N - 1, 0) / kDMC * kDMC));  // next chunk (the last trip re-reads its own)
+    for (int m0 = 0; m0 < cols16; m0 += 16) {
+      f32x4 S = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < T4; ++kk) S = mfma16(qsw[(m0 + j) * kPS + 4 * kk + quad], bfrag[kk], S);
+      const int mq = m0 + 4 * quad;  // this lane's 4 columns: mq .. mq+3
+      float sv[4];
+      if (m0 + 16 > cols) {  // wave-uniform: only the chunk's last tile can hold padding columns
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) sv[rr] = (mq + rr < cols) ? S[rr] : -3.0e38f;
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) sv[rr] = S[rr];
+      }
+      const float cm = max3(max3(sv[0], sv[1], sv[2]), sv[3], sv[3]);
+      if (__any(cm > m + kDefer)) {  // rare (deferred re-base); the row's 4 quads must agree on m
+        float cx = fmaxf(cm, __shfl_xor(cm, 16));
+        cx = fmaxf(cx, __shfl_xor(cx, 32));
+        const float mn = fmaxf(m, cx);
+        const float sc = fast_exp2(m - mn);  // m at its floor on the first tile -> 0
+        m = mn;
+        lsum *= sc;
+        if (WITH_PQ) {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) { da[rr] *= sc; db[rr] *= sc; dc[rr] *= sc; dd[rr] *= sc; }
+        }
+      }
+      float p[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) p[rr] = fast_exp2(sv[rr] - m);
+      lsum += (p[0] + p[1]) + (p[2] + p[3]);
+      if (WITH_PQ) {
+        // A2[i = s][k = quad] = q[column mq + rr][s = j]; B2[k = quad][j = row] = p[rr]
+        da = mfma16(qsw[(mq + 0) * kPS + j], p[0], da);
+        db = mfma16(qsw[(mq + 1) * kPS + j], p[1], db);
+        dc = mfma16(qsw[(mq + 2) * kPS + j], p[2], dc);
+        dd = mfma16(qsw[(mq + 3) * kPS + j], p[3], dd);
+      }
+    }
+    if (c0 == 0) MSGAT_STAMP(2);
+  }
+
+  MSGAT_STAMP(3);
+  // the row's 4 quads share m: their partial sums simply add
+  lsum += __shfl_xor(lsum, 16);
+  lsum += __shfl_xor(lsum, 32);
+  const float lse2 = m + fast_log2(lsum);
+  if (quad == 0) {
+    lse2s[16 * wave + j] = lse2;
+    if (valid) lse[(size_t)g * N + n] = lse2;  // log2 units: backward re-creates the exponent bit for bit
+  }
+  if (WITH_PQ && valid && quad < T4) {  // D2[s = 4*quad + rr][row]: this lane owns pq[n][4*quad .. +3]
+    const float inv = 1.0f / lsum;
+    reinterpret_cast<float4*>(pq + ((size_t)g * N + n) * T)[quad] =
+        make_float4(((da[0] + db[0]) + (dc[0] + dd[0])) * inv, ((da[1] + db[1]) + (dc[1] + dd[1])) * inv,
+                    ((da[2] + db[2]) + (dc[2] + dd[2])) * inv, ((da[3] + db[3]) + (dc[3] + dd[3])) * inv);
+  }
+  __syncthreads();
+  MSGAT_STAMP(4);
+
+  // edge coefficients of this block's rows: one lane per CSR edge, coalesced over e.  The VALU
+  // chain below is the MFMA's k order starting from 0, exactly what k_bwd_dense_col re-creates.
+  const int e0 = rowptr[n0];
+  const int e1 = rowptr[min(n0 + kDRows, N)];
+  for (int e = e0 + threadIdx.x; e < e1; e += kDBlock) {
+    const int nl = erow[e] - n0;
+    const float4* qm = reinterpret_cast<const float4*>(qg + (size_t)col[e] * T);
+    float a = 0.f;
+#pragma unroll
+    for (int t4 = 0; t4 < T4; ++t4) {
+      const float4 v = qm[t4];
+      a = fmaf(v.x, kw2s[nl][4 * t4 + 0], a);
+      a = fmaf(v.y, kw2s[nl][4 * t4 + 1], a);
+      a = fmaf(v.z, kw2s[nl][4 * t4 + 2], a);
+      a = fmaf(v.w, kw2s[nl][4 * t4 + 3], a);
+    }
+    E[(size_t)g * nnz + e] = fast_exp2(a - lse2s[nl]) * val[e];
+  }
+  MSGAT_STAMP(5);
+}
+
+template <int T>
+static int launch_scores_t(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW,
+                           float* lse, float* pq, float* E, int G, int Bg, int N, hipStream_t s) {
+  dim3 grid(cdiv(N, kDRows), G);
+  const size_t static_lds = sizeof(float) * (kDMC * kPS + kDRows * T + kDRows);
+  const size_t pad = balance_pad_bytes((int)(grid.x * grid.y), static_lds);
+  if (pq != nullptr)
+    hipLaunchKernelGGL((k_scores<T, true>), grid, dim3(kDBlock), pad, s, q, Wg, gr.rowptr, gr.col, gr.val,
+                       gr.erow, kW, lse, pq, E, Bg, N, gr.nnz);
+  else
+    hipLaunchKernelGGL((k_scores<T, false>), grid, dim3(kDBlock), pad, s, q, Wg, gr.rowptr, gr.col, gr.val,
+                       gr.erow, kW, lse, pq, E, Bg, N, gr.nnz);
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
+}
+
+int launch_scores(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW, float* lse,
+                  float* pq, float* E, int G, int Bg, int N, int T, hipStream_t s) {
+  switch (T) {
+    case 4: return launch_scores_t<4>(gr, q, Wg, kW, lse, pq, E, G, Bg, N, s);
+    case 8: return launch_scores_t<8>(gr, q, Wg, kW, lse, pq, E, G, Bg, N, s);
+    case 12: return launch_scores_t<12>(gr, q, Wg, kW, lse, pq, E, G, Bg, N, s);
+    case 16: return launch_scores_t<16>(gr, q, Wg, kW, lse, pq, E, G, Bg, N, s);
+  }
+  return MSGAT_ERR_UNSUPPORTED;
+}
+
+// ---- backward: dense column pass ------------------------------------------------------------------------
+// Wave w owns columns m0 + 16w .. +15 (B operand of the score product: their q) and streams all rows
+// through LDS: kW2 rows (A operand), delta*kW rows (payload) and lse2.  Score tile D[i = row][j = column]:
+// lane (column j, quad) holds rows rb + 4*quad + r.  Payload tile D2[i = s][j = column] +=
+// (delta kW)[row][s] P[row][column].
+//   dq[m] += sum_{e into m} g_e kW[row_e]  -  sum_n 2^(kW2[n].q[m] - lse2[n]) delta[n] kW[n]
+template <int T>
+__global__ __launch_bounds__(kDBlock) void k_bwd_dense_col(
+    const float* __restrict__ q, const float* __restrict__ kW, const float* __restrict__ lse,
+    const float* __restrict__ delta, const float* __restrict__ gE, const int* __restrict__ colptr,
+    const int* __restrict__ crow, const int* __restrict__ cperm, float* __restrict__ dq, int N,
+    int nnz) {
+  constexpr int T4 = T / 4;
+  __shared__ float4 kwr4[kDMC * T4];        // [row][kW2(T)]
+  __shared__ float4 dkr4[kDMC * kPS / 4];   // [row][delta*kW(T) | zeros]
+  __shared__ float4 lse4[kDMC / 4];         // [row] lse2 (+inf past the end)
+  const float* kwr = reinterpret_cast<const float*>(kwr4);
+  const float* dkr = reinterpret_cast<const float*>(dkr4);
+  float* lsew = reinterpret_cast<float*>(lse4);
+
+  const int g = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = lane & 15, quad = lane >> 4;
+  const int mcol = blockIdx.x * kDRows + 16 * wave + j;  // this lane's column (shared by its 4 quads)
+  const bool valid = mcol < N;
+  const float* qg = q + (size_t)g * N * T;
+  const float* kWg = kW + (size_t)g * N * T;
+
+  float bfrag[T4];  // B fragment: q[mcol][4*kk + quad]
+#pragma unroll
+  for (int kk = 0; kk < T4; ++kk) bfrag[kk] = valid ? qg[(size_t)mcol * T + 4 * kk + quad] : 0.f;
+
+  f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = da, dc = da, dd = da;  // four independent accumulate chains
+
+  // register-prefetched staging (see k_scores): one row per lane per chunk
+  static_assert(kDMC <= kDBlock, "at most one staged row per lane");
+  float4 prek[T4];
+  float pred = 0.f, prel = 0.f;
+  auto prefetch = [&](int r0) {
+    const int rows = min(kDMC, N - r0);
+    const bool live = (int)threadIdx.x < rows;  // lanes >= kDMC never stage
+    const int nr = r0 + (live ? (int)threadIdx.x : 0);
+    const float keep = live ? 1.f : 0.f;  // multiply, not select: keeps the loads out of a branch
+    const float4* kr = reinterpret_cast<const float4*>(kWg + (size_t)nr * T);
+#pragma unroll
+    for (int t4 = 0; t4 < T4; ++t4) {
+      const float4 v = kr[t4];
+      prek[t4] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
+    }
+    pred = delta[(size_t)g * N + nr] * keep;
+    const float lv = lse[(size_t)g * N + nr];
+    prel = live ? lv : INFINITY;  // exp2(s - inf) = 0 for rows past the end
+  };
+  prefetch(0);
+  for (int r0 = 0; r0 < N; r0 += kDMC) {
+    const int rows = min(kDMC, N - r0);
+    const int rows16 = (rows + 15) & ~15;
+    __syncthreads();  // every wave is done with the previous chunk
+    if (threadIdx.x < kDMC) {
+      const int i = threadIdx.x;
+#pragma unroll
+      for (int t4 = 0; t4 < kPS / 4; ++t4) {
+        const float4 v = (t4 < T4) ? prek[t4 < T4 ? t4 : 0] : f4zero();
+        if (t4 < T4) kwr4[i * T4 + t4] = make_float4(v.x * kLog2e, v.y * kLog2e, v.z * kLog2e, v.w * kLog2e);
+        dkr4[i * (kPS / 4) + t4] = make_float4(v.x * pred, v.y * pred, v.z * pred, v.w * pred);
+      }
+      lsew[i] = prel;
+    }
+    __syncthreads();
+    prefetch(min(r0 + kDMC, max(N - 1, 0) / kDMC * kDMC));  // next chunk (the last trip re-reads its own)
+    // same products in the same k order as the forward's edge pass, accumulator starting at 0: the
+    // score is re-created bit for bit, so 2^(s - lse2) equals the forward's softmax value (rows that
+    // are one-hot on an edge cancel against the sparse term; a 1e-4 slip in the exponent would not).
+    for (int rb = 0; rb < rows16; rb += 16) {
+      f32x4 S = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < T4; ++kk) S = mfma16(kwr[(rb + j) * T + 4 * kk + quad], bfrag[kk], S);
+      const int rq = rb + 4 * quad;            // this lane's 4 rows: rq .. rq+3
+      const float4 l4 = lse4[rq >> 2];         // quad-uniform
+      const float p0 = fast_exp2(S[0] - l4.x), p1 = fast_exp2(S[1] - l4.y);
+      const float p2 = fast_exp2(S[2] - l4.z), p3 = fast_exp2(S[3] - l4.w);
+      // A2[i = s][k = quad] = (delta kW)[row rq + rr][s = j]; B2[k = quad][j = column] = p[rr]
+      da = mfma16(dkr[(rq + 0) * kPS + j], p0, da);
+      db = mfma16(dkr[(rq + 1) * kPS + j], p1, db);
+      dc = mfma16(dkr[(rq + 2) * kPS + j], p2, dc);
+      dd = mfma16(dkr[(rq + 3) * kPS + j], p3, dd);
+    }
+  }
+  if (!valid || quad >= T4) return;
+
+  // D2[s = 4*quad + rr][column]: this lane owns dq[mcol][4*quad .. +3]; add the sparse in-edge term
+  float4 sp = f4zero();
+  for (int k = colptr[mcol]; k < colptr[mcol + 1]; ++k) {
+    const float ge = gE[(size_t)g * nnz + cperm[k]];
+    const float4 v = reinterpret_cast<const float4*>(kWg + (size_t)crow[k] * T)[quad];
+    sp.x = fmaf(ge, v.x, sp.x);
+    sp.y = fmaf(ge, v.y, sp.y);
+    sp.z = fmaf(ge, v.z, sp.z);
+    sp.w = fmaf(ge, v.w, sp.w);
+  }
+  float4* dst = reinterpret_cast<float4*>(dq + ((size_t)g * N + mcol) * T) + quad;
+  float4 v = *dst;
+  v.x += sp.x - ((da[0] + db[0]) + (dc[0] + dd[0]));
+  v.y += sp.y - ((da[1] + db[1]) + (dc[1] + dd[1]));
+  v.z += sp.z - ((da[2] + db[2]) + (dc[2] + dd[2]));
+  v.w += sp.w - ((da[3] + db[3]) + (dc[3] + dd[3]));
+  *dst = v;
+}
+
+int launch_bwd_dense_col(const msgat_graph_t& gr, const float* q, const float* kW,
+                         const float* lse, const float* delta, const float* gE, float* dq, int G,
+                         int N, int T, hipStream_t s) {
+  dim3 grid(cdiv(N, kDRows), G);
+  const size_t static_lds = sizeof(float) * (kDMC * T + kDMC * kPS + kDMC);
+  const size_t pad = balance_pad_bytes((int)(grid.x * grid.y), static_lds);
+#define MSGAT_DCOL(TT)                                                                                \
+  hipLaunchKernelGGL(k_bwd_dense_col<TT>, grid, dim3(kDBlock), pad, s, q, kW, lse, delta, gE, gr.colptr, \
+                     gr.crow, gr.cperm, dq, N, gr.nnz)
+  switch (T) {
+    case 4: MSGAT_DCOL(4); break;
+    case 8: MSGAT_DCOL(8); break;
+    case 12: MSGAT_DCOL(12); break;
+    case 16: MSGAT_DCOL(16); break;
+    default: return MSGAT_ERR_UNSUPPORTED;
+  }
+#undef MSGAT_DCOL
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
+}
+
+}  // namespace msgat
