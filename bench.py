@@ -141,6 +141,54 @@ def time_aggregate_kernel(hp, reps=20):
     return sec, bytes_
 
 
+class _DenseGACN(torch.nn.Module):
+    """The reference's dense GACN (oracle/dense_torch.py) behind the GACN interface: the eager
+    baseline for the full-model comparison.  Shares the parameters of the module it replaces."""
+
+    def __init__(self, gacn):
+        super().__init__()
+        self.gatt, self.W = gacn.gatt, gacn.W
+
+    def forward(self, signals, adjacency):
+        from oracle import dense_torch
+        return dense_torch.gacn_dense(signals, adjacency, self.gatt.Wg, self.gatt.alpha, self.W)
+
+
+def full_model_step_ms(wl, dev, dense, steps=6, warmup=3):
+    """One training step (forward, Huber loss, backward, Adam) of the whole msgat72 model with the HIP
+    graph branch, or with the reference's dense eager graph branch (`dense=True`)."""
+    from ms_gat_amd import engine, model
+    import ms_gat_amd
+    torch.manual_seed(0)
+    adj = ms_gat_amd.synthetic_adjacency(wl["N"], wl["E"], seed=0)
+    net = model.msgat72(n_components=wl["R"], in_channels=wl["Cin"], in_timesteps=wl["T"], out_timesteps=wl["T"],
+                        use_te=True, adj=adj).to(dev)
+    if dense:
+        for tpc in net.tpcs:
+            for meam in tpc.tgacns:
+                meam.gacn = _DenseGACN(meam.gacn)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=5e-4)
+    loss_fn = engine.HuberLoss(50.0)
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(wl["B"], wl["R"], wl["Cin"], wl["N"], wl["T"], generator=g).to(dev)
+    H = torch.randint(0, 24, (wl["B"],), generator=g).to(dev)
+    D = torch.randint(0, 7, (wl["B"],), generator=g).to(dev)
+    Y = (torch.randn(wl["B"], wl["N"], wl["T"], generator=g) * 30).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss_fn(net(X, H, D), Y).backward()
+        opt.step()
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
 def recorded_traffic(workload):
     """HBM bytes per launch of k_agg_lds from the PMC passes committed under profiles/ (FETCH_SIZE and
     WRITE_SIZE collected separately, gfx950 x2 correction on the fetch side; see profiles/*/hbm_traffic.json).
@@ -250,6 +298,13 @@ def main():
         out["forward_ms"] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
         out["speedup_vs_eager_rocm_forward"] = round(out["eager_rocm_forward_ms"] / out["forward_ms"], 2)
         out["speedup_vs_eager_rocm_fwd_bwd"] = round(out["eager_rocm_fwd_bwd_ms"] / ms_per_step, 2)
+
+        # secondary: the whole msgat72 training step, HIP graph branch vs the reference's dense eager one
+        try:
+            out["full_model_step_ms"] = round(full_model_step_ms(wl, dev, dense=False), 3)
+            out["full_model_dense_gacn_step_ms"] = round(full_model_step_ms(wl, dev, dense=True), 3)
+        except RuntimeError as e:  # e.g. the dense [B,N,N] tensors of the stress graph do not fit
+            out["full_model_error"] = str(e).splitlines()[0][:120]
 
         # CPU baseline: same op sequence on the host cores, bounded sample of the same workload
         cores = min(len(os.sched_getaffinity(0)), 16)  # the GPU box gives one GPU a 16-core share

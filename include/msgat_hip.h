@@ -187,6 +187,20 @@ int msgat_stage_contract(const msgat_shape_t* shape, int32_t Ca, int32_t Cb, con
                          const float* Aextra, const float* B, float* partials, float* dst0, int32_t n0,
                          float* dst1, int32_t n1, void* stream);
 
+/* ---- device: the producer of every GACN input -- LayerNorm over the timestep axis ----
+ * Replaces nn.LayerNorm([n_timesteps]) of the callers (src/models/msgat.py:114 applied at :122,
+ * :152 applied at :158): x is [rows, T] contiguous (rows = B*C*N), weight / bias are [T] or NULL
+ * (identity), eps as torch's (1e-5 in the reference), biased variance.
+ * Backward re-derives mean / rstd from x (nothing is saved but x): dx [rows,T], dweight / dbias [T]
+ * (either may be NULL) summed in a fixed order through `partials`
+ * (msgat_layernorm_partial_floats() floats).  T in {4, 8, 12, 16}. */
+int msgat_layernorm_forward(const float* x, const float* weight, const float* bias, float* y,
+                            int64_t rows, int32_t T, float eps, void* stream);
+size_t msgat_layernorm_partial_floats(int64_t rows, int32_t T);
+int msgat_layernorm_backward(const float* x, const float* weight, const float* dy, float* dx,
+                             float* dweight, float* dbias, float* partials, int64_t rows, int32_t T,
+                             float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

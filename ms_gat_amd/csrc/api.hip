@@ -171,6 +171,30 @@ extern "C" int msgat_stage_contract(const msgat_shape_t* sh, int32_t Ca, int32_t
                          sh->N * sh->T, (hipStream_t)stream);
 }
 
+// ---- LayerNorm over T (the producer of the GACN inputs) ----------------------------------------------
+extern "C" int msgat_layernorm_forward(const float* x, const float* weight, const float* bias, float* y,
+                                       int64_t rows, int32_t T, float eps, void* stream) {
+  if (!x || !y) return MSGAT_ERR_NULL;
+  if (rows < 0 || !(eps >= 0.f)) return MSGAT_ERR_SHAPE;
+  if (!t_supported(T)) return MSGAT_ERR_UNSUPPORTED;
+  if (rows == 0) return MSGAT_OK;
+  return launch_layernorm_fwd(x, weight, bias, y, rows, T, eps, (hipStream_t)stream);
+}
+
+extern "C" size_t msgat_layernorm_partial_floats(int64_t rows, int32_t T) {
+  if (rows <= 0 || !t_supported(T)) return 0;
+  return layernorm_partial_floats(rows, T);
+}
+
+extern "C" int msgat_layernorm_backward(const float* x, const float* weight, const float* dy, float* dx,
+                                        float* dweight, float* dbias, float* partials, int64_t rows,
+                                        int32_t T, float eps, void* stream) {
+  if (!x || !dy || !dx || !partials) return MSGAT_ERR_NULL;
+  if (rows <= 0 || !(eps >= 0.f)) return MSGAT_ERR_SHAPE;
+  if (!t_supported(T)) return MSGAT_ERR_UNSUPPORTED;
+  return launch_layernorm_bwd(x, weight, dy, dx, dweight, dbias, partials, rows, T, eps, (hipStream_t)stream);
+}
+
 // ---- fused forward ---------------------------------------------------------------------------------
 extern "C" int msgat_gacn_forward(const msgat_shape_t* sh, const msgat_graph_t* gr,
                                   const msgat_fwd_t* io, void* stream) {

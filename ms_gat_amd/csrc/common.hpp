@@ -125,5 +125,14 @@ size_t chanpair_partial_floats(int G, int Bg, int Ca, int Cb);
 int launch_chanpair(const float* A, const float* Aextra, const float* B, float* part, float* dst0,
                     int n0, float* dst1, int n1, int G, int Bg, int Ca, int Cb, int P,
                     hipStream_t s);
+// out[i] = sum_j part[j,i], i < Wd, split over dst0 (first n0) and dst1 (next n1); fixed order
+int launch_reduce_rows(const float* part, int J, int Wd, float* dst0, int n0, float* dst1, int n1,
+                       hipStream_t s);
+// LayerNorm over the last axis of [rows, T] (layernorm.hip)
+size_t layernorm_partial_floats(long long rows, int T);
+int launch_layernorm_fwd(const float* x, const float* w, const float* b, float* y, long long rows, int T,
+                         float eps, hipStream_t s);
+int launch_layernorm_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
+                         float* part, long long rows, int T, float eps, hipStream_t s);
 
 }  // namespace msgat

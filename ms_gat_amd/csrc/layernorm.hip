@@ -1,0 +1,143 @@
+// LayerNorm over the timestep axis: the producer of every GACN input.
+//
+// Reference: nn.LayerNorm([n_timesteps]) at /root/reference/src/models/msgat.py:114 (MEAM.ln, applied
+// at :122 right before the graph branch) and :152 (TPC.ln, applied at :158).  The normalised axis is
+// T = 12 contiguous floats; a [B,C,N,T] activation is B*C*N such rows (2 M rows at PEMSD7, B = 32,
+// C = 72).  PyTorch's LayerNorm kernels give every row its own thread group and run at ~80 GB/s here
+// (1.26 ms per call, 28 ms of a 61 ms training step in profiles/r01); one lane per row streams the
+// tensor at HBM speed instead.
+//
+//   forward   y = (x - mean) * rstd * w + b,   mean/var over the T values of a row (biased variance)
+//   backward  dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w
+//             dw[t] = sum_rows dy * xhat,  db[t] = sum_rows dy     (per-block partials, fixed-order sum)
+#include "common.hpp"
+
+namespace msgat {
+
+template <int T>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, float (&v)[T]) {
+#pragma unroll
+  for (int t4 = 0; t4 < T / 4; ++t4) {
+    const float4 a = reinterpret_cast<const float4*>(p)[t4];
+    v[4 * t4 + 0] = a.x; v[4 * t4 + 1] = a.y; v[4 * t4 + 2] = a.z; v[4 * t4 + 3] = a.w;
+  }
+}
+template <int T>
+__device__ __forceinline__ void store_row(float* __restrict__ p, const float (&v)[T]) {
+#pragma unroll
+  for (int t4 = 0; t4 < T / 4; ++t4)
+    reinterpret_cast<float4*>(p)[t4] = make_float4(v[4 * t4], v[4 * t4 + 1], v[4 * t4 + 2], v[4 * t4 + 3]);
+}
+// Centres a row in place and returns rstd.  The mean is taken of the differences to the row's first
+// value (exact for nearby floats), so a large common offset costs no accuracy -- the two-pass
+// formula on shifted data.
+template <int T>
+__device__ __forceinline__ float centre_row(float (&x)[T], float eps) {
+  const float x0 = x[0];
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < T; ++t) { x[t] -= x0; s += x[t]; }
+  const float md = s * (1.0f / T);
+  float v = 0.f;
+#pragma unroll
+  for (int t = 0; t < T; ++t) { x[t] -= md; v = fmaf(x[t], x[t], v); }
+  return rsqrtf(v * (1.0f / T) + eps);
+}
+
+template <int T>
+__global__ __launch_bounds__(kBlock) void k_ln_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ b, float* __restrict__ y,
+                                                   long long rows, float eps) {
+  float wv[T], bv[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) { wv[t] = w ? w[t] : 1.f; bv[t] = b ? b[t] : 0.f; }
+  for (long long r = (long long)blockIdx.x * kBlock + threadIdx.x; r < rows; r += (long long)gridDim.x * kBlock) {
+    float v[T];
+    load_row<T>(x + r * T, v);
+    const float rstd = centre_row<T>(v, eps);
+#pragma unroll
+    for (int t = 0; t < T; ++t) v[t] = fmaf(v[t] * rstd, wv[t], bv[t]);
+    store_row<T>(y + r * T, v);
+  }
+}
+
+template <int T>
+__global__ __launch_bounds__(kBlock) void k_ln_bwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ dy, float* __restrict__ dx,
+                                                   float* __restrict__ part, long long rows, float eps) {
+  __shared__ float red[kBlock / kWave][2 * T];
+  float wv[T], dw[T], db[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) { wv[t] = w ? w[t] : 1.f; dw[t] = 0.f; db[t] = 0.f; }
+  for (long long r = (long long)blockIdx.x * kBlock + threadIdx.x; r < rows; r += (long long)gridDim.x * kBlock) {
+    float xv[T], gv[T];
+    load_row<T>(x + r * T, xv);
+    load_row<T>(dy + r * T, gv);
+    const float rstd = centre_row<T>(xv, eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      xv[t] *= rstd;                  // xhat
+      db[t] += gv[t];
+      dw[t] = fmaf(gv[t], xv[t], dw[t]);
+      gv[t] *= wv[t];                 // g = dy * w
+      s1 += gv[t];
+      s2 = fmaf(gv[t], xv[t], s2);
+    }
+    s1 *= (1.0f / T);
+    s2 *= (1.0f / T);
+#pragma unroll
+    for (int t = 0; t < T; ++t) gv[t] = rstd * (gv[t] - s1 - xv[t] * s2);
+    store_row<T>(dx + r * T, gv);
+  }
+  // block partial of (dw, db): wave shuffle tree, then the 4 waves in a fixed order
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    float a = dw[t], c = db[t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); c += __shfl_xor(c, o); }
+    if (lane == 0) { red[wave][t] = a; red[wave][T + t] = c; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * T)
+    part[(size_t)blockIdx.x * 2 * T + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+static int ln_blocks(long long rows) {
+  const long long need = (rows + kBlock - 1) / kBlock;
+  return (int)(need < 2048 ? (need < 1 ? 1 : need) : 2048);  // 8 blocks per CU, grid-stride beyond
+}
+
+size_t layernorm_partial_floats(long long rows, int T) { return (size_t)ln_blocks(rows) * 2 * T; }
+
+int launch_layernorm_fwd(const float* x, const float* w, const float* b, float* y, long long rows, int T,
+                         float eps, hipStream_t s) {
+  const int nb = ln_blocks(rows);
+  switch (T) {
+    case 4: hipLaunchKernelGGL(k_ln_fwd<4>, dim3(nb), dim3(kBlock), 0, s, x, w, b, y, rows, eps); break;
+    case 8: hipLaunchKernelGGL(k_ln_fwd<8>, dim3(nb), dim3(kBlock), 0, s, x, w, b, y, rows, eps); break;
+    case 12: hipLaunchKernelGGL(k_ln_fwd<12>, dim3(nb), dim3(kBlock), 0, s, x, w, b, y, rows, eps); break;
+    case 16: hipLaunchKernelGGL(k_ln_fwd<16>, dim3(nb), dim3(kBlock), 0, s, x, w, b, y, rows, eps); break;
+    default: return MSGAT_ERR_UNSUPPORTED;
+  }
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
+}
+
+int launch_layernorm_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
+                         float* part, long long rows, int T, float eps, hipStream_t s) {
+  const int nb = ln_blocks(rows);
+  switch (T) {
+    case 4: hipLaunchKernelGGL(k_ln_bwd<4>, dim3(nb), dim3(kBlock), 0, s, x, w, dy, dx, part, rows, eps); break;
+    case 8: hipLaunchKernelGGL(k_ln_bwd<8>, dim3(nb), dim3(kBlock), 0, s, x, w, dy, dx, part, rows, eps); break;
+    case 12: hipLaunchKernelGGL(k_ln_bwd<12>, dim3(nb), dim3(kBlock), 0, s, x, w, dy, dx, part, rows, eps); break;
+    case 16: hipLaunchKernelGGL(k_ln_bwd<16>, dim3(nb), dim3(kBlock), 0, s, x, w, dy, dx, part, rows, eps); break;
+    default: return MSGAT_ERR_UNSUPPORTED;
+  }
+  MSGAT_CHECK_LAUNCH();
+  return launch_reduce_rows(part, nb, 2 * T, dw, T, db, T, s);
+}
+
+}  // namespace msgat

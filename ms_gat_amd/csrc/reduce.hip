@@ -58,6 +58,11 @@ static int launch_reduce_partials(const float* part, int R, int J, int Wd, float
   return MSGAT_OK;
 }
 
+int launch_reduce_rows(const float* part, int J, int Wd, float* dst0, int n0, float* dst1, int n1,
+                       hipStream_t s) {
+  return launch_reduce_partials(part, 1, J, Wd, dst0, n0, dst1, n1, s);
+}
+
 // ---- dWg -------------------------------------------------------------------------------------------
 constexpr int kRB = 128;  // rows per block
 

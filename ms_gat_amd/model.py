@@ -4,8 +4,8 @@
 Reference: /root/reference/src/models/msgat.py (GACN :17, TACN :57, CACN :83, MEAM :103,
 TPC :137, MSGAT :166, factories :220-229), attention.py (TemporalAttention :42,
 ChannelAttention :72), embeddings.py (TimeEmbedding :12).  Only the graph branch runs in
-the HIP library; the temporal / channel branches, LayerNorms and convolutions are dense
-PyTorch-ROCm ops here (SURVEY.md section 8f lists them as the next rows, not this round's).
+the HIP library, and so does the LayerNorm over T that produces its input (`LayerNormT`, SURVEY.md
+section 8 row f-1); the temporal / channel branches and convolutions are dense PyTorch-ROCm ops.
 
 Parameter names and shapes are the reference's (`tpcs.{r}.tgacns.{l}.gacn.gatt.Wg`, ...):
 `tests/test_model_cpu.py` checks every key and shape against a reference checkpoint.
@@ -17,7 +17,20 @@ from typing import Dict, List, Sequence
 import torch
 from torch import nn
 
+from . import ops
 from .attention import GACN
+
+
+class LayerNormT(nn.LayerNorm):
+    """`nn.LayerNorm([n_timesteps])` (msgat.py:114, :152) with the reference's `weight` / `bias` keys,
+    evaluated by the library's one-pass kernel (`ops.layer_norm_t`): PyTorch's LayerNorm kernels spend
+    a thread group per 12-element row and were 46% of the training step (profiles/r01/full_model_*)."""
+
+    def __init__(self, n_timesteps: int, eps: float = 1e-5):
+        super().__init__([n_timesteps], eps=eps)
+
+    def forward(self, signals: torch.Tensor) -> torch.Tensor:
+        return ops.layer_norm_t(signals, self.weight, self.bias, self.eps)
 
 
 class TemporalAttention(nn.Module):
@@ -122,7 +135,7 @@ class MEAM(nn.Module):
         self.in_channels, self.out_channels, self.n_nodes, self.n_timesteps, self.dilations = (
             in_channels, out_channels, n_nodes, n_timesteps, list(dilations))
         branch = out_channels // 3
-        self.ln = nn.LayerNorm([n_timesteps])
+        self.ln = LayerNormT(n_timesteps)
         self.res = nn.Conv2d(in_channels, out_channels, kernel_size=1)
         self.cacn = CACN(in_channels, branch, n_nodes=n_nodes, n_timesteps=n_timesteps)
         self.tacn = TACN(in_channels, branch, n_nodes=n_nodes, dilations=dilations)
@@ -145,7 +158,7 @@ class TPC(nn.Module):
         self.tgacns = nn.ModuleList(
             MEAM(channels[i], channels[i + 1], n_nodes=n_nodes, n_timesteps=in_timesteps, dilations=d)
             for i, d in enumerate(dilations))
-        self.ln = nn.LayerNorm([in_timesteps])
+        self.ln = LayerNormT(in_timesteps)
         self.fc = nn.Conv2d(in_timesteps, out_timesteps, kernel_size=(1, channels[-1]))
 
     def forward(self, signals: torch.Tensor, adjacency) -> torch.Tensor:

@@ -142,3 +142,57 @@ def gacn(x: torch.Tensor, alpha: torch.Tensor, Wg: torch.Tensor, W: Optional[tor
 def graph_attention(x, alpha, Wg, adjacency):
     """`GraphAttention.forward` (attention.py:32-36) for R stacked relations."""
     return gacn(x, alpha, Wg, None, adjacency)
+
+
+class _LayerNormTFunction(torch.autograd.Function):
+    """x[..., T], weight[T] | None, bias[T] | None -> LayerNorm over the last axis."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps: float):
+        L = _lib.lib()
+        x = x.contiguous()
+        T = x.shape[-1]
+        rows = x.numel() // T if T else 0
+        y = torch.empty_like(x)
+        w = None if weight is None else weight.contiguous()
+        b = None if bias is None else bias.contiguous()
+        st = L.msgat_layernorm_forward(_ptr(x), _ptr(w), _ptr(b), _ptr(y), rows, T, eps, _stream_handle(x.device))
+        _lib.check(st, "msgat_layernorm_forward")
+        ctx.eps, ctx.has_w, ctx.has_b = eps, weight is not None, bias is not None
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(*([x] + ([w] if w is not None else [])))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        saved = ctx.saved_tensors
+        x, w = saved[0], (saved[1] if ctx.has_w else None)
+        T = x.shape[-1]
+        rows = x.numel() // T
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dw = torch.empty(T, device=x.device, dtype=torch.float32) if ctx.has_w else None
+        db = torch.empty(T, device=x.device, dtype=torch.float32) if ctx.has_b else None
+        part = torch.empty(max(int(L.msgat_layernorm_partial_floats(rows, T)), 1), device=x.device,
+                           dtype=torch.float32)
+        st = L.msgat_layernorm_backward(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db), _ptr(part),
+                                        rows, T, ctx.eps, _stream_handle(x.device))
+        _lib.check(st, "msgat_layernorm_backward")
+        return dx, dw, db, None
+
+
+def layer_norm_t(x: torch.Tensor, weight: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+                 eps: float = 1e-5) -> torch.Tensor:
+    """`F.layer_norm(x, [T], weight, bias, eps)` over the timestep axis, the op the reference applies
+    to every GACN input (msgat.py:122, :158), as one HBM-speed pass in libmsgat_hip.so."""
+    _require_device_tensor("signals", x)
+    T = x.shape[-1]
+    for name, t in (("weight", weight), ("bias", bias)):
+        if t is not None:
+            _require_device_tensor(name, t, x.device)
+            if tuple(t.shape) != (T,):
+                raise ValueError(f"{name} must be [{T}], got {tuple(t.shape)}")
+    if x.numel() == 0:
+        return torch.empty_like(x)
+    return _LayerNormTFunction.apply(x, weight, bias, float(eps))

@@ -22,6 +22,7 @@ def load_golden(name):
 
 def rel_err(a, b):
     """max|a-b| / max|b| -- the parity figure quoted everywhere (bar: 1e-4 in fp32)."""
+    a, b = (t.detach().cpu().numpy() if hasattr(t, "detach") else t for t in (a, b))
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     scale = max(float(np.abs(b).max()), 1e-30)

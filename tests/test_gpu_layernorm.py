@@ -1,0 +1,114 @@
+"""GPU: LayerNorm over the timestep axis (the producer of every GACN
+input; reference nn.LayerNorm([T]) at src/models/msgat.py:114/:122 and :152/:158) against a float64
+evaluation of the same formula, with torch's own fp32 kernel as the error yardstick.
+
+Tolerance: 1e-4 relative (the path's stated bar); in practice both fp32 implementations sit at ~1e-7.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _ref64(x, w, b, dy, eps):
+    x64 = x.double().requires_grad_(True)
+    w64 = None if w is None else w.double().requires_grad_(True)
+    b64 = None if b is None else b.double().requires_grad_(True)
+    y = F.layer_norm(x64, [x.shape[-1]], w64, b64, eps)
+    y.backward(dy.double())
+    return y.detach(), x64.grad, (None if w64 is None else w64.grad), (None if b64 is None else b64.grad)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 12), (2, 3, 5, 12), (4, 24, 883, 12), (3, 7, 129, 4), (2, 5, 300, 8),
+                                   (1, 9, 1025, 16), (32, 72, 883, 12)])
+@pytest.mark.parametrize("affine", [True, False])
+def test_layernorm_matches_float64_reference(shape, affine):
+    from ms_gat_amd import ops
+    if not affine and shape[0] == 32:
+        pytest.skip("full size once")
+    dev = _dev()
+    gen = torch.Generator(device="cpu").manual_seed(sum(shape))
+    T = shape[-1]
+    x = (torch.randn(shape, generator=gen) * 3 + 1.5).to(dev)
+    dy = torch.randn(shape, generator=gen).to(dev)
+    w = (1 + 0.3 * torch.randn(T, generator=gen)).to(dev) if affine else None
+    b = (0.2 * torch.randn(T, generator=gen)).to(dev) if affine else None
+    xs = x.clone().requires_grad_(True)
+    ws = None if w is None else w.clone().requires_grad_(True)
+    bs = None if b is None else b.clone().requires_grad_(True)
+    y = ops.layer_norm_t(xs, ws, bs, 1e-5)
+    y.backward(dy)
+    y64, dx64, dw64, db64 = _ref64(x, w, b, dy, 1e-5)
+    assert rel_err(y.detach().double(), y64) < TOL
+    assert rel_err(xs.grad.double(), dx64) < TOL
+    if affine:
+        assert rel_err(ws.grad.double(), dw64) < TOL
+        assert rel_err(bs.grad.double(), db64) < TOL
+    # yardstick: no worse than 4x torch's own fp32 kernel (plus a floor for exact-zero errors)
+    xt = x.clone().requires_grad_(True)
+    yt = F.layer_norm(xt, [T], w, b, 1e-5)
+    yt.backward(dy)
+    assert rel_err(y.detach().double(), y64) <= 4 * rel_err(yt.detach().double(), y64) + 1e-6
+    assert rel_err(xs.grad.double(), dx64) <= 4 * rel_err(xt.grad.double(), dx64) + 1e-6
+
+
+def test_constant_rows_and_large_offsets():
+    """var = 0 rows give exactly `bias`; a large common offset must not destroy the variance
+    (two-pass statistics, not E[x^2] - E[x]^2)."""
+    from ms_gat_amd import ops
+    dev = _dev()
+    x = torch.full((3, 4, 12), 7.25, device=dev)
+    w, b = torch.linspace(0.5, 1.5, 12, device=dev), torch.linspace(-1, 1, 12, device=dev)
+    assert torch.equal(ops.layer_norm_t(x, w, b), b.expand_as(x))
+    gen = torch.Generator().manual_seed(3)
+    x = (1e4 + torch.randn(5, 6, 77, 12, generator=gen)).to(dev)
+    y64 = F.layer_norm(x.double(), [12], w.double(), b.double(), 1e-5)
+    assert rel_err(ops.layer_norm_t(x, w, b).double(), y64) < TOL
+
+
+def test_non_contiguous_input_empty_input_and_unsupported_T():
+    from ms_gat_amd import _lib, ops
+    dev = _dev()
+    x = torch.randn(4, 12, 6, 5, device=dev).transpose(1, 3)          # [4,5,6,12] view, strided
+    assert rel_err(ops.layer_norm_t(x), F.layer_norm(x, [12])) < 1e-6
+    assert ops.layer_norm_t(torch.empty(0, 3, 12, device=dev)).shape == (0, 3, 12)
+    with pytest.raises(_lib.MsgatError):
+        ops.layer_norm_t(torch.randn(4, 10, device=dev))
+
+
+def test_gradients_are_bitwise_reproducible():
+    from ms_gat_amd import ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(8, 24, 883, 12, generator=gen).to(dev)
+    dy = torch.randn(8, 24, 883, 12, generator=gen).to(dev)
+    w, b = torch.rand(12, device=dev) + 0.5, torch.rand(12, device=dev)
+    outs = []
+    for _ in range(2):
+        xs, ws, bs = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        ops.layer_norm_t(xs, ws, bs).backward(dy)
+        outs.append((xs.grad, ws.grad, bs.grad))
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
+
+
+def test_module_is_drop_in_for_nn_layernorm():
+    from ms_gat_amd import model
+    dev = _dev()
+    ref = torch.nn.LayerNorm([12]).to(dev)
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5)
+        ref.bias.uniform_(-0.5, 0.5)
+    mine = model.LayerNormT(12).to(dev)
+    mine.load_state_dict(ref.state_dict())
+    x = torch.randn(2, 72, 100, 12, device=dev)
+    assert rel_err(mine(x), ref(x)) < 1e-6

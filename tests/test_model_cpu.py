@@ -3,6 +3,7 @@ loss / metrics, and the engine loop (with a CPU stand-in model -- the real model
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from conftest import load_golden, rel_err
@@ -63,10 +64,19 @@ def test_dense_branches_match_reference_meam_intermediates():
         m = model.MEAM(cin, 72, n_nodes=32, n_timesteps=12, dilations=[1, 2])
         m.load_state_dict(ref)
         x, adj = torch.from_numpy(g["x"]), torch.from_numpy(g["adj"])
-        normed = m.ln(x)
+        normed = F.layer_norm(x, [12], m.ln.weight, m.ln.bias, m.ln.eps)   # oracle of LayerNormT, CPU
         graph = dense_torch.gacn_dense(normed, adj, m.gacn.gatt.Wg, m.gacn.gatt.alpha, m.gacn.W)  # oracle, CPU
         out = torch.relu(torch.cat([m.cacn(normed), m.tacn(normed), graph], dim=1) + m.res(x))
         assert rel_err(out.detach(), g["out"]) < 1e-5, tag
+
+
+def test_layernorm_t_keeps_reference_keys_and_refuses_cpu():
+    from ms_gat_amd import _lib, model
+    ln = model.LayerNormT(12)
+    assert set(ln.state_dict()) == {"weight", "bias"} and tuple(ln.weight.shape) == (12,)
+    assert ln.eps == 1e-5
+    with pytest.raises(_lib.MsgatError):
+        ln(torch.zeros(2, 3, 4, 12))
 
 
 def test_periodic_windows_and_zscore_match_reference_slices():
