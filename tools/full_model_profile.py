@@ -8,4 +8,4 @@ import bench
 
 wl = bench.WORKLOADS["pemsd7"]
 dev = torch.device("cuda:0")
-print("full model step ms:", bench.full_model_step_ms(wl, dev, dense=False, steps=5, warmup=2))
+print("full model step ms:", bench.full_model_step_ms(wl, dev, dense=False, steps=4, warmup=4))
