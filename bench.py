@@ -41,7 +41,7 @@ WORKLOADS = {
     # name: (N nodes, E undirected edges, B per GPU, R relations, in_channels of the first MEAM, hidden, Co)
     "pemsd7": dict(N=883, E=866, B=32, R=3, Cin=1, hidden=72, Co=24, T=12),
     "pemsd4": dict(N=307, E=340, B=64, R=1, Cin=3, hidden=72, Co=24, T=12),
-    "stress": dict(N=8192, E=65536, B=8, R=4, Cin=1, hidden=72, Co=24, T=12),
+    "stress": dict(N=8192, E=65536, B=64, R=4, Cin=1, hidden=72, Co=24, T=12),
 }
 
 

@@ -21,22 +21,30 @@ namespace msgat {
 // blocks per CU keep the CU's 32 wave slots full while one block streams its slab in or out.
 constexpr int kAggBlock = 1024;
 
-// up to 4 edges per trip: the index/weight loads of a trip are independent and issue together
+// 4 edges per trip, fetched as ONE 16-byte load of indices and one of weights.  Edge ranges start
+// at arbitrary dword offsets; gfx950 global loads of 128 bits need only dword alignment, which the
+// packed types tell the compiler.  A trip may read past the row's last edge (into the next row's,
+// always inside the array: the window is clamped to end at nnz) -- those slots get weight 0.
+struct __attribute__((packed, aligned(4))) int4u { int v[4]; };
+struct __attribute__((packed, aligned(4))) float4u { float v[4]; };
+
 template <int T4, typename RowPtr>
 __device__ __forceinline__ float4 gather_row(const int* __restrict__ idx, const float* __restrict__ Eg,
-                                             int e0, int e1, RowPtr rows, int j) {
+                                             int e0, int e1, int nnz, RowPtr rows, int j) {
   float4 acc = f4zero();
+  if (nnz < 4) {  // tiny graphs: scalar walk
+    for (int e = e0; e < e1; ++e) f4fma(Eg[e], rows[(size_t)idx[e] * T4 + j], acc);
+    return acc;
+  }
   for (int e = e0; e < e1; e += 4) {
-    int m[4];
-    float w[4];
+    const int b = min(e, nnz - 4);
+    const int4u m = *reinterpret_cast<const int4u*>(idx + b);
+    const float4u w = *reinterpret_cast<const float4u*>(Eg + b);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int ee = min(e + k, e1 - 1);
-      m[k] = idx[ee];
-      w[k] = (e + k < e1) ? Eg[ee] : 0.f;
+      const float wk = (b + k >= e && b + k < e1) ? w.v[k] : 0.f;
+      f4fma(wk, rows[(size_t)m.v[k] * T4 + j], acc);
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) f4fma(w[k], rows[(size_t)m[k] * T4 + j], acc);
   }
   return acc;
 }
@@ -67,14 +75,47 @@ __global__ __launch_bounds__(kAggBlock) void k_agg_lds(
     float4 ex = f4zero();
     if (addvec != nullptr) ex = extra4[(size_t)g * NT4 + s];
     for (int c = 0; c < ch; ++c) {
-      float4 acc = gather_row<T4>(idx, Eg, e0, e1, slab + c * NT4, j);
+      float4 acc = gather_row<T4>(idx, Eg, e0, e1, nnz, slab + c * NT4, j);
       if (addvec != nullptr) f4fma(addvec[r * Cu + c0 + c], ex, acc);
       v4[base + (size_t)c * NT4 + s] = acc;
     }
   }
 }
 
-// ---- gather-from-L2 aggregate (slab too large for LDS) ------------------------------------------
+// ---- LDS aggregate for slabs larger than LDS: one 4-timestep column of the slab at a time --------------
+// N*T*4 bytes exceed the CU's LDS from N ~ 3400 (T = 12), but one float4 column of the slab (N*16 B)
+// fits up to N ~ 10 000 (the N = 8192 stress graph: 128 KB).  The block walks the T/4 columns: stage
+// column j (16-B pieces, 4T-byte stride -- every line of the slab is fetched T/4 times, but from
+// L2 / infinity cache, within microseconds), gather neighbour rows from LDS, store column j of v.
+// Against the gather-from-L2 kernel below this trades ~deg x 128-B line fetches per output row for
+// T/4 passes over the slab: 8.3 ms -> 4.4 ms per launch at N = 8192, degree 17, 256 groups x 24 channels
+// (requesting several rows' windows at once did not help: the pass is bound by LDS bank conflicts of
+// the random 16-B gathers plus the strided edge-window loads, not by latency).
+template <int T4>
+__global__ __launch_bounds__(kAggBlock) void k_agg_cols(
+    const int* __restrict__ ptr, const int* __restrict__ idx, const float4* __restrict__ u4,
+    const float* __restrict__ E, const float* __restrict__ addvec,
+    const float4* __restrict__ extra4, float4* __restrict__ v4, int Bg, int Cu, int N, int nnz) {
+  extern __shared__ float4 slab[];  // [N]: column j of the [N][T4] slab
+  const int g = blockIdx.y;
+  const int r = g / Bg;
+  const int c = blockIdx.x;
+  const size_t base = ((size_t)g * Cu + c) * N * T4;
+  const float* Eg = E + (size_t)g * nnz;
+  const float av = (addvec != nullptr) ? addvec[r * Cu + c] : 0.f;
+  for (int j = 0; j < T4; ++j) {
+    for (int n = threadIdx.x; n < N; n += kAggBlock) slab[n] = u4[base + (size_t)n * T4 + j];
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += kAggBlock) {
+      float4 acc = gather_row<1>(idx, Eg, ptr[n], ptr[n + 1], nnz, slab, 0);
+      if (addvec != nullptr) f4fma(av, extra4[((size_t)g * N + n) * T4 + j], acc);
+      v4[base + (size_t)n * T4 + j] = acc;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- gather-from-L2 aggregate (not even one column fits LDS) ------------------------------------------
 template <int T4>
 __global__ __launch_bounds__(kBlock) void k_agg_glb(
     const int* __restrict__ ptr, const int* __restrict__ idx, const float4* __restrict__ u4,
@@ -89,7 +130,7 @@ __global__ __launch_bounds__(kBlock) void k_agg_glb(
   const int n = s / T4;
   const int j = s - n * T4;
   const float4* sl = u4 + ((size_t)g * Cu + c) * NT4;
-  float4 acc = gather_row<T4>(idx, E + (size_t)g * nnz, ptr[n], ptr[n + 1], sl, j);
+  float4 acc = gather_row<T4>(idx, E + (size_t)g * nnz, ptr[n], ptr[n + 1], nnz, sl, j);
   if (addvec != nullptr) f4fma(addvec[r * Cu + c], extra4[(size_t)g * NT4 + s], acc);
   v4[((size_t)g * Cu + c) * NT4 + s] = acc;
 }
@@ -110,6 +151,15 @@ static int launch_aggregate_t(const int* ptr, const int* idx, int nnz, const flo
     dim3 grid(cdiv(Cu, CH), G);
     hipLaunchKernelGGL(k_agg_lds<T4>, grid, dim3(kAggBlock), lds, s, ptr, idx, (const float4*)u, E, addvec,
                        (const float4*)extra, (float4*)v, Bg, Cu, N, nnz, CH);
+  } else if ((size_t)N * sizeof(float4) <= (size_t)kLdsMax - 1024 && nnz >= 4) {
+    const size_t lds = (size_t)N * sizeof(float4);
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_cols<T4>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
+    }
+    hipLaunchKernelGGL(k_agg_cols<T4>, dim3(Cu, G), dim3(kAggBlock), lds, s, ptr, idx, (const float4*)u, E,
+                       addvec, (const float4*)extra, (float4*)v, Bg, Cu, N, nnz);
   } else {
     dim3 grid(cdiv(N * T4, kBlock), Cu, G);
     hipLaunchKernelGGL(k_agg_glb<T4>, grid, dim3(kBlock), 0, s, ptr, idx, (const float4*)u, E, addvec,
@@ -179,7 +229,7 @@ __global__ __launch_bounds__(kBlock) void k_agg_proj(
   for (int oo = 0; oo < OT; ++oo) acc[oo] = f4zero();
   for (int c = 0; c < C; ++c) {
     const float4* sl = x4 + ((size_t)g * C + c) * NT4;
-    float4 y = gather_row<T4>(col, Eg, e0, e1, sl, j);
+    float4 y = gather_row<T4>(col, Eg, e0, e1, nnz, sl, j);
     if (y4 != nullptr && blockIdx.z == 0) y4[((size_t)g * C + c) * NT4 + s] = y;
     const float4* wrow = reinterpret_cast<const float4*>(Wl + c * OT);
 #pragma unroll

@@ -329,7 +329,12 @@ def test_full_size_linearity_in_W_and_in_cotangent():
 
 
 def test_stress_graph_uses_the_large_n_path():
-    """N large enough that an [N,T] slab does not fit LDS: gather-from-L2 kernels."""
+    """N large enough that an [N,T] slab does not fit LDS: one 4-timestep column of the slab per
+    pass (N*16 B <= LDS, the BASELINE stress graph N = 8192 at degree 16), gather-from-L2 beyond."""
+    prob = random_problem(1, 1, 12, 4, 8192, 12, 65536, seed=65)
+    assert_close(run_ours(*prob), _dense_oracle_gpu(*prob), what="N=8192 deg16 PROJ_FIRST")
+    prob = random_problem(1, 1, 6, 4, 10400, 12, 20000, seed=66)
+    assert_close(run_ours(*prob), _dense_oracle_gpu(*prob), what="N=10400 PROJ_FIRST (gather from L2)")
     prob = random_problem(1, 1, 3, 24, 4000, 12, 8000, seed=61)
     got = run_ours(*prob)
     want = _dense_oracle_gpu(*prob)
