@@ -201,6 +201,44 @@ int msgat_layernorm_backward(const float* x, const float* weight, const float* d
                              float* dweight, float* dbias, float* partials, int64_t rows, int32_t T,
                              float eps, void* stream);
 
+/* ---- device: the temporal and channel branches of MEAM ----
+ * Building blocks for TACN (src/models/msgat.py:57-80, TemporalAttention attention.py:58-66) and CACN
+ * (msgat.py:83-100, ChannelAttention attention.py:88-94) and for the block's residual tail
+ * (msgat.py:130-131).  The tiny [T,T] / [C,C] attention matrices are built by the caller from the
+ * pooled signals; these entry points are the passes over the [B,C,N,T] activations.
+ *
+ * msgat_stage_mix_epilogue: msgat_stage_mix plus out = relu?(... + bias[r*bias_per_relation*Co + co]
+ *     + add[g,co,p]): a 1x1 convolution with bias when R = 1; a per-sample matrix (CACN's
+ *     Wconv att_b) when R = batch, Bg = 1; the residual tail relu(cat(branches) + res(x)) with `add`.
+ * msgat_time_mix: forward (backward = 0)
+ *         dst[g,o,n,t] = bias[o] + sum_k sum_i A[ga,k,t,i] src[g,k*Co+o,n,i]      src [G,K*Co,N,T]
+ *     backward (backward = 1): dst[g,k*Co+o,n,i] = sum_t A[ga,k,t,i] src[g,o,n,t]  src [G,Co,N,T]
+ *     A is [G,K,T,T] (a_per_group = 1) or [K,T,T] shared; K in {1, 2}.  With A_1 = att_b and
+ *     A_0 = att_b shifted down by the dilation this is conv_[1,2],dilated(TemporalAttention(x)) after the
+ *     channel mixing src = [W_0; W_1] x; with constant shift matrices it is a plain causal convolution.
+ * msgat_time_mix_grad_matrix: dA[g,k,t,i] = sum_{o,n} dout[g,o,n,t] y[g,k*Co+o,n,i];
+ *     `partials` needs msgat_time_mix_partial_floats() floats.
+ * msgat_node_pool: pooled[s,t] = sum_n w[n] x[s,n,t] over `slabs` (sample, channel) slabs (attention.py:89);
+ *     msgat_node_pool_grad_signal: dx[s,n,t] = w[n] dpooled[s,t];
+ *     msgat_node_pool_grad_weight: dw[n] = sum_{g,c,t} x[g,c,n,t] dpooled[g,c,t] (partials:
+ *     msgat_node_pool_partial_floats()).
+ * The channel pooling sum_c alpha_c x[b,c] (attention.py:59) is msgat_stage_project with W = u = NULL. */
+int msgat_stage_mix_epilogue(const msgat_shape_t* shape, int32_t Ci, int32_t Co, const float* in, const float* M,
+                             int32_t m_in_major, const float* bias, int32_t bias_per_relation, const float* add,
+                             int32_t relu, float* out, void* stream);
+int msgat_time_mix(const float* src, const float* A, int32_t a_per_group, const float* bias, float* dst,
+                   int32_t G, int32_t Co, int32_t K, int32_t N, int32_t T, int32_t backward, void* stream);
+size_t msgat_time_mix_partial_floats(int32_t G, int32_t K, int32_t T);
+int msgat_time_mix_grad_matrix(const float* dout, const float* y, float* dA, float* partials, int32_t G,
+                               int32_t Co, int32_t K, int32_t N, int32_t T, void* stream);
+int msgat_node_pool(const float* x, const float* w, float* pooled, int64_t slabs, int32_t N, int32_t T,
+                    void* stream);
+int msgat_node_pool_grad_signal(const float* w, const float* dpooled, float* dx, int64_t slabs, int32_t N,
+                                int32_t T, void* stream);
+size_t msgat_node_pool_partial_floats(int32_t G, int32_t C, int32_t N);
+int msgat_node_pool_grad_weight(const float* x, const float* dpooled, float* dw, float* partials, int32_t G,
+                                int32_t C, int32_t N, int32_t T, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,16 @@ _PROTOTYPES = {
     "msgat_contract_partial_floats": (C.c_size_t, [C.POINTER(Shape), C.c_int32, C.c_int32]),
     "msgat_stage_contract": (C.c_int, [C.POINTER(Shape), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "msgat_stage_mix_epilogue": (C.c_int, [C.POINTER(Shape), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                           C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "msgat_time_mix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 6
+                       + [C.c_void_p]),
+    "msgat_time_mix_partial_floats": (C.c_size_t, [C.c_int32] * 3),
+    "msgat_time_mix_grad_matrix": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 5 + [C.c_void_p]),
+    "msgat_node_pool": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "msgat_node_pool_grad_signal": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "msgat_node_pool_partial_floats": (C.c_size_t, [C.c_int32] * 3),
+    "msgat_node_pool_grad_weight": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]),
     "msgat_layernorm_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "msgat_layernorm_partial_floats": (C.c_size_t, [C.c_int64, C.c_int32]),
     "msgat_layernorm_backward": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_float, C.c_void_p]),

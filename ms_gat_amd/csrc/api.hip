@@ -171,6 +171,83 @@ extern "C" int msgat_stage_contract(const msgat_shape_t* sh, int32_t Ca, int32_t
                          sh->N * sh->T, (hipStream_t)stream);
 }
 
+// ---- temporal / channel branches -------------------------------------------------------------------------
+extern "C" int msgat_stage_mix_epilogue(const msgat_shape_t* sh, int32_t Ci, int32_t Co, const float* in,
+                                        const float* M, int32_t m_in_major, const float* bias,
+                                        int32_t bias_per_relation, const float* add, int32_t relu, float* out,
+                                        void* stream) {
+  int st = check_shape(sh);
+  if (st) return st;
+  if (!in || !M || !out) return MSGAT_ERR_NULL;
+  if (Ci <= 0 || Co <= 0 || Ci > kMaxC || Co > kMaxC) return MSGAT_ERR_SHAPE;
+  MixEpilogue epi;
+  epi.bias = bias;
+  epi.bias_rstride = bias_per_relation ? Co : 0;
+  epi.add4 = reinterpret_cast<const float4*>(add);
+  epi.relu = relu;
+  return launch_project_epi(in, M, m_in_major, nullptr, nullptr, nullptr, out, nullptr, sh->R * sh->Bg, sh->Bg, Ci,
+                            Co, sh->N * sh->T, epi, (hipStream_t)stream);
+}
+
+static int check_rows(int32_t G, int32_t Co, int32_t K, int32_t N, int32_t T) {
+  if (G <= 0 || Co <= 0 || N <= 0) return MSGAT_ERR_SHAPE;
+  if (!t_supported(T) || K < 1 || K > 2) return MSGAT_ERR_UNSUPPORTED;
+  if ((int64_t)G * K * Co * N * T >= ((int64_t)1 << 40) || (int64_t)Co * N > 0x7fffffff || G > 65535) return MSGAT_ERR_SHAPE;
+  return MSGAT_OK;
+}
+
+extern "C" int msgat_time_mix(const float* src, const float* A, int32_t a_per_group, const float* bias,
+                              float* dst, int32_t G, int32_t Co, int32_t K, int32_t N, int32_t T,
+                              int32_t backward, void* stream) {
+  if (!src || !A || !dst) return MSGAT_ERR_NULL;
+  int st = check_rows(G, Co, K, N, T);
+  if (st) return st;
+  return launch_tmix(src, A, a_per_group, backward ? nullptr : bias, dst, G, Co, K, N, T, backward,
+                     (hipStream_t)stream);
+}
+
+extern "C" size_t msgat_time_mix_partial_floats(int32_t G, int32_t K, int32_t T) {
+  if (G <= 0 || K < 1 || K > 2 || !t_supported(T)) return 0;
+  return tmix_partial_floats(G, K, T);
+}
+
+extern "C" int msgat_time_mix_grad_matrix(const float* dout, const float* y, float* dA, float* partials,
+                                          int32_t G, int32_t Co, int32_t K, int32_t N, int32_t T, void* stream) {
+  if (!dout || !y || !dA || !partials) return MSGAT_ERR_NULL;
+  int st = check_rows(G, Co, K, N, T);
+  if (st) return st;
+  return launch_tmix_dA(dout, y, dA, partials, G, Co, K, N, T, (hipStream_t)stream);
+}
+
+extern "C" int msgat_node_pool(const float* x, const float* w, float* pooled, int64_t slabs, int32_t N, int32_t T,
+                               void* stream) {
+  if (!x || !w || !pooled) return MSGAT_ERR_NULL;
+  if (slabs <= 0 || slabs > 0x7fffffff || N <= 0) return MSGAT_ERR_SHAPE;
+  if (!t_supported(T)) return MSGAT_ERR_UNSUPPORTED;
+  return launch_node_pool(x, w, pooled, slabs, N, T, (hipStream_t)stream);
+}
+
+extern "C" int msgat_node_pool_grad_signal(const float* w, const float* dpooled, float* dx, int64_t slabs,
+                                           int32_t N, int32_t T, void* stream) {
+  if (!w || !dpooled || !dx) return MSGAT_ERR_NULL;
+  if (slabs <= 0 || slabs > 0x7fffffff || N <= 0) return MSGAT_ERR_SHAPE;
+  if (!t_supported(T)) return MSGAT_ERR_UNSUPPORTED;
+  return launch_node_pool_dx(w, dpooled, dx, slabs, N, T, (hipStream_t)stream);
+}
+
+extern "C" size_t msgat_node_pool_partial_floats(int32_t G, int32_t C, int32_t N) {
+  if (G <= 0 || C <= 0 || N <= 0) return 0;
+  return node_pool_partial_floats(G, C, N);
+}
+
+extern "C" int msgat_node_pool_grad_weight(const float* x, const float* dpooled, float* dw, float* partials,
+                                           int32_t G, int32_t C, int32_t N, int32_t T, void* stream) {
+  if (!x || !dpooled || !dw || !partials) return MSGAT_ERR_NULL;
+  if (G <= 0 || G > 65535 || C <= 0 || N <= 0) return MSGAT_ERR_SHAPE;
+  if (!t_supported(T)) return MSGAT_ERR_UNSUPPORTED;
+  return launch_node_pool_dw(x, dpooled, dw, partials, G, C, N, T, (hipStream_t)stream);
+}
+
 // ---- LayerNorm over T (the producer of the GACN inputs) ----------------------------------------------
 extern "C" int msgat_layernorm_forward(const float* x, const float* weight, const float* bias, float* y,
                                        int64_t rows, int32_t T, float eps, void* stream) {

@@ -1,0 +1,294 @@
+// The temporal and channel branches of MEAM: the streaming kernels that
+// the hot path's channel-mixing kernels (project.hip / mfma.hip) do not already cover.
+//
+// Reference: TemporalAttention /root/reference/src/models/attention.py:58-66, ChannelAttention :88-94,
+// TACN src/models/msgat.py:57-80 (attention, then causal dilated [1,2] convolutions), CACN :83-100.
+//
+// Both branches factor into (a) tiny per-sample attention matrices ([T,T], [C,C]) built from pooled
+// signals, and (b) applying them to the whole [B,C,N,T] activation.  (b) is what costs: in eager
+// PyTorch it is a batched matmul with K = 12 or M = 72 (hipBLASLt at 5-10% of HBM speed) between
+// layout copies.  Here:
+//   channel side  out = (Wconv att_b) x_b + bias      one channel-mixing pass with a per-sample matrix
+//                                                     (k_project_mfma, R = B "relations")
+//   temporal side conv_d(TA(x)) = sum_k (W_k x) x_t A_k[b]^T   with A_1 = att_b, A_0 = att_b shifted down
+//                 by the dilation: channel mixing FIRST (C -> 2 Co, shared matrix), then ONE pass that
+//                 applies the two [T,T] matrices along time and adds the taps (k_tmix below).  Later
+//                 convolutions of the stack use the same kernels with constant shift matrices.
+//   pooling       pooled[b,c,:] = sum_n w_n x[b,c,n,:]  (k_node_pool);  sum_c alpha_c x[b,c] is k_qonly.
+// Every kernel reads and writes the reference's [B,C,N,T] layout: a lane owns one row of T contiguous
+// floats (T/4 16-byte loads), neighbouring lanes neighbouring rows.  All are HBM-bound.
+#include "common.hpp"
+
+namespace msgat {
+
+template <int T>
+__device__ __forceinline__ void ld_row(const float* __restrict__ p, float (&v)[T]) {
+#pragma unroll
+  for (int t4 = 0; t4 < T / 4; ++t4) {
+    const float4 a = reinterpret_cast<const float4*>(p)[t4];
+    v[4 * t4 + 0] = a.x; v[4 * t4 + 1] = a.y; v[4 * t4 + 2] = a.z; v[4 * t4 + 3] = a.w;
+  }
+}
+template <int T>
+__device__ __forceinline__ void st_row(float* __restrict__ p, const float (&v)[T]) {
+#pragma unroll
+  for (int t4 = 0; t4 < T / 4; ++t4)
+    reinterpret_cast<float4*>(p)[t4] = make_float4(v[4 * t4], v[4 * t4 + 1], v[4 * t4 + 2], v[4 * t4 + 3]);
+}
+
+// ---- time mixing --------------------------------------------------------------------------------------
+// forward  (BWD = false): dst[g,o,n,t]        = bias[o] + sum_k sum_i A[ga,k,t,i] src[g,k*Co+o,n,i]
+// backward (BWD = true):  dst[g,k*Co+o,n,i]   =           sum_t  A[ga,k,t,i] src[g,o,n,t]
+// ga = g when the matrices are per sample (a_gstride = K*T*T), 0 when shared (a_gstride = 0).
+// The matrices sit in LDS, transposed for the backward form so that both read rows as float4 broadcasts.
+template <int T, int K, bool BWD>
+__global__ __launch_bounds__(kBlock) void k_tmix(const float* __restrict__ src, const float* __restrict__ A,
+                                                 int a_gstride, const float* __restrict__ bias,
+                                                 float* __restrict__ dst, int Co, int N) {
+  __shared__ float Al[K][T][T];
+  const int g = blockIdx.y;
+  for (int i = threadIdx.x; i < K * T * T; i += kBlock) {
+    const int k = i / (T * T), t = (i / T) % T, c = i % T;
+    const float a = A[(size_t)g * a_gstride + i];
+    if (BWD) Al[k][c][t] = a; else Al[k][t][c] = a;
+  }
+  __syncthreads();
+  const int rr = blockIdx.x * kBlock + threadIdx.x;  // row (o, n) of this group
+  if (rr >= Co * N) return;
+  const int o = rr / N;
+  if (!BWD) {
+    float acc[T];
+    const float b = bias ? bias[o] : 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = b;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float v[T];
+      ld_row<T>(src + ((size_t)g * K * Co * N + (size_t)k * Co * N + rr) * T, v);
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int i = 0; i < T; ++i) acc[t] = fmaf(Al[k][t][i], v[i], acc[t]);
+    }
+    st_row<T>(dst + ((size_t)g * Co * N + rr) * T, acc);
+  } else {
+    float v[T];
+    ld_row<T>(src + ((size_t)g * Co * N + rr) * T, v);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float acc[T];
+#pragma unroll
+      for (int i = 0; i < T; ++i) {
+        acc[i] = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[i] = fmaf(Al[k][i][t], v[t], acc[i]);
+      }
+      st_row<T>(dst + ((size_t)g * K * Co * N + (size_t)k * Co * N + rr) * T, acc);
+    }
+  }
+}
+
+template <int T, int K>
+static int launch_tmix_tk(const float* src, const float* A, int per_group, const float* bias, float* dst, int G,
+                          int Co, int N, int backward, hipStream_t s) {
+  dim3 grid(cdiv(Co * N, kBlock), G);
+  const int gs = per_group ? K * T * T : 0;
+  if (backward) hipLaunchKernelGGL((k_tmix<T, K, true>), grid, dim3(kBlock), 0, s, src, A, gs, bias, dst, Co, N);
+  else hipLaunchKernelGGL((k_tmix<T, K, false>), grid, dim3(kBlock), 0, s, src, A, gs, bias, dst, Co, N);
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
+}
+
+template <int T>
+static int launch_tmix_t(const float* src, const float* A, int per_group, const float* bias, float* dst, int G,
+                         int Co, int K, int N, int backward, hipStream_t s) {
+  if (K == 1) return launch_tmix_tk<T, 1>(src, A, per_group, bias, dst, G, Co, N, backward, s);
+  if (K == 2) return launch_tmix_tk<T, 2>(src, A, per_group, bias, dst, G, Co, N, backward, s);
+  return MSGAT_ERR_UNSUPPORTED;
+}
+
+int launch_tmix(const float* src, const float* A, int per_group, const float* bias, float* dst, int G, int Co,
+                int K, int N, int T, int backward, hipStream_t s) {
+  switch (T) {
+    case 4: return launch_tmix_t<4>(src, A, per_group, bias, dst, G, Co, K, N, backward, s);
+    case 8: return launch_tmix_t<8>(src, A, per_group, bias, dst, G, Co, K, N, backward, s);
+    case 12: return launch_tmix_t<12>(src, A, per_group, bias, dst, G, Co, K, N, backward, s);
+    case 16: return launch_tmix_t<16>(src, A, per_group, bias, dst, G, Co, K, N, backward, s);
+  }
+  return MSGAT_ERR_UNSUPPORTED;
+}
+
+// ---- gradient of the time-mixing matrices -------------------------------------------------------------
+// dA[g,k,t,i] = sum_{o,n} dout[g,o,n,t] y[g,k*Co+o,n,i]: a [T x T] outer-product sum over the Co*N rows of
+// a group.  A lane keeps the T*T accumulators in registers over its rows; waves reduce by shuffles, the
+// block through LDS, and kTmixChunks blocks per (g, k) leave partials for the fixed-order final sum.
+constexpr int kTmixChunks = 4;
+
+template <int T>
+__global__ __launch_bounds__(kBlock) void k_tmix_dA(const float* __restrict__ dout, const float* __restrict__ y,
+                                                    float* __restrict__ part, int Co, int K, int N) {
+  __shared__ float red[kBlock / kWave][T * T];
+  const int g = blockIdx.z, k = blockIdx.y;
+  const int rows = Co * N;
+  const int per = cdiv(rows, (int)gridDim.x);
+  const int r0 = blockIdx.x * per, r1 = min(r0 + per, rows);
+  float acc[T][T];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int i = 0; i < T; ++i) acc[t][i] = 0.f;
+  const float* dbase = dout + (size_t)g * rows * T;
+  const float* ybase = y + ((size_t)g * K + k) * rows * T;
+  for (int rr = r0 + threadIdx.x; rr < r1; rr += kBlock) {
+    float dv[T], yv[T];
+    ld_row<T>(dbase + (size_t)rr * T, dv);
+    ld_row<T>(ybase + (size_t)rr * T, yv);
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int i = 0; i < T; ++i) acc[t][i] = fmaf(dv[t], yv[i], acc[t][i]);
+  }
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+      float a = acc[t][i];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+      if (lane == 0) red[wave][t * T + i] = a;
+    }
+  __syncthreads();
+  if (threadIdx.x < T * T)
+    part[(((size_t)g * K + k) * gridDim.x + blockIdx.x) * (T * T) + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+size_t tmix_partial_floats(int G, int K, int T) { return (size_t)G * K * kTmixChunks * T * T; }
+
+int launch_tmix_dA(const float* dout, const float* y, float* dA, float* part, int G, int Co, int K, int N, int T,
+                   hipStream_t s) {
+  dim3 grid(kTmixChunks, K, G);
+  switch (T) {
+    case 4: hipLaunchKernelGGL(k_tmix_dA<4>, grid, dim3(kBlock), 0, s, dout, y, part, Co, K, N); break;
+    case 8: hipLaunchKernelGGL(k_tmix_dA<8>, grid, dim3(kBlock), 0, s, dout, y, part, Co, K, N); break;
+    case 12: hipLaunchKernelGGL(k_tmix_dA<12>, grid, dim3(kBlock), 0, s, dout, y, part, Co, K, N); break;
+    case 16: hipLaunchKernelGGL(k_tmix_dA<16>, grid, dim3(kBlock), 0, s, dout, y, part, Co, K, N); break;
+    default: return MSGAT_ERR_UNSUPPORTED;
+  }
+  MSGAT_CHECK_LAUNCH();
+  return launch_reduce_groups(part, G * K, kTmixChunks, T * T, dA, s);
+}
+
+// ---- node pooling -------------------------------------------------------------------------------------
+// pooled[s,t] = sum_n w[n] x[s,n,t] for every (sample, channel) slab s (attention.py:89).
+template <int T>
+__global__ __launch_bounds__(kBlock) void k_node_pool(const float* __restrict__ x, const float* __restrict__ w,
+                                                      float* __restrict__ pooled, int N) {
+  __shared__ float red[kBlock / kWave][T];
+  const size_t sl = blockIdx.x;
+  float acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = 0.f;
+  for (int n = threadIdx.x; n < N; n += kBlock) {
+    float v[T];
+    ld_row<T>(x + (sl * N + n) * T, v);
+    const float wn = w[n];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = fmaf(wn, v[t], acc[t]);
+  }
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    float a = acc[t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0) red[wave][t] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < T)
+    pooled[sl * T + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// dx[s,n,t] = w[n] dpooled[s,t]
+template <int T>
+__global__ __launch_bounds__(kBlock) void k_node_pool_dx(const float* __restrict__ w, const float* __restrict__ dp,
+                                                         float* __restrict__ dx, int N) {
+  const size_t sl = blockIdx.x;
+  const int n = blockIdx.y * kBlock + threadIdx.x;
+  if (n >= N) return;
+  float v[T];
+  const float wn = w[n];
+#pragma unroll
+  for (int t = 0; t < T; ++t) v[t] = wn * dp[sl * T + t];
+  st_row<T>(dx + (sl * N + n) * T, v);
+}
+
+// dw partial[g*nck + ck, n] = sum_{c in chunk ck} sum_t x[g,c,n,t] dpooled[g,c,t]
+constexpr int kPoolCC = 16;  // channels per block
+
+template <int T>
+__global__ __launch_bounds__(kBlock) void k_node_pool_dw(const float* __restrict__ x, const float* __restrict__ dp,
+                                                         float* __restrict__ part, int C, int N) {
+  __shared__ float dl[kPoolCC][T];
+  const int g = blockIdx.z, ck = blockIdx.y;
+  const int c0 = ck * kPoolCC, cn = min(kPoolCC, C - c0);
+  for (int i = threadIdx.x; i < cn * T; i += kBlock) dl[i / T][i % T] = dp[((size_t)g * C + c0) * T + i];
+  __syncthreads();
+  const int n = blockIdx.x * kBlock + threadIdx.x;
+  if (n >= N) return;
+  float acc = 0.f;
+  for (int c = 0; c < cn; ++c) {
+    float v[T];
+    ld_row<T>(x + (((size_t)g * C + c0 + c) * N + n) * T, v);
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc = fmaf(v[t], dl[c][t], acc);
+  }
+  part[((size_t)g * gridDim.y + ck) * N + n] = acc;
+}
+
+int launch_node_pool(const float* x, const float* w, float* pooled, long long slabs, int N, int T, hipStream_t s) {
+  dim3 grid((unsigned)slabs);
+  switch (T) {
+    case 4: hipLaunchKernelGGL(k_node_pool<4>, grid, dim3(kBlock), 0, s, x, w, pooled, N); break;
+    case 8: hipLaunchKernelGGL(k_node_pool<8>, grid, dim3(kBlock), 0, s, x, w, pooled, N); break;
+    case 12: hipLaunchKernelGGL(k_node_pool<12>, grid, dim3(kBlock), 0, s, x, w, pooled, N); break;
+    case 16: hipLaunchKernelGGL(k_node_pool<16>, grid, dim3(kBlock), 0, s, x, w, pooled, N); break;
+    default: return MSGAT_ERR_UNSUPPORTED;
+  }
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
+}
+
+int launch_node_pool_dx(const float* w, const float* dp, float* dx, long long slabs, int N, int T, hipStream_t s) {
+  dim3 grid((unsigned)slabs, cdiv(N, kBlock));
+  switch (T) {
+    case 4: hipLaunchKernelGGL(k_node_pool_dx<4>, grid, dim3(kBlock), 0, s, w, dp, dx, N); break;
+    case 8: hipLaunchKernelGGL(k_node_pool_dx<8>, grid, dim3(kBlock), 0, s, w, dp, dx, N); break;
+    case 12: hipLaunchKernelGGL(k_node_pool_dx<12>, grid, dim3(kBlock), 0, s, w, dp, dx, N); break;
+    case 16: hipLaunchKernelGGL(k_node_pool_dx<16>, grid, dim3(kBlock), 0, s, w, dp, dx, N); break;
+    default: return MSGAT_ERR_UNSUPPORTED;
+  }
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
+}
+
+size_t node_pool_partial_floats(int G, int C, int N) { return (size_t)G * cdiv(C, kPoolCC) * N; }
+
+int launch_node_pool_dw(const float* x, const float* dp, float* dw, float* part, int G, int C, int N, int T,
+                        hipStream_t s) {
+  const int nck = cdiv(C, kPoolCC);
+  dim3 grid(cdiv(N, kBlock), nck, G);
+  switch (T) {
+    case 4: hipLaunchKernelGGL(k_node_pool_dw<4>, grid, dim3(kBlock), 0, s, x, dp, part, C, N); break;
+    case 8: hipLaunchKernelGGL(k_node_pool_dw<8>, grid, dim3(kBlock), 0, s, x, dp, part, C, N); break;
+    case 12: hipLaunchKernelGGL(k_node_pool_dw<12>, grid, dim3(kBlock), 0, s, x, dp, part, C, N); break;
+    case 16: hipLaunchKernelGGL(k_node_pool_dw<16>, grid, dim3(kBlock), 0, s, x, dp, part, C, N); break;
+    default: return MSGAT_ERR_UNSUPPORTED;
+  }
+  MSGAT_CHECK_LAUNCH();
+  return launch_reduce_rows(part, G * nck, N, dw, N, nullptr, 0, s);
+}
+
+}  // namespace msgat

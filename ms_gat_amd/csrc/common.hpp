@@ -80,6 +80,30 @@ __device__ unsigned g_hwid[4096];  // (XCC_ID << 16) | HW_ID of the block's firs
 #define MSGAT_STAMP(i)
 #endif
 
+// Epilogue of the channel-mixing kernels: v + bias[r,co] + add[g,co,p], then ReLU -- what turns
+// "W x" into a 1x1 convolution with bias, and the residual convolution of MEAM (msgat.py:130-131)
+// into one pass: relu(cat(branches) + res(x)).
+struct MixEpilogue {
+  const float* bias = nullptr;   // [R?, Co]: element r * bias_rstride + co
+  int bias_rstride = 0;
+  const float4* add4 = nullptr;  // same layout as the output
+  int relu = 0;
+#if defined(__HIPCC__)
+  __device__ __forceinline__ float4 apply(float4 v, int r, int co, size_t off) const {
+    if (bias != nullptr) {
+      const float b = bias[(size_t)r * bias_rstride + co];
+      v.x += b; v.y += b; v.z += b; v.w += b;
+    }
+    if (add4 != nullptr) {
+      const float4 a = add4[off];
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    return v;
+  }
+#endif
+};
+
 // ---- kernel launchers (defined in the .hip files) ---------------------------------
 int launch_qonly(const float* x, const float* alpha, float* q, int G, int Bg, int C, int P,
                  hipStream_t s);
@@ -87,11 +111,14 @@ int launch_qonly(const float* x, const float* alpha, float* q, int G, int Bg, in
 int launch_project(const float* in, const float* M, int m_in_major, const float* qvec,
                    const float* addvec, const float* extra, float* out, float* q, int G, int Bg,
                    int Ci, int Co, int P, hipStream_t s);
+int launch_project_epi(const float* in, const float* M, int m_in_major, const float* qvec,
+                       const float* addvec, const float* extra, float* out, float* q, int G, int Bg,
+                       int Ci, int Co, int P, const MixEpilogue& epi, hipStream_t s);
 // MFMA forms (mfma.hip); launch_project / launch_chanpair dispatch to them
 size_t project_mfma_lds_bytes(int Ci, int Co, bool has_extra);
 int launch_project_mfma(const float* in, const float* M, int m_in_major, const float* qvec,
                         const float* addvec, const float* extra, float* out, float* q, int G, int Bg,
-                        int Ci, int Co, int P, hipStream_t s);
+                        int Ci, int Co, int P, const MixEpilogue& epi, hipStream_t s);
 int chanpair_mfma_blocks(int R);  // blocks (= partials) per relation
 int launch_chanpair_mfma(const float* A, const float* Aextra, const float* B, float* part, int R, int Bg,
                          int Ca, int Cb, int P, int nblk, hipStream_t s);
@@ -128,6 +155,19 @@ int launch_chanpair(const float* A, const float* Aextra, const float* B, float* 
 // out[i] = sum_j part[j,i], i < Wd, split over dst0 (first n0) and dst1 (next n1); fixed order
 int launch_reduce_rows(const float* part, int J, int Wd, float* dst0, int n0, float* dst1, int n1,
                        hipStream_t s);
+// out[r,i] = sum_j part[r,j,i]
+int launch_reduce_groups(const float* part, int R, int J, int Wd, float* dst, hipStream_t s);
+// temporal / channel branch kernels (branches.hip)
+int launch_tmix(const float* src, const float* A, int per_group, const float* bias, float* dst, int G, int Co,
+                int K, int N, int T, int backward, hipStream_t s);
+size_t tmix_partial_floats(int G, int K, int T);
+int launch_tmix_dA(const float* dout, const float* y, float* dA, float* part, int G, int Co, int K, int N, int T,
+                   hipStream_t s);
+int launch_node_pool(const float* x, const float* w, float* pooled, long long slabs, int N, int T, hipStream_t s);
+int launch_node_pool_dx(const float* w, const float* dp, float* dx, long long slabs, int N, int T, hipStream_t s);
+size_t node_pool_partial_floats(int G, int C, int N);
+int launch_node_pool_dw(const float* x, const float* dp, float* dw, float* part, int G, int C, int N, int T,
+                        hipStream_t s);
 // LayerNorm over the last axis of [rows, T] (layernorm.hip)
 size_t layernorm_partial_floats(long long rows, int T);
 int launch_layernorm_fwd(const float* x, const float* w, const float* b, float* y, long long rows, int T,

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kBlock) void k_project_mfma(
     const float4* __restrict__ in4, const float* __restrict__ M, int m_in_major,
     const float* __restrict__ qvec, const float* __restrict__ addvec,
     const float4* __restrict__ extra4, float4* __restrict__ out4, float4* __restrict__ q4, int Bg,
-    int Ci, int Co, int P4) {
+    int Ci, int Co, int P4, MixEpilogue epi) {
   extern __shared__ float lds[];
   const bool has_extra = addvec != nullptr;
   const int Kx = Ci + (has_extra ? 1 : 0);  // the extra "channel" carries addvec (x) extra
@@ -134,9 +134,11 @@ __global__ __launch_bounds__(kBlock) void k_project_mfma(
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int co = (m0 + mg) * 16 + 4 * kq + reg;
-        if (co < Co && pvalid)
-          out4[((size_t)g * Co + co) * P4 + p4] =
-              make_float4(acc[mg][0][reg], acc[mg][1][reg], acc[mg][2][reg], acc[mg][3][reg]);
+        if (co < Co && pvalid) {
+          float4 v = make_float4(acc[mg][0][reg], acc[mg][1][reg], acc[mg][2][reg], acc[mg][3][reg]);
+          const size_t o = ((size_t)g * Co + co) * P4 + p4;
+          out4[o] = epi.apply(v, r, co, o);
+        }
       }
   }
   if (DO_Q) {  // the four lane quarters hold the 4k + kq channels' share of q
@@ -163,31 +165,31 @@ size_t project_mfma_lds_bytes(int Ci, int Co, bool has_extra) {
 template <int MG>
 static int launch_project_mg(const float* in, const float* M, int m_in_major, const float* qvec,
                              const float* addvec, const float* extra, float* out, float* q, int G, int Bg,
-                             int Ci, int Co, int P4, hipStream_t s) {
+                             int Ci, int Co, int P4, const MixEpilogue& epi, hipStream_t s) {
   const size_t lds = project_mfma_lds_bytes(Ci, Co, addvec != nullptr);
   dim3 grid(cdiv(P4, 64), G);
   if (qvec != nullptr)
     hipLaunchKernelGGL((k_project_mfma<MG, true>), grid, dim3(kBlock), lds, s, (const float4*)in, M, m_in_major,
-                       qvec, addvec, (const float4*)extra, (float4*)out, (float4*)q, Bg, Ci, Co, P4);
+                       qvec, addvec, (const float4*)extra, (float4*)out, (float4*)q, Bg, Ci, Co, P4, epi);
   else
     hipLaunchKernelGGL((k_project_mfma<MG, false>), grid, dim3(kBlock), lds, s, (const float4*)in, M,
-                       m_in_major, qvec, addvec, (const float4*)extra, (float4*)out, (float4*)q, Bg, Ci, Co, P4);
+                       m_in_major, qvec, addvec, (const float4*)extra, (float4*)out, (float4*)q, Bg, Ci, Co, P4, epi);
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
 
 int launch_project_mfma(const float* in, const float* M, int m_in_major, const float* qvec,
                         const float* addvec, const float* extra, float* out, float* q, int G, int Bg,
-                        int Ci, int Co, int P, hipStream_t s) {
+                        int Ci, int Co, int P, const MixEpilogue& epi, hipStream_t s) {
   const int P4 = P / 4;
   int MG;
   proj_passes_mg(Co, &MG);
   switch (MG) {
-    case 1: return launch_project_mg<1>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, s);
-    case 2: return launch_project_mg<2>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, s);
-    case 3: return launch_project_mg<3>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, s);
-    case 4: return launch_project_mg<4>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, s);
-    default: return launch_project_mg<5>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, s);
+    case 1: return launch_project_mg<1>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, epi, s);
+    case 2: return launch_project_mg<2>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, epi, s);
+    case 3: return launch_project_mg<3>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, epi, s);
+    case 4: return launch_project_mg<4>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, epi, s);
+    default: return launch_project_mg<5>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, epi, s);
   }
 }
 

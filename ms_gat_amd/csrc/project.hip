@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kBlock) void k_project(
     const float4* __restrict__ in4, const float* __restrict__ M, int m_in_major,
     const float* __restrict__ qvec, const float* __restrict__ addvec,
     const float4* __restrict__ extra4, float4* __restrict__ out4, float4* __restrict__ q4, int Bg,
-    int Ci, int Co, int P4) {
+    int Ci, int Co, int P4, MixEpilogue epi) {
   extern __shared__ float lds[];
   float* Ml = lds;            // [Ci][OT]
   float* ql = lds + Ci * OT;  // [Ci]
@@ -94,7 +94,8 @@ __global__ __launch_bounds__(kBlock) void k_project(
     if (o < Co) {
       float4 v = acc[oo];
       if (addvec != nullptr) f4fma(addvec[r * Co + o], ex, v);
-      out4[((size_t)g * Co + o) * P4 + p4] = v;
+      const size_t off = ((size_t)g * Co + o) * P4 + p4;
+      out4[off] = epi.apply(v, r, o, off);
     }
   }
   if (do_q) q4[(size_t)g * P4 + p4] = qa;
@@ -103,11 +104,11 @@ __global__ __launch_bounds__(kBlock) void k_project(
 template <int OT>
 static int launch_project_t(const float* in, const float* M, int m_in_major, const float* qvec,
                             const float* addvec, const float* extra, float* out, float* q, int G,
-                            int Bg, int Ci, int Co, int P4, hipStream_t s) {
+                            int Bg, int Ci, int Co, int P4, const MixEpilogue& epi, hipStream_t s) {
   dim3 grid(cdiv(P4, kBlock), G, cdiv(Co, OT));
   const size_t lds = (size_t)(Ci * OT + Ci) * sizeof(float);
   hipLaunchKernelGGL(k_project<OT>, grid, dim3(kBlock), lds, s, (const float4*)in, M, m_in_major,
-                     qvec, addvec, (const float4*)extra, (float4*)out, (float4*)q, Bg, Ci, Co, P4);
+                     qvec, addvec, (const float4*)extra, (float4*)out, (float4*)q, Bg, Ci, Co, P4, epi);
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
@@ -115,17 +116,23 @@ static int launch_project_t(const float* in, const float* M, int m_in_major, con
 int launch_project(const float* in, const float* M, int m_in_major, const float* qvec,
                    const float* addvec, const float* extra, float* out, float* q, int G, int Bg,
                    int Ci, int Co, int P, hipStream_t s) {
+  return launch_project_epi(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P, MixEpilogue{}, s);
+}
+
+int launch_project_epi(const float* in, const float* M, int m_in_major, const float* qvec,
+                       const float* addvec, const float* extra, float* out, float* q, int G, int Bg,
+                       int Ci, int Co, int P, const MixEpilogue& epi, hipStream_t s) {
   // matrix cores whenever there are enough output channels to fill a tile and the matrix fits LDS
   if (Co >= 8 && project_mfma_lds_bytes(Ci, Co, addvec != nullptr) <= 64 * 1024)
-    return launch_project_mfma(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P, s);
+    return launch_project_mfma(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P, epi, s);
   const int P4 = P / 4;
   // VALU fallback (few outputs or a very large matrix): widest tile that divides the work evenly; 24 and 32 cover the reference's widths
   // (Co = 16/24/32 forward, C = 48/72/96 backward)
-  if (Co % 24 == 0) return launch_project_t<24>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, s);
-  if (Co % 32 == 0) return launch_project_t<32>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, s);
-  if (Co % 16 == 0) return launch_project_t<16>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, s);
-  if (Co <= 4) return launch_project_t<4>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, s);
-  return launch_project_t<8>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, s);
+  if (Co % 24 == 0) return launch_project_t<24>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, epi, s);
+  if (Co % 32 == 0) return launch_project_t<32>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, epi, s);
+  if (Co % 16 == 0) return launch_project_t<16>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, epi, s);
+  if (Co <= 4) return launch_project_t<4>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, epi, s);
+  return launch_project_t<8>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, epi, s);
 }
 
 }  // namespace msgat

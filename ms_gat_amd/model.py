@@ -4,8 +4,10 @@
 Reference: /root/reference/src/models/msgat.py (GACN :17, TACN :57, CACN :83, MEAM :103,
 TPC :137, MSGAT :166, factories :220-229), attention.py (TemporalAttention :42,
 ChannelAttention :72), embeddings.py (TimeEmbedding :12).  Only the graph branch runs in
-the HIP library, and so does the LayerNorm over T that produces its input (`LayerNormT`, SURVEY.md
-section 8 row f-1); the temporal / channel branches and convolutions are dense PyTorch-ROCm ops.
+the HIP library at first; SURVEY.md section 8 rows f-1 and f-2 then pulled in every pass over the
+[B,C,N,T] activations of a MEAM block: the LayerNorm over T (`LayerNormT`), the temporal and channel
+branches (`ops.channel_pool / node_pool / mix / time_mix`) and the residual tail.  What stays in
+PyTorch is tiny: the [B,T,T] / [B,C,C] attention matrices and their softmax.
 
 Parameter names and shapes are the reference's (`tpcs.{r}.tgacns.{l}.gacn.gatt.Wg`, ...):
 `tests/test_model_cpu.py` checks every key and shape against a reference checkpoint.
@@ -34,7 +36,11 @@ class LayerNormT(nn.LayerNorm):
 
 
 class TemporalAttention(nn.Module):
-    """[T,T] attention from rank-10 node projections (attention.py:58-66).  signals [B,C,N,T]."""
+    """[T,T] attention from rank-10 node projections (attention.py:58-66).  signals [B,C,N,T].
+
+    The two passes over the activation run in the library: the channel-weighted sum (`ops.channel_pool`,
+    the hot path's q kernel) and the product with the [T,T] matrix (`ops.time_mix`); the rank-10
+    projections and the softmax over [B,T,T] are tiny and stay in PyTorch."""
 
     rank = 10
 
@@ -45,13 +51,16 @@ class TemporalAttention(nn.Module):
         self.Wt2 = nn.Parameter(torch.empty(self.rank, n_nodes))
         self.alpha = nn.Parameter(torch.empty(n_channels))
 
-    def forward(self, signals: torch.Tensor) -> torch.Tensor:
-        mixed = torch.tensordot(signals, self.alpha, dims=([1], [0]))   # [B,N,T]: channel-weighted sum
-        per_t = mixed.transpose(1, 2)                                    # [B,T,N]
+    def attention(self, signals: torch.Tensor) -> torch.Tensor:
+        """-> att [B,T,T], rows = output step."""
+        per_t = ops.channel_pool(signals, self.alpha).transpose(1, 2)   # [B,T,N]
         left = per_t @ self.Wt1.t()                                      # [B,T,10]
         right = per_t @ self.Wt2.t()                                     # [B,T,10]
-        att = torch.softmax(left @ right.transpose(1, 2), dim=-1)        # [B,T,T], rows = output step
-        return signals @ att.transpose(1, 2).unsqueeze(1)                # out[..,t] = sum_i att[t,i] x[..,i]
+        return torch.softmax(left @ right.transpose(1, 2), dim=-1)
+
+    def forward(self, signals: torch.Tensor) -> torch.Tensor:
+        # out[..,t] = sum_i att[t,i] x[..,i]
+        return ops.time_mix(signals, self.attention(signals).unsqueeze(1))
 
     def extra_repr(self) -> str:
         return f"n_channels={self.n_channels}, n_nodes={self.n_nodes}"
@@ -66,11 +75,13 @@ class ChannelAttention(nn.Module):
         self.Wc = nn.Parameter(torch.empty(n_timesteps, n_timesteps))
         self.alpha = nn.Parameter(torch.empty(n_nodes))
 
+    def attention(self, signals: torch.Tensor) -> torch.Tensor:
+        """-> att [B,C,C]."""
+        pooled = ops.node_pool(signals, self.alpha)                      # [B,C,T]: node-weighted sum
+        return torch.softmax(pooled @ self.Wc @ pooled.transpose(1, 2), dim=-1)
+
     def forward(self, signals: torch.Tensor) -> torch.Tensor:
-        B, C, N, T = signals.shape
-        pooled = torch.tensordot(signals, self.alpha, dims=([2], [0]))   # [B,C,T]: node-weighted sum
-        att = torch.softmax(pooled @ self.Wc @ pooled.transpose(1, 2), dim=-1)   # [B,C,C]
-        return (att @ signals.reshape(B, C, N * T)).view(B, C, N, T)
+        return ops.mix(signals, self.attention(signals))                 # per-sample [C,C] channel matrix
 
     def extra_repr(self) -> str:
         return f"n_nodes={self.n_nodes}, n_timesteps={self.n_timesteps}"
@@ -90,8 +101,22 @@ class TrimRight(nn.Module):
         return f"n={self.n}"
 
 
+def _shift_down(att: torch.Tensor, d: int) -> torch.Tensor:
+    """rows t >= d of the result are rows t - d of `att` ([..,T,T]); rows < d are zero."""
+    T = att.size(-2)
+    if d >= T:
+        return torch.zeros_like(att)
+    return torch.nn.functional.pad(att[..., : T - d, :], (0, 0, d, 0))
+
+
 class TACN(nn.Module):
-    """Temporal attention, then a stack of causal dilated [1,2] convolutions (msgat.py:57-80)."""
+    """Temporal attention, then a stack of causal dilated [1,2] convolutions (msgat.py:57-80).
+
+    `seq` keeps the reference's layout (seq.0 attention, seq.1/3/.. Conv2d weights, seq.2/4/.. trims) so
+    checkpoints interchange; the forward does not run the Conv2d modules.  A padded, right-trimmed
+    [1,2] convolution with dilation d is out[t] = W_0 in[t-d] + W_1 in[t]; with in = attention(x) that is
+    sum_k (W_k x) applied along time with A_1 = att, A_0 = att shifted down by d.  So each layer is one
+    channel-mixing pass (C -> 2 Co) and one `ops.time_mix` pass; the attention product is never stored."""
 
     def __init__(self, in_channels: int, out_channels: int, n_nodes: int, dilations: Sequence[int]):
         super().__init__()
@@ -106,11 +131,27 @@ class TACN(nn.Module):
         self.seq = nn.Sequential(*layers)
 
     def forward(self, signals: torch.Tensor) -> torch.Tensor:
-        return self.seq(signals)
+        ta = self.seq[0]
+        if not self.dilations:
+            return ta(signals)
+        T = signals.size(-1)
+        h, taps = signals, None
+        for i, d in enumerate(self.dilations):
+            conv = self.seq[1 + 2 * i]
+            stacked = torch.cat([conv.weight[:, :, 0, 0], conv.weight[:, :, 0, 1]], dim=0).unsqueeze(0)   # [1,2Co,Ci]
+            if i == 0:
+                att = ta.attention(signals)                                                   # [B,T,T]
+                taps = torch.stack([_shift_down(att, d), att], dim=1)                         # [B,2,T,T]
+            else:
+                eye = torch.eye(T, device=signals.device, dtype=signals.dtype)
+                taps = torch.stack([_shift_down(eye, d), eye], dim=0).unsqueeze(0)            # [1,2,T,T]
+            h = ops.time_mix(ops.mix(h, stacked), taps, conv.bias)
+        return h
 
 
 class CACN(nn.Module):
-    """Channel attention, then a 1x1 convolution (msgat.py:83-100)."""
+    """Channel attention, then a 1x1 convolution (msgat.py:83-100): one pass with the per-sample
+    matrix `conv.weight @ att_b`."""
 
     def __init__(self, in_channels: int, out_channels: int, n_nodes: int, n_timesteps: int):
         super().__init__()
@@ -119,7 +160,8 @@ class CACN(nn.Module):
         self.seq = nn.Sequential(ChannelAttention(n_nodes, n_timesteps), nn.Conv2d(in_channels, out_channels, 1))
 
     def forward(self, signals: torch.Tensor) -> torch.Tensor:
-        return self.seq(signals)
+        conv = self.seq[1]
+        return ops.mix(signals, conv.weight[:, :, 0, 0] @ self.seq[0].attention(signals), conv.bias)
 
 
 class MEAM(nn.Module):
@@ -144,7 +186,8 @@ class MEAM(nn.Module):
     def forward(self, signals: torch.Tensor, adjacency) -> torch.Tensor:
         normed = self.ln(signals)
         branches = torch.cat([self.cacn(normed), self.tacn(normed), self.gacn(normed, adjacency)], dim=1)
-        return torch.relu(branches + self.res(signals))
+        # relu(branches + res(signals)): the 1x1 residual convolution with the add and the ReLU in its epilogue
+        return ops.mix(signals, self.res.weight[:, :, 0, 0].unsqueeze(0), self.res.bias, add=branches, relu=True)
 
 
 class TPC(nn.Module):

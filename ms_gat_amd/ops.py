@@ -196,3 +196,216 @@ def layer_norm_t(x: torch.Tensor, weight: Optional[torch.Tensor] = None, bias: O
     if x.numel() == 0:
         return torch.empty_like(x)
     return _LayerNormTFunction.apply(x, weight, bias, float(eps))
+
+
+# ---- the temporal / channel branches of MEAM and its residual tail -----------
+
+def _new(like: torch.Tensor, *shape) -> torch.Tensor:
+    return torch.empty(shape, device=like.device, dtype=torch.float32)
+
+
+class _MixFunction(torch.autograd.Function):
+    """x[G,Ci,N,T], M[R,Co,Ci] (R | G), bias[Co] | None, add[G,Co,N,T] | None -> relu?(M x + bias + add)."""
+
+    @staticmethod
+    def forward(ctx, x, M, bias, add, relu: bool):
+        L = _lib.lib()
+        x, M = x.contiguous(), M.contiguous()
+        G, Ci, N, T = x.shape
+        R, Co = M.shape[0], M.shape[1]
+        shape = _lib.Shape(R, G // R, Ci, Co, N, T)
+        out = _new(x, G, Co, N, T)
+        b = None if bias is None else bias.contiguous()
+        a = None if add is None else add.contiguous()
+        st = L.msgat_stage_mix_epilogue(C.byref(shape), Ci, Co, _ptr(x), _ptr(M), 0, _ptr(b), 0, _ptr(a), int(relu),
+                                        _ptr(out), _stream_handle(x.device))
+        _lib.check(st, "msgat_stage_mix_epilogue")
+        ctx.relu, ctx.has_bias, ctx.has_add = relu, bias is not None, add is not None
+        ctx.save_for_backward(x, M, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        x, M, out = ctx.saved_tensors
+        G, Ci, N, T = x.shape
+        R, Co = M.shape[0], M.shape[1]
+        dpre = (dout * (out > 0)) if ctx.relu else dout.contiguous()
+        stream = _stream_handle(x.device)
+        need = ctx.needs_input_grad
+        dx = dM = dbias = None
+        if need[0]:
+            dx = torch.empty_like(x)
+            shape = _lib.Shape(R, G // R, Co, Ci, N, T)
+            st = L.msgat_stage_mix(C.byref(shape), Co, Ci, _ptr(dpre), _ptr(M), 1, None, None, _ptr(dx), stream)
+            _lib.check(st, "msgat_stage_mix")
+        if need[1]:
+            dM = torch.empty_like(M)
+            shape = _lib.Shape(R, G // R, Ci, Co, N, T)
+            part = _new(x, max(int(L.msgat_contract_partial_floats(C.byref(shape), Co, Ci)), 1))
+            st = L.msgat_stage_contract(C.byref(shape), Co, Ci, _ptr(dpre), None, _ptr(x), _ptr(part), _ptr(dM),
+                                        Co * Ci, None, 0, stream)
+            _lib.check(st, "msgat_stage_contract")
+        if ctx.has_bias and need[2]:
+            dbias = dpre.sum(dim=(0, 2, 3))
+        return dx, dM, dbias, (dpre if ctx.has_add and need[3] else None), None
+
+
+def mix(x: torch.Tensor, M: torch.Tensor, bias: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None,
+        relu: bool = False) -> torch.Tensor:
+    """out[g,o] = relu?(sum_c M[r,o,c] x[g,c] + bias[o] + add[g,o]), r = g // (G/R): a 1x1 convolution (R = 1), a
+    per-sample channel matrix (R = batch), or MEAM's tail relu(cat(branches) + res(x)) (msgat.py:130-131)."""
+    _require_device_tensor("signals", x)
+    _require_device_tensor("matrix", M, x.device)
+    if x.dim() != 4 or M.dim() != 3 or M.shape[2] != x.shape[1] or x.shape[0] % M.shape[0]:
+        raise ValueError(f"mix: signals {tuple(x.shape)} and matrix {tuple(M.shape)} do not match")
+    if bias is not None and tuple(bias.shape) != (M.shape[1],):
+        raise ValueError(f"bias must be [{M.shape[1]}]")
+    if add is not None and tuple(add.shape) != (x.shape[0], M.shape[1], x.shape[2], x.shape[3]):
+        raise ValueError(f"add must be [{x.shape[0]},{M.shape[1]},{x.shape[2]},{x.shape[3]}], got {tuple(add.shape)}")
+    return _MixFunction.apply(x, M, bias, add, bool(relu))
+
+
+class _TimeMixFunction(torch.autograd.Function):
+    """y[G,K*Co,N,T], A[G|1,K,T,T], bias[Co] | None -> out[g,o,n,t] = bias[o] + sum_k sum_i A[g,k,t,i] y[g,k*Co+o,n,i]."""
+
+    @staticmethod
+    def forward(ctx, y, A, bias):
+        L = _lib.lib()
+        y, A = y.contiguous(), A.contiguous()
+        G, KC, N, T = y.shape
+        K = A.shape[1]
+        Co = KC // K
+        per_group = int(A.shape[0] != 1 or G == 1)
+        out = _new(y, G, Co, N, T)
+        b = None if bias is None else bias.contiguous()
+        st = L.msgat_time_mix(_ptr(y), _ptr(A), per_group, _ptr(b), _ptr(out), G, Co, K, N, T, 0,
+                              _stream_handle(y.device))
+        _lib.check(st, "msgat_time_mix")
+        ctx.dims, ctx.per_group, ctx.has_bias = (G, Co, K, N, T), per_group, bias is not None
+        ctx.save_for_backward(y, A)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        y, A = ctx.saved_tensors
+        G, Co, K, N, T = ctx.dims
+        dout = dout.contiguous()
+        stream = _stream_handle(y.device)
+        need = ctx.needs_input_grad
+        dy = dA = dbias = None
+        if need[0]:
+            dy = torch.empty_like(y)
+            st = L.msgat_time_mix(_ptr(dout), _ptr(A), ctx.per_group, None, _ptr(dy), G, Co, K, N, T, 1, stream)
+            _lib.check(st, "msgat_time_mix (backward)")
+        if need[1]:
+            dAg = _new(y, G, K, T, T)
+            part = _new(y, max(int(L.msgat_time_mix_partial_floats(G, K, T)), 1))
+            st = L.msgat_time_mix_grad_matrix(_ptr(dout), _ptr(y), _ptr(dAg), _ptr(part), G, Co, K, N, T, stream)
+            _lib.check(st, "msgat_time_mix_grad_matrix")
+            dA = dAg if A.shape[0] == G else dAg.sum(dim=0, keepdim=True)
+        if ctx.has_bias and need[2]:
+            dbias = dout.sum(dim=(0, 2, 3))
+        return dy, dA, dbias
+
+
+def time_mix(y: torch.Tensor, A: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Applies K [T,T] matrices along the time axis of K channel groups and adds them up (see
+    include/msgat_hip.h: msgat_time_mix).  K = 1 with A = att is TemporalAttention's product
+    (attention.py:66); K = 2 is a causal dilated [1,2] convolution after its channel mixing."""
+    _require_device_tensor("signals", y)
+    _require_device_tensor("matrices", A, y.device)
+    if y.dim() != 4 or A.dim() != 4 or A.shape[2] != y.shape[3] or A.shape[3] != y.shape[3]:
+        raise ValueError(f"time_mix: signals {tuple(y.shape)} and matrices {tuple(A.shape)} do not match")
+    if A.shape[0] not in (1, y.shape[0]) or y.shape[1] % A.shape[1]:
+        raise ValueError(f"time_mix: {tuple(A.shape)} matrices for signals {tuple(y.shape)}")
+    return _TimeMixFunction.apply(y, A, bias)
+
+
+class _NodePoolFunction(torch.autograd.Function):
+    """x[B,C,N,T], w[N] -> pooled[B,C,T] = sum_n w[n] x[b,c,n,:]   (attention.py:89)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        L = _lib.lib()
+        x, w = x.contiguous(), w.contiguous()
+        B, Cc, N, T = x.shape
+        pooled = _new(x, B, Cc, T)
+        st = L.msgat_node_pool(_ptr(x), _ptr(w), _ptr(pooled), B * Cc, N, T, _stream_handle(x.device))
+        _lib.check(st, "msgat_node_pool")
+        ctx.save_for_backward(x, w)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dp):
+        L = _lib.lib()
+        x, w = ctx.saved_tensors
+        B, Cc, N, T = x.shape
+        dp = dp.contiguous()
+        stream = _stream_handle(x.device)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.check(L.msgat_node_pool_grad_signal(_ptr(w), _ptr(dp), _ptr(dx), B * Cc, N, T, stream),
+                       "msgat_node_pool_grad_signal")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            part = _new(x, max(int(L.msgat_node_pool_partial_floats(B, Cc, N)), 1))
+            _lib.check(L.msgat_node_pool_grad_weight(_ptr(x), _ptr(dp), _ptr(dw), _ptr(part), B, Cc, N, T, stream),
+                       "msgat_node_pool_grad_weight")
+        return dx, dw
+
+
+def node_pool(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    _require_device_tensor("signals", x)
+    _require_device_tensor("weights", w, x.device)
+    if x.dim() != 4 or tuple(w.shape) != (x.shape[2],):
+        raise ValueError(f"node_pool: signals {tuple(x.shape)}, weights {tuple(w.shape)}")
+    return _NodePoolFunction.apply(x, w)
+
+
+class _ChannelPoolFunction(torch.autograd.Function):
+    """x[B,C,N,T], alpha[C] -> mixed[B,N,T] = sum_c alpha[c] x[b,c]   (attention.py:59; the hot path's q)."""
+
+    @staticmethod
+    def forward(ctx, x, alpha):
+        L = _lib.lib()
+        x, alpha = x.contiguous(), alpha.contiguous()
+        B, Cc, N, T = x.shape
+        shape = _lib.Shape(1, B, Cc, 0, N, T)
+        q = _new(x, B, N, T)
+        st = L.msgat_stage_project(C.byref(shape), _ptr(x), _ptr(alpha), None, _ptr(q), None, _stream_handle(x.device))
+        _lib.check(st, "msgat_stage_project")
+        ctx.save_for_backward(x, alpha)
+        return q
+
+    @staticmethod
+    def backward(ctx, dq):
+        L = _lib.lib()
+        x, alpha = ctx.saved_tensors
+        B, Cc, N, T = x.shape
+        dq = dq.contiguous()
+        stream = _stream_handle(x.device)
+        dx = dalpha = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            shape = _lib.Shape(1, B, 1, Cc, N, T)
+            st = L.msgat_stage_mix(C.byref(shape), 1, Cc, _ptr(dq), _ptr(alpha), 0, None, None, _ptr(dx), stream)
+            _lib.check(st, "msgat_stage_mix")
+        if ctx.needs_input_grad[1]:
+            dalpha = torch.empty_like(alpha)
+            shape = _lib.Shape(1, B, Cc, 0, N, T)
+            part = _new(x, max(int(L.msgat_contract_partial_floats(C.byref(shape), 1, Cc)), 1))
+            st = L.msgat_stage_contract(C.byref(shape), 1, Cc, None, _ptr(dq), _ptr(x), _ptr(part), _ptr(dalpha), Cc,
+                                        None, 0, stream)
+            _lib.check(st, "msgat_stage_contract")
+        return dx, dalpha
+
+
+def channel_pool(x: torch.Tensor, alpha: torch.Tensor) -> torch.Tensor:
+    _require_device_tensor("signals", x)
+    _require_device_tensor("alpha", alpha, x.device)
+    if x.dim() != 4 or tuple(alpha.shape) != (x.shape[1],):
+        raise ValueError(f"channel_pool: signals {tuple(x.shape)}, alpha {tuple(alpha.shape)}")
+    return _ChannelPoolFunction.apply(x, alpha)

@@ -37,3 +37,47 @@ def huber(output: torch.Tensor, target: torch.Tensor, delta: float) -> torch.Ten
     """loss.py:51-52."""
     err = (output - target).abs()
     return torch.where(err <= delta, 0.5 * err * err, delta * err - 0.5 * delta * delta).mean()
+
+
+# ---- the dense branches of MEAM (SURVEY section 8 row f-2), same rules: test / baseline only ----------
+
+def temporal_attention_dense(x, Wt1, Wt2, alpha):
+    """attention.py:58-66.  x [B,C,N,T] -> [B,C,N,T]: [T,T] attention from rank-10 node projections."""
+    mixed = torch.tensordot(x, alpha, dims=([1], [0]))                  # [B,N,T]
+    per_t = mixed.transpose(1, 2)                                       # [B,T,N]
+    att = torch.softmax((per_t @ Wt1.t()) @ (per_t @ Wt2.t()).transpose(1, 2), dim=-1)
+    return x @ att.transpose(1, 2).unsqueeze(1)
+
+
+def channel_attention_dense(x, Wc, alpha):
+    """attention.py:88-94.  [C,C] attention from node-weighted signals."""
+    B, C, N, T = x.shape
+    pooled = torch.tensordot(x, alpha, dims=([2], [0]))                 # [B,C,T]
+    att = torch.softmax(pooled @ Wc @ pooled.transpose(1, 2), dim=-1)
+    return (att @ x.reshape(B, C, N * T)).view(B, C, N, T)
+
+
+def tacn_dense(x, Wt1, Wt2, alpha, convs):
+    """msgat.py:57-80.  convs = [(weight [Co,Ci,1,2], bias [Co], dilation), ...]: padded dilated conv, right-trimmed."""
+    h = temporal_attention_dense(x, Wt1, Wt2, alpha)
+    for weight, bias, d in convs:
+        h = torch.nn.functional.conv2d(h, weight, bias, padding=(0, d), dilation=(1, d))
+        h = h[..., : h.size(-1) - d]
+    return h
+
+
+def cacn_dense(x, Wc, alpha, weight, bias):
+    """msgat.py:83-100: channel attention, then a 1x1 convolution."""
+    return torch.nn.functional.conv2d(channel_attention_dense(x, Wc, alpha), weight, bias)
+
+
+def meam_dense(x, adj, p, dilations, eps=1e-5):
+    """msgat.py:117-131 with the parameters of one MEAM in `p` (reference state_dict keys)."""
+    T = x.shape[-1]
+    normed = torch.nn.functional.layer_norm(x, [T], p["ln.weight"], p["ln.bias"], eps)
+    convs = [(p[f"tacn.seq.{2 * i + 1}.weight"], p[f"tacn.seq.{2 * i + 1}.bias"], d) for i, d in enumerate(dilations)]
+    branches = torch.cat([
+        cacn_dense(normed, p["cacn.seq.0.Wc"], p["cacn.seq.0.alpha"], p["cacn.seq.1.weight"], p["cacn.seq.1.bias"]),
+        tacn_dense(normed, p["tacn.seq.0.Wt1"], p["tacn.seq.0.Wt2"], p["tacn.seq.0.alpha"], convs),
+        gacn_dense(normed, adj, p["gacn.gatt.Wg"], p["gacn.gatt.alpha"], p["gacn.W"])], dim=1)
+    return torch.relu(branches + torch.nn.functional.conv2d(x, p["res.weight"], p["res.bias"]))

@@ -1,0 +1,171 @@
+"""GPU: the temporal / channel branch kernels against the dense restatement
+of the reference ops (oracle/dense_torch.py, evaluated in float64), forward and every gradient.
+
+Reference: TemporalAttention attention.py:58-66, ChannelAttention :88-94, TACN msgat.py:57-80,
+CACN :83-100, MEAM tail :130-131.  Tolerance 1e-4 relative (the path's bar)."""
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _rand(gen, *shape, scale=1.0):
+    return (torch.randn(*shape, generator=gen) * scale).to(_dev())
+
+
+def _grads(out, inputs, dout):
+    return torch.autograd.grad(out, inputs, dout, allow_unused=True)
+
+
+def _check(ours, ref64, names):
+    for name, a, b in zip(names, ours, ref64):
+        assert rel_err(a.double(), b) < TOL, name
+
+
+def _leaf(*ts):
+    return [t.clone().requires_grad_(True) for t in ts]
+
+
+def _leaf64(*ts):
+    return [t.double().clone().requires_grad_(True) for t in ts]
+
+
+@pytest.mark.parametrize("G,R,Ci,Co,N,T,bias,add,relu", [
+    (4, 1, 72, 24, 57, 12, True, False, False),     # 1x1 convolution with bias
+    (6, 6, 72, 24, 33, 12, True, False, False),     # per-sample matrix (CACN)
+    (3, 1, 72, 72, 41, 12, True, True, True),       # MEAM tail
+    (2, 1, 3, 72, 19, 12, True, True, True),        # first MEAM: 3 input channels
+    (2, 2, 5, 4, 23, 8, False, False, True),        # few outputs: VALU kernel
+    (32, 1, 72, 48, 883, 12, False, False, False),  # PEMSD7 size: TACN's channel mixing
+])
+def test_mix_matches_dense_ops(G, R, Ci, Co, N, T, bias, add, relu):
+    from ms_gat_amd import ops
+    gen = torch.Generator().manual_seed(G * 100 + Ci)
+    x, M = _rand(gen, G, Ci, N, T), _rand(gen, R, Co, Ci, scale=Ci ** -0.5)
+    b = _rand(gen, Co) if bias else None
+    a = _rand(gen, G, Co, N, T) if add else None
+    dout = _rand(gen, G, Co, N, T)
+    ins = [t for t in (x, M, b, a) if t is not None]
+    mine = _leaf(*ins)
+    it = iter(mine)
+    out = ops.mix(next(it), next(it), next(it) if bias else None, next(it) if add else None, relu)
+    g_mine = _grads(out, mine, dout)
+
+    ref = _leaf64(*ins)
+    it = iter(ref)
+    x64, M64 = next(it), next(it)
+    o64 = torch.einsum("roc,rgcnt->rgont", M64, x64.view(R, G // R, Ci, N, T)).reshape(G, Co, N, T)
+    if bias:
+        o64 = o64 + next(it).view(1, Co, 1, 1)
+    if add:
+        o64 = o64 + next(it)
+    if relu:
+        o64 = torch.relu(o64)
+    g_ref = _grads(o64, ref, dout.double())
+    assert rel_err(out.double(), o64) < TOL
+    _check(g_mine, g_ref, ["dx", "dM", "dbias", "dadd"])
+
+
+@pytest.mark.parametrize("B,C,N,T", [(2, 3, 17, 12), (4, 72, 307, 12), (3, 5, 64, 8), (32, 72, 883, 12)])
+def test_temporal_attention_module(B, C, N, T):
+    from ms_gat_amd import model
+    from oracle import dense_torch
+    gen = torch.Generator().manual_seed(B + C)
+    m = model.TemporalAttention(C, N).to(_dev())
+    with torch.no_grad():
+        m.Wt1.copy_(_rand(gen, 10, N, scale=N ** -0.5))
+        m.Wt2.copy_(_rand(gen, 10, N, scale=N ** -0.5))
+        m.alpha.copy_(_rand(gen, C, scale=C ** -0.5))
+    x = _rand(gen, B, C, N, T).requires_grad_(True)
+    dout = _rand(gen, B, C, N, T)
+    out = m(x)
+    g_mine = _grads(out, [x, m.Wt1, m.Wt2, m.alpha], dout)
+    r = _leaf64(x.detach(), m.Wt1.detach(), m.Wt2.detach(), m.alpha.detach())
+    o64 = dense_torch.temporal_attention_dense(*r)
+    assert rel_err(out.double(), o64) < TOL
+    _check(g_mine, _grads(o64, r, dout.double()), ["dx", "dWt1", "dWt2", "dalpha"])
+
+
+@pytest.mark.parametrize("B,C,N,T", [(2, 3, 17, 12), (4, 72, 307, 12), (3, 20, 64, 16), (32, 72, 883, 12)])
+def test_channel_attention_module(B, C, N, T):
+    from ms_gat_amd import model
+    from oracle import dense_torch
+    gen = torch.Generator().manual_seed(B + C + 1)
+    m = model.ChannelAttention(N, T).to(_dev())
+    with torch.no_grad():
+        m.Wc.copy_(_rand(gen, T, T, scale=0.05))
+        m.alpha.copy_(_rand(gen, N, scale=N ** -0.5))
+    x = _rand(gen, B, C, N, T).requires_grad_(True)
+    dout = _rand(gen, B, C, N, T)
+    out = m(x)
+    g_mine = _grads(out, [x, m.Wc, m.alpha], dout)
+    r = _leaf64(x.detach(), m.Wc.detach(), m.alpha.detach())
+    o64 = dense_torch.channel_attention_dense(*r)
+    assert rel_err(out.double(), o64) < TOL
+    _check(g_mine, _grads(o64, r, dout.double()), ["dx", "dWc", "dalpha"])
+
+
+@pytest.mark.parametrize("B,Ci,Co,N,T,dil", [
+    (2, 3, 24, 21, 12, [1, 2]), (2, 72, 24, 50, 12, [2, 4]), (2, 8, 16, 30, 12, [1, 1, 2, 2]), (2, 6, 8, 20, 12, [4, 4]),
+    (2, 5, 8, 13, 8, [3]), (2, 4, 8, 11, 4, [4, 1]), (2, 6, 8, 9, 12, []), (32, 72, 24, 883, 12, [2, 4]),
+])
+def test_tacn_module(B, Ci, Co, N, T, dil):
+    from ms_gat_amd import model
+    from oracle import dense_torch
+    gen = torch.Generator().manual_seed(B + Ci + len(dil))
+    m = model.TACN(Ci, Co, N, dil).to(_dev())
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(_rand(gen, *p.shape, scale=(p.shape[-1] if p.dim() > 1 else p.shape[0]) ** -0.5))
+    x = _rand(gen, B, Ci, N, T).requires_grad_(True)
+    out = m(x)
+    dout = _rand(gen, *out.shape)
+    params = list(m.parameters())
+    g_mine = _grads(out, [x] + params, dout)
+    ta = m.seq[0]
+    r = _leaf64(x.detach(), *[p.detach() for p in params])
+    byname = dict(zip([n for n, _ in m.named_parameters()], r[1:]))
+    convs = [(byname[f"seq.{2 * i + 1}.weight"], byname[f"seq.{2 * i + 1}.bias"], d) for i, d in enumerate(dil)]
+    o64 = dense_torch.tacn_dense(r[0], byname["seq.0.Wt1"], byname["seq.0.Wt2"], byname["seq.0.alpha"], convs)
+    assert out.shape == o64.shape
+    assert rel_err(out.double(), o64) < TOL
+    _check(g_mine, _grads(o64, r, dout.double()), ["dx"] + [n for n, _ in m.named_parameters()])
+
+
+@pytest.mark.parametrize("B,Ci,Co,N,T", [(2, 3, 24, 21, 12), (3, 72, 24, 50, 12), (32, 72, 24, 883, 12)])
+def test_cacn_module(B, Ci, Co, N, T):
+    from ms_gat_amd import model
+    from oracle import dense_torch
+    gen = torch.Generator().manual_seed(B + Ci + 7)
+    m = model.CACN(Ci, Co, N, T).to(_dev())
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(_rand(gen, *p.shape, scale=0.1))
+    x = _rand(gen, B, Ci, N, T).requires_grad_(True)
+    out = m(x)
+    dout = _rand(gen, *out.shape)
+    params = list(m.parameters())
+    g_mine = _grads(out, [x] + params, dout)
+    r = _leaf64(x.detach(), *[p.detach() for p in params])
+    byname = dict(zip([n for n, _ in m.named_parameters()], r[1:]))
+    o64 = dense_torch.cacn_dense(r[0], byname["seq.0.Wc"], byname["seq.0.alpha"], byname["seq.1.weight"],
+                                 byname["seq.1.bias"])
+    assert rel_err(out.double(), o64) < TOL
+    _check(g_mine, _grads(o64, r, dout.double()), ["dx"] + [n for n, _ in m.named_parameters()])
+
+
+def test_branch_ops_refuse_cpu_tensors():
+    from ms_gat_amd import _lib, ops
+    x = torch.zeros(2, 3, 5, 12)
+    for call in (lambda: ops.mix(x, torch.zeros(1, 4, 3)), lambda: ops.time_mix(x, torch.zeros(1, 1, 12, 12)),
+                 lambda: ops.node_pool(x, torch.zeros(5)), lambda: ops.channel_pool(x, torch.zeros(3))):
+        with pytest.raises(_lib.MsgatError):
+            call()
