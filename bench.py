@@ -141,22 +141,34 @@ def time_aggregate_kernel(hp, reps=20):
     return sec, bytes_
 
 
-class _DenseGACN(torch.nn.Module):
-    """The reference's dense GACN (oracle/dense_torch.py) behind the GACN interface: the eager
-    baseline for the full-model comparison.  Shares the parameters of the module it replaces."""
+class _EagerMEAM(torch.nn.Module):
+    """The reference's op sequence for a whole MEAM block (oracle/dense_torch.py: LayerNorm, CACN, TACN, dense
+    GACN, residual tail -- all PyTorch-ROCm eager ops) behind the MEAM interface, sharing the parameters of the
+    module it replaces: the eager baseline of the full-model comparison."""
 
-    def __init__(self, gacn):
+    def __init__(self, meam):
         super().__init__()
-        self.gatt, self.W = gacn.gatt, gacn.W
+        self.inner = meam
 
     def forward(self, signals, adjacency):
         from oracle import dense_torch
-        return dense_torch.gacn_dense(signals, adjacency, self.gatt.Wg, self.gatt.alpha, self.W)
+        return dense_torch.meam_dense(signals, adjacency, dict(self.inner.named_parameters()), self.inner.dilations,
+                                      self.inner.ln.eps)
 
 
-def full_model_step_ms(wl, dev, dense, steps=6, warmup=3):
-    """One training step (forward, Huber loss, backward, Adam) of the whole msgat72 model with the HIP
-    graph branch, or with the reference's dense eager graph branch (`dense=True`)."""
+class _EagerLayerNorm(torch.nn.Module):
+    def __init__(self, ln):
+        super().__init__()
+        self.inner = ln
+
+    def forward(self, x):
+        return torch.nn.functional.layer_norm(x, self.inner.normalized_shape, self.inner.weight, self.inner.bias,
+                                              self.inner.eps)
+
+
+def full_model_step_ms(wl, dev, dense, steps=6, warmup=5):
+    """One training step (forward, Huber loss, backward, Adam) of the whole msgat72 model: MEAM blocks in the
+    library (LayerNorm, the three branches, the tail), or -- `dense=True` -- the reference's eager op sequence."""
     from ms_gat_amd import engine, model
     import ms_gat_amd
     torch.manual_seed(0)
@@ -165,8 +177,8 @@ def full_model_step_ms(wl, dev, dense, steps=6, warmup=3):
                         use_te=True, adj=adj).to(dev)
     if dense:
         for tpc in net.tpcs:
-            for meam in tpc.tgacns:
-                meam.gacn = _DenseGACN(meam.gacn)
+            tpc.tgacns = torch.nn.ModuleList(_EagerMEAM(m) for m in tpc.tgacns)
+            tpc.ln = _EagerLayerNorm(tpc.ln)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=5e-4)
     loss_fn = engine.HuberLoss(50.0)
     g = torch.Generator().manual_seed(3)
@@ -187,6 +199,29 @@ def full_model_step_ms(wl, dev, dense, steps=6, warmup=3):
         step()
     torch.cuda.synchronize(dev)
     return (time.perf_counter() - t0) / steps * 1e3
+
+
+def full_model_graph_step_ms(wl, dev, steps=10):
+    """The same training step through `engine.Trainer(hip_graph=True)`: one HIP-graph replay per batch."""
+    import tempfile
+    import ms_gat_amd
+    from ms_gat_amd import engine, model
+    torch.manual_seed(0)
+    adj = ms_gat_amd.synthetic_adjacency(wl["N"], wl["E"], seed=0)
+    net = model.msgat72(n_components=wl["R"], in_channels=wl["Cin"], in_timesteps=wl["T"], out_timesteps=wl["T"],
+                        use_te=True, adj=adj).to(dev)
+    g = torch.Generator().manual_seed(3)
+    batch = [torch.randn(wl["B"], wl["R"], wl["Cin"], wl["N"], wl["T"], generator=g).to(dev),
+             torch.randint(0, 24, (wl["B"],), generator=g).to(dev), torch.randint(0, 7, (wl["B"],), generator=g).to(dev),
+             (torch.randn(wl["B"], wl["N"], wl["T"], generator=g) * 30).to(dev)]
+    with tempfile.TemporaryDirectory() as tmp:
+        tr = engine.Trainer(net, 50.0, tmp, hip_graph=True)
+        tr.run_epoch([batch] * 2, gpu_id=dev.index, epoch=0, mode="train")   # captures
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        tr.run_epoch([batch] * steps, gpu_id=dev.index, epoch=1, mode="train")
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / steps * 1e3
 
 
 def recorded_traffic(workload):
@@ -302,7 +337,8 @@ def main():
         # secondary: the whole msgat72 training step, HIP graph branch vs the reference's dense eager one
         try:
             out["full_model_step_ms"] = round(full_model_step_ms(wl, dev, dense=False), 3)
-            out["full_model_dense_gacn_step_ms"] = round(full_model_step_ms(wl, dev, dense=True), 3)
+            out["full_model_hip_graph_step_ms"] = round(full_model_graph_step_ms(wl, dev), 3)
+            out["full_model_eager_rocm_step_ms"] = round(full_model_step_ms(wl, dev, dense=True), 3)
         except RuntimeError as e:  # e.g. the dense [B,N,N] tensors of the stress graph do not fit
             out["full_model_error"] = str(e).splitlines()[0][:120]
 

@@ -13,6 +13,10 @@ Differences that are the point of this build:
     `.item()` syncs per batch (engine.py:66, metrics.py:24,30,34).
   * under `torch.distributed` every rank runs its batch shard and gradients are averaged with one
     flat all-reduce (`parallel.FlatGradAllReduce`); `nn.DataParallel` (main.py:52-55) is not used.
+  * `hip_graph=True` captures one training step (forward, loss, backward, Adam) per batch shape in a
+    HIP graph and replays it: a step is ~1100 kernel launches whose host-side issue cost otherwise
+    exceeds the GPU time of the small kernels.  The library never allocates or synchronises, so its
+    launches are capturable as they are.
 """
 from __future__ import annotations
 
@@ -87,6 +91,69 @@ class Metrics:
         return {"MAE": self.MAE, "MAPE": self.MAPE, "RMSE": self.RMSE}
 
 
+class _GraphedStep:
+    """One captured step for one batch shape: static input buffers, `replay()` per batch.
+
+    Training steps are captured whole (forward, loss, backward and, on a single GPU, the optimizer
+    step); with several ranks the graph ends after backward and the all-reduce and the optimizer run
+    eagerly.  Capture follows PyTorch's whole-network recipe: warm-up iterations on a side stream
+    (they initialise Adam's lazy state), then capture -- with parameters and optimizer state put back
+    afterwards, so the captured run starts from exactly the state an eager run would."""
+
+    def __init__(self, engine: "Engine", batch, training: bool, step_in_graph: bool):
+        model, loss_fn, opt = engine.model, engine.loss_fn, engine.optimizer
+        self.static = [t.clone() for t in batch]
+        *inputs, truth = self.static
+        self.training = training
+        saved_params = saved_state = None
+        if training:
+            trained = [p for group in opt.param_groups for p in group["params"] if p.requires_grad]
+            saved_params = [p.detach().clone() for p in trained]
+            saved_state = {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state.get(p, {}).items()}
+                           for group in opt.param_groups for p in group["params"]}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                if training:
+                    opt.zero_grad(set_to_none=True)
+                    loss_fn(model(*inputs), truth).backward()
+                    if step_in_graph:
+                        opt.step()
+                else:
+                    with torch.no_grad():
+                        model(*inputs)
+        torch.cuda.current_stream().wait_stream(side)
+        if training:   # undo the warm-up: parameters and optimizer state as before it (fresh state = zeros)
+            with torch.no_grad():
+                for p, old in zip(trained, saved_params):   # not the frozen adjacency: its version keys the CSR cache
+                    p.copy_(old)
+                for p, st in opt.state.items():
+                    for k, v in st.items():
+                        if torch.is_tensor(v):
+                            old = saved_state.get(p, {}).get(k)
+                            v.copy_(old) if old is not None else v.zero_()
+            opt.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            if training:
+                self.pred = model(*inputs)
+                self.loss = loss_fn(self.pred, truth)
+                self.loss.backward()
+                if step_in_graph:
+                    opt.step()
+            else:
+                with torch.no_grad():
+                    self.pred = model(*inputs)
+                    self.loss = loss_fn(self.pred, truth)
+
+    def replay(self, batch):
+        for dst, src in zip(self.static, batch):
+            dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.pred, self.loss, self.static[-1]
+
+
 class Engine:
     __labels__ = {"train": "[Train   ]", "validate": "[Validate]", "evaluate": "[Evaluate]"}
 
@@ -97,6 +164,8 @@ class Engine:
         self.log_file = self.out_dir / "run.log"
         self.optimizer = None
         self._grad_sync = None
+        self.hip_graph = False
+        self._graphs = {}
 
     # -- helpers -------------------------------------------------------------------------
     def _device(self, gpu_id):
@@ -123,12 +192,22 @@ class Engine:
             for batch in data:
                 if world > 1:
                     batch = parallel.shard_batch(batch, rank, world)
-                *inputs, truth = [t.to(device, non_blocking=True) for t in batch]
-                pred = self.model(*inputs)
-                loss = self.loss_fn(pred, truth)
-                if training:
-                    self.optimizer.zero_grad(set_to_none=True)
-                    loss.backward()
+                batch = [t.to(device, non_blocking=True) for t in batch]
+                *inputs, truth = batch
+                if self.hip_graph:
+                    key = (training, tuple(tuple(t.shape) for t in batch))
+                    graphed = self._graphs.get(key)
+                    if graphed is None:
+                        with torch.enable_grad():
+                            graphed = self._graphs[key] = _GraphedStep(self, batch, training, step_in_graph=world == 1)
+                    pred, loss, truth = graphed.replay(batch)
+                else:
+                    pred = self.model(*inputs)
+                    loss = self.loss_fn(pred, truth)
+                    if training:
+                        self.optimizer.zero_grad(set_to_none=True)
+                        loss.backward()
+                if training and (world > 1 or not self.hip_graph):
                     if world > 1:
                         if self._grad_sync is None:
                             self._grad_sync = parallel.FlatGradAllReduce(self.model.parameters())
@@ -163,9 +242,17 @@ class Trainer(Engine):
     """Adam(lr 1e-3, wd 5e-4), StepLR(30, 0.1), early stopping after 20 stale epochs, best-val checkpoints
     after epoch 20 (engine.py:104-133)."""
 
-    def __init__(self, model: nn.Module, loss_delta: float, out_dir: str):
+    def __init__(self, model: nn.Module, loss_delta: float, out_dir: str, hip_graph: bool = False):
         super().__init__(model, loss_delta=loss_delta, out_dir=out_dir)
-        self.optimizer = optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4)
+        self.hip_graph = hip_graph
+        if hip_graph:
+            # a captured Adam reads its learning rate from device memory: keep ONE tensor alive and write
+            # the scheduler's value into it (`_sync_lr`), or replays would keep the captured rate
+            dev = next(model.parameters()).device
+            self._lr = torch.tensor(1e-3, device=dev)
+            self.optimizer = optim.Adam(model.parameters(), lr=self._lr, weight_decay=5e-4, capturable=True)
+        else:
+            self.optimizer = optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4)
         self.scheduler = lr_scheduler.StepLR(self.optimizer, step_size=30, gamma=0.1)
         self.best = {"epoch": 0, "loss": float("inf"), "ckpt": ""}
         self.epoch = 1
@@ -178,6 +265,7 @@ class Trainer(Engine):
             self.run_epoch(train, gpu_id=gpu_id, epoch=self.epoch, mode="train")
             loss = self.run_epoch(val, gpu_id=gpu_id, epoch=self.epoch, mode="validate")
             self.scheduler.step()
+            self._sync_lr()
             if self.epoch > self.min_epochs:
                 if loss < (1 - self.min_delta) * self.best["loss"]:
                     self.best = dict(epoch=self.epoch, loss=loss, ckpt=self.out_dir / f"{self.epoch}_{loss:.2f}.pkl")
@@ -186,6 +274,13 @@ class Trainer(Engine):
                 elif self.epoch > self.best["epoch"] + self.patience:
                     break
             self.epoch += 1
+
+    def _sync_lr(self) -> None:
+        if self.hip_graph:
+            for group in self.optimizer.param_groups:
+                if group["lr"] is not self._lr:
+                    self._lr.fill_(float(group["lr"]))
+                    group["lr"] = self._lr
 
     def save(self, ckpt) -> None:
         torch.save(dict(best=self.best, epoch=self.epoch, model=self.model.state_dict(),
@@ -199,6 +294,7 @@ class Trainer(Engine):
         self.model.load_state_dict(strip_data_parallel_prefix(states["model"]))
         self.optimizer.load_state_dict(states["optimizer"])
         self.scheduler.load_state_dict(states["scheduler"])
+        self._sync_lr()
 
 
 class Evaluator(Engine):

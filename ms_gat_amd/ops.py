@@ -204,6 +204,23 @@ def _new(like: torch.Tensor, *shape) -> torch.Tensor:
     return torch.empty(shape, device=like.device, dtype=torch.float32)
 
 
+_ones_cache = {}
+
+
+def _channel_sums(t: torch.Tensor) -> torch.Tensor:
+    """[G,C,N,T] -> [C]: the bias gradient of a convolution.  One streaming pass (node pooling with unit
+    weights) instead of torch's strided reduction kernel (87 us vs 12 us at [32,24,883,12])."""
+    G, Cc, N, T = t.shape
+    key = (t.device, N)
+    ones = _ones_cache.get(key)
+    if ones is None:
+        ones = _ones_cache[key] = torch.ones(N, device=t.device, dtype=torch.float32)
+    pooled = _new(t, G, Cc, T)
+    st = _lib.lib().msgat_node_pool(_ptr(t), _ptr(ones), _ptr(pooled), G * Cc, N, T, _stream_handle(t.device))
+    _lib.check(st, "msgat_node_pool")
+    return pooled.sum(dim=(0, 2))
+
+
 class _MixFunction(torch.autograd.Function):
     """x[G,Ci,N,T], M[R,Co,Ci] (R | G), bias[Co] | None, add[G,Co,N,T] | None -> relu?(M x + bias + add)."""
 
@@ -247,7 +264,7 @@ class _MixFunction(torch.autograd.Function):
                                         Co * Ci, None, 0, stream)
             _lib.check(st, "msgat_stage_contract")
         if ctx.has_bias and need[2]:
-            dbias = dpre.sum(dim=(0, 2, 3))
+            dbias = _channel_sums(dpre)
         return dx, dM, dbias, (dpre if ctx.has_add and need[3] else None), None
 
 
@@ -306,7 +323,7 @@ class _TimeMixFunction(torch.autograd.Function):
             _lib.check(st, "msgat_time_mix_grad_matrix")
             dA = dAg if A.shape[0] == G else dAg.sum(dim=0, keepdim=True)
         if ctx.has_bias and need[2]:
-            dbias = dout.sum(dim=(0, 2, 3))
+            dbias = _channel_sums(dout)
         return dy, dA, dbias
 
 
