@@ -239,6 +239,21 @@ size_t msgat_node_pool_partial_floats(int32_t G, int32_t C, int32_t N);
 int msgat_node_pool_grad_weight(const float* x, const float* dpooled, float* dw, float* partials, int32_t G,
                                 int32_t C, int32_t N, int32_t T, void* stream);
 
+/* ---- device: the prediction head of a component ----
+ * TPC's Conv2d(T_in -> T_out, kernel [1, C]) over the transposed activation (src/models/msgat.py:153,
+ * applied :158-159):  out[b,n,o] = bias[o] + sum_c sum_t W[o,t,0,c] x[b,c,n,t].
+ * x [B,C,N,T]; W in the convolution's own layout [T_out,T,1,C]; out [B,N,T_out] (what the reference has after
+ * its squeeze + transpose); T_out <= 16.  Backward: dx [B,C,N,T]; dWc [C,T_out,T] (the caller permutes to
+ * the convolution layout); partial buffers sized by the *_partial_floats queries. */
+size_t msgat_head_forward_partial_floats(int32_t B, int32_t C, int32_t N, int32_t T_out);
+int msgat_head_forward(const float* x, const float* W, const float* bias, float* out, float* partials,
+                       int32_t B, int32_t C, int32_t N, int32_t T, int32_t T_out, void* stream);
+int msgat_head_grad_signal(const float* dout, const float* W, float* dx, int32_t B, int32_t C, int32_t N,
+                           int32_t T, int32_t T_out, void* stream);
+size_t msgat_head_grad_weight_partial_floats(int32_t C, int32_t T, int32_t T_out);
+int msgat_head_grad_weight(const float* dout, const float* x, float* dWc, float* partials, int32_t B, int32_t C,
+                           int32_t N, int32_t T, int32_t T_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

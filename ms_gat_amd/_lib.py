@@ -72,6 +72,11 @@ _PROTOTYPES = {
     "msgat_node_pool_grad_signal": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "msgat_node_pool_partial_floats": (C.c_size_t, [C.c_int32] * 3),
     "msgat_node_pool_grad_weight": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]),
+    "msgat_head_forward_partial_floats": (C.c_size_t, [C.c_int32] * 4),
+    "msgat_head_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_void_p]),
+    "msgat_head_grad_signal": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 5 + [C.c_void_p]),
+    "msgat_head_grad_weight_partial_floats": (C.c_size_t, [C.c_int32] * 3),
+    "msgat_head_grad_weight": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 5 + [C.c_void_p]),
     "msgat_layernorm_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "msgat_layernorm_partial_floats": (C.c_size_t, [C.c_int64, C.c_int32]),
     "msgat_layernorm_backward": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_float, C.c_void_p]),

@@ -248,6 +248,47 @@ extern "C" int msgat_node_pool_grad_weight(const float* x, const float* dpooled,
   return launch_node_pool_dw(x, dpooled, dw, partials, G, C, N, T, (hipStream_t)stream);
 }
 
+// ---- prediction head ----------------------------------------------------------------------------------
+static int check_head(int32_t B, int32_t C, int32_t N, int32_t T, int32_t To) {
+  if (B <= 0 || B > 65535 || C <= 0 || C > 65535 || N <= 0 || To <= 0) return MSGAT_ERR_SHAPE;
+  if (!t_supported(T) || To > 16) return MSGAT_ERR_UNSUPPORTED;
+  return MSGAT_OK;
+}
+
+extern "C" size_t msgat_head_forward_partial_floats(int32_t B, int32_t C, int32_t N, int32_t To) {
+  if (B <= 0 || C <= 0 || N <= 0 || To <= 0) return 0;
+  return head_fwd_partial_floats(B, C, N, To);
+}
+
+extern "C" int msgat_head_forward(const float* x, const float* W, const float* bias, float* out, float* partials,
+                                  int32_t B, int32_t C, int32_t N, int32_t T, int32_t To, void* stream) {
+  if (!x || !W || !out || !partials) return MSGAT_ERR_NULL;
+  int st = check_head(B, C, N, T, To);
+  if (st) return st;
+  return launch_head_fwd(x, W, bias, out, partials, B, C, N, T, To, (hipStream_t)stream);
+}
+
+extern "C" int msgat_head_grad_signal(const float* dout, const float* W, float* dx, int32_t B, int32_t C, int32_t N,
+                                      int32_t T, int32_t To, void* stream) {
+  if (!dout || !W || !dx) return MSGAT_ERR_NULL;
+  int st = check_head(B, C, N, T, To);
+  if (st) return st;
+  return launch_head_dx(dout, W, dx, B, C, N, T, To, (hipStream_t)stream);
+}
+
+extern "C" size_t msgat_head_grad_weight_partial_floats(int32_t C, int32_t T, int32_t To) {
+  if (C <= 0 || To <= 0 || !t_supported(T)) return 0;
+  return head_dw_partial_floats(C, T, To);
+}
+
+extern "C" int msgat_head_grad_weight(const float* dout, const float* x, float* dWc, float* partials, int32_t B,
+                                      int32_t C, int32_t N, int32_t T, int32_t To, void* stream) {
+  if (!dout || !x || !dWc || !partials) return MSGAT_ERR_NULL;
+  int st = check_head(B, C, N, T, To);
+  if (st) return st;
+  return launch_head_dW(dout, x, dWc, partials, B, C, N, T, To, (hipStream_t)stream);
+}
+
 // ---- LayerNorm over T (the producer of the GACN inputs) ----------------------------------------------
 extern "C" int msgat_layernorm_forward(const float* x, const float* weight, const float* bias, float* y,
                                        int64_t rows, int32_t T, float eps, void* stream) {

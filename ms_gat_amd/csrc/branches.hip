@@ -291,4 +291,151 @@ int launch_node_pool_dw(const float* x, const float* dp, float* dw, float* part,
   return launch_reduce_rows(part, G * nck, N, dw, N, nullptr, 0, s);
 }
 
+// ---- prediction head -----------------------------------------------------------------------------------
+// TPC's last step (msgat.py:153, applied :158-159): Conv2d(T_in -> T_out, kernel [1, C]) over the transposed
+// activation, i.e. out[b,n,o] = bias[o] + sum_c sum_t W[o,t,c] x[b,c,n,t].  MIOpen runs it as one im2col +
+// GEMM per sample between layout transposes; here a lane owns one (b, n) and walks a chunk of channels
+// (a row of T floats per channel), the chunk's [kHeadCC][T_out][T] weights broadcast from LDS.  Channel
+// chunks leave partials that are summed in a fixed order.
+constexpr int kHeadCC = 8;
+constexpr int kHeadTo = 16;  // T_out <= 16
+
+template <int T>
+__global__ __launch_bounds__(kBlock) void k_head_fwd(const float* __restrict__ x, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, float* __restrict__ part,
+                                                     int C, int N, int To) {
+  __shared__ float Wl[kHeadCC][kHeadTo][T];
+  const int b = blockIdx.z, ck = blockIdx.y;
+  const int c0 = ck * kHeadCC, cn = min(kHeadCC, C - c0);
+  for (int i = threadIdx.x; i < kHeadCC * kHeadTo * T; i += kBlock) {
+    const int c = i / (kHeadTo * T), o = (i / T) % kHeadTo, t = i % T;
+    Wl[c][o][t] = (c < cn && o < To) ? W[((size_t)o * T + t) * C + c0 + c] : 0.f;  // W is [To][T][1][C]
+  }
+  __syncthreads();
+  const int n = blockIdx.x * kBlock + threadIdx.x;
+  if (n >= N) return;
+  float acc[kHeadTo];
+#pragma unroll
+  for (int o = 0; o < kHeadTo; ++o) acc[o] = (ck == 0 && bias != nullptr && o < To) ? bias[o] : 0.f;
+  for (int c = 0; c < cn; ++c) {
+    float v[T];
+    ld_row<T>(x + (((size_t)b * C + c0 + c) * N + n) * T, v);
+#pragma unroll
+    for (int o = 0; o < kHeadTo; ++o)
+#pragma unroll
+      for (int t = 0; t < T; ++t) acc[o] = fmaf(Wl[c][o][t], v[t], acc[o]);
+  }
+  float* dst = part + (((size_t)b * gridDim.y + ck) * N + n) * To;
+  for (int o = 0; o < To; ++o) dst[o] = acc[o];
+}
+
+// dx[b,c,n,t] = sum_o W[o,t,c] dout[b,n,o]
+template <int T>
+__global__ __launch_bounds__(kBlock) void k_head_dx(const float* __restrict__ dout, const float* __restrict__ W,
+                                                    float* __restrict__ dx, int C, int N, int To) {
+  __shared__ float Wl[kHeadCC][T][kHeadTo];
+  const int b = blockIdx.z, ck = blockIdx.y;
+  const int c0 = ck * kHeadCC, cn = min(kHeadCC, C - c0);
+  for (int i = threadIdx.x; i < kHeadCC * kHeadTo * T; i += kBlock) {
+    const int c = i / (kHeadTo * T), t = (i / kHeadTo) % T, o = i % kHeadTo;
+    Wl[c][t][o] = (c < cn && o < To) ? W[((size_t)o * T + t) * C + c0 + c] : 0.f;
+  }
+  __syncthreads();
+  const int n = blockIdx.x * kBlock + threadIdx.x;
+  if (n >= N) return;
+  float d[kHeadTo];
+#pragma unroll
+  for (int o = 0; o < kHeadTo; ++o) d[o] = 0.f;
+  const float* src = dout + ((size_t)b * N + n) * To;
+  for (int o = 0; o < To; ++o) d[o] = src[o];
+  for (int c = 0; c < cn; ++c) {
+    float v[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      v[t] = 0.f;
+#pragma unroll
+      for (int o = 0; o < kHeadTo; ++o) v[t] = fmaf(Wl[c][t][o], d[o], v[t]);
+    }
+    st_row<T>(dx + (((size_t)b * C + c0 + c) * N + n) * T, v);
+  }
+}
+
+// dW partial[c, j, o, t] = sum over the j-th share of samples, all nodes: dout[b,n,o] x[b,c,n,t]
+constexpr int kHeadChunks = 4;
+
+template <int T>
+__global__ __launch_bounds__(kBlock) void k_head_dW(const float* __restrict__ dout, const float* __restrict__ x,
+                                                    float* __restrict__ part, int B, int C, int N, int To) {
+  __shared__ float red[kBlock / kWave][kHeadTo * T];
+  const int c = blockIdx.y, j = blockIdx.x;
+  const int b0 = (int)((long long)B * j / gridDim.x), b1 = (int)((long long)B * (j + 1) / gridDim.x);
+  float acc[kHeadTo][T];
+#pragma unroll
+  for (int o = 0; o < kHeadTo; ++o)
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[o][t] = 0.f;
+  for (int b = b0; b < b1; ++b)
+    for (int n = threadIdx.x; n < N; n += kBlock) {
+      float v[T], d[kHeadTo];
+      ld_row<T>(x + (((size_t)b * C + c) * N + n) * T, v);
+      const float* src = dout + ((size_t)b * N + n) * To;
+#pragma unroll
+      for (int o = 0; o < kHeadTo; ++o) d[o] = (o < To) ? src[min(o, To - 1)] : 0.f;
+#pragma unroll
+      for (int o = 0; o < kHeadTo; ++o)
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[o][t] = fmaf(d[o], v[t], acc[o][t]);
+    }
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 0; o < kHeadTo; ++o)
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      float a = acc[o][t];
+#pragma unroll
+      for (int s = 32; s > 0; s >>= 1) a += __shfl_xor(a, s);
+      if (lane == 0) red[wave][o * T + t] = a;
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < To * T; i += kBlock)
+    part[(((size_t)c * gridDim.x + j) * To * T) + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+
+size_t head_fwd_partial_floats(int B, int C, int N, int To) { return (size_t)B * cdiv(C, kHeadCC) * N * To; }
+size_t head_dw_partial_floats(int C, int T, int To) { return (size_t)C * kHeadChunks * To * T; }
+
+#define MSGAT_T_SWITCH(T, CALL)                 \
+  switch (T) {                                  \
+    case 4: { constexpr int TT = 4; CALL; } break;   \
+    case 8: { constexpr int TT = 8; CALL; } break;   \
+    case 12: { constexpr int TT = 12; CALL; } break; \
+    case 16: { constexpr int TT = 16; CALL; } break; \
+    default: return MSGAT_ERR_UNSUPPORTED;      \
+  }
+
+int launch_head_fwd(const float* x, const float* W, const float* bias, float* out, float* part, int B, int C, int N,
+                    int T, int To, hipStream_t s) {
+  const int nck = cdiv(C, kHeadCC);
+  dim3 grid(cdiv(N, kBlock), nck, B);
+  MSGAT_T_SWITCH(T, hipLaunchKernelGGL(k_head_fwd<TT>, grid, dim3(kBlock), 0, s, x, W, bias, part, C, N, To));
+  MSGAT_CHECK_LAUNCH();
+  return launch_reduce_groups(part, B, nck, N * To, out, s);
+}
+
+int launch_head_dx(const float* dout, const float* W, float* dx, int B, int C, int N, int T, int To, hipStream_t s) {
+  dim3 grid(cdiv(N, kBlock), cdiv(C, kHeadCC), B);
+  MSGAT_T_SWITCH(T, hipLaunchKernelGGL(k_head_dx<TT>, grid, dim3(kBlock), 0, s, dout, W, dx, C, N, To));
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
+}
+
+// dWc[c][o][t] (the caller permutes to the convolution's [To][T][1][C] layout)
+int launch_head_dW(const float* dout, const float* x, float* dWc, float* part, int B, int C, int N, int T, int To,
+                   hipStream_t s) {
+  dim3 grid(kHeadChunks, C);
+  MSGAT_T_SWITCH(T, hipLaunchKernelGGL(k_head_dW<TT>, grid, dim3(kBlock), 0, s, dout, x, part, B, C, N, To));
+  MSGAT_CHECK_LAUNCH();
+  return launch_reduce_groups(part, C, kHeadChunks, To * T, dWc, s);
+}
+
 }  // namespace msgat

@@ -168,6 +168,13 @@ int launch_node_pool_dx(const float* w, const float* dp, float* dx, long long sl
 size_t node_pool_partial_floats(int G, int C, int N);
 int launch_node_pool_dw(const float* x, const float* dp, float* dw, float* part, int G, int C, int N, int T,
                         hipStream_t s);
+size_t head_fwd_partial_floats(int B, int C, int N, int To);
+size_t head_dw_partial_floats(int C, int T, int To);
+int launch_head_fwd(const float* x, const float* W, const float* bias, float* out, float* part, int B, int C, int N,
+                    int T, int To, hipStream_t s);
+int launch_head_dx(const float* dout, const float* W, float* dx, int B, int C, int N, int T, int To, hipStream_t s);
+int launch_head_dW(const float* dout, const float* x, float* dWc, float* part, int B, int C, int N, int T, int To,
+                   hipStream_t s);
 // LayerNorm over the last axis of [rows, T] (layernorm.hip)
 size_t layernorm_partial_floats(long long rows, int T);
 int launch_layernorm_fwd(const float* x, const float* w, const float* b, float* y, long long rows, int T,

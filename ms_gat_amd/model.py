@@ -207,8 +207,8 @@ class TPC(nn.Module):
     def forward(self, signals: torch.Tensor, adjacency) -> torch.Tensor:
         for block in self.tgacns:
             signals = block(signals, adjacency)
-        out = self.fc(self.ln(signals).transpose(1, 3))       # [B,T_out,N,1]
-        return out.squeeze(-1).transpose(1, 2)                # [B,N,T_out]
+        # fc over the transposed activation, squeezed and transposed back (msgat.py:159-160): one pass
+        return ops.head(self.ln(signals), self.fc.weight, self.fc.bias)            # [B,N,T_out]
 
 
 class TimeEmbedding(nn.Module):

@@ -247,7 +247,8 @@ class _MixFunction(torch.autograd.Function):
         x, M, out = ctx.saved_tensors
         G, Ci, N, T = x.shape
         R, Co = M.shape[0], M.shape[1]
-        dpre = (dout * (out > 0)) if ctx.relu else dout.contiguous()
+        # ReLU mask in one pass: aten's threshold_backward is dout where out > 0, else 0
+        dpre = torch.ops.aten.threshold_backward(dout.contiguous(), out, 0.0) if ctx.relu else dout.contiguous()
         stream = _stream_handle(x.device)
         need = ctx.needs_input_grad
         dx = dM = dbias = None
@@ -426,3 +427,56 @@ def channel_pool(x: torch.Tensor, alpha: torch.Tensor) -> torch.Tensor:
     if x.dim() != 4 or tuple(alpha.shape) != (x.shape[1],):
         raise ValueError(f"channel_pool: signals {tuple(x.shape)}, alpha {tuple(alpha.shape)}")
     return _ChannelPoolFunction.apply(x, alpha)
+
+
+class _HeadFunction(torch.autograd.Function):
+    """x[B,C,N,T], W[To,T,1,C], bias[To] | None -> out[B,N,To] = bias + sum_{c,t} W[o,t,0,c] x[b,c,n,t]  (msgat.py:153,:159)."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias):
+        L = _lib.lib()
+        x, W = x.contiguous(), W.contiguous()
+        B, Cc, N, T = x.shape
+        To = W.shape[0]
+        out = _new(x, B, N, To)
+        part = _new(x, max(int(L.msgat_head_forward_partial_floats(B, Cc, N, To)), 1))
+        b = None if bias is None else bias.contiguous()
+        st = L.msgat_head_forward(_ptr(x), _ptr(W), _ptr(b), _ptr(out), _ptr(part), B, Cc, N, T, To,
+                                  _stream_handle(x.device))
+        _lib.check(st, "msgat_head_forward")
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        x, W = ctx.saved_tensors
+        B, Cc, N, T = x.shape
+        To = W.shape[0]
+        dout = dout.contiguous()
+        stream = _stream_handle(x.device)
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.check(L.msgat_head_grad_signal(_ptr(dout), _ptr(W), _ptr(dx), B, Cc, N, T, To, stream),
+                       "msgat_head_grad_signal")
+        if ctx.needs_input_grad[1]:
+            dWc = _new(x, Cc, To, T)
+            part = _new(x, max(int(L.msgat_head_grad_weight_partial_floats(Cc, T, To)), 1))
+            _lib.check(L.msgat_head_grad_weight(_ptr(dout), _ptr(x), _ptr(dWc), _ptr(part), B, Cc, N, T, To, stream),
+                       "msgat_head_grad_weight")
+            dW = dWc.permute(1, 2, 0).unsqueeze(2)          # [To,T,1,C]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dout.sum(dim=(0, 1))
+        return dx, dW, db
+
+
+def head(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The component's prediction head: `fc(x.transpose(1, 3))[..., 0].transpose(1, 2)` of msgat.py:159-160
+    with `fc = Conv2d(T, T_out, [1, C])`, as one pass over x."""
+    _require_device_tensor("signals", x)
+    _require_device_tensor("weight", W, x.device)
+    if x.dim() != 4 or W.dim() != 4 or W.shape[1] != x.shape[3] or W.shape[2] != 1 or W.shape[3] != x.shape[1]:
+        raise ValueError(f"head: signals {tuple(x.shape)} and weight {tuple(W.shape)} do not match")
+    return _HeadFunction.apply(x, W, bias)

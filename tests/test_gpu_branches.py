@@ -169,3 +169,20 @@ def test_branch_ops_refuse_cpu_tensors():
                  lambda: ops.node_pool(x, torch.zeros(5)), lambda: ops.channel_pool(x, torch.zeros(3))):
         with pytest.raises(_lib.MsgatError):
             call()
+
+
+@pytest.mark.parametrize("B,C,N,T,To", [(2, 72, 33, 12, 12), (3, 5, 300, 12, 6), (2, 9, 17, 8, 16), (32, 72, 883, 12, 12)])
+def test_prediction_head_matches_the_transposed_convolution(B, C, N, T, To):
+    """TPC.fc (msgat.py:153,:159-160): Conv2d(T, T_out, [1, C]) on x.transpose(1, 3), squeezed, transposed."""
+    from ms_gat_amd import ops
+    gen = torch.Generator().manual_seed(B + C + To)
+    x, W, b = _rand(gen, B, C, N, T), _rand(gen, To, T, 1, C, scale=(T * C) ** -0.5), _rand(gen, To)
+    dout = _rand(gen, B, N, To)
+    mine = _leaf(x, W, b)
+    out = ops.head(*mine)
+    g_mine = _grads(out, mine, dout)
+    ref = _leaf64(x, W, b)
+    o64 = torch.nn.functional.conv2d(ref[0].transpose(1, 3), ref[1], ref[2])[..., 0].transpose(1, 2)
+    assert out.shape == o64.shape
+    assert rel_err(out.double(), o64) < TOL
+    _check(g_mine, _grads(o64, ref, dout.double()), ["dx", "dW", "dbias"])
