@@ -46,7 +46,7 @@ __host__ __device__ static inline int proj_kpad(int Kx) {
 // k + kKC right after k-step k consumed it.  Every load is unconditional (addresses are clamped,
 // padding is neutralised by zero matrix entries): a load inside a branch makes hipcc fall back
 // to s_waitcnt vmcnt(0), which serialises the prefetch against the MFMAs.
-template <int MG, bool DO_Q>
+template <int MG, bool DO_Q, bool ONEPASS>
 __global__ __launch_bounds__(kBlock) void k_project_mfma(
     const float4* __restrict__ in4, const float* __restrict__ M, int m_in_major,
     const float* __restrict__ qvec, const float* __restrict__ addvec,
@@ -64,19 +64,6 @@ __global__ __launch_bounds__(kBlock) void k_project_mfma(
   const int g = blockIdx.y;
   const int r = g / Bg;
 
-  for (int i = threadIdx.x; i < Mrows * Kpad; i += kBlock) {
-    const int co = i / Kpad, k = i - co * Kpad;
-    float w = 0.f;
-    if (co < Co) {
-      if (k < Ci) w = m_in_major ? M[((size_t)r * Ci + k) * Co + co] : M[((size_t)r * Co + co) * Ci + k];
-      else if (k == Ci && has_extra) w = addvec[r * Co + co];
-    }
-    Wl[i] = w;
-  }
-  if (DO_Q)
-    for (int i = threadIdx.x; i < 4 * K4; i += kBlock) ql[i] = (i < Ci) ? qvec[r * Ci + i] : 0.f;
-  __syncthreads();
-
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = lane & 15, kq = lane >> 4;
   const int p4 = (blockIdx.x * 4 + wave) * 16 + j;
@@ -93,6 +80,37 @@ __global__ __launch_bounds__(kBlock) void k_project_mfma(
     return *p;
   };
 
+  // ONEPASS (all output tiles fit the accumulators, the usual case): the first chunk of the stream is
+  // requested BEFORE the matrix is staged, so the block's prologue (matrix -> LDS, barrier) runs under
+  // the HBM latency of those loads instead of ahead of it.  With several passes the ring is (re)loaded
+  // at the top of each pass -- never inside a branch, which would cost the counted vmcnt waits.
+  float4 ring[kKC];
+  if (ONEPASS) {
+#pragma unroll
+    for (int i = 0; i < kKC; ++i) ring[i] = loadB(i);
+  }
+
+  // matrix -> LDS: 4 independent, unconditional (clamped) loads per trip, padding zeroed by select
+  const int total = Mrows * Kpad;
+  for (int i0 = threadIdx.x; i0 < total; i0 += 4 * kBlock) {
+    float w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = min(i0 + u * kBlock, total - 1);
+      const int co = i / Kpad, k = i - co * Kpad;
+      const int coc = min(co, Co - 1), kc = min(k, Ci - 1);
+      const float m = m_in_major ? M[((size_t)r * Ci + kc) * Co + coc] : M[((size_t)r * Co + coc) * Ci + kc];
+      const float a = has_extra ? addvec[r * Co + coc] : 0.f;
+      w[u] = (co < Co) ? ((k < Ci) ? m : ((k == Ci) ? a : 0.f)) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + u * kBlock < total) Wl[i0 + u * kBlock] = w[u];
+  }
+  if (DO_Q)
+    for (int i = threadIdx.x; i < 4 * K4; i += kBlock) ql[i] = (i < Ci) ? qvec[r * Ci + i] : 0.f;
+  __syncthreads();
+
   float4 qa = f4zero();
   for (int m0 = 0; m0 < Mt; m0 += MG) {
     f32x4 acc[MG][4];
@@ -101,9 +119,10 @@ __global__ __launch_bounds__(kBlock) void k_project_mfma(
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[mg][i] = zero4();
     const float* wrow = Wl + (m0 * 16 + j) * Kpad + kq;  // A fragment: row co = tile*16 + j, column 4k + kq
-    float4 ring[kKC];
+    if (!ONEPASS) {
 #pragma unroll
-    for (int i = 0; i < kKC; ++i) ring[i] = loadB(i);
+      for (int i = 0; i < kKC; ++i) ring[i] = loadB(i);
+    }
     auto step = [&](int kk, const float4& b) {
 #pragma unroll
       for (int mg = 0; mg < MG; ++mg) {
@@ -168,12 +187,13 @@ static int launch_project_mg(const float* in, const float* M, int m_in_major, co
                              int Ci, int Co, int P4, const MixEpilogue& epi, hipStream_t s) {
   const size_t lds = project_mfma_lds_bytes(Ci, Co, addvec != nullptr);
   dim3 grid(cdiv(P4, 64), G);
-  if (qvec != nullptr)
-    hipLaunchKernelGGL((k_project_mfma<MG, true>), grid, dim3(kBlock), lds, s, (const float4*)in, M, m_in_major,
-                       qvec, addvec, (const float4*)extra, (float4*)out, (float4*)q, Bg, Ci, Co, P4, epi);
-  else
-    hipLaunchKernelGGL((k_project_mfma<MG, false>), grid, dim3(kBlock), lds, s, (const float4*)in, M,
-                       m_in_major, qvec, addvec, (const float4*)extra, (float4*)out, (float4*)q, Bg, Ci, Co, P4, epi);
+  const bool one = cdiv(Co, 16) <= MG;
+#define MSGAT_PROJ(Q, ONE)                                                                                          \
+  hipLaunchKernelGGL((k_project_mfma<MG, Q, ONE>), grid, dim3(kBlock), lds, s, (const float4*)in, M, m_in_major, qvec, \
+                     addvec, (const float4*)extra, (float4*)out, (float4*)q, Bg, Ci, Co, P4, epi)
+  if (qvec != nullptr) { if (one) MSGAT_PROJ(true, true); else MSGAT_PROJ(true, false); }
+  else { if (one) MSGAT_PROJ(false, true); else MSGAT_PROJ(false, false); }
+#undef MSGAT_PROJ
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
