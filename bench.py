@@ -37,6 +37,10 @@ sys.path.insert(0, ROOT)
 METRIC = "MS-GAT fwd+bwd samples/sec (B×T node-updates/s), PEMSD7 N=883 T=12"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
 
+# rehearsal switch: run the RCCL path (process group, gradient all-reduce, MAX over ranks) even with one rank,
+# so the multi-GPU code is exercised on a one-GPU box:  MSGAT_BENCH_FORCE_DIST=1 python -m torch.distributed.run ...
+FORCE_DIST = os.environ.get("MSGAT_BENCH_FORCE_DIST") == "1"
+
 WORKLOADS = {
     # name: (N nodes, E undirected edges, B per GPU, R relations, in_channels of the first MEAM, hidden, Co)
     "pemsd7": dict(N=883, E=866, B=32, R=3, Cin=1, hidden=72, Co=24, T=12),
@@ -85,7 +89,7 @@ class HotPath:
                 p.grad = None
             z = m(x, self.graph)
             z.backward(dz)
-        if world > 1:  # one flat bucket: the payload is KBs, the collective is latency-bound
+        if world > 1 or FORCE_DIST:  # one flat bucket: the payload is KBs, the collective is latency-bound
             self.sync(weight=float(self.wl["B"]))
 
     def forward_only(self):
@@ -262,7 +266,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    multi = world > 1 or FORCE_DIST
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -270,7 +275,7 @@ def main():
     hp = HotPath(wl, dev, seed=rank)
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -282,7 +287,7 @@ def main():
         hp.step(world)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -362,7 +367,7 @@ def main():
         }
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
