@@ -23,6 +23,30 @@ WL = {"pemsd7": dict(N=883, E=866, B=32, R=3, C=72, Co=24, T=12),
 
 
 def timeit(fn, reps):
+    """Per-launch GPU time: `reps` launches captured in one HIP graph and replayed, so host-side launch
+    cost (20+ us per launch from Python on the GPU box) cannot hide in the figure."""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(reps):
+                fn()
+    graph.replay()
+    s = torch.cuda.current_stream()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record(s)
+    for _ in range(3):
+        graph.replay()
+    t1.record(s)
+    t1.synchronize()
+    return t0.elapsed_time(t1) * 1e-3 / (3 * reps)
+
+
+def timeit_eager(fn, reps):
     for _ in range(3):
         fn()
     s = torch.cuda.current_stream()
@@ -49,7 +73,7 @@ def main():
     graph = ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(N, w["E"], 0))
     gs, _keep = graph.on(dev)
     nnz = graph.nnz
-    st = torch.cuda.current_stream().cuda_stream
+    st = lambda: torch.cuda.current_stream().cuda_stream  # noqa: E731  (read at call time: graph capture runs on a side stream)
     rnd = lambda *s: torch.randn(*s, device=dev)  # noqa: E731
     x, u, dz = rnd(G, Cc, N, T), rnd(G, Co, N, T), rnd(G, Co, N, T)
     alpha, Wg, W = rnd(R, Cc) * 0.1, rnd(R, T, T) * 0.3, rnd(R, Co, Cc) * 0.1
@@ -66,21 +90,21 @@ def main():
         stages[name] = (nbytes, fn)
 
     reg("project_fwd  x->u,q", 4 * G * P * (Cc + Co + 1),
-        lambda: _lib.check(L.msgat_stage_project(sp, ptr(x), ptr(alpha), ptr(W), ptr(q), ptr(out_u), st), "p"))
+        lambda: _lib.check(L.msgat_stage_project(sp, ptr(x), ptr(alpha), ptr(W), ptr(q), ptr(out_u), st()), "p"))
     reg("scores       q->kW,lse,pq,E", 4 * G * P * 4,
-        lambda: _lib.check(L.msgat_stage_scores(sp, gp, ptr(q), ptr(Wg), ptr(kW), ptr(lse), ptr(pq), ptr(E), st), "s"))
+        lambda: _lib.check(L.msgat_stage_scores(sp, gp, ptr(q), ptr(Wg), ptr(kW), ptr(lse), ptr(pq), ptr(E), st()), "s"))
     reg("scores_nopq  q->kW,lse,E", 4 * G * P * 3,
-        lambda: _lib.check(L.msgat_stage_scores(sp, gp, ptr(q), ptr(Wg), ptr(kW), ptr(lse), None, ptr(E), st), "s"))
+        lambda: _lib.check(L.msgat_stage_scores(sp, gp, ptr(q), ptr(Wg), ptr(kW), ptr(lse), None, ptr(E), st()), "s"))
     reg("aggregate    u->z (Cu=Co)", 8 * G * Co * P,
-        lambda: _lib.check(L.msgat_stage_aggregate(sp, gp, Co, ptr(u), ptr(E), ptr(out_u), st), "a"))
+        lambda: _lib.check(L.msgat_stage_aggregate(sp, gp, Co, ptr(u), ptr(E), ptr(out_u), st()), "a"))
     reg("mix_bwd      du,dq->dx", 4 * G * P * (Co + 1 + Cc),
-        lambda: _lib.check(L.msgat_stage_mix(sp, Co, Cc, ptr(u), ptr(W), 1, ptr(alpha), ptr(dq), ptr(out_x), st), "m"))
+        lambda: _lib.check(L.msgat_stage_mix(sp, Co, Cc, ptr(u), ptr(W), 1, ptr(alpha), ptr(dq), ptr(out_x), st()), "m"))
     nfl = L.msgat_contract_partial_floats(sp, Co + 1, Cc)
     part = torch.empty(nfl, device=dev)
     dW, da = torch.empty(R, Co, Cc, device=dev), torch.empty(R, Cc, device=dev)
     reg("contract     du,dq,x->dW,dalpha", 4 * G * P * (Co + 1 + Cc),
         lambda: _lib.check(L.msgat_stage_contract(sp, Co + 1, Cc, ptr(u), ptr(dq), ptr(x), ptr(part), ptr(dW),
-                                                  Co * Cc, ptr(da), Cc, st), "c"))
+                                                  Co * Cc, ptr(da), Cc, st()), "c"))
     only = [s for s in a.only.split(",") if s]
     for name, (nbytes, fn) in stages.items():
         if only and not any(o in name for o in only):
