@@ -106,3 +106,48 @@ def test_hip_graph_training_matches_eager_training(tmp_path):
         graphed.scheduler.step()
     graphed._sync_lr()
     assert abs(float(graphed._lr) - 1e-4) < 1e-9 and graphed.optimizer.param_groups[0]["lr"] is graphed._lr
+
+
+@pytest.mark.parametrize("factory,cin,R", [("msgat48", 1, 2), ("msgat96", 3, 1), ("msgat72", 3, 2)])
+def test_whole_model_matches_the_dense_op_sequence(factory, cin, R):
+    """Every width / dilation recipe of the reference's factories (msgat.py:220-229; msgat96 stacks four
+    convolutions in its first TACN) through the library, against the same parameters evaluated with the
+    reference's dense op sequence (oracle/dense_torch.py) in float64: prediction and every gradient."""
+    from ms_gat_amd import model
+    from oracle import dense_torch
+    torch.manual_seed(7)
+    N, T, B = 23, 12, 3
+    gen = torch.Generator().manual_seed(11)
+    import ms_gat_amd
+    adj = ms_gat_amd.synthetic_adjacency(N, 30, seed=5)
+    net = getattr(model, factory)(n_components=R, in_channels=cin, in_timesteps=T, out_timesteps=T, use_te=True,
+                                  adj=adj).to(_dev())
+    X = torch.randn(B, R, cin, N, T, generator=gen).to(_dev())
+    H = torch.randint(0, 24, (B,), generator=gen).to(_dev())
+    D = torch.randint(0, 7, (B,), generator=gen).to(_dev())
+    dout = torch.randn(B, N, T, generator=gen).to(_dev())
+    pred = net(X, H, D)
+    params = [p for p in net.parameters() if p.requires_grad]
+    grads = torch.autograd.grad(pred, params, dout)
+
+    # float64 restatement with the same parameters
+    P = {k: v.detach().double() for k, v in net.state_dict().items()}
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items() if k != "adj"}
+    gate = (leaves["te.h_ebd.weight"][H] + leaves["te.d_ebd.weight"][D]).view(B, R, N, T)
+    out = 0
+    for r in range(R):
+        x = X[:, r].double()
+        tpc = net.tpcs[r]
+        for l, meam in enumerate(tpc.tgacns):
+            sub = {k[len(f"tpcs.{r}.tgacns.{l}."):]: v for k, v in leaves.items() if k.startswith(f"tpcs.{r}.tgacns.{l}.")}
+            x = dense_torch.meam_dense(x, P["adj"], sub, meam.dilations)
+        x = torch.nn.functional.layer_norm(x, [T], leaves[f"tpcs.{r}.ln.weight"], leaves[f"tpcs.{r}.ln.bias"], 1e-5)
+        y = torch.nn.functional.conv2d(x.transpose(1, 3), leaves[f"tpcs.{r}.fc.weight"], leaves[f"tpcs.{r}.fc.bias"])
+        out = out + y[..., 0].transpose(1, 2) * gate[:, r]
+    assert rel_err(pred.double(), out) < TOL
+    names = [n for n, p in net.named_parameters() if p.requires_grad]
+    g64 = torch.autograd.grad(out, [leaves[n] for n in names], dout.double(), allow_unused=True)
+    for n, a, b in zip(names, grads, g64):
+        if b is None:
+            continue
+        assert rel_err(a.double(), b) < TOL, n
