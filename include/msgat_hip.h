@@ -239,6 +239,41 @@ size_t msgat_node_pool_partial_floats(int32_t G, int32_t C, int32_t N);
 int msgat_node_pool_grad_weight(const float* x, const float* dpooled, float* dw, float* partials, int32_t G,
                                 int32_t C, int32_t N, int32_t T, void* stream);
 
+/* ---- device: channel axes assembled from several tensors ("segments") ----
+ * A segment is `channels` channels of a [G, group_stride, N, T] tensor starting at `ptr` (group_stride = 0
+ * means `channels`: the whole tensor; a larger value makes it a channel slice of a wider tensor).  The
+ * segments of a list are concatenated along the channel axis -- without a concatenation pass:
+ *   msgat_mix_segments:      out_segments = relu?(M cat(in_segments) + bias + cat(add_segments)); M is
+ *       [R, Co_total, Ci_total] (or [R, Ci_total, Co_total] when m_in_major).  One pass reads cat(...) and
+ *       writes each output range to its own tensor: MEAM's tail (msgat.py:123-131) without the cat, and all
+ *       channel mixings of one activation (CACN's per-sample matrix, TACN's first convolution, GACN's
+ *       projection and the two alpha poolings) in ONE pass; m_in_major = 1 is its backward (one dx).
+ *   msgat_contract_segments: dst[r,a,c] = sum_{g in r, p} cat(A_segments)[g,a,p] B[g,c,p].
+ * At most 6 segments per list. */
+typedef struct {
+  float* ptr;
+  int32_t channels;
+  int32_t group_stride;
+} msgat_seg_t;
+int msgat_mix_segments(int32_t R, int32_t Bg, int32_t N, int32_t T, const msgat_seg_t* in, int32_t n_in,
+                       const float* M, int32_t m_in_major, const float* bias, int32_t bias_per_relation,
+                       const msgat_seg_t* add, int32_t n_add, int32_t relu, const msgat_seg_t* out,
+                       int32_t n_out, void* stream);
+size_t msgat_contract_segments_partial_floats(int32_t R, int32_t Ca, int32_t Cb);
+int msgat_contract_segments(int32_t R, int32_t Bg, int32_t N, int32_t T, const msgat_seg_t* A, int32_t n_a,
+                            const float* B, int32_t Cb, float* partials, float* dst, void* stream);
+
+/* ---- device: the attention core on already projected features ----
+ * Forward = msgat_stage_scores(q) + msgat_stage_aggregate(u) (above).  Backward of exactly that pair, for
+ * callers that produced u and q themselves (e.g. in a merged channel-mixing pass):
+ *   du = E^T dv  [G,Cu,N,T],   dq = total gradient at q  [G,N,T],   dWg [R,T,T].
+ * shape->C is Cu (the channels of u), shape->Co is ignored. */
+size_t msgat_attention_bwd_workspace_bytes(const msgat_shape_t* shape, int32_t nnz);
+int msgat_attention_backward(const msgat_shape_t* shape, const msgat_graph_t* graph, const float* u,
+                             const float* dv, const float* q, const float* kW, const float* lse,
+                             const float* pq, const float* E, const float* Wg, float* du, float* dq,
+                             float* dWg, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- device: the prediction head of a component ----
  * TPC's Conv2d(T_in -> T_out, kernel [1, C]) over the transposed activation (src/models/msgat.py:153,
  * applied :158-159):  out[b,n,o] = bias[o] + sum_c sum_t W[o,t,0,c] x[b,c,n,t].

@@ -43,6 +43,10 @@ class Bwd(C.Structure):
         "workspace")] + [("workspace_bytes", C.c_size_t)]
 
 
+class Seg(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("channels", C.c_int32), ("group_stride", C.c_int32)]
+
+
 _PROTOTYPES = {
     "msgat_abi_version": (C.c_int, []),
     "msgat_status_string": (C.c_char_p, [C.c_int]),
@@ -72,6 +76,13 @@ _PROTOTYPES = {
     "msgat_node_pool_grad_signal": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "msgat_node_pool_partial_floats": (C.c_size_t, [C.c_int32] * 3),
     "msgat_node_pool_grad_weight": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]),
+    "msgat_mix_segments": (C.c_int, [C.c_int32] * 4 + [C.POINTER(Seg), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                     C.POINTER(Seg), C.c_int32, C.c_int32, C.POINTER(Seg), C.c_int32, C.c_void_p]),
+    "msgat_contract_segments_partial_floats": (C.c_size_t, [C.c_int32] * 3),
+    "msgat_contract_segments": (C.c_int, [C.c_int32] * 4 + [C.POINTER(Seg), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]),
+    "msgat_attention_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Shape), C.c_int32]),
+    "msgat_attention_backward": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)] + [C.c_void_p] * 12 + [C.c_size_t, C.c_void_p]),
     "msgat_head_forward_partial_floats": (C.c_size_t, [C.c_int32] * 4),
     "msgat_head_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_void_p]),
     "msgat_head_grad_signal": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 5 + [C.c_void_p]),

@@ -183,7 +183,7 @@ extern "C" int msgat_stage_mix_epilogue(const msgat_shape_t* sh, int32_t Ci, int
   MixEpilogue epi;
   epi.bias = bias;
   epi.bias_rstride = bias_per_relation ? Co : 0;
-  epi.add4 = reinterpret_cast<const float4*>(add);
+  if (add != nullptr) epi.add = seg_single(add, Co);
   epi.relu = relu;
   return launch_project_epi(in, M, m_in_major, nullptr, nullptr, nullptr, out, nullptr, sh->R * sh->Bg, sh->Bg, Ci,
                             Co, sh->N * sh->T, epi, (hipStream_t)stream);
@@ -246,6 +246,120 @@ extern "C" int msgat_node_pool_grad_weight(const float* x, const float* dpooled,
   if (G <= 0 || G > 65535 || C <= 0 || N <= 0) return MSGAT_ERR_SHAPE;
   if (!t_supported(T)) return MSGAT_ERR_UNSUPPORTED;
   return launch_node_pool_dw(x, dpooled, dw, partials, G, C, N, T, (hipStream_t)stream);
+}
+
+// ---- segment lists ----------------------------------------------------------------------------------------
+static int to_seglist(const msgat_seg_t* segs, int32_t n, SegList* out) {
+  SegList s{};
+  if (n < 0 || n > kMaxSeg) return MSGAT_ERR_SHAPE;
+  if (n > 0 && !segs) return MSGAT_ERR_NULL;
+  int c = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!segs[i].ptr) return MSGAT_ERR_NULL;
+    if (segs[i].channels <= 0 || (segs[i].group_stride != 0 && segs[i].group_stride < segs[i].channels)) return MSGAT_ERR_SHAPE;
+    s.ptr[i] = segs[i].ptr;
+    s.begin[i] = c;
+    s.gstride[i] = segs[i].group_stride ? segs[i].group_stride : segs[i].channels;
+    if (s.gstride[i] > 4 * kMaxC) return MSGAT_ERR_UNSUPPORTED;
+    c += segs[i].channels;
+  }
+  s.begin[n] = c;
+  s.n = n;
+  if (c > kMaxC) return MSGAT_ERR_UNSUPPORTED;
+  *out = s;
+  return MSGAT_OK;
+}
+
+static int check_rgnt(int32_t R, int32_t Bg, int32_t N, int32_t T) {
+  if (R <= 0 || Bg <= 0 || N <= 0) return MSGAT_ERR_SHAPE;
+  if (!t_supported(T)) return MSGAT_ERR_UNSUPPORTED;
+  if ((int64_t)R * Bg > 65535 || (int64_t)4 * kMaxC * N * T >= (1ll << 31)) return MSGAT_ERR_UNSUPPORTED;
+  return MSGAT_OK;
+}
+
+extern "C" int msgat_mix_segments(int32_t R, int32_t Bg, int32_t N, int32_t T, const msgat_seg_t* in, int32_t n_in,
+                                  const float* M, int32_t m_in_major, const float* bias, int32_t bias_per_relation,
+                                  const msgat_seg_t* add, int32_t n_add, int32_t relu, const msgat_seg_t* out,
+                                  int32_t n_out, void* stream) {
+  int st = check_rgnt(R, Bg, N, T);
+  if (st) return st;
+  if (!M) return MSGAT_ERR_NULL;
+  SegList si, so;
+  MixEpilogue epi;
+  if ((st = to_seglist(in, n_in, &si)) || (st = to_seglist(out, n_out, &so)) || (st = to_seglist(add, n_add, &epi.add))) return st;
+  if (si.n == 0 || so.n == 0) return MSGAT_ERR_SHAPE;
+  if (epi.add.n > 0 && epi.add.total() != so.total()) return MSGAT_ERR_SHAPE;
+  epi.bias = bias;
+  epi.bias_rstride = bias_per_relation ? so.total() : 0;
+  epi.relu = relu;
+  return launch_project_seg(si, M, m_in_major, nullptr, nullptr, nullptr, so, nullptr, R * Bg, Bg, N * T, epi,
+                            (hipStream_t)stream);
+}
+
+extern "C" size_t msgat_contract_segments_partial_floats(int32_t R, int32_t Ca, int32_t Cb) {
+  if (R <= 0 || Ca <= 0 || Cb <= 0) return 0;
+  return chanpair_partial_floats(R, 1, Ca, Cb);
+}
+
+extern "C" int msgat_contract_segments(int32_t R, int32_t Bg, int32_t N, int32_t T, const msgat_seg_t* A, int32_t n_a,
+                                       const float* B, int32_t Cb, float* partials, float* dst, void* stream) {
+  int st = check_rgnt(R, Bg, N, T);
+  if (st) return st;
+  if (!B || !partials || !dst) return MSGAT_ERR_NULL;
+  if (Cb <= 0 || Cb > kMaxC) return MSGAT_ERR_SHAPE;
+  SegList sa;
+  if ((st = to_seglist(A, n_a, &sa))) return st;
+  if (sa.n == 0) return MSGAT_ERR_SHAPE;
+  return launch_chanpair_seg(sa, B, partials, dst, sa.total() * Cb, nullptr, 0, R * Bg, Bg, Cb, N * T,
+                             (hipStream_t)stream);
+}
+
+// ---- attention core on projected features: backward --------------------------------------------------------
+static msgat_shape_t plain_shape(const msgat_shape_t* sh) {
+  msgat_shape_t s = *sh;
+  s.Co = 0;
+  return s;
+}
+
+extern "C" size_t msgat_attention_bwd_workspace_bytes(const msgat_shape_t* sh, int32_t nnz) {
+  if (check_shape(sh) != MSGAT_OK || nnz < 0) return 0;
+  return plan_bwd(plain_shape(sh), nnz).total;
+}
+
+extern "C" int msgat_attention_backward(const msgat_shape_t* shp, const msgat_graph_t* gr, const float* u,
+                                        const float* dv, const float* q, const float* kW, const float* lse,
+                                        const float* pq, const float* E, const float* Wg, float* du, float* dq,
+                                        float* dWg, void* workspace, size_t workspace_bytes, void* stream) {
+  int st = check_shape(shp);
+  if (st) return st;
+  const msgat_shape_t shv = plain_shape(shp);
+  const msgat_shape_t* sh = &shv;
+  st = check_graph(sh, gr);
+  if (st) return st;
+  if (!u || !dv || !q || !kW || !lse || !pq || !Wg || !du || !dq || !dWg) return MSGAT_ERR_NULL;
+  if (gr->nnz > 0 && !E) return MSGAT_ERR_NULL;
+  const BwdPlan p = plan_bwd(*sh, gr->nnz);
+  if (p.total > 0 && (!workspace || workspace_bytes < p.total)) return MSGAT_ERR_WORKSPACE;
+  char* ws = (char*)workspace;
+  hipStream_t s = (hipStream_t)stream;
+  float* dEp = (float*)(ws + p.off_dEp);
+  float* gE = (float*)(ws + p.off_gE);
+  float* Ec = (float*)(ws + p.off_Ec);
+  float* delta = (float*)(ws + p.off_delta);
+  float* dkW = (float*)(ws + p.off_dkW);
+  float* dwgp = (float*)(ws + p.off_dwg);
+  const int G = p.G, Bg = sh->Bg, N = sh->N, T = sh->T;
+  st = launch_sddmm(*gr, u, dv, dEp, G, sh->C, N, T, s);
+  if (st) return st;
+  st = launch_bwd_edge(*gr, dEp, p.nch, E, q, pq, Wg, gE, delta, dkW, dq, G, Bg, N, T, s);
+  if (st) return st;
+  st = launch_bwd_dense_col(*gr, q, kW, lse, delta, gE, dq, G, N, T, s);
+  if (st) return st;
+  st = launch_dwg(q, dkW, dwgp, dWg, G, Bg, N, T, s);
+  if (st) return st;
+  st = launch_permute_edges(E, gr->cperm, Ec, G, gr->nnz, s);
+  if (st) return st;
+  return launch_aggregate(gr->colptr, gr->crow, gr->nnz, dv, Ec, nullptr, nullptr, du, G, Bg, sh->C, N, T, s);
 }
 
 // ---- prediction head ----------------------------------------------------------------------------------

@@ -80,22 +80,64 @@ __device__ unsigned g_hwid[4096];  // (XCC_ID << 16) | HW_ID of the block's firs
 #define MSGAT_STAMP(i)
 #endif
 
+// A channel axis assembled from up to kMaxSeg tensors ("segments"): channel c of group g lives in the
+// segment k with begin[k] <= c < begin[k+1], at ptr[k] + (g * gstride[k] + c - begin[k]) * P.  gstride is
+// the channel count of the tensor the segment is a slice of (>= its own width), so a segment may be a
+// channel slice [:, a:b] of a wider contiguous [G,C,N,T] tensor.  This is what lets one channel-mixing
+// pass read cat(...) without the concatenation and write its outputs into separate tensors.
+constexpr int kMaxSeg = 6;
+struct SegList {
+  const float* ptr[kMaxSeg];
+  int begin[kMaxSeg + 1];
+  int gstride[kMaxSeg];
+  int n;
+  __host__ __device__ int total() const { return begin[n]; }
+#if defined(__HIPCC__)
+  // SEGS = false: the caller guarantees n == 1 and the lookup folds to one multiply-add
+  template <bool SEGS = true>
+  __device__ __forceinline__ const float* row(int g, int c, int P) const {
+    if (!SEGS) return ptr[0] + ((size_t)g * gstride[0] + c) * P;
+    const float* p = ptr[0];
+    int b = begin[0], gs = gstride[0];
+#pragma unroll
+    for (int i = 1; i < kMaxSeg; ++i)
+      if (i < n && c >= begin[i]) { p = ptr[i]; b = begin[i]; gs = gstride[i]; }
+    return p + ((size_t)g * gs + (c - b)) * P;
+  }
+#endif
+};
+inline SegList seg_none() {
+  SegList s{};
+  return s;
+}
+inline SegList seg_single(const float* p, int C) {
+  SegList s{};
+  s.ptr[0] = p; s.begin[0] = 0; s.begin[1] = C; s.gstride[0] = C; s.n = 1;
+  return s;
+}
+inline SegList seg_pair(const float* a, int Ca, const float* b, int Cb) {  // [a | b]
+  SegList s = seg_single(a, Ca);
+  if (b != nullptr && Cb > 0) { s.ptr[1] = b; s.begin[2] = Ca + Cb; s.gstride[1] = Cb; s.n = 2; }
+  return s;
+}
+
 // Epilogue of the channel-mixing kernels: v + bias[r,co] + add[g,co,p], then ReLU -- what turns
 // "W x" into a 1x1 convolution with bias, and the residual convolution of MEAM (msgat.py:130-131)
 // into one pass: relu(cat(branches) + res(x)).
 struct MixEpilogue {
   const float* bias = nullptr;   // [R?, Co]: element r * bias_rstride + co
   int bias_rstride = 0;
-  const float4* add4 = nullptr;  // same layout as the output
+  SegList add = {};              // channel axis of the output, possibly several tensors (n = 0: none)
   int relu = 0;
 #if defined(__HIPCC__)
-  __device__ __forceinline__ float4 apply(float4 v, int r, int co, size_t off) const {
+  template <bool SEGS = true>
+  __device__ __forceinline__ float4 apply(float4 v, int r, int g, int co, int p4, int P4) const {
     if (bias != nullptr) {
       const float b = bias[(size_t)r * bias_rstride + co];
       v.x += b; v.y += b; v.z += b; v.w += b;
     }
-    if (add4 != nullptr) {
-      const float4 a = add4[off];
+    if (add.n > 0) {
+      const float4 a = reinterpret_cast<const float4*>(add.template row<SEGS>(g, co, 4 * P4))[p4];
       v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
     }
     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -114,14 +156,18 @@ int launch_project(const float* in, const float* M, int m_in_major, const float*
 int launch_project_epi(const float* in, const float* M, int m_in_major, const float* qvec,
                        const float* addvec, const float* extra, float* out, float* q, int G, int Bg,
                        int Ci, int Co, int P, const MixEpilogue& epi, hipStream_t s);
+// the general form: input and output channel axes are segment lists (Ci = in.total(), Co = out.total())
+int launch_project_seg(const SegList& in, const float* M, int m_in_major, const float* qvec, const float* addvec,
+                       const float* extra, const SegList& out, float* q, int G, int Bg, int P,
+                       const MixEpilogue& epi, hipStream_t s);
 // MFMA forms (mfma.hip); launch_project / launch_chanpair dispatch to them
 size_t project_mfma_lds_bytes(int Ci, int Co, bool has_extra);
-int launch_project_mfma(const float* in, const float* M, int m_in_major, const float* qvec,
-                        const float* addvec, const float* extra, float* out, float* q, int G, int Bg,
-                        int Ci, int Co, int P, const MixEpilogue& epi, hipStream_t s);
+int launch_project_mfma(const SegList& in, const float* M, int m_in_major, const float* qvec,
+                        const float* addvec, const float* extra, const SegList& out, float* q, int G, int Bg,
+                        int P, const MixEpilogue& epi, hipStream_t s);
 int chanpair_mfma_blocks(int R);  // blocks (= partials) per relation
-int launch_chanpair_mfma(const float* A, const float* Aextra, const float* B, float* part, int R, int Bg,
-                         int Ca, int Cb, int P, int nblk, hipStream_t s);
+int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
+                         hipStream_t s);
 int launch_scores(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW, float* lse,
                   float* pq, float* E, int G, int Bg, int N, int T, hipStream_t s);
 // v[g,c,n,:] = sum_{e in ptr[n]..ptr[n+1]} E[g,e] u[g,c,idx[e],:] (+ addvec[r,c]*extra[g,n,:])
@@ -152,6 +198,8 @@ size_t chanpair_partial_floats(int G, int Bg, int Ca, int Cb);
 int launch_chanpair(const float* A, const float* Aextra, const float* B, float* part, float* dst0,
                     int n0, float* dst1, int n1, int G, int Bg, int Ca, int Cb, int P,
                     hipStream_t s);
+int launch_chanpair_seg(const SegList& A, const float* B, float* part, float* dst0, int n0, float* dst1, int n1,
+                        int G, int Bg, int Cb, int P, hipStream_t s);
 // out[i] = sum_j part[j,i], i < Wd, split over dst0 (first n0) and dst1 (next n1); fixed order
 int launch_reduce_rows(const float* part, int J, int Wd, float* dst0, int n0, float* dst1, int n1,
                        hipStream_t s);

@@ -46,13 +46,14 @@ __host__ __device__ static inline int proj_kpad(int Kx) {
 // k + kKC right after k-step k consumed it.  Every load is unconditional (addresses are clamped,
 // padding is neutralised by zero matrix entries): a load inside a branch makes hipcc fall back
 // to s_waitcnt vmcnt(0), which serialises the prefetch against the MFMAs.
-template <int MG, bool DO_Q, bool ONEPASS>
+template <int MG, bool DO_Q, bool ONEPASS, bool SEGS>
 __global__ __launch_bounds__(kBlock) void k_project_mfma(
-    const float4* __restrict__ in4, const float* __restrict__ M, int m_in_major,
+    SegList in, const float* __restrict__ M, int m_in_major,
     const float* __restrict__ qvec, const float* __restrict__ addvec,
-    const float4* __restrict__ extra4, float4* __restrict__ out4, float4* __restrict__ q4, int Bg,
-    int Ci, int Co, int P4, MixEpilogue epi) {
+    const float4* __restrict__ extra4, SegList out, float4* __restrict__ q4, int Bg,
+    int P4, MixEpilogue epi) {
   extern __shared__ float lds[];
+  const int Ci = in.total(), Co = out.total();
   const bool has_extra = addvec != nullptr;
   const int Kx = Ci + (has_extra ? 1 : 0);  // the extra "channel" carries addvec (x) extra
   const int K4 = (Kx + 3) >> 2;             // k-steps
@@ -69,14 +70,14 @@ __global__ __launch_bounds__(kBlock) void k_project_mfma(
   const int p4 = (blockIdx.x * 4 + wave) * 16 + j;
   const bool pvalid = p4 < P4;
   const int p4c = min(p4, P4 - 1);  // out-of-range lanes re-read the last position; their stores are masked
-  const float4* src = in4 + (size_t)g * Ci * P4 + p4c;
-  const float4* ex = has_extra ? extra4 + (size_t)g * P4 + p4c : src;
+  const float4* ex = has_extra ? extra4 + (size_t)g * P4 + p4c : nullptr;
 
   // channel 4*kk + kq of this lane's 4 positions; padding channels alias a real one (their matrix
   // column is zero) -- never a branch
   auto loadB = [&](int kk) -> float4 {
     const int ci = 4 * min(kk, K4 - 1) + kq;
-    const float4* p = (ci < Ci) ? src + (size_t)ci * P4 : ((ci == Ci) ? ex : src);
+    const float4* row = reinterpret_cast<const float4*>(in.template row<SEGS>(g, min(ci, Ci - 1), 4 * P4)) + p4c;
+    const float4* p = (ci == Ci && has_extra) ? ex : row;
     return *p;
   };
 
@@ -155,8 +156,8 @@ __global__ __launch_bounds__(kBlock) void k_project_mfma(
         const int co = (m0 + mg) * 16 + 4 * kq + reg;
         if (co < Co && pvalid) {
           float4 v = make_float4(acc[mg][0][reg], acc[mg][1][reg], acc[mg][2][reg], acc[mg][3][reg]);
-          const size_t o = ((size_t)g * Co + co) * P4 + p4;
-          out4[o] = epi.apply(v, r, co, o);
+          float4* dst = reinterpret_cast<float4*>(const_cast<float*>(out.template row<SEGS>(g, co, 4 * P4)));
+          dst[p4] = epi.template apply<SEGS>(v, r, g, co, p4, P4);
         }
       }
   }
@@ -174,7 +175,7 @@ static int proj_passes_mg(int Co, int* mg_out) {
   return passes;
 }
 
-size_t project_mfma_lds_bytes(int Ci, int Co, bool has_extra) {
+size_t project_mfma_lds_bytes(int Ci, int Co, bool has_extra) {  // Ci, Co: totals over the segments
   const int Kx = Ci + (has_extra ? 1 : 0);
   int MG;
   const int passes = proj_passes_mg(Co, &MG);
@@ -182,34 +183,38 @@ size_t project_mfma_lds_bytes(int Ci, int Co, bool has_extra) {
 }
 
 template <int MG>
-static int launch_project_mg(const float* in, const float* M, int m_in_major, const float* qvec,
-                             const float* addvec, const float* extra, float* out, float* q, int G, int Bg,
-                             int Ci, int Co, int P4, const MixEpilogue& epi, hipStream_t s) {
+static int launch_project_mg(const SegList& in, const float* M, int m_in_major, const float* qvec,
+                             const float* addvec, const float* extra, const SegList& out, float* q, int G, int Bg,
+                             int P4, const MixEpilogue& epi, hipStream_t s) {
+  const int Ci = in.total(), Co = out.total();
   const size_t lds = project_mfma_lds_bytes(Ci, Co, addvec != nullptr);
   dim3 grid(cdiv(P4, 64), G);
   const bool one = cdiv(Co, 16) <= MG;
-#define MSGAT_PROJ(Q, ONE)                                                                                          \
-  hipLaunchKernelGGL((k_project_mfma<MG, Q, ONE>), grid, dim3(kBlock), lds, s, (const float4*)in, M, m_in_major, qvec, \
-                     addvec, (const float4*)extra, (float4*)out, (float4*)q, Bg, Ci, Co, P4, epi)
-  if (qvec != nullptr) { if (one) MSGAT_PROJ(true, true); else MSGAT_PROJ(true, false); }
-  else { if (one) MSGAT_PROJ(false, true); else MSGAT_PROJ(false, false); }
+  const bool segs = in.n > 1 || out.n > 1 || epi.add.n > 1;
+#define MSGAT_PROJ(Q, ONE, SG)                                                                                      \
+  hipLaunchKernelGGL((k_project_mfma<MG, Q, ONE, SG>), grid, dim3(kBlock), lds, s, in, M, m_in_major, qvec, addvec, \
+                     (const float4*)extra, out, (float4*)q, Bg, P4, epi)
+#define MSGAT_PROJ2(Q, ONE) do { if (segs) MSGAT_PROJ(Q, ONE, true); else MSGAT_PROJ(Q, ONE, false); } while (0)
+  if (qvec != nullptr) { if (one) MSGAT_PROJ2(true, true); else MSGAT_PROJ2(true, false); }
+  else { if (one) MSGAT_PROJ2(false, true); else MSGAT_PROJ2(false, false); }
+#undef MSGAT_PROJ2
 #undef MSGAT_PROJ
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
 
-int launch_project_mfma(const float* in, const float* M, int m_in_major, const float* qvec,
-                        const float* addvec, const float* extra, float* out, float* q, int G, int Bg,
-                        int Ci, int Co, int P, const MixEpilogue& epi, hipStream_t s) {
+int launch_project_mfma(const SegList& in, const float* M, int m_in_major, const float* qvec,
+                        const float* addvec, const float* extra, const SegList& out, float* q, int G, int Bg,
+                        int P, const MixEpilogue& epi, hipStream_t s) {
   const int P4 = P / 4;
   int MG;
-  proj_passes_mg(Co, &MG);
+  proj_passes_mg(out.total(), &MG);
   switch (MG) {
-    case 1: return launch_project_mg<1>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, epi, s);
-    case 2: return launch_project_mg<2>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, epi, s);
-    case 3: return launch_project_mg<3>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, epi, s);
-    case 4: return launch_project_mg<4>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, epi, s);
-    default: return launch_project_mg<5>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, epi, s);
+    case 1: return launch_project_mg<1>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, P4, epi, s);
+    case 2: return launch_project_mg<2>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, P4, epi, s);
+    case 3: return launch_project_mg<3>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, P4, epi, s);
+    case 4: return launch_project_mg<4>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, P4, epi, s);
+    default: return launch_project_mg<5>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, P4, epi, s);
   }
 }
 
@@ -247,8 +252,8 @@ constexpr int kRowF4 = kTile / 4 + 1;  // float4s per LDS row (piece + 16 B pad)
 
 template <int MA, int NB>
 __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
-    const float* __restrict__ A, const float* __restrict__ Aextra, const float* __restrict__ B,
-    float* __restrict__ part, int Ca, int Cb, int P, int Bg, int nzb) {
+    SegList A, const float* __restrict__ B, float* __restrict__ part, int Cb, int P, int Bg, int nzb) {
+  const int Ca = A.total();
   extern __shared__ float4 lds4[];
   constexpr int RPW = ((MA + NB) * 16 + kCpWaves * kRPI - 1) / (kCpWaves * kRPI);  // load instructions per wave per tile
   const int r = blockIdx.y;
@@ -261,7 +266,6 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
   const int ca = min(MA * 16, Ca - a0), cb = min(NB * 16, Cb - c0);
   const int rows = ca + cb;  // rows [0,ca) = A channels, [ca,rows) = B channels
   constexpr int kZeroRow = (MA + NB) * 16;  // an all-zero row for absent channels
-  const int CaMain = (Aextra != nullptr) ? Ca - 1 : Ca;
   // this block's run of the relation's tile stream
   const int tpg = cdiv(P, kTile);  // tiles per group (the last one is partial)
   const long long ntot = (long long)Bg * tpg;
@@ -283,10 +287,16 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
     const int row = rr < rows ? rr : 0;
     const size_t g0 = (size_t)r * Bg;
     const float* p;
-    if (row < ca) {
+    if (row < ca) {  // A channel a0 + row: its segment's tensor and group stride
       const int a = a0 + row;
-      if (a < CaMain) { p = A + (g0 * CaMain + a) * P; gstride[k] = CaMain * P; }
-      else            { p = Aextra + g0 * P;           gstride[k] = P; }
+      int sk = 0;
+#pragma unroll
+      for (int i = 1; i < kMaxSeg; ++i) sk += (i < A.n && a >= A.begin[i]) ? 1 : 0;
+      p = A.row((int)g0, a, P);
+      int gs = A.gstride[0];
+#pragma unroll
+      for (int i = 1; i < kMaxSeg; ++i) gs = (i == sk) ? A.gstride[i] : gs;
+      gstride[k] = gs * P;
     } else {
       p = B + (g0 * Cb + (c0 + row - ca)) * P;
       gstride[k] = Cb * P;
@@ -410,8 +420,9 @@ int chanpair_mfma_blocks(int R) {
 }
 
 template <int MA, int NB>
-static int launch_chanpair_t(const float* A, const float* Aextra, const float* B, float* part, int R, int Bg,
-                             int Ca, int Cb, int P, int nblk, hipStream_t s) {
+static int launch_chanpair_t(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
+                             hipStream_t s) {
+  const int Ca = A.total();
   const int nza = cdiv(Ca, MA * 16), nzb = cdiv(Cb, NB * 16);
   // tile rows + the zero row, reused for the 8 x MA*NB*256-float reduction
   const size_t lds = sizeof(float4) * (size_t)max(((MA + NB) * 16 + 1) * kRowF4, kCpWaves * MA * NB * 64);
@@ -421,17 +432,17 @@ static int launch_chanpair_t(const float* A, const float* Aextra, const float* B
     if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
   }
   dim3 grid(nblk, R, nza * nzb);
-  hipLaunchKernelGGL((k_chanpair_mfma<MA, NB>), grid, dim3(kCpBlock), lds, s, A, Aextra, B, part, Ca, Cb, P, Bg,
-                     nzb);
+  hipLaunchKernelGGL((k_chanpair_mfma<MA, NB>), grid, dim3(kCpBlock), lds, s, A, B, part, Cb, P, Bg, nzb);
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
 
-int launch_chanpair_mfma(const float* A, const float* Aextra, const float* B, float* part, int R, int Bg,
-                         int Ca, int Cb, int P, int nblk, hipStream_t s) {
+int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
+                         hipStream_t s) {
+  const int Ca = A.total();
   const int MA = min(cdiv(Ca, 16), 3), NB = min(cdiv(Cb, 16), 6);
 #define MSGAT_CP(ma, nb) \
-  if (MA == ma && NB == nb) return launch_chanpair_t<ma, nb>(A, Aextra, B, part, R, Bg, Ca, Cb, P, nblk, s);
+  if (MA == ma && NB == nb) return launch_chanpair_t<ma, nb>(A, B, part, R, Bg, Cb, P, nblk, s);
   MSGAT_CP(1, 1) MSGAT_CP(1, 2) MSGAT_CP(1, 3) MSGAT_CP(1, 4) MSGAT_CP(1, 5) MSGAT_CP(1, 6)
   MSGAT_CP(2, 1) MSGAT_CP(2, 2) MSGAT_CP(2, 3) MSGAT_CP(2, 4) MSGAT_CP(2, 5) MSGAT_CP(2, 6)
   MSGAT_CP(3, 1) MSGAT_CP(3, 2) MSGAT_CP(3, 3) MSGAT_CP(3, 4) MSGAT_CP(3, 5) MSGAT_CP(3, 6)

@@ -39,13 +39,14 @@ int launch_qonly(const float* x, const float* alpha, float* q, int G, int Bg, in
 // One block = 256 lanes x 4 positions of one group, OT output channels (blockIdx.z picks
 // the tile).  The [Ci x OT] slice of the matrix sits in LDS and is read as wave-uniform
 // broadcasts (one ds_read_b128 feeds 4 output channels x 4 positions = 16 FMAs).
-template <int OT>
+template <int OT, bool SEGS>
 __global__ __launch_bounds__(kBlock) void k_project(
-    const float4* __restrict__ in4, const float* __restrict__ M, int m_in_major,
+    SegList in, const float* __restrict__ M, int m_in_major,
     const float* __restrict__ qvec, const float* __restrict__ addvec,
-    const float4* __restrict__ extra4, float4* __restrict__ out4, float4* __restrict__ q4, int Bg,
-    int Ci, int Co, int P4, MixEpilogue epi) {
+    const float4* __restrict__ extra4, SegList out, float4* __restrict__ q4, int Bg,
+    int P4, MixEpilogue epi) {
   extern __shared__ float lds[];
+  const int Ci = in.total(), Co = out.total();
   float* Ml = lds;            // [Ci][OT]
   float* ql = lds + Ci * OT;  // [Ci]
   const int g = blockIdx.y;
@@ -69,11 +70,9 @@ __global__ __launch_bounds__(kBlock) void k_project(
 #pragma unroll
   for (int oo = 0; oo < OT; ++oo) acc[oo] = f4zero();
   float4 qa = f4zero();
-  const float4* src = in4 + (size_t)g * Ci * P4 + p4;
-
 #pragma unroll 4
   for (int ci = 0; ci < Ci; ++ci) {
-    const float4 xv = src[(size_t)ci * P4];
+    const float4 xv = reinterpret_cast<const float4*>(in.template row<SEGS>(g, ci, 4 * P4))[p4];
     const float4* wrow = reinterpret_cast<const float4*>(Ml + ci * OT);
 #pragma unroll
     for (int o4 = 0; o4 < OT / 4; ++o4) {
@@ -94,21 +93,26 @@ __global__ __launch_bounds__(kBlock) void k_project(
     if (o < Co) {
       float4 v = acc[oo];
       if (addvec != nullptr) f4fma(addvec[r * Co + o], ex, v);
-      const size_t off = ((size_t)g * Co + o) * P4 + p4;
-      out4[off] = epi.apply(v, r, o, off);
+      reinterpret_cast<float4*>(const_cast<float*>(out.template row<SEGS>(g, o, 4 * P4)))[p4] =
+          epi.template apply<SEGS>(v, r, g, o, p4, P4);
     }
   }
   if (do_q) q4[(size_t)g * P4 + p4] = qa;
 }
 
 template <int OT>
-static int launch_project_t(const float* in, const float* M, int m_in_major, const float* qvec,
-                            const float* addvec, const float* extra, float* out, float* q, int G,
-                            int Bg, int Ci, int Co, int P4, const MixEpilogue& epi, hipStream_t s) {
+static int launch_project_t(const SegList& in, const float* M, int m_in_major, const float* qvec,
+                            const float* addvec, const float* extra, const SegList& out, float* q, int G,
+                            int Bg, int P4, const MixEpilogue& epi, hipStream_t s) {
+  const int Ci = in.total(), Co = out.total();
   dim3 grid(cdiv(P4, kBlock), G, cdiv(Co, OT));
   const size_t lds = (size_t)(Ci * OT + Ci) * sizeof(float);
-  hipLaunchKernelGGL(k_project<OT>, grid, dim3(kBlock), lds, s, (const float4*)in, M, m_in_major,
-                     qvec, addvec, (const float4*)extra, (float4*)out, (float4*)q, Bg, Ci, Co, P4, epi);
+  if (in.n > 1 || out.n > 1 || epi.add.n > 1)
+    hipLaunchKernelGGL((k_project<OT, true>), grid, dim3(kBlock), lds, s, in, M, m_in_major, qvec, addvec,
+                       (const float4*)extra, out, (float4*)q, Bg, P4, epi);
+  else
+    hipLaunchKernelGGL((k_project<OT, false>), grid, dim3(kBlock), lds, s, in, M, m_in_major, qvec, addvec,
+                       (const float4*)extra, out, (float4*)q, Bg, P4, epi);
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
@@ -122,17 +126,25 @@ int launch_project(const float* in, const float* M, int m_in_major, const float*
 int launch_project_epi(const float* in, const float* M, int m_in_major, const float* qvec,
                        const float* addvec, const float* extra, float* out, float* q, int G, int Bg,
                        int Ci, int Co, int P, const MixEpilogue& epi, hipStream_t s) {
+  return launch_project_seg(seg_single(in, Ci), M, m_in_major, qvec, addvec, extra, seg_single(out, Co), q, G, Bg, P,
+                            epi, s);
+}
+
+int launch_project_seg(const SegList& in, const float* M, int m_in_major, const float* qvec, const float* addvec,
+                       const float* extra, const SegList& out, float* q, int G, int Bg, int P,
+                       const MixEpilogue& epi, hipStream_t s) {
+  const int Ci = in.total(), Co = out.total();
   // matrix cores whenever there are enough output channels to fill a tile and the matrix fits LDS
   if (Co >= 8 && project_mfma_lds_bytes(Ci, Co, addvec != nullptr) <= 64 * 1024)
-    return launch_project_mfma(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P, epi, s);
+    return launch_project_mfma(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, P, epi, s);
   const int P4 = P / 4;
   // VALU fallback (few outputs or a very large matrix): widest tile that divides the work evenly; 24 and 32 cover the reference's widths
   // (Co = 16/24/32 forward, C = 48/72/96 backward)
-  if (Co % 24 == 0) return launch_project_t<24>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, epi, s);
-  if (Co % 32 == 0) return launch_project_t<32>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, epi, s);
-  if (Co % 16 == 0) return launch_project_t<16>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, epi, s);
-  if (Co <= 4) return launch_project_t<4>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, epi, s);
-  return launch_project_t<8>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, Ci, Co, P4, epi, s);
+  if (Co % 24 == 0) return launch_project_t<24>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, P4, epi, s);
+  if (Co % 32 == 0) return launch_project_t<32>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, P4, epi, s);
+  if (Co % 16 == 0) return launch_project_t<16>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, P4, epi, s);
+  if (Co <= 4) return launch_project_t<4>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, P4, epi, s);
+  return launch_project_t<8>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, P4, epi, s);
 }
 
 }  // namespace msgat

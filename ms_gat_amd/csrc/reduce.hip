@@ -119,14 +119,22 @@ size_t chanpair_partial_floats(int G, int Bg, int Ca, int Cb) {
   return (size_t)R * chanpair_mfma_blocks(R) * Ca * Cb;
 }
 
+int launch_chanpair_seg(const SegList& A, const float* B, float* part, float* dst0, int n0, float* dst1, int n1,
+                        int G, int Bg, int Cb, int P, hipStream_t s) {
+  const int R = G / Bg;
+  const int nblk = chanpair_mfma_blocks(R);
+  const int st = launch_chanpair_mfma(A, B, part, R, Bg, Cb, P, nblk, s);
+  if (st) return st;
+  return launch_reduce_partials(part, R, nblk, A.total() * Cb, dst0, n0, dst1, n1, s);
+}
+
 int launch_chanpair(const float* A, const float* Aextra, const float* B, float* part, float* dst0,
                     int n0, float* dst1, int n1, int G, int Bg, int Ca, int Cb, int P,
                     hipStream_t s) {
-  const int R = G / Bg;
-  const int nblk = chanpair_mfma_blocks(R);
-  const int st = launch_chanpair_mfma(A, Aextra, B, part, R, Bg, Ca, Cb, P, nblk, s);
-  if (st) return st;
-  return launch_reduce_partials(part, R, nblk, Ca * Cb, dst0, n0, dst1, n1, s);
+  // channel axis [A | Aextra]: Aextra, when given, supplies the last row
+  const SegList seg = (Aextra == nullptr) ? seg_single(A, Ca)
+                      : (Ca == 1 ? seg_single(Aextra, 1) : seg_pair(A, Ca - 1, Aextra, 1));
+  return launch_chanpair_seg(seg, B, part, dst0, n0, dst1, n1, G, Bg, Cb, P, s);
 }
 
 }  // namespace msgat

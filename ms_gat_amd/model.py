@@ -51,9 +51,12 @@ class TemporalAttention(nn.Module):
         self.Wt2 = nn.Parameter(torch.empty(self.rank, n_nodes))
         self.alpha = nn.Parameter(torch.empty(n_channels))
 
-    def attention(self, signals: torch.Tensor) -> torch.Tensor:
-        """-> att [B,T,T], rows = output step."""
-        per_t = ops.channel_pool(signals, self.alpha).transpose(1, 2)   # [B,T,N]
+    def attention(self, signals: torch.Tensor, pooled: torch.Tensor = None) -> torch.Tensor:
+        """-> att [B,T,T], rows = output step.  `pooled` = sum_c alpha_c signals_c [B,N,T] when the caller has
+        it already (MEAM computes it in its merged channel-mixing pass)."""
+        if pooled is None:
+            pooled = ops.channel_pool(signals, self.alpha)
+        per_t = pooled.transpose(1, 2)                                   # [B,T,N]
         left = per_t @ self.Wt1.t()                                      # [B,T,10]
         right = per_t @ self.Wt2.t()                                     # [B,T,10]
         return torch.softmax(left @ right.transpose(1, 2), dim=-1)
@@ -130,22 +133,31 @@ class TACN(nn.Module):
             width = out_channels
         self.seq = nn.Sequential(*layers)
 
+    def stacked_taps(self, layer: int) -> torch.Tensor:
+        """[2*Co, Ci]: the two taps of convolution `layer` stacked on the output axis (tap 0 acts on in[t-d])."""
+        w = self.seq[1 + 2 * layer].weight
+        return torch.cat([w[:, :, 0, 0], w[:, :, 0, 1]], dim=0)
+
     def forward(self, signals: torch.Tensor) -> torch.Tensor:
-        ta = self.seq[0]
         if not self.dilations:
-            return ta(signals)
-        T = signals.size(-1)
-        h, taps = signals, None
+            return self.seq[0](signals)
+        mixed = ops.mix(signals, self.stacked_taps(0).unsqueeze(0))
+        return self.finish(mixed, self.seq[0].attention(signals))
+
+    def finish(self, mixed: torch.Tensor, att: torch.Tensor) -> torch.Tensor:
+        """The stack from the channel-mixed input of its first convolution (`mixed` = stacked_taps(0) applied to
+        the signals, [B,2Co,N,T]) and the temporal attention matrix `att` [B,T,T]."""
+        T = att.size(-1)
+        h = None
         for i, d in enumerate(self.dilations):
             conv = self.seq[1 + 2 * i]
-            stacked = torch.cat([conv.weight[:, :, 0, 0], conv.weight[:, :, 0, 1]], dim=0).unsqueeze(0)   # [1,2Co,Ci]
             if i == 0:
-                att = ta.attention(signals)                                                   # [B,T,T]
                 taps = torch.stack([_shift_down(att, d), att], dim=1)                         # [B,2,T,T]
             else:
-                eye = torch.eye(T, device=signals.device, dtype=signals.dtype)
+                eye = torch.eye(T, device=att.device, dtype=att.dtype)
                 taps = torch.stack([_shift_down(eye, d), eye], dim=0).unsqueeze(0)            # [1,2,T,T]
-            h = ops.time_mix(ops.mix(h, stacked), taps, conv.bias)
+                mixed = ops.mix(h, self.stacked_taps(i).unsqueeze(0))
+            h = ops.time_mix(mixed, taps, conv.bias)
         return h
 
 
@@ -185,9 +197,38 @@ class MEAM(nn.Module):
 
     def forward(self, signals: torch.Tensor, adjacency) -> torch.Tensor:
         normed = self.ln(signals)
-        branches = torch.cat([self.cacn(normed), self.tacn(normed), self.gacn(normed, adjacency)], dim=1)
-        # relu(branches + res(signals)): the 1x1 residual convolution with the add and the ReLU in its epilogue
-        return ops.mix(signals, self.res.weight[:, :, 0, 0].unsqueeze(0), self.res.bias, add=branches, relu=True)
+        res_w = self.res.weight[:, :, 0, 0].unsqueeze(0)
+        if self.in_channels <= self.out_channels // 3 or not self.dilations:
+            # few input channels (the first block of a component): the graph branch aggregates before it
+            # projects, nothing to merge -- branch by branch
+            branches = [self.cacn(normed), self.tacn(normed), self.gacn(normed, adjacency)]
+        else:
+            branches = self._merged_branches(normed, adjacency)
+        # relu(cat(branches) + res(signals)): the 1x1 residual convolution reads the three branch tensors as
+        # its add operand (no concatenation) and applies the ReLU in its store epilogue
+        return ops.mix_multi([signals], res_w, self.res.bias, adds=branches, relu=True)[0]
+
+    def _merged_branches(self, normed: torch.Tensor, adjacency):
+        """All channel mixings of the normalised input in ONE pass: CACN's per-sample
+        matrix `conv @ att_b` (msgat.py:93-94), the two taps of TACN's first convolution (msgat.py:66-74), GACN's
+        projection W (msgat.py:27, applied before the aggregation as C > out/3) and the two alpha-weighted channel
+        poolings (attention.py:33 and :59) are rows of one [B, 4*Cb + 2, C] matrix.  The backward is then ONE
+        transposed pass producing the gradient at the LayerNorm output, instead of five passes plus four adds."""
+        B, C = normed.shape[:2]
+        cb = self.out_channels // 3
+        ca, ta, gatt = self.cacn.seq[0], self.tacn.seq[0], self.gacn.gatt
+        conv_c = self.cacn.seq[1]
+        rows = torch.cat([
+            conv_c.weight[:, :, 0, 0] @ ca.attention(normed),                    # [B,cb,C]   needs the node pooling first
+            self.tacn.stacked_taps(0).unsqueeze(0).expand(B, -1, -1),            # [B,2cb,C]
+            self.gacn.W.unsqueeze(0).expand(B, -1, -1),                          # [B,cb,C]
+            gatt.alpha.view(1, 1, C).expand(B, -1, -1),                          # [B,1,C]    q of the graph attention
+            ta.alpha.view(1, 1, C).expand(B, -1, -1)], dim=1)                    # [B,1,C]    pooled signal of the temporal attention
+        bias = torch.cat([conv_c.bias, conv_c.bias.new_zeros(3 * cb + 2)])
+        cacn, mixed, u, q, pooled_t = ops.mix_multi([normed], rows, bias, out_channels=[cb, 2 * cb, cb, 1, 1])
+        tacn = self.tacn.finish(mixed, ta.attention(normed, pooled=pooled_t[:, 0]))
+        gacn = ops.attention_core(u, q[:, 0], gatt.Wg.unsqueeze(0), adjacency)
+        return [cacn, tacn, gacn]
 
 
 class TPC(nn.Module):

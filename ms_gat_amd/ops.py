@@ -480,3 +480,182 @@ def head(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None) 
     if x.dim() != 4 or W.dim() != 4 or W.shape[1] != x.shape[3] or W.shape[2] != 1 or W.shape[3] != x.shape[1]:
         raise ValueError(f"head: signals {tuple(x.shape)} and weight {tuple(W.shape)} do not match")
     return _HeadFunction.apply(x, W, bias)
+
+
+# ---- channel axes assembled from several tensors: one pass instead of cat / several mixes -------------------
+
+def _as_segment(t: torch.Tensor):
+    """(tensor to keep alive, Seg) for a [G,Ck,N,T] tensor: used in place when it is contiguous or a channel
+    slice [:, a:b] of a contiguous wider tensor (the library addresses such slices directly), copied otherwise."""
+    G, Ck, N, T = t.shape
+    st = t.stride()
+    if t.numel() > 0 and st[1:] == (N * T, T, 1) and st[0] % (N * T) == 0 and st[0] // (N * T) >= Ck:
+        return t, _lib.Seg(t.data_ptr(), Ck, st[0] // (N * T))
+    t = t.contiguous()
+    return t, _lib.Seg(t.data_ptr(), Ck, 0)
+
+
+def _seg_array(tensors):
+    keep, segs = [], []
+    for t in tensors:
+        k, sg = _as_segment(t)
+        keep.append(k)
+        segs.append(sg)
+    arr = (_lib.Seg * max(len(segs), 1))(*segs)
+    return keep, arr, len(segs)
+
+
+class _MixMultiFunction(torch.autograd.Function):
+    """outs = split(relu?(M cat(ins) + bias + cat(adds))): see include/msgat_hip.h, msgat_mix_segments."""
+
+    @staticmethod
+    def forward(ctx, M, bias, relu, n_in, n_add, out_channels, *tensors):
+        L = _lib.lib()
+        ins, adds = tensors[:n_in], tensors[n_in:n_in + n_add]
+        G, _, N, T = ins[0].shape
+        M = M.contiguous()
+        R = M.shape[0]
+        outs = [_new(ins[0], G, c, N, T) for c in out_channels]
+        kin, ain, _ = _seg_array(ins)
+        _kad, aad, _ = _seg_array(adds)
+        _, aout, _ = _seg_array(outs)
+        b = None if bias is None else bias.contiguous()
+        st = L.msgat_mix_segments(R, G // R, N, T, ain, n_in, _ptr(M), 0, _ptr(b), 0, aad, n_add, int(relu), aout,
+                                  len(outs), _stream_handle(M.device))
+        _lib.check(st, "msgat_mix_segments")
+        ctx.meta = (relu, n_in, tuple(out_channels), bias is not None, [t.shape[1] for t in ins],
+                    [t.shape[1] for t in adds])
+        ctx.save_for_backward(M, *kin, *(outs if relu else []))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        L = _lib.lib()
+        relu, n_in, out_channels, has_bias, in_channels, add_channels = ctx.meta
+        saved = ctx.saved_tensors
+        M, ins, outs = saved[0], saved[1:1 + n_in], saved[1 + n_in:]
+        like = ins[0]
+        G, _, N, T = like.shape
+        R = M.shape[0]
+        stream = _stream_handle(M.device)
+        dpre = []
+        for i, (d, c) in enumerate(zip(douts, out_channels)):
+            if d is None:
+                d = torch.zeros(G, c, N, T, device=like.device, dtype=torch.float32)
+            if relu:  # ReLU mask in one pass: dout where out > 0, else 0
+                d = torch.ops.aten.threshold_backward(d.contiguous(), outs[i], 0.0)
+            dpre.append(d)
+        kd, ad, nd = _seg_array(dpre)
+        need = ctx.needs_input_grad
+        dM = dbias = None
+        d_ins = [None] * n_in
+        if any(need[6:6 + n_in]):   # one pass: d cat(ins) = M^T cat(dpre), each input's range to its own tensor
+            d_ins = [_new(like, G, c, N, T) for c in in_channels]
+            _, ai, _ = _seg_array(d_ins)
+            st = L.msgat_mix_segments(R, G // R, N, T, ad, nd, _ptr(M), 1, None, 0, None, 0, 0, ai, n_in, stream)
+            _lib.check(st, "msgat_mix_segments (backward)")
+        if need[0]:
+            Co = sum(out_channels)
+            parts = []
+            for x, c in zip(ins, in_channels):
+                x = x.contiguous()
+                dMi = _new(like, R, Co, c)
+                part = _new(like, max(int(L.msgat_contract_segments_partial_floats(R, Co, c)), 1))
+                st = L.msgat_contract_segments(R, G // R, N, T, ad, nd, _ptr(x), c, _ptr(part), _ptr(dMi), stream)
+                _lib.check(st, "msgat_contract_segments")
+                parts.append(dMi)
+            dM = parts[0] if len(parts) == 1 else torch.cat(parts, dim=2)
+        if has_bias and need[1]:
+            dbias = torch.cat([_channel_sums(k.contiguous()) for k in kd])
+        d_adds = []
+        if add_channels:   # channel ranges of cat(dpre), as views (the library reads channel slices in place)
+            whole = dpre[0] if len(dpre) == 1 else torch.cat(dpre, dim=1)
+            a = 0
+            for c in add_channels:
+                d_adds.append(whole[:, a:a + c])
+                a += c
+        return (dM, dbias, None, None, None, None, *d_ins, *d_adds)
+
+
+def mix_multi(ins, M, bias=None, adds=(), relu=False, out_channels=None):
+    """One channel-mixing pass over cat(ins) with the [R, Co, Ci] matrix M (R | batch): relu?(M cat(ins) + bias +
+    cat(adds)), the output channel ranges `out_channels` written to separate tensors (default: one).  Returns a
+    tuple.  Replaces torch.cat + several 1x1 convolutions by a single read of the inputs."""
+    ins, adds = list(ins), list(adds)
+    for t in ins + adds:
+        _require_device_tensor("signals", t)
+    _require_device_tensor("matrix", M, ins[0].device)
+    Ci, Co = sum(t.shape[1] for t in ins), M.shape[1]
+    out_channels = [Co] if out_channels is None else list(out_channels)
+    if M.dim() != 3 or M.shape[2] != Ci or sum(out_channels) != Co or ins[0].shape[0] % M.shape[0]:
+        raise ValueError(f"mix_multi: matrix {tuple(M.shape)} for {Ci} input / {out_channels} output channels")
+    if adds and sum(t.shape[1] for t in adds) != Co:
+        raise ValueError("mix_multi: the add operands must cover the output channels")
+    if relu and len(out_channels) != 1:
+        raise ValueError("mix_multi: relu needs a single output tensor")
+    if bias is not None and tuple(bias.shape) != (Co,):
+        raise ValueError(f"bias must be [{Co}]")
+    if max(len(ins), len(adds), len(out_channels)) > 6:
+        raise ValueError("mix_multi: at most 6 tensors per channel axis")
+    return _MixMultiFunction.apply(M, bias, bool(relu), len(ins), len(adds), tuple(out_channels), *ins, *adds)
+
+
+class _AttentionCoreFunction(torch.autograd.Function):
+    """u[G,Cu,N,T], q[G,N,T], Wg[R,T,T] -> z = (softmax(q Wg q^T) . adj) u: attention.py:34-36 on features and
+    pooled signals that were produced elsewhere (msgat_stage_scores + msgat_stage_aggregate; backward
+    msgat_attention_backward)."""
+
+    @staticmethod
+    def forward(ctx, u, q, Wg, graph: SparseGraph):
+        L = _lib.lib()
+        u, q, Wg = u.contiguous(), q.contiguous(), Wg.contiguous()
+        G, Cu, N, T = u.shape
+        R = Wg.shape[0]
+        dev = u.device
+        shape = _lib.Shape(R, G // R, Cu, 0, N, T)
+        gstruct, _keep = graph.on(dev)
+        need_bwd = any(ctx.needs_input_grad)
+        kW, lse, E = _new(u, G, N, T), _new(u, G, N), _new(u, G, max(graph.nnz, 1))
+        pq = _new(u, G, N, T) if need_bwd else None
+        z = torch.empty_like(u)
+        stream = _stream_handle(dev)
+        _lib.check(L.msgat_stage_scores(C.byref(shape), C.byref(gstruct), _ptr(q), _ptr(Wg), _ptr(kW), _ptr(lse), _ptr(pq),
+                                        _ptr(E), stream), "msgat_stage_scores")
+        _lib.check(L.msgat_stage_aggregate(C.byref(shape), C.byref(gstruct), Cu, _ptr(u), _ptr(E), _ptr(z), stream),
+                   "msgat_stage_aggregate")
+        if need_bwd:
+            ctx.graph, ctx.R = graph, R
+            ctx.save_for_backward(u, q, Wg, kW, lse, pq, E)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        L = _lib.lib()
+        u, q, Wg, kW, lse, pq, E = ctx.saved_tensors
+        G, Cu, N, T = u.shape
+        dev = u.device
+        shape = _lib.Shape(ctx.R, G // ctx.R, Cu, 0, N, T)
+        gstruct, _keep = ctx.graph.on(dev)
+        dz = dz.contiguous()
+        du, dq, dWg = torch.empty_like(u), torch.empty_like(q), torch.empty_like(Wg)
+        nbytes = L.msgat_attention_bwd_workspace_bytes(C.byref(shape), ctx.graph.nnz)
+        ws = torch.empty(max(int(nbytes), 256), device=dev, dtype=torch.uint8)
+        st = L.msgat_attention_backward(C.byref(shape), C.byref(gstruct), _ptr(u), _ptr(dz), _ptr(q), _ptr(kW), _ptr(lse),
+                                        _ptr(pq), _ptr(E), _ptr(Wg), _ptr(du), _ptr(dq), _ptr(dWg), _ptr(ws), ws.numel(),
+                                        _stream_handle(dev))
+        _lib.check(st, "msgat_attention_backward")
+        return du, dq, dWg, None
+
+
+def attention_core(u: torch.Tensor, q: torch.Tensor, Wg: torch.Tensor, adjacency) -> torch.Tensor:
+    """Graph attention on already projected features `u` [G,Cu,N,T] with pooled signals `q` [G,N,T]."""
+    _require_device_tensor("features", u)
+    _require_device_tensor("pooled signals", q, u.device)
+    _require_device_tensor("Wg", Wg, u.device)
+    G, Cu, N, T = u.shape
+    if tuple(q.shape) != (G, N, T) or Wg.dim() != 3 or tuple(Wg.shape[1:]) != (T, T) or G % Wg.shape[0]:
+        raise ValueError(f"attention_core: u {tuple(u.shape)}, q {tuple(q.shape)}, Wg {tuple(Wg.shape)}")
+    graph = adjacency if isinstance(adjacency, SparseGraph) else graph_of(adjacency)
+    if graph.n_nodes != N:
+        raise ValueError(f"adjacency has {graph.n_nodes} nodes, signals have {N}")
+    return _AttentionCoreFunction.apply(u, q, Wg, graph)
