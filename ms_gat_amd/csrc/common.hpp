@@ -130,6 +130,19 @@ struct MixEpilogue {
   SegList add = {};              // channel axis of the output, possibly several tensors (n = 0: none)
   int relu = 0;
 #if defined(__HIPCC__)
+  // same, with the add operand's address already resolved (nullptr: none)
+  __device__ __forceinline__ float4 apply_rows(float4 v, int r, int co, const float4* addp) const {
+    if (bias != nullptr) {
+      const float b = bias[(size_t)r * bias_rstride + co];
+      v.x += b; v.y += b; v.z += b; v.w += b;
+    }
+    if (addp != nullptr) {
+      const float4 a = *addp;
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    return v;
+  }
   template <bool SEGS = true>
   __device__ __forceinline__ float4 apply(float4 v, int r, int g, int co, int p4, int P4) const {
     if (bias != nullptr) {

@@ -72,11 +72,25 @@ __global__ __launch_bounds__(kBlock) void k_project_mfma(
   const int p4c = min(p4, P4 - 1);  // out-of-range lanes re-read the last position; their stores are masked
   const float4* ex = has_extra ? extra4 + (size_t)g * P4 + p4c : nullptr;
 
+  // SEGS: the segment lists (3 x 26 scalars) are resolved ONCE per block into a row-pointer table in LDS
+  // -- entry c = address of channel c of this group.  Looked up per load from the kernel arguments they
+  // spilled the scalar registers and halved the occupancy (203 us for a pass that takes 66 us unsegmented).
+  const float** rowtab = reinterpret_cast<const float**>(lds + ((Mrows * Kpad + 4 * K4 + 1) & ~1));  // [Ci | Co | Co]
+  if (SEGS) {
+    for (int c = threadIdx.x; c < Ci; c += kBlock) rowtab[c] = in.row(g, c, 4 * P4);
+    for (int c = threadIdx.x; c < Co; c += kBlock) {
+      rowtab[Ci + c] = out.row(g, c, 4 * P4);
+      rowtab[Ci + Co + c] = (epi.add.n > 0) ? epi.add.row(g, c, 4 * P4) : nullptr;
+    }
+    __syncthreads();
+  }
+
   // channel 4*kk + kq of this lane's 4 positions; padding channels alias a real one (their matrix
   // column is zero) -- never a branch
   auto loadB = [&](int kk) -> float4 {
     const int ci = 4 * min(kk, K4 - 1) + kq;
-    const float4* row = reinterpret_cast<const float4*>(in.template row<SEGS>(g, min(ci, Ci - 1), 4 * P4)) + p4c;
+    const float* base = SEGS ? rowtab[min(ci, Ci - 1)] : in.template row<false>(g, min(ci, Ci - 1), 4 * P4);
+    const float4* row = reinterpret_cast<const float4*>(base) + p4c;
     const float4* p = (ci == Ci && has_extra) ? ex : row;
     return *p;
   };
@@ -156,8 +170,14 @@ __global__ __launch_bounds__(kBlock) void k_project_mfma(
         const int co = (m0 + mg) * 16 + 4 * kq + reg;
         if (co < Co && pvalid) {
           float4 v = make_float4(acc[mg][0][reg], acc[mg][1][reg], acc[mg][2][reg], acc[mg][3][reg]);
-          float4* dst = reinterpret_cast<float4*>(const_cast<float*>(out.template row<SEGS>(g, co, 4 * P4)));
-          dst[p4] = epi.template apply<SEGS>(v, r, g, co, p4, P4);
+          if (SEGS) {
+            const float* arow = rowtab[Ci + Co + co];
+            v = epi.apply_rows(v, r, co, arow != nullptr ? reinterpret_cast<const float4*>(arow) + p4 : nullptr);
+            reinterpret_cast<float4*>(const_cast<float*>(rowtab[Ci + co]))[p4] = v;
+          } else {
+            float4* dst = reinterpret_cast<float4*>(const_cast<float*>(out.template row<false>(g, co, 4 * P4)));
+            dst[p4] = epi.template apply<false>(v, r, g, co, p4, P4);
+          }
         }
       }
   }
@@ -179,7 +199,9 @@ size_t project_mfma_lds_bytes(int Ci, int Co, bool has_extra) {  // Ci, Co: tota
   const int Kx = Ci + (has_extra ? 1 : 0);
   int MG;
   const int passes = proj_passes_mg(Co, &MG);
-  return (size_t)(passes * MG * 16 * proj_kpad(Kx) + 4 * ((Kx + 3) / 4)) * sizeof(float);
+  // matrix + q vector (+ 1 float of alignment) + the row-pointer table of the segmented form
+  return (size_t)(passes * MG * 16 * proj_kpad(Kx) + 4 * ((Kx + 3) / 4) + 1) * sizeof(float) +
+         (size_t)(Ci + 2 * Co) * sizeof(float*);
 }
 
 template <int MG>
