@@ -16,6 +16,7 @@ Fixtures:
   msgat72_n32.npz  msgat72 fwd + HuberLoss(50) + all grads (msgat.py:166-229, loss.py:51-52)
   adj_n12.npz  sym-normalised adjacency from a csv edge list (data_loader.py:49-66)
   slices_*.npz TimeSeriesSlice / normalize (data_loader.py:92-120)
+  msgat72_cfg1_pemsd4.npz  BASELINE.json configs[0]: msgat72 forward, N=307, 3 features, B=4, five components
 """
 import os
 import sys
@@ -138,6 +139,35 @@ def msgat_case(seed):
     save("msgat72_n32.npz", X=X, H=H, D=D, Y=Y, pred=pred, loss=loss, **arrays)
 
 
+def cfg1_case(seed):
+    """BASELINE.json configs[0]: PEMSD4-like (307 nodes, 3 features, T=12, B=4), the reference's default five
+    components (main.py:14, `-i 1,2,3,24,168`), full msgat72 forward on the CPU.  The time-embedding tables are
+    31 x 18 420 floats each component set; only the rows H and D select are stored (the others cannot
+    influence the forward), which keeps the fixture under 1 MB."""
+    torch.manual_seed(seed)
+    N, B, R, C, T = 307, 4, 5, 3, 12
+    adj = synthetic_adjacency(N, 340, seed + 1)
+    net = msgat72(n_components=R, in_channels=C, in_timesteps=T, out_timesteps=T, use_te=True, adj=t(adj))
+    X = torch.randn(B, R, C, N, T).half().float()   # exactly representable in fp16: stored at half the size
+    H = torch.randint(0, 24, (B,))
+    D = torch.randint(0, 7, (B,))
+    with torch.no_grad():
+        pred = net(X, H, D)
+    arrays = {}
+    for k, v in net.state_dict().items():
+        if k == "te.h_ebd.weight":
+            arrays["te_h_rows"] = v[H]
+        elif k == "te.d_ebd.weight":
+            arrays["te_d_rows"] = v[D]
+        elif k == "adj":
+            continue
+        else:
+            arrays[f"p.{k}"] = v
+    rows, cols = np.nonzero(adj)   # the [307,307] adjacency has 987 non-zeros: stored as coordinates
+    save("msgat72_cfg1_pemsd4.npz", X=X.half(), H=H, D=D, adj_rows=rows.astype(np.int16), adj_cols=cols.astype(np.int16),
+         adj_vals=adj[rows, cols], pred=pred, **arrays)
+
+
 def adjacency_case():
     """Runs the reference's private csv -> adjacency routine on a temp edge list."""
     n = 12
@@ -189,3 +219,4 @@ if __name__ == "__main__":
     msgat_case(700)
     adjacency_case()
     slices_case(800)
+    cfg1_case(900)

@@ -151,3 +151,23 @@ def test_whole_model_matches_the_dense_op_sequence(factory, cin, R):
         if b is None:
             continue
         assert rel_err(a.double(), b) < TOL, n
+
+
+def test_cfg1_pemsd4_five_components_forward_matches_the_reference():
+    """BASELINE.json configs[0] on the device: msgat72, 307 nodes, 3 features, B=4, the reference's default five
+    components, against the prediction the reference computed on the CPU (tests/golden/make_golden.py: cfg1_case)."""
+    from ms_gat_amd import model
+    from test_oracle_golden import _cfg1_state
+    g = load_golden("msgat72_cfg1_pemsd4.npz")
+    adj = torch.zeros(307, 307)
+    adj[torch.from_numpy(g["adj_rows"].astype(np.int64)), torch.from_numpy(g["adj_cols"].astype(np.int64))] = \
+        torch.from_numpy(g["adj_vals"])
+    net = model.msgat72(n_components=5, in_channels=3, in_timesteps=12, out_timesteps=12, use_te=True, adj=adj)
+    state = _cfg1_state(g)
+    state["adj"] = adj
+    net.load_state_dict(state)
+    net.to(_dev())
+    with torch.no_grad():
+        pred = net(torch.from_numpy(g["X"]).float().to(_dev()), torch.from_numpy(g["H"]).to(_dev()),
+                   torch.from_numpy(g["D"]).to(_dev()))
+    assert rel_err(pred.cpu(), g["pred"]) < TOL

@@ -94,3 +94,41 @@ def test_huber_matches_reference():
     assert abs(got - float(m["loss"])) < 1e-4 * abs(float(m["loss"]))
     got_t = dense_torch.huber(torch.from_numpy(m["pred"]), torch.from_numpy(m["Y"]), 50.0)
     assert abs(float(got_t) - float(m["loss"])) < 1e-5 * abs(float(m["loss"]))
+
+
+def _cfg1_state(g, n_components=5, n_nodes=307, T=12):
+    """state_dict of msgat72 from the cfg1 fixture: the time-embedding tables are rebuilt with the stored rows at
+    the indices H and D select (the other rows cannot influence the forward)."""
+    import torch
+    state = {k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("p.")}
+    width = n_components * n_nodes * T
+    h, d = torch.zeros(24, width), torch.zeros(7, width)
+    h[torch.from_numpy(g["H"])] = torch.from_numpy(g["te_h_rows"])
+    d[torch.from_numpy(g["D"])] = torch.from_numpy(g["te_d_rows"])
+    state["te.h_ebd.weight"], state["te.d_ebd.weight"] = h, d
+    return state
+
+
+def test_cfg1_pemsd4_full_forward_of_the_oracle_matches_the_reference():
+    """BASELINE.json configs[0]: PEMSD4-like (307 nodes, 3 features, T=12, B=4), five components, msgat72 forward on
+    the CPU -- the dense restatement of every block (oracle/dense_torch.py) against the reference's prediction."""
+    g = load_golden("msgat72_cfg1_pemsd4.npz")
+    state = _cfg1_state(g)
+    X, H, D = torch.from_numpy(g["X"]).float(), torch.from_numpy(g["H"]), torch.from_numpy(g["D"])
+    adj = torch.zeros(307, 307)
+    adj[torch.from_numpy(g["adj_rows"].astype(np.int64)), torch.from_numpy(g["adj_cols"].astype(np.int64))] = \
+        torch.from_numpy(g["adj_vals"])
+    B, R, T = X.shape[0], X.shape[1], X.shape[-1]
+    gate = (state["te.h_ebd.weight"][H] + state["te.d_ebd.weight"][D]).view(B, R, 307, T)
+    out = 0
+    with torch.no_grad():
+        for r in range(R):
+            x = X[:, r]
+            for l in range(2):
+                pre = f"tpcs.{r}.tgacns.{l}."
+                sub = {k[len(pre):]: v for k, v in state.items() if k.startswith(pre)}
+                x = dense_torch.meam_dense(x, adj, sub, [1, 2] if l == 0 else [2, 4])
+            x = torch.nn.functional.layer_norm(x, [T], state[f"tpcs.{r}.ln.weight"], state[f"tpcs.{r}.ln.bias"], 1e-5)
+            y = torch.nn.functional.conv2d(x.transpose(1, 3), state[f"tpcs.{r}.fc.weight"], state[f"tpcs.{r}.fc.bias"])
+            out = out + y[..., 0].transpose(1, 2) * gate[:, r]
+    assert rel_err(out, g["pred"]) < 1e-5
