@@ -311,7 +311,11 @@ def main():
     if rank == 0:
         sec, nbytes = time_aggregate_kernel(hp)
         out["roofline"] = {
-            "kernel": "k_agg_lds (attention-aggregate, second GACN depth)", "bound": "hbm",
+            # the library picks the variant by slab size: whole [N,T] slab in LDS, one 4-timestep column of it,
+            # or gather from L2 (aggregate.hip)
+            "kernel": ("k_agg_lds" if wl["N"] * wl["T"] * 4 <= 159 * 1024 else
+                       "k_agg_cols" if wl["N"] * 16 <= 159 * 1024 else "k_agg_glb")
+                      + " (attention-aggregate, second GACN depth)", "bound": "hbm",
             "achieved": round(nbytes / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": recorded_traffic(args.workload),
             "us_per_launch": round(sec * 1e6, 2), "algorithmic_bytes": nbytes,
