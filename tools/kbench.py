@@ -64,7 +64,10 @@ def main():
     ap.add_argument("--workload", default="pemsd7")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--eager", action="store_true", help="plain launches instead of graph replay (counter collection)")
     a = ap.parse_args()
+    if a.eager:
+        globals()["timeit"] = timeit_eager
     w = WL[a.workload]
     N, T, R, B, Cc, Co = w["N"], w["T"], w["R"], w["B"], w["C"], w["Co"]
     G, P = R * B, N * T
