@@ -32,13 +32,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
-__device__ __forceinline__ float max3(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
+// NOT inline asm: hipcc's hazard recognizer does not look inside an asm statement, so an asm v_max3 that
+// reads an MFMA result straight out of VGPRs gets no wait states after the MFMA and sees stale registers
+// (found with 8-wave blocks, where the accumulators live in VGPRs: the deferred re-base then missed new
+// row maxima and saturated softmax rows overflowed, differently from run to run).  The compiler fuses
+// the nested fmaxf into v_max3_f32 by itself.
+__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
-constexpr int kDWaves = 4;             // the whole grid must be resident at once: leftover blocks run as a second round
+constexpr int kDWaves = 8;             // the whole grid must be resident at once: leftover blocks run as a second round
 constexpr int kDBlock = 64 * kDWaves;
 constexpr int kDRows = 16 * kDWaves;   // own rows (forward) / columns (backward) per block
 constexpr int kDMC = 128;              // streamed columns (forward) / rows (backward) staged per step
