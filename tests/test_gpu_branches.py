@@ -186,3 +186,67 @@ def test_prediction_head_matches_the_transposed_convolution(B, C, N, T, To):
     assert out.shape == o64.shape
     assert rel_err(out.double(), o64) < TOL
     _check(g_mine, _grads(o64, ref, dout.double()), ["dx", "dW", "dbias"])
+
+
+def test_mix_multi_reads_channel_slices_in_place_and_writes_several_outputs():
+    """Segment lists (include/msgat_hip.h: msgat_mix_segments): inputs that are channel slices of wider tensors,
+    several inputs, several outputs, add operands given as separate tensors -- against cat + matmul in float64."""
+    from ms_gat_amd import ops
+    gen = torch.Generator().manual_seed(21)
+    G, N, T = 4, 37, 12
+    wide = _rand(gen, G, 20, N, T)
+    a, b = wide[:, 2:9], wide[:, 11:20]                   # 7 and 9 channels, strided in the group axis
+    c = _rand(gen, G, 5, N, T)
+    M = _rand(gen, 2, 30, 21, scale=0.2)                   # R = 2 relations, 21 -> 30 channels
+    bias = _rand(gen, 30)
+    adds = [_rand(gen, G, 8, N, T), _rand(gen, G, 22, N, T)]
+    leaves = _leaf(wide, c, M, bias, *adds)
+    w_, c_, M_, b_, *ad_ = leaves
+    outs = ops.mix_multi([w_[:, 2:9], w_[:, 11:20], c_], M_, b_, adds=ad_, out_channels=[4, 16, 10])
+    douts = [_rand(gen, *o.shape) for o in outs]
+    g_mine = torch.autograd.grad(outs, leaves, douts)
+
+    ref = _leaf64(wide, c, M, bias, *adds)
+    w64, c64, M64, b64, *ad64 = ref
+    x = torch.cat([w64[:, 2:9], w64[:, 11:20], c64], dim=1)
+    o = torch.einsum("roc,rgcnt->rgont", M64, x.view(2, 2, 21, N, T)).reshape(G, 30, N, T) + b64.view(1, 30, 1, 1)
+    o = o + torch.cat(ad64, dim=1)
+    o_split = torch.split(o, [4, 16, 10], dim=1)
+    for mine, want in zip(outs, o_split):
+        assert rel_err(mine.double(), want) < TOL
+    g_ref = torch.autograd.grad(o_split, ref, [d.double() for d in douts])
+    _check(g_mine, g_ref, ["dwide", "dc", "dM", "dbias", "dadd0", "dadd1"])
+
+
+def test_mix_multi_six_segments_and_limits():
+    from ms_gat_amd import ops
+    gen = torch.Generator().manual_seed(22)
+    G, N, T = 2, 11, 12
+    ins = [_rand(gen, G, 3, N, T) for _ in range(6)]
+    M = _rand(gen, 1, 8, 18, scale=0.3)
+    (out,) = ops.mix_multi(ins, M)
+    want = torch.einsum("oc,gcnt->gont", M[0].double(), torch.cat(ins, 1).double())
+    assert rel_err(out.double(), want) < TOL
+    with pytest.raises(ValueError):
+        ops.mix_multi(ins + [ins[0]], torch.cat([M, M[:, :, :3]], dim=2))
+
+
+def test_attention_core_equals_the_graph_attention_on_projected_features():
+    """attention_core(u, q) on u = W x, q = alpha . x is GACN (msgat.py:25-28) with the projection applied first."""
+    import ms_gat_amd
+    from ms_gat_amd import ops
+    gen = torch.Generator().manual_seed(23)
+    B, C, Co, N, T = 3, 40, 8, 61, 12
+    adj = ms_gat_amd.synthetic_adjacency(N, 80, seed=3)
+    x, W, alpha, Wg = _rand(gen, B, C, N, T), _rand(gen, Co, C, scale=0.2), _rand(gen, C, scale=0.2), _rand(gen, T, T, scale=0.3)
+    dz = _rand(gen, B, Co, N, T)
+    xa, Wa, aa, ga = _leaf(x, W, alpha, Wg)
+    u = torch.einsum("oc,bcnt->bont", Wa, xa)
+    q = torch.einsum("c,bcnt->bnt", aa, xa)
+    z = ops.attention_core(u, q, ga.unsqueeze(0), adj.to(_dev()))
+    g_mine = torch.autograd.grad(z, [xa, Wa, aa, ga], dz)
+    xb, Wb, ab, gb = _leaf(x, W, alpha, Wg)
+    z2 = ops.gacn(xb, ab.unsqueeze(0), gb.unsqueeze(0), Wb.unsqueeze(0), adj.to(_dev()))
+    g_ref = torch.autograd.grad(z2, [xb, Wb, ab, gb], dz)
+    assert rel_err(z, z2) < TOL
+    _check(g_mine, [g.double() for g in g_ref], ["dx", "dW", "dalpha", "dWg"])
