@@ -229,6 +229,15 @@ def test_mix_multi_six_segments_and_limits():
     assert rel_err(out.double(), want) < TOL
     with pytest.raises(ValueError):
         ops.mix_multi(ins + [ins[0]], torch.cat([M, M[:, :, :3]], dim=2))
+    # few output channels: the VALU kernel's segmented form, two outputs, with its backward
+    M4 = _rand(gen, 1, 4, 18, scale=0.3).requires_grad_(True)
+    o1, o2 = ops.mix_multi(ins, M4, out_channels=[1, 3])
+    want = torch.einsum("oc,gcnt->gont", M4[0].detach().double(), torch.cat(ins, 1).double())
+    assert rel_err(torch.cat([o1, o2], 1).double(), want) < TOL
+    d1, d2 = _rand(gen, *o1.shape), _rand(gen, *o2.shape)
+    (dM,) = torch.autograd.grad([o1, o2], [M4], [d1, d2])
+    want_dM = torch.einsum("gont,gcnt->oc", torch.cat([d1, d2], 1).double(), torch.cat(ins, 1).double())
+    assert rel_err(dM[0].double(), want_dM) < TOL
 
 
 def test_attention_core_equals_the_graph_attention_on_projected_features():
