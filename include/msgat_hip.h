@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MSGAT_ABI_VERSION 1
+#define MSGAT_ABI_VERSION 2
 
 enum {
   MSGAT_OK = 0,
@@ -193,13 +193,19 @@ int msgat_stage_contract(const msgat_shape_t* shape, int32_t Ca, int32_t Cb, con
  * (identity), eps as torch's (1e-5 in the reference), biased variance.
  * Backward re-derives mean / rstd from x (nothing is saved but x): dx [rows,T], dweight / dbias [T]
  * (either may be NULL) summed in a fixed order through `partials`
- * (msgat_layernorm_partial_floats() floats).  T in {4, 8, 12, 16}. */
+ * (msgat_layernorm_partial_floats() floats).  T in {4, 8, 12, 16}.
+ *
+ * R ("relations") in this and the following entry points: the number of parameter sets evaluated in one
+ * launch.  The reference loops over its components (src/models/msgat.py:204), each with its own weights;
+ * here the components ride on the leading (batch) axis, relation-major -- rows / slabs / groups of relation r
+ * are contiguous and R divides their count -- and every parameter gets a leading [R] axis (weight [R,T],
+ * w [R,N], bias [R,Co], W [R,T_out,T,1,C]).  R = 1 is the single-module case. */
 int msgat_layernorm_forward(const float* x, const float* weight, const float* bias, float* y,
-                            int64_t rows, int32_t T, float eps, void* stream);
-size_t msgat_layernorm_partial_floats(int64_t rows, int32_t T);
+                            int64_t rows, int32_t T, float eps, int32_t R, void* stream);
+size_t msgat_layernorm_partial_floats(int64_t rows, int32_t T, int32_t R);
 int msgat_layernorm_backward(const float* x, const float* weight, const float* dy, float* dx,
                              float* dweight, float* dbias, float* partials, int64_t rows, int32_t T,
-                             float eps, void* stream);
+                             float eps, int32_t R, void* stream);
 
 /* ---- device: the temporal and channel branches of MEAM ----
  * Building blocks for TACN (src/models/msgat.py:57-80, TemporalAttention attention.py:58-66) and CACN
@@ -227,17 +233,18 @@ int msgat_stage_mix_epilogue(const msgat_shape_t* shape, int32_t Ci, int32_t Co,
                              int32_t m_in_major, const float* bias, int32_t bias_per_relation, const float* add,
                              int32_t relu, float* out, void* stream);
 int msgat_time_mix(const float* src, const float* A, int32_t a_per_group, const float* bias, float* dst,
-                   int32_t G, int32_t Co, int32_t K, int32_t N, int32_t T, int32_t backward, void* stream);
+                   int32_t G, int32_t Co, int32_t K, int32_t N, int32_t T, int32_t backward, int32_t R,
+                   void* stream);
 size_t msgat_time_mix_partial_floats(int32_t G, int32_t K, int32_t T);
 int msgat_time_mix_grad_matrix(const float* dout, const float* y, float* dA, float* partials, int32_t G,
                                int32_t Co, int32_t K, int32_t N, int32_t T, void* stream);
 int msgat_node_pool(const float* x, const float* w, float* pooled, int64_t slabs, int32_t N, int32_t T,
-                    void* stream);
+                    int32_t R, void* stream);
 int msgat_node_pool_grad_signal(const float* w, const float* dpooled, float* dx, int64_t slabs, int32_t N,
-                                int32_t T, void* stream);
+                                int32_t T, int32_t R, void* stream);
 size_t msgat_node_pool_partial_floats(int32_t G, int32_t C, int32_t N);
 int msgat_node_pool_grad_weight(const float* x, const float* dpooled, float* dw, float* partials, int32_t G,
-                                int32_t C, int32_t N, int32_t T, void* stream);
+                                int32_t C, int32_t N, int32_t T, int32_t R, void* stream);
 
 /* ---- device: channel axes assembled from several tensors ("segments") ----
  * A segment is `channels` channels of a [G, group_stride, N, T] tensor starting at `ptr` (group_stride = 0
@@ -278,16 +285,16 @@ int msgat_attention_backward(const msgat_shape_t* shape, const msgat_graph_t* gr
  * TPC's Conv2d(T_in -> T_out, kernel [1, C]) over the transposed activation (src/models/msgat.py:153,
  * applied :158-159):  out[b,n,o] = bias[o] + sum_c sum_t W[o,t,0,c] x[b,c,n,t].
  * x [B,C,N,T]; W in the convolution's own layout [T_out,T,1,C]; out [B,N,T_out] (what the reference has after
- * its squeeze + transpose); T_out <= 16.  Backward: dx [B,C,N,T]; dWc [C,T_out,T] (the caller permutes to
+ * its squeeze + transpose); T_out <= 16.  Backward: dx [B,C,N,T]; dWc [R,C,T_out,T] (the caller permutes to
  * the convolution layout); partial buffers sized by the *_partial_floats queries. */
 size_t msgat_head_forward_partial_floats(int32_t B, int32_t C, int32_t N, int32_t T_out);
 int msgat_head_forward(const float* x, const float* W, const float* bias, float* out, float* partials,
-                       int32_t B, int32_t C, int32_t N, int32_t T, int32_t T_out, void* stream);
+                       int32_t B, int32_t C, int32_t N, int32_t T, int32_t T_out, int32_t R, void* stream);
 int msgat_head_grad_signal(const float* dout, const float* W, float* dx, int32_t B, int32_t C, int32_t N,
-                           int32_t T, int32_t T_out, void* stream);
-size_t msgat_head_grad_weight_partial_floats(int32_t C, int32_t T, int32_t T_out);
+                           int32_t T, int32_t T_out, int32_t R, void* stream);
+size_t msgat_head_grad_weight_partial_floats(int32_t C, int32_t T, int32_t T_out, int32_t R);
 int msgat_head_grad_weight(const float* dout, const float* x, float* dWc, float* partials, int32_t B, int32_t C,
-                           int32_t N, int32_t T, int32_t T_out, void* stream);
+                           int32_t N, int32_t T, int32_t T_out, int32_t R, void* stream);
 
 #ifdef __cplusplus
 }

@@ -68,14 +68,14 @@ _PROTOTYPES = {
                                        C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "msgat_stage_mix_epilogue": (C.c_int, [C.POINTER(Shape), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                            C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
-    "msgat_time_mix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 6
+    "msgat_time_mix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 7
                        + [C.c_void_p]),
     "msgat_time_mix_partial_floats": (C.c_size_t, [C.c_int32] * 3),
     "msgat_time_mix_grad_matrix": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 5 + [C.c_void_p]),
-    "msgat_node_pool": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
-    "msgat_node_pool_grad_signal": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "msgat_node_pool": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "msgat_node_pool_grad_signal": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "msgat_node_pool_partial_floats": (C.c_size_t, [C.c_int32] * 3),
-    "msgat_node_pool_grad_weight": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]),
+    "msgat_node_pool_grad_weight": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 5 + [C.c_void_p]),
     "msgat_mix_segments": (C.c_int, [C.c_int32] * 4 + [C.POINTER(Seg), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                      C.POINTER(Seg), C.c_int32, C.c_int32, C.POINTER(Seg), C.c_int32, C.c_void_p]),
     "msgat_contract_segments_partial_floats": (C.c_size_t, [C.c_int32] * 3),
@@ -84,13 +84,13 @@ _PROTOTYPES = {
     "msgat_attention_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Shape), C.c_int32]),
     "msgat_attention_backward": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)] + [C.c_void_p] * 12 + [C.c_size_t, C.c_void_p]),
     "msgat_head_forward_partial_floats": (C.c_size_t, [C.c_int32] * 4),
-    "msgat_head_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_void_p]),
-    "msgat_head_grad_signal": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 5 + [C.c_void_p]),
-    "msgat_head_grad_weight_partial_floats": (C.c_size_t, [C.c_int32] * 3),
-    "msgat_head_grad_weight": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 5 + [C.c_void_p]),
-    "msgat_layernorm_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
-    "msgat_layernorm_partial_floats": (C.c_size_t, [C.c_int64, C.c_int32]),
-    "msgat_layernorm_backward": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
+    "msgat_head_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p]),
+    "msgat_head_grad_signal": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 6 + [C.c_void_p]),
+    "msgat_head_grad_weight_partial_floats": (C.c_size_t, [C.c_int32] * 4),
+    "msgat_head_grad_weight": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 6 + [C.c_void_p]),
+    "msgat_layernorm_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
+    "msgat_layernorm_partial_floats": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "msgat_layernorm_backward": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
 }
 
 _lock = threading.Lock()
@@ -116,7 +116,7 @@ def lib() -> C.CDLL:
             for name, (res, args) in _PROTOTYPES.items():
                 fn = getattr(h, name)  # AttributeError here = header/library mismatch
                 fn.restype, fn.argtypes = res, args
-            if h.msgat_abi_version() != 1:
+            if h.msgat_abi_version() != 2:
                 raise MsgatError("libmsgat_hip.so ABI version mismatch; rebuild")
             _handle = h
     return _handle

@@ -198,11 +198,12 @@ static int check_rows(int32_t G, int32_t Co, int32_t K, int32_t N, int32_t T) {
 
 extern "C" int msgat_time_mix(const float* src, const float* A, int32_t a_per_group, const float* bias,
                               float* dst, int32_t G, int32_t Co, int32_t K, int32_t N, int32_t T,
-                              int32_t backward, void* stream) {
+                              int32_t backward, int32_t R, void* stream) {
   if (!src || !A || !dst) return MSGAT_ERR_NULL;
   int st = check_rows(G, Co, K, N, T);
   if (st) return st;
-  return launch_tmix(src, A, a_per_group, backward ? nullptr : bias, dst, G, Co, K, N, T, backward,
+  if (R <= 0 || G % R) return MSGAT_ERR_SHAPE;
+  return launch_tmix(src, A, a_per_group, backward ? nullptr : bias, dst, G, Co, K, N, T, backward, R,
                      (hipStream_t)stream);
 }
 
@@ -220,19 +221,19 @@ extern "C" int msgat_time_mix_grad_matrix(const float* dout, const float* y, flo
 }
 
 extern "C" int msgat_node_pool(const float* x, const float* w, float* pooled, int64_t slabs, int32_t N, int32_t T,
-                               void* stream) {
+                               int32_t R, void* stream) {
   if (!x || !w || !pooled) return MSGAT_ERR_NULL;
-  if (slabs <= 0 || slabs > 0x7fffffff || N <= 0) return MSGAT_ERR_SHAPE;
+  if (slabs <= 0 || slabs > 0x7fffffff || N <= 0 || R <= 0 || slabs % R) return MSGAT_ERR_SHAPE;
   if (!t_supported(T)) return MSGAT_ERR_UNSUPPORTED;
-  return launch_node_pool(x, w, pooled, slabs, N, T, (hipStream_t)stream);
+  return launch_node_pool(x, w, pooled, slabs, N, T, R, (hipStream_t)stream);
 }
 
 extern "C" int msgat_node_pool_grad_signal(const float* w, const float* dpooled, float* dx, int64_t slabs,
-                                           int32_t N, int32_t T, void* stream) {
+                                           int32_t N, int32_t T, int32_t R, void* stream) {
   if (!w || !dpooled || !dx) return MSGAT_ERR_NULL;
-  if (slabs <= 0 || slabs > 0x7fffffff || N <= 0) return MSGAT_ERR_SHAPE;
+  if (slabs <= 0 || slabs > 0x7fffffff || N <= 0 || R <= 0 || slabs % R) return MSGAT_ERR_SHAPE;
   if (!t_supported(T)) return MSGAT_ERR_UNSUPPORTED;
-  return launch_node_pool_dx(w, dpooled, dx, slabs, N, T, (hipStream_t)stream);
+  return launch_node_pool_dx(w, dpooled, dx, slabs, N, T, R, (hipStream_t)stream);
 }
 
 extern "C" size_t msgat_node_pool_partial_floats(int32_t G, int32_t C, int32_t N) {
@@ -241,11 +242,11 @@ extern "C" size_t msgat_node_pool_partial_floats(int32_t G, int32_t C, int32_t N
 }
 
 extern "C" int msgat_node_pool_grad_weight(const float* x, const float* dpooled, float* dw, float* partials,
-                                           int32_t G, int32_t C, int32_t N, int32_t T, void* stream) {
+                                           int32_t G, int32_t C, int32_t N, int32_t T, int32_t R, void* stream) {
   if (!x || !dpooled || !dw || !partials) return MSGAT_ERR_NULL;
-  if (G <= 0 || G > 65535 || C <= 0 || N <= 0) return MSGAT_ERR_SHAPE;
+  if (G <= 0 || G > 65535 || C <= 0 || N <= 0 || R <= 0 || G % R) return MSGAT_ERR_SHAPE;
   if (!t_supported(T)) return MSGAT_ERR_UNSUPPORTED;
-  return launch_node_pool_dw(x, dpooled, dw, partials, G, C, N, T, (hipStream_t)stream);
+  return launch_node_pool_dw(x, dpooled, dw, partials, G, C, N, T, R, (hipStream_t)stream);
 }
 
 // ---- segment lists ----------------------------------------------------------------------------------------
@@ -375,56 +376,59 @@ extern "C" size_t msgat_head_forward_partial_floats(int32_t B, int32_t C, int32_
 }
 
 extern "C" int msgat_head_forward(const float* x, const float* W, const float* bias, float* out, float* partials,
-                                  int32_t B, int32_t C, int32_t N, int32_t T, int32_t To, void* stream) {
+                                  int32_t B, int32_t C, int32_t N, int32_t T, int32_t To, int32_t R, void* stream) {
   if (!x || !W || !out || !partials) return MSGAT_ERR_NULL;
   int st = check_head(B, C, N, T, To);
   if (st) return st;
-  return launch_head_fwd(x, W, bias, out, partials, B, C, N, T, To, (hipStream_t)stream);
+  if (R <= 0 || B % R) return MSGAT_ERR_SHAPE;
+  return launch_head_fwd(x, W, bias, out, partials, B, C, N, T, To, R, (hipStream_t)stream);
 }
 
 extern "C" int msgat_head_grad_signal(const float* dout, const float* W, float* dx, int32_t B, int32_t C, int32_t N,
-                                      int32_t T, int32_t To, void* stream) {
+                                      int32_t T, int32_t To, int32_t R, void* stream) {
   if (!dout || !W || !dx) return MSGAT_ERR_NULL;
   int st = check_head(B, C, N, T, To);
   if (st) return st;
-  return launch_head_dx(dout, W, dx, B, C, N, T, To, (hipStream_t)stream);
+  if (R <= 0 || B % R) return MSGAT_ERR_SHAPE;
+  return launch_head_dx(dout, W, dx, B, C, N, T, To, R, (hipStream_t)stream);
 }
 
-extern "C" size_t msgat_head_grad_weight_partial_floats(int32_t C, int32_t T, int32_t To) {
-  if (C <= 0 || To <= 0 || !t_supported(T)) return 0;
-  return head_dw_partial_floats(C, T, To);
+extern "C" size_t msgat_head_grad_weight_partial_floats(int32_t C, int32_t T, int32_t To, int32_t R) {
+  if (C <= 0 || To <= 0 || R <= 0 || !t_supported(T)) return 0;
+  return head_dw_partial_floats(C, T, To, R);
 }
 
 extern "C" int msgat_head_grad_weight(const float* dout, const float* x, float* dWc, float* partials, int32_t B,
-                                      int32_t C, int32_t N, int32_t T, int32_t To, void* stream) {
+                                      int32_t C, int32_t N, int32_t T, int32_t To, int32_t R, void* stream) {
   if (!dout || !x || !dWc || !partials) return MSGAT_ERR_NULL;
   int st = check_head(B, C, N, T, To);
   if (st) return st;
-  return launch_head_dW(dout, x, dWc, partials, B, C, N, T, To, (hipStream_t)stream);
+  if (R <= 0 || B % R) return MSGAT_ERR_SHAPE;
+  return launch_head_dW(dout, x, dWc, partials, B, C, N, T, To, R, (hipStream_t)stream);
 }
 
 // ---- LayerNorm over T (the producer of the GACN inputs) ----------------------------------------------
 extern "C" int msgat_layernorm_forward(const float* x, const float* weight, const float* bias, float* y,
-                                       int64_t rows, int32_t T, float eps, void* stream) {
+                                       int64_t rows, int32_t T, float eps, int32_t R, void* stream) {
   if (!x || !y) return MSGAT_ERR_NULL;
-  if (rows < 0 || !(eps >= 0.f)) return MSGAT_ERR_SHAPE;
+  if (rows < 0 || !(eps >= 0.f) || R <= 0 || R > 65535 || rows % R) return MSGAT_ERR_SHAPE;
   if (!t_supported(T)) return MSGAT_ERR_UNSUPPORTED;
   if (rows == 0) return MSGAT_OK;
-  return launch_layernorm_fwd(x, weight, bias, y, rows, T, eps, (hipStream_t)stream);
+  return launch_layernorm_fwd(x, weight, bias, y, rows, T, eps, R, (hipStream_t)stream);
 }
 
-extern "C" size_t msgat_layernorm_partial_floats(int64_t rows, int32_t T) {
-  if (rows <= 0 || !t_supported(T)) return 0;
-  return layernorm_partial_floats(rows, T);
+extern "C" size_t msgat_layernorm_partial_floats(int64_t rows, int32_t T, int32_t R) {
+  if (rows <= 0 || R <= 0 || rows % R || !t_supported(T)) return 0;
+  return layernorm_partial_floats(rows, T, R);
 }
 
 extern "C" int msgat_layernorm_backward(const float* x, const float* weight, const float* dy, float* dx,
                                         float* dweight, float* dbias, float* partials, int64_t rows,
-                                        int32_t T, float eps, void* stream) {
+                                        int32_t T, float eps, int32_t R, void* stream) {
   if (!x || !dy || !dx || !partials) return MSGAT_ERR_NULL;
-  if (rows <= 0 || !(eps >= 0.f)) return MSGAT_ERR_SHAPE;
+  if (rows <= 0 || !(eps >= 0.f) || R <= 0 || R > 65535 || rows % R) return MSGAT_ERR_SHAPE;
   if (!t_supported(T)) return MSGAT_ERR_UNSUPPORTED;
-  return launch_layernorm_bwd(x, weight, dy, dx, dweight, dbias, partials, rows, T, eps, (hipStream_t)stream);
+  return launch_layernorm_bwd(x, weight, dy, dx, dweight, dbias, partials, rows, T, eps, R, (hipStream_t)stream);
 }
 
 // ---- fused forward ---------------------------------------------------------------------------------

@@ -43,7 +43,7 @@ __device__ __forceinline__ void st_row(float* __restrict__ p, const float (&v)[T
 // The matrices sit in LDS, transposed for the backward form so that both read rows as float4 broadcasts.
 template <int T, int K, bool BWD>
 __global__ __launch_bounds__(kBlock) void k_tmix(const float* __restrict__ src, const float* __restrict__ A,
-                                                 int a_gstride, const float* __restrict__ bias,
+                                                 int a_gstride, const float* __restrict__ bias, int Bg,
                                                  float* __restrict__ dst, int Co, int N) {
   __shared__ float Al[K][T][T];
   const int g = blockIdx.y;
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(kBlock) void k_tmix(const float* __restrict__ src, 
   const int o = rr / N;
   if (!BWD) {
     float acc[T];
-    const float b = bias ? bias[o] : 0.f;
+    const float b = bias ? bias[(g / Bg) * Co + o] : 0.f;  // bias [R,Co], Bg groups per relation
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = b;
 #pragma unroll
@@ -90,30 +90,31 @@ __global__ __launch_bounds__(kBlock) void k_tmix(const float* __restrict__ src, 
 
 template <int T, int K>
 static int launch_tmix_tk(const float* src, const float* A, int per_group, const float* bias, float* dst, int G,
-                          int Co, int N, int backward, hipStream_t s) {
+                          int Co, int N, int backward, int Bg, hipStream_t s) {
   dim3 grid(cdiv(Co * N, kBlock), G);
   const int gs = per_group ? K * T * T : 0;
-  if (backward) hipLaunchKernelGGL((k_tmix<T, K, true>), grid, dim3(kBlock), 0, s, src, A, gs, bias, dst, Co, N);
-  else hipLaunchKernelGGL((k_tmix<T, K, false>), grid, dim3(kBlock), 0, s, src, A, gs, bias, dst, Co, N);
+  if (backward) hipLaunchKernelGGL((k_tmix<T, K, true>), grid, dim3(kBlock), 0, s, src, A, gs, bias, Bg, dst, Co, N);
+  else hipLaunchKernelGGL((k_tmix<T, K, false>), grid, dim3(kBlock), 0, s, src, A, gs, bias, Bg, dst, Co, N);
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
 
 template <int T>
 static int launch_tmix_t(const float* src, const float* A, int per_group, const float* bias, float* dst, int G,
-                         int Co, int K, int N, int backward, hipStream_t s) {
-  if (K == 1) return launch_tmix_tk<T, 1>(src, A, per_group, bias, dst, G, Co, N, backward, s);
-  if (K == 2) return launch_tmix_tk<T, 2>(src, A, per_group, bias, dst, G, Co, N, backward, s);
+                         int Co, int K, int N, int backward, int Bg, hipStream_t s) {
+  if (K == 1) return launch_tmix_tk<T, 1>(src, A, per_group, bias, dst, G, Co, N, backward, Bg, s);
+  if (K == 2) return launch_tmix_tk<T, 2>(src, A, per_group, bias, dst, G, Co, N, backward, Bg, s);
   return MSGAT_ERR_UNSUPPORTED;
 }
 
 int launch_tmix(const float* src, const float* A, int per_group, const float* bias, float* dst, int G, int Co,
-                int K, int N, int T, int backward, hipStream_t s) {
+                int K, int N, int T, int backward, int R, hipStream_t s) {
+  const int Bg = G / R;
   switch (T) {
-    case 4: return launch_tmix_t<4>(src, A, per_group, bias, dst, G, Co, K, N, backward, s);
-    case 8: return launch_tmix_t<8>(src, A, per_group, bias, dst, G, Co, K, N, backward, s);
-    case 12: return launch_tmix_t<12>(src, A, per_group, bias, dst, G, Co, K, N, backward, s);
-    case 16: return launch_tmix_t<16>(src, A, per_group, bias, dst, G, Co, K, N, backward, s);
+    case 4: return launch_tmix_t<4>(src, A, per_group, bias, dst, G, Co, K, N, backward, Bg, s);
+    case 8: return launch_tmix_t<8>(src, A, per_group, bias, dst, G, Co, K, N, backward, Bg, s);
+    case 12: return launch_tmix_t<12>(src, A, per_group, bias, dst, G, Co, K, N, backward, Bg, s);
+    case 16: return launch_tmix_t<16>(src, A, per_group, bias, dst, G, Co, K, N, backward, Bg, s);
   }
   return MSGAT_ERR_UNSUPPORTED;
 }
@@ -184,9 +185,10 @@ int launch_tmix_dA(const float* dout, const float* y, float* dA, float* part, in
 // pooled[s,t] = sum_n w[n] x[s,n,t] for every (sample, channel) slab s (attention.py:89).
 template <int T>
 __global__ __launch_bounds__(kBlock) void k_node_pool(const float* __restrict__ x, const float* __restrict__ w,
-                                                      float* __restrict__ pooled, int N) {
+                                                      float* __restrict__ pooled, int N, int spr) {
   __shared__ float red[kBlock / kWave][T];
   const size_t sl = blockIdx.x;
+  w += (size_t)(blockIdx.x / spr) * N;  // weights [R,N]: spr slabs per relation
   float acc[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) acc[t] = 0.f;
@@ -214,8 +216,9 @@ __global__ __launch_bounds__(kBlock) void k_node_pool(const float* __restrict__ 
 // dx[s,n,t] = w[n] dpooled[s,t]
 template <int T>
 __global__ __launch_bounds__(kBlock) void k_node_pool_dx(const float* __restrict__ w, const float* __restrict__ dp,
-                                                         float* __restrict__ dx, int N) {
+                                                         float* __restrict__ dx, int N, int spr) {
   const size_t sl = blockIdx.x;
+  w += (size_t)(blockIdx.x / spr) * N;
   const int n = blockIdx.y * kBlock + threadIdx.x;
   if (n >= N) return;
   float v[T];
@@ -248,26 +251,30 @@ __global__ __launch_bounds__(kBlock) void k_node_pool_dw(const float* __restrict
   part[((size_t)g * gridDim.y + ck) * N + n] = acc;
 }
 
-int launch_node_pool(const float* x, const float* w, float* pooled, long long slabs, int N, int T, hipStream_t s) {
+int launch_node_pool(const float* x, const float* w, float* pooled, long long slabs, int N, int T, int R,
+                     hipStream_t s) {
   dim3 grid((unsigned)slabs);
+  const int spr = (int)(slabs / R);
   switch (T) {
-    case 4: hipLaunchKernelGGL(k_node_pool<4>, grid, dim3(kBlock), 0, s, x, w, pooled, N); break;
-    case 8: hipLaunchKernelGGL(k_node_pool<8>, grid, dim3(kBlock), 0, s, x, w, pooled, N); break;
-    case 12: hipLaunchKernelGGL(k_node_pool<12>, grid, dim3(kBlock), 0, s, x, w, pooled, N); break;
-    case 16: hipLaunchKernelGGL(k_node_pool<16>, grid, dim3(kBlock), 0, s, x, w, pooled, N); break;
+    case 4: hipLaunchKernelGGL(k_node_pool<4>, grid, dim3(kBlock), 0, s, x, w, pooled, N, spr); break;
+    case 8: hipLaunchKernelGGL(k_node_pool<8>, grid, dim3(kBlock), 0, s, x, w, pooled, N, spr); break;
+    case 12: hipLaunchKernelGGL(k_node_pool<12>, grid, dim3(kBlock), 0, s, x, w, pooled, N, spr); break;
+    case 16: hipLaunchKernelGGL(k_node_pool<16>, grid, dim3(kBlock), 0, s, x, w, pooled, N, spr); break;
     default: return MSGAT_ERR_UNSUPPORTED;
   }
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
 
-int launch_node_pool_dx(const float* w, const float* dp, float* dx, long long slabs, int N, int T, hipStream_t s) {
+int launch_node_pool_dx(const float* w, const float* dp, float* dx, long long slabs, int N, int T, int R,
+                        hipStream_t s) {
   dim3 grid((unsigned)slabs, cdiv(N, kBlock));
+  const int spr = (int)(slabs / R);
   switch (T) {
-    case 4: hipLaunchKernelGGL(k_node_pool_dx<4>, grid, dim3(kBlock), 0, s, w, dp, dx, N); break;
-    case 8: hipLaunchKernelGGL(k_node_pool_dx<8>, grid, dim3(kBlock), 0, s, w, dp, dx, N); break;
-    case 12: hipLaunchKernelGGL(k_node_pool_dx<12>, grid, dim3(kBlock), 0, s, w, dp, dx, N); break;
-    case 16: hipLaunchKernelGGL(k_node_pool_dx<16>, grid, dim3(kBlock), 0, s, w, dp, dx, N); break;
+    case 4: hipLaunchKernelGGL(k_node_pool_dx<4>, grid, dim3(kBlock), 0, s, w, dp, dx, N, spr); break;
+    case 8: hipLaunchKernelGGL(k_node_pool_dx<8>, grid, dim3(kBlock), 0, s, w, dp, dx, N, spr); break;
+    case 12: hipLaunchKernelGGL(k_node_pool_dx<12>, grid, dim3(kBlock), 0, s, w, dp, dx, N, spr); break;
+    case 16: hipLaunchKernelGGL(k_node_pool_dx<16>, grid, dim3(kBlock), 0, s, w, dp, dx, N, spr); break;
     default: return MSGAT_ERR_UNSUPPORTED;
   }
   MSGAT_CHECK_LAUNCH();
@@ -276,7 +283,7 @@ int launch_node_pool_dx(const float* w, const float* dp, float* dx, long long sl
 
 size_t node_pool_partial_floats(int G, int C, int N) { return (size_t)G * cdiv(C, kPoolCC) * N; }
 
-int launch_node_pool_dw(const float* x, const float* dp, float* dw, float* part, int G, int C, int N, int T,
+int launch_node_pool_dw(const float* x, const float* dp, float* dw, float* part, int G, int C, int N, int T, int R,
                         hipStream_t s) {
   const int nck = cdiv(C, kPoolCC);
   dim3 grid(cdiv(N, kBlock), nck, G);
@@ -288,7 +295,7 @@ int launch_node_pool_dw(const float* x, const float* dp, float* dw, float* part,
     default: return MSGAT_ERR_UNSUPPORTED;
   }
   MSGAT_CHECK_LAUNCH();
-  return launch_reduce_rows(part, G * nck, N, dw, N, nullptr, 0, s);
+  return launch_reduce_groups(part, R, (G / R) * nck, N, dw, s);  // dw [R,N]: the groups of a relation are contiguous
 }
 
 // ---- prediction head -----------------------------------------------------------------------------------
@@ -303,9 +310,11 @@ constexpr int kHeadTo = 16;  // T_out <= 16
 template <int T>
 __global__ __launch_bounds__(kBlock) void k_head_fwd(const float* __restrict__ x, const float* __restrict__ W,
                                                      const float* __restrict__ bias, float* __restrict__ part,
-                                                     int C, int N, int To) {
+                                                     int C, int N, int To, int Bg) {
   __shared__ float Wl[kHeadCC][kHeadTo][T];
   const int b = blockIdx.z, ck = blockIdx.y;
+  W += (size_t)(b / Bg) * To * T * C;   // weights [R,To,T,1,C], bias [R,To]: Bg samples per relation
+  if (bias != nullptr) bias += (size_t)(b / Bg) * To;
   const int c0 = ck * kHeadCC, cn = min(kHeadCC, C - c0);
   for (int i = threadIdx.x; i < kHeadCC * kHeadTo * T; i += kBlock) {
     const int c = i / (kHeadTo * T), o = (i / T) % kHeadTo, t = i % T;
@@ -332,9 +341,10 @@ __global__ __launch_bounds__(kBlock) void k_head_fwd(const float* __restrict__ x
 // dx[b,c,n,t] = sum_o W[o,t,c] dout[b,n,o]
 template <int T>
 __global__ __launch_bounds__(kBlock) void k_head_dx(const float* __restrict__ dout, const float* __restrict__ W,
-                                                    float* __restrict__ dx, int C, int N, int To) {
+                                                    float* __restrict__ dx, int C, int N, int To, int Bg) {
   __shared__ float Wl[kHeadCC][T][kHeadTo];
   const int b = blockIdx.z, ck = blockIdx.y;
+  W += (size_t)(b / Bg) * To * T * C;
   const int c0 = ck * kHeadCC, cn = min(kHeadCC, C - c0);
   for (int i = threadIdx.x; i < kHeadCC * kHeadTo * T; i += kBlock) {
     const int c = i / (kHeadTo * T), t = (i / kHeadTo) % T, o = i % kHeadTo;
@@ -367,8 +377,8 @@ template <int T>
 __global__ __launch_bounds__(kBlock) void k_head_dW(const float* __restrict__ dout, const float* __restrict__ x,
                                                     float* __restrict__ part, int B, int C, int N, int To) {
   __shared__ float red[kBlock / kWave][kHeadTo * T];
-  const int c = blockIdx.y, j = blockIdx.x;
-  const int b0 = (int)((long long)B * j / gridDim.x), b1 = (int)((long long)B * (j + 1) / gridDim.x);
+  const int c = blockIdx.y, j = blockIdx.x, rel = blockIdx.z;   // B = samples per relation
+  const int b0 = rel * B + (int)((long long)B * j / gridDim.x), b1 = rel * B + (int)((long long)B * (j + 1) / gridDim.x);
   float acc[kHeadTo][T];
 #pragma unroll
   for (int o = 0; o < kHeadTo; ++o)
@@ -398,11 +408,11 @@ __global__ __launch_bounds__(kBlock) void k_head_dW(const float* __restrict__ do
     }
   __syncthreads();
   for (int i = threadIdx.x; i < To * T; i += kBlock)
-    part[(((size_t)c * gridDim.x + j) * To * T) + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    part[((((size_t)rel * gridDim.y + c) * gridDim.x + j) * To * T) + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
 
 size_t head_fwd_partial_floats(int B, int C, int N, int To) { return (size_t)B * cdiv(C, kHeadCC) * N * To; }
-size_t head_dw_partial_floats(int C, int T, int To) { return (size_t)C * kHeadChunks * To * T; }
+size_t head_dw_partial_floats(int C, int T, int To, int R) { return (size_t)R * C * kHeadChunks * To * T; }
 
 #define MSGAT_T_SWITCH(T, CALL)                 \
   switch (T) {                                  \
@@ -414,28 +424,31 @@ size_t head_dw_partial_floats(int C, int T, int To) { return (size_t)C * kHeadCh
   }
 
 int launch_head_fwd(const float* x, const float* W, const float* bias, float* out, float* part, int B, int C, int N,
-                    int T, int To, hipStream_t s) {
+                    int T, int To, int R, hipStream_t s) {
+  const int Bg = B / R;
   const int nck = cdiv(C, kHeadCC);
   dim3 grid(cdiv(N, kBlock), nck, B);
-  MSGAT_T_SWITCH(T, hipLaunchKernelGGL(k_head_fwd<TT>, grid, dim3(kBlock), 0, s, x, W, bias, part, C, N, To));
+  MSGAT_T_SWITCH(T, hipLaunchKernelGGL(k_head_fwd<TT>, grid, dim3(kBlock), 0, s, x, W, bias, part, C, N, To, Bg));
   MSGAT_CHECK_LAUNCH();
   return launch_reduce_groups(part, B, nck, N * To, out, s);
 }
 
-int launch_head_dx(const float* dout, const float* W, float* dx, int B, int C, int N, int T, int To, hipStream_t s) {
+int launch_head_dx(const float* dout, const float* W, float* dx, int B, int C, int N, int T, int To, int R,
+                   hipStream_t s) {
+  const int Bg = B / R;
   dim3 grid(cdiv(N, kBlock), cdiv(C, kHeadCC), B);
-  MSGAT_T_SWITCH(T, hipLaunchKernelGGL(k_head_dx<TT>, grid, dim3(kBlock), 0, s, dout, W, dx, C, N, To));
+  MSGAT_T_SWITCH(T, hipLaunchKernelGGL(k_head_dx<TT>, grid, dim3(kBlock), 0, s, dout, W, dx, C, N, To, Bg));
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
 
 // dWc[c][o][t] (the caller permutes to the convolution's [To][T][1][C] layout)
 int launch_head_dW(const float* dout, const float* x, float* dWc, float* part, int B, int C, int N, int T, int To,
-                   hipStream_t s) {
-  dim3 grid(kHeadChunks, C);
-  MSGAT_T_SWITCH(T, hipLaunchKernelGGL(k_head_dW<TT>, grid, dim3(kBlock), 0, s, dout, x, part, B, C, N, To));
+                   int R, hipStream_t s) {
+  dim3 grid(kHeadChunks, C, R);
+  MSGAT_T_SWITCH(T, hipLaunchKernelGGL(k_head_dW<TT>, grid, dim3(kBlock), 0, s, dout, x, part, B / R, C, N, To));
   MSGAT_CHECK_LAUNCH();
-  return launch_reduce_groups(part, C, kHeadChunks, To * T, dWc, s);
+  return launch_reduce_groups(part, R * C, kHeadChunks, To * T, dWc, s);   // dWc [R,C,To,T]
 }
 
 }  // namespace msgat

@@ -220,27 +220,32 @@ int launch_reduce_rows(const float* part, int J, int Wd, float* dst0, int n0, fl
 int launch_reduce_groups(const float* part, int R, int J, int Wd, float* dst, hipStream_t s);
 // temporal / channel branch kernels (branches.hip)
 int launch_tmix(const float* src, const float* A, int per_group, const float* bias, float* dst, int G, int Co,
-                int K, int N, int T, int backward, hipStream_t s);
+                int K, int N, int T, int backward, int R, hipStream_t s);
 size_t tmix_partial_floats(int G, int K, int T);
 int launch_tmix_dA(const float* dout, const float* y, float* dA, float* part, int G, int Co, int K, int N, int T,
                    hipStream_t s);
-int launch_node_pool(const float* x, const float* w, float* pooled, long long slabs, int N, int T, hipStream_t s);
-int launch_node_pool_dx(const float* w, const float* dp, float* dx, long long slabs, int N, int T, hipStream_t s);
+int launch_node_pool(const float* x, const float* w, float* pooled, long long slabs, int N, int T, int R,
+                     hipStream_t s);
+int launch_node_pool_dx(const float* w, const float* dp, float* dx, long long slabs, int N, int T, int R,
+                        hipStream_t s);
 size_t node_pool_partial_floats(int G, int C, int N);
-int launch_node_pool_dw(const float* x, const float* dp, float* dw, float* part, int G, int C, int N, int T,
+int launch_node_pool_dw(const float* x, const float* dp, float* dw, float* part, int G, int C, int N, int T, int R,
                         hipStream_t s);
 size_t head_fwd_partial_floats(int B, int C, int N, int To);
-size_t head_dw_partial_floats(int C, int T, int To);
+size_t head_dw_partial_floats(int C, int T, int To, int R);
 int launch_head_fwd(const float* x, const float* W, const float* bias, float* out, float* part, int B, int C, int N,
-                    int T, int To, hipStream_t s);
-int launch_head_dx(const float* dout, const float* W, float* dx, int B, int C, int N, int T, int To, hipStream_t s);
-int launch_head_dW(const float* dout, const float* x, float* dWc, float* part, int B, int C, int N, int T, int To,
+                    int T, int To, int R, hipStream_t s);
+int launch_head_dx(const float* dout, const float* W, float* dx, int B, int C, int N, int T, int To, int R,
                    hipStream_t s);
+int launch_head_dW(const float* dout, const float* x, float* dWc, float* part, int B, int C, int N, int T, int To,
+                   int R, hipStream_t s);
 // LayerNorm over the last axis of [rows, T] (layernorm.hip)
-size_t layernorm_partial_floats(long long rows, int T);
+size_t layernorm_partial_floats(long long rows, int T, int R);
+int launch_reduce_split(const float* part, int R, int J, int Wd, float* dst0, int n0, float* dst1, int n1,
+                        hipStream_t s);
 int launch_layernorm_fwd(const float* x, const float* w, const float* b, float* y, long long rows, int T,
-                         float eps, hipStream_t s);
+                         float eps, int R, hipStream_t s);
 int launch_layernorm_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
-                         float* part, long long rows, int T, float eps, hipStream_t s);
+                         float* part, long long rows, int T, float eps, int R, hipStream_t s);
 
 }  // namespace msgat

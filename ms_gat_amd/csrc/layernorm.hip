@@ -48,9 +48,12 @@ template <int T>
 __global__ __launch_bounds__(kBlock) void k_ln_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                    const float* __restrict__ b, float* __restrict__ y,
                                                    long long rows, float eps) {
+  // blockIdx.y = relation (parameter set): its `rows` rows are contiguous, its weight / bias are row y of [R,T]
+  x += (size_t)blockIdx.y * rows * T;
+  y += (size_t)blockIdx.y * rows * T;
   float wv[T], bv[T];
 #pragma unroll
-  for (int t = 0; t < T; ++t) { wv[t] = w ? w[t] : 1.f; bv[t] = b ? b[t] : 0.f; }
+  for (int t = 0; t < T; ++t) { wv[t] = w ? w[blockIdx.y * T + t] : 1.f; bv[t] = b ? b[blockIdx.y * T + t] : 0.f; }
   for (long long r = (long long)blockIdx.x * kBlock + threadIdx.x; r < rows; r += (long long)gridDim.x * kBlock) {
     float v[T];
     load_row<T>(x + r * T, v);
@@ -66,9 +69,12 @@ __global__ __launch_bounds__(kBlock) void k_ln_bwd(const float* __restrict__ x, 
                                                    const float* __restrict__ dy, float* __restrict__ dx,
                                                    float* __restrict__ part, long long rows, float eps) {
   __shared__ float red[kBlock / kWave][2 * T];
+  x += (size_t)blockIdx.y * rows * T;
+  dy += (size_t)blockIdx.y * rows * T;
+  dx += (size_t)blockIdx.y * rows * T;
   float wv[T], dw[T], db[T];
 #pragma unroll
-  for (int t = 0; t < T; ++t) { wv[t] = w ? w[t] : 1.f; dw[t] = 0.f; db[t] = 0.f; }
+  for (int t = 0; t < T; ++t) { wv[t] = w ? w[blockIdx.y * T + t] : 1.f; dw[t] = 0.f; db[t] = 0.f; }
   for (long long r = (long long)blockIdx.x * kBlock + threadIdx.x; r < rows; r += (long long)gridDim.x * kBlock) {
     float xv[T], gv[T];
     load_row<T>(x + r * T, xv);
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(kBlock) void k_ln_bwd(const float* __restrict__ x, 
   }
   __syncthreads();
   if (threadIdx.x < 2 * T)
-    part[(size_t)blockIdx.x * 2 * T + threadIdx.x] =
+    part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * T + threadIdx.x] =
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
@@ -110,16 +116,17 @@ static int ln_blocks(long long rows) {
   return (int)(need < 2048 ? (need < 1 ? 1 : need) : 2048);  // 8 blocks per CU, grid-stride beyond
 }
 
-size_t layernorm_partial_floats(long long rows, int T) { return (size_t)ln_blocks(rows) * 2 * T; }
+size_t layernorm_partial_floats(long long rows, int T, int R) { return (size_t)R * ln_blocks(rows / R) * 2 * T; }
 
 int launch_layernorm_fwd(const float* x, const float* w, const float* b, float* y, long long rows, int T,
-                         float eps, hipStream_t s) {
+                         float eps, int R, hipStream_t s) {
+  rows /= R;  // per relation
   const int nb = ln_blocks(rows);
   switch (T) {
-    case 4: hipLaunchKernelGGL(k_ln_fwd<4>, dim3(nb), dim3(kBlock), 0, s, x, w, b, y, rows, eps); break;
-    case 8: hipLaunchKernelGGL(k_ln_fwd<8>, dim3(nb), dim3(kBlock), 0, s, x, w, b, y, rows, eps); break;
-    case 12: hipLaunchKernelGGL(k_ln_fwd<12>, dim3(nb), dim3(kBlock), 0, s, x, w, b, y, rows, eps); break;
-    case 16: hipLaunchKernelGGL(k_ln_fwd<16>, dim3(nb), dim3(kBlock), 0, s, x, w, b, y, rows, eps); break;
+    case 4: hipLaunchKernelGGL(k_ln_fwd<4>, dim3(nb, R), dim3(kBlock), 0, s, x, w, b, y, rows, eps); break;
+    case 8: hipLaunchKernelGGL(k_ln_fwd<8>, dim3(nb, R), dim3(kBlock), 0, s, x, w, b, y, rows, eps); break;
+    case 12: hipLaunchKernelGGL(k_ln_fwd<12>, dim3(nb, R), dim3(kBlock), 0, s, x, w, b, y, rows, eps); break;
+    case 16: hipLaunchKernelGGL(k_ln_fwd<16>, dim3(nb, R), dim3(kBlock), 0, s, x, w, b, y, rows, eps); break;
     default: return MSGAT_ERR_UNSUPPORTED;
   }
   MSGAT_CHECK_LAUNCH();
@@ -127,17 +134,18 @@ int launch_layernorm_fwd(const float* x, const float* w, const float* b, float* 
 }
 
 int launch_layernorm_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
-                         float* part, long long rows, int T, float eps, hipStream_t s) {
+                         float* part, long long rows, int T, float eps, int R, hipStream_t s) {
+  rows /= R;  // per relation
   const int nb = ln_blocks(rows);
   switch (T) {
-    case 4: hipLaunchKernelGGL(k_ln_bwd<4>, dim3(nb), dim3(kBlock), 0, s, x, w, dy, dx, part, rows, eps); break;
-    case 8: hipLaunchKernelGGL(k_ln_bwd<8>, dim3(nb), dim3(kBlock), 0, s, x, w, dy, dx, part, rows, eps); break;
-    case 12: hipLaunchKernelGGL(k_ln_bwd<12>, dim3(nb), dim3(kBlock), 0, s, x, w, dy, dx, part, rows, eps); break;
-    case 16: hipLaunchKernelGGL(k_ln_bwd<16>, dim3(nb), dim3(kBlock), 0, s, x, w, dy, dx, part, rows, eps); break;
+    case 4: hipLaunchKernelGGL(k_ln_bwd<4>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, dx, part, rows, eps); break;
+    case 8: hipLaunchKernelGGL(k_ln_bwd<8>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, dx, part, rows, eps); break;
+    case 12: hipLaunchKernelGGL(k_ln_bwd<12>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, dx, part, rows, eps); break;
+    case 16: hipLaunchKernelGGL(k_ln_bwd<16>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, dx, part, rows, eps); break;
     default: return MSGAT_ERR_UNSUPPORTED;
   }
   MSGAT_CHECK_LAUNCH();
-  return launch_reduce_rows(part, nb, 2 * T, dw, T, db, T, s);
+  return launch_reduce_split(part, R, nb, 2 * T, dw, T, db, T, s);
 }
 
 }  // namespace msgat

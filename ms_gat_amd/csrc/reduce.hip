@@ -63,6 +63,11 @@ int launch_reduce_rows(const float* part, int J, int Wd, float* dst0, int n0, fl
   return launch_reduce_partials(part, 1, J, Wd, dst0, n0, dst1, n1, s);
 }
 
+int launch_reduce_split(const float* part, int R, int J, int Wd, float* dst0, int n0, float* dst1, int n1,
+                        hipStream_t s) {
+  return launch_reduce_partials(part, R, J, Wd, dst0, n0, dst1, n1, s);
+}
+
 int launch_reduce_groups(const float* part, int R, int J, int Wd, float* dst, hipStream_t s) {
   return launch_reduce_partials(part, R, J, Wd, dst, Wd, nullptr, 0, s);
 }

@@ -156,9 +156,10 @@ class _LayerNormTFunction(torch.autograd.Function):
         y = torch.empty_like(x)
         w = None if weight is None else weight.contiguous()
         b = None if bias is None else bias.contiguous()
-        st = L.msgat_layernorm_forward(_ptr(x), _ptr(w), _ptr(b), _ptr(y), rows, T, eps, _stream_handle(x.device))
+        R = 1 if w is None else w.numel() // T          # weight [T] or [R,T]: R parameter sets, relation-major rows
+        st = L.msgat_layernorm_forward(_ptr(x), _ptr(w), _ptr(b), _ptr(y), rows, T, eps, R, _stream_handle(x.device))
         _lib.check(st, "msgat_layernorm_forward")
-        ctx.eps, ctx.has_w, ctx.has_b = eps, weight is not None, bias is not None
+        ctx.eps, ctx.has_w, ctx.has_b, ctx.R = eps, weight is not None, bias is not None, R
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(*([x] + ([w] if w is not None else [])))
         return y
@@ -172,12 +173,13 @@ class _LayerNormTFunction(torch.autograd.Function):
         rows = x.numel() // T
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dw = torch.empty(T, device=x.device, dtype=torch.float32) if ctx.has_w else None
-        db = torch.empty(T, device=x.device, dtype=torch.float32) if ctx.has_b else None
-        part = torch.empty(max(int(L.msgat_layernorm_partial_floats(rows, T)), 1), device=x.device,
+        R = ctx.R
+        dw = torch.empty_like(w) if ctx.has_w else None
+        db = torch.empty(w.shape if ctx.has_w else (T,), device=x.device, dtype=torch.float32) if ctx.has_b else None
+        part = torch.empty(max(int(L.msgat_layernorm_partial_floats(rows, T, R)), 1), device=x.device,
                            dtype=torch.float32)
         st = L.msgat_layernorm_backward(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db), _ptr(part),
-                                        rows, T, ctx.eps, _stream_handle(x.device))
+                                        rows, T, ctx.eps, R, _stream_handle(x.device))
         _lib.check(st, "msgat_layernorm_backward")
         return dx, dw, db, None
 
@@ -191,8 +193,10 @@ def layer_norm_t(x: torch.Tensor, weight: Optional[torch.Tensor] = None, bias: O
     for name, t in (("weight", weight), ("bias", bias)):
         if t is not None:
             _require_device_tensor(name, t, x.device)
-            if tuple(t.shape) != (T,):
-                raise ValueError(f"{name} must be [{T}], got {tuple(t.shape)}")
+            if t.shape[-1] != T or t.dim() > 2 or (t.dim() == 2 and x.shape[0] % t.shape[0]):
+                raise ValueError(f"{name} must be [{T}] or [R,{T}] with R dividing the leading axis, got {tuple(t.shape)}")
+    if weight is not None and bias is not None and weight.shape != bias.shape:
+        raise ValueError("weight and bias must have the same shape")
     if x.numel() == 0:
         return torch.empty_like(x)
     return _LayerNormTFunction.apply(x, weight, bias, float(eps))
@@ -207,17 +211,20 @@ def _new(like: torch.Tensor, *shape) -> torch.Tensor:
 _ones_cache = {}
 
 
-def _channel_sums(t: torch.Tensor) -> torch.Tensor:
-    """[G,C,N,T] -> [C]: the bias gradient of a convolution.  One streaming pass (node pooling with unit
-    weights) instead of torch's strided reduction kernel (87 us vs 12 us at [32,24,883,12])."""
+def _channel_sums(t: torch.Tensor, R: int = 0) -> torch.Tensor:
+    """[G,C,N,T] -> [C] (or [R,C] per relation when R > 0): the bias gradient of a convolution.  One streaming
+    pass (node pooling with unit weights) instead of torch's strided reduction kernel (87 us vs 12 us at
+    [32,24,883,12])."""
     G, Cc, N, T = t.shape
     key = (t.device, N)
     ones = _ones_cache.get(key)
     if ones is None:
         ones = _ones_cache[key] = torch.ones(N, device=t.device, dtype=torch.float32)
     pooled = _new(t, G, Cc, T)
-    st = _lib.lib().msgat_node_pool(_ptr(t), _ptr(ones), _ptr(pooled), G * Cc, N, T, _stream_handle(t.device))
+    st = _lib.lib().msgat_node_pool(_ptr(t), _ptr(ones), _ptr(pooled), G * Cc, N, T, 1, _stream_handle(t.device))
     _lib.check(st, "msgat_node_pool")
+    if R > 0:
+        return pooled.view(R, G // R, Cc, T).sum(dim=(1, 3))
     return pooled.sum(dim=(0, 2))
 
 
@@ -297,10 +304,12 @@ class _TimeMixFunction(torch.autograd.Function):
         per_group = int(A.shape[0] != 1 or G == 1)
         out = _new(y, G, Co, N, T)
         b = None if bias is None else bias.contiguous()
-        st = L.msgat_time_mix(_ptr(y), _ptr(A), per_group, _ptr(b), _ptr(out), G, Co, K, N, T, 0,
+        Rb = 1 if b is None or b.dim() == 1 else b.shape[0]     # bias [Co] or [R,Co]
+        st = L.msgat_time_mix(_ptr(y), _ptr(A), per_group, _ptr(b), _ptr(out), G, Co, K, N, T, 0, Rb,
                               _stream_handle(y.device))
         _lib.check(st, "msgat_time_mix")
         ctx.dims, ctx.per_group, ctx.has_bias = (G, Co, K, N, T), per_group, bias is not None
+        ctx.bias_R = 0 if b is None or b.dim() == 1 else b.shape[0]
         ctx.save_for_backward(y, A)
         return out
 
@@ -315,7 +324,7 @@ class _TimeMixFunction(torch.autograd.Function):
         dy = dA = dbias = None
         if need[0]:
             dy = torch.empty_like(y)
-            st = L.msgat_time_mix(_ptr(dout), _ptr(A), ctx.per_group, None, _ptr(dy), G, Co, K, N, T, 1, stream)
+            st = L.msgat_time_mix(_ptr(dout), _ptr(A), ctx.per_group, None, _ptr(dy), G, Co, K, N, T, 1, 1, stream)
             _lib.check(st, "msgat_time_mix (backward)")
         if need[1]:
             dAg = _new(y, G, K, T, T)
@@ -324,7 +333,7 @@ class _TimeMixFunction(torch.autograd.Function):
             _lib.check(st, "msgat_time_mix_grad_matrix")
             dA = dAg if A.shape[0] == G else dAg.sum(dim=0, keepdim=True)
         if ctx.has_bias and need[2]:
-            dbias = _channel_sums(dout)
+            dbias = _channel_sums(dout, ctx.bias_R)
         return dy, dA, dbias
 
 
@@ -350,7 +359,8 @@ class _NodePoolFunction(torch.autograd.Function):
         x, w = x.contiguous(), w.contiguous()
         B, Cc, N, T = x.shape
         pooled = _new(x, B, Cc, T)
-        st = L.msgat_node_pool(_ptr(x), _ptr(w), _ptr(pooled), B * Cc, N, T, _stream_handle(x.device))
+        R = w.numel() // N                                   # weights [N] or [R,N]
+        st = L.msgat_node_pool(_ptr(x), _ptr(w), _ptr(pooled), B * Cc, N, T, R, _stream_handle(x.device))
         _lib.check(st, "msgat_node_pool")
         ctx.save_for_backward(x, w)
         return pooled
@@ -362,15 +372,16 @@ class _NodePoolFunction(torch.autograd.Function):
         B, Cc, N, T = x.shape
         dp = dp.contiguous()
         stream = _stream_handle(x.device)
+        R = w.numel() // N
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _lib.check(L.msgat_node_pool_grad_signal(_ptr(w), _ptr(dp), _ptr(dx), B * Cc, N, T, stream),
+            _lib.check(L.msgat_node_pool_grad_signal(_ptr(w), _ptr(dp), _ptr(dx), B * Cc, N, T, R, stream),
                        "msgat_node_pool_grad_signal")
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             part = _new(x, max(int(L.msgat_node_pool_partial_floats(B, Cc, N)), 1))
-            _lib.check(L.msgat_node_pool_grad_weight(_ptr(x), _ptr(dp), _ptr(dw), _ptr(part), B, Cc, N, T, stream),
+            _lib.check(L.msgat_node_pool_grad_weight(_ptr(x), _ptr(dp), _ptr(dw), _ptr(part), B, Cc, N, T, R, stream),
                        "msgat_node_pool_grad_weight")
         return dx, dw
 
@@ -378,7 +389,7 @@ class _NodePoolFunction(torch.autograd.Function):
 def node_pool(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     _require_device_tensor("signals", x)
     _require_device_tensor("weights", w, x.device)
-    if x.dim() != 4 or tuple(w.shape) != (x.shape[2],):
+    if x.dim() != 4 or w.shape[-1] != x.shape[2] or w.dim() > 2 or (w.dim() == 2 and x.shape[0] % w.shape[0]):
         raise ValueError(f"node_pool: signals {tuple(x.shape)}, weights {tuple(w.shape)}")
     return _NodePoolFunction.apply(x, w)
 
@@ -391,7 +402,8 @@ class _ChannelPoolFunction(torch.autograd.Function):
         L = _lib.lib()
         x, alpha = x.contiguous(), alpha.contiguous()
         B, Cc, N, T = x.shape
-        shape = _lib.Shape(1, B, Cc, 0, N, T)
+        R = alpha.numel() // Cc                              # alpha [C] or [R,C]
+        shape = _lib.Shape(R, B // R, Cc, 0, N, T)
         q = _new(x, B, N, T)
         st = L.msgat_stage_project(C.byref(shape), _ptr(x), _ptr(alpha), None, _ptr(q), None, _stream_handle(x.device))
         _lib.check(st, "msgat_stage_project")
@@ -405,15 +417,16 @@ class _ChannelPoolFunction(torch.autograd.Function):
         B, Cc, N, T = x.shape
         dq = dq.contiguous()
         stream = _stream_handle(x.device)
+        R = alpha.numel() // Cc
         dx = dalpha = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            shape = _lib.Shape(1, B, 1, Cc, N, T)
+            shape = _lib.Shape(R, B // R, 1, Cc, N, T)
             st = L.msgat_stage_mix(C.byref(shape), 1, Cc, _ptr(dq), _ptr(alpha), 0, None, None, _ptr(dx), stream)
             _lib.check(st, "msgat_stage_mix")
         if ctx.needs_input_grad[1]:
             dalpha = torch.empty_like(alpha)
-            shape = _lib.Shape(1, B, Cc, 0, N, T)
+            shape = _lib.Shape(R, B // R, Cc, 0, N, T)
             part = _new(x, max(int(L.msgat_contract_partial_floats(C.byref(shape), 1, Cc)), 1))
             st = L.msgat_stage_contract(C.byref(shape), 1, Cc, None, _ptr(dq), _ptr(x), _ptr(part), _ptr(dalpha), Cc,
                                         None, 0, stream)
@@ -424,7 +437,7 @@ class _ChannelPoolFunction(torch.autograd.Function):
 def channel_pool(x: torch.Tensor, alpha: torch.Tensor) -> torch.Tensor:
     _require_device_tensor("signals", x)
     _require_device_tensor("alpha", alpha, x.device)
-    if x.dim() != 4 or tuple(alpha.shape) != (x.shape[1],):
+    if x.dim() != 4 or alpha.shape[-1] != x.shape[1] or alpha.dim() > 2 or (alpha.dim() == 2 and x.shape[0] % alpha.shape[0]):
         raise ValueError(f"channel_pool: signals {tuple(x.shape)}, alpha {tuple(alpha.shape)}")
     return _ChannelPoolFunction.apply(x, alpha)
 
@@ -437,11 +450,12 @@ class _HeadFunction(torch.autograd.Function):
         L = _lib.lib()
         x, W = x.contiguous(), W.contiguous()
         B, Cc, N, T = x.shape
-        To = W.shape[0]
+        To = W.shape[-4]
+        R = 1 if W.dim() == 4 else W.shape[0]               # weight [To,T,1,C] or [R,To,T,1,C]
         out = _new(x, B, N, To)
         part = _new(x, max(int(L.msgat_head_forward_partial_floats(B, Cc, N, To)), 1))
         b = None if bias is None else bias.contiguous()
-        st = L.msgat_head_forward(_ptr(x), _ptr(W), _ptr(b), _ptr(out), _ptr(part), B, Cc, N, T, To,
+        st = L.msgat_head_forward(_ptr(x), _ptr(W), _ptr(b), _ptr(out), _ptr(part), B, Cc, N, T, To, R,
                                   _stream_handle(x.device))
         _lib.check(st, "msgat_head_forward")
         ctx.has_bias = bias is not None
@@ -453,22 +467,25 @@ class _HeadFunction(torch.autograd.Function):
         L = _lib.lib()
         x, W = ctx.saved_tensors
         B, Cc, N, T = x.shape
-        To = W.shape[0]
+        To = W.shape[-4]
+        R = 1 if W.dim() == 4 else W.shape[0]
         dout = dout.contiguous()
         stream = _stream_handle(x.device)
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _lib.check(L.msgat_head_grad_signal(_ptr(dout), _ptr(W), _ptr(dx), B, Cc, N, T, To, stream),
+            _lib.check(L.msgat_head_grad_signal(_ptr(dout), _ptr(W), _ptr(dx), B, Cc, N, T, To, R, stream),
                        "msgat_head_grad_signal")
         if ctx.needs_input_grad[1]:
-            dWc = _new(x, Cc, To, T)
-            part = _new(x, max(int(L.msgat_head_grad_weight_partial_floats(Cc, T, To)), 1))
-            _lib.check(L.msgat_head_grad_weight(_ptr(dout), _ptr(x), _ptr(dWc), _ptr(part), B, Cc, N, T, To, stream),
+            dWc = _new(x, R, Cc, To, T)
+            part = _new(x, max(int(L.msgat_head_grad_weight_partial_floats(Cc, T, To, R)), 1))
+            _lib.check(L.msgat_head_grad_weight(_ptr(dout), _ptr(x), _ptr(dWc), _ptr(part), B, Cc, N, T, To, R, stream),
                        "msgat_head_grad_weight")
-            dW = dWc.permute(1, 2, 0).unsqueeze(2)          # [To,T,1,C]
+            dW = dWc.permute(0, 2, 3, 1).unsqueeze(3)       # [R,To,T,1,C]
+            if W.dim() == 4:
+                dW = dW[0]
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dout.sum(dim=(0, 1))
+            db = dout.view(R, B // R, N, To).sum(dim=(1, 2)) if W.dim() == 5 else dout.sum(dim=(0, 1))
         return dx, dW, db
 
 
@@ -477,7 +494,8 @@ def head(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None) 
     with `fc = Conv2d(T, T_out, [1, C])`, as one pass over x."""
     _require_device_tensor("signals", x)
     _require_device_tensor("weight", W, x.device)
-    if x.dim() != 4 or W.dim() != 4 or W.shape[1] != x.shape[3] or W.shape[2] != 1 or W.shape[3] != x.shape[1]:
+    if (x.dim() != 4 or W.dim() not in (4, 5) or W.shape[-3] != x.shape[3] or W.shape[-2] != 1 or W.shape[-1] != x.shape[1]
+            or (W.dim() == 5 and x.shape[0] % W.shape[0])):
         raise ValueError(f"head: signals {tuple(x.shape)} and weight {tuple(W.shape)} do not match")
     return _HeadFunction.apply(x, W, bias)
 
@@ -520,11 +538,12 @@ class _MixMultiFunction(torch.autograd.Function):
         _kad, aad, _ = _seg_array(adds)
         _, aout, _ = _seg_array(outs)
         b = None if bias is None else bias.contiguous()
-        st = L.msgat_mix_segments(R, G // R, N, T, ain, n_in, _ptr(M), 0, _ptr(b), 0, aad, n_add, int(relu), aout,
+        per_rel = int(b is not None and b.dim() == 2)         # bias [Co] or [R,Co] (one row per matrix)
+        st = L.msgat_mix_segments(R, G // R, N, T, ain, n_in, _ptr(M), 0, _ptr(b), per_rel, aad, n_add, int(relu), aout,
                                   len(outs), _stream_handle(M.device))
         _lib.check(st, "msgat_mix_segments")
-        ctx.meta = (relu, n_in, tuple(out_channels), bias is not None, [t.shape[1] for t in ins],
-                    [t.shape[1] for t in adds])
+        ctx.meta = (relu, n_in, tuple(out_channels), (0 if bias is None else (R if per_rel else -1)),
+                    [t.shape[1] for t in ins], [t.shape[1] for t in adds])
         ctx.save_for_backward(M, *kin, *(outs if relu else []))
         return tuple(outs)
 
@@ -565,8 +584,8 @@ class _MixMultiFunction(torch.autograd.Function):
                 _lib.check(st, "msgat_contract_segments")
                 parts.append(dMi)
             dM = parts[0] if len(parts) == 1 else torch.cat(parts, dim=2)
-        if has_bias and need[1]:
-            dbias = torch.cat([_channel_sums(k.contiguous()) for k in kd])
+        if has_bias and need[1]:   # has_bias: 0 none, -1 shared [Co], R per matrix [R,Co]
+            dbias = torch.cat([_channel_sums(k.contiguous(), max(has_bias, 0)) for k in kd], dim=-1)
         d_adds = []
         if add_channels:   # channel ranges of cat(dpre), as views (the library reads channel slices in place)
             whole = dpre[0] if len(dpre) == 1 else torch.cat(dpre, dim=1)
@@ -593,8 +612,8 @@ def mix_multi(ins, M, bias=None, adds=(), relu=False, out_channels=None):
         raise ValueError("mix_multi: the add operands must cover the output channels")
     if relu and len(out_channels) != 1:
         raise ValueError("mix_multi: relu needs a single output tensor")
-    if bias is not None and tuple(bias.shape) != (Co,):
-        raise ValueError(f"bias must be [{Co}]")
+    if bias is not None and tuple(bias.shape) not in ((Co,), (M.shape[0], Co)):
+        raise ValueError(f"bias must be [{Co}] or [{M.shape[0]},{Co}]")
     if max(len(ins), len(adds), len(out_channels)) > 6:
         raise ValueError("mix_multi: at most 6 tensors per channel axis")
     return _MixMultiFunction.apply(M, bias, bool(relu), len(ins), len(adds), tuple(out_channels), *ins, *adds)
