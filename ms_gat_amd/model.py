@@ -19,7 +19,7 @@ from typing import Dict, List, Sequence
 import torch
 from torch import nn
 
-from . import ops
+from . import ops, stacked
 from .attention import GACN
 
 
@@ -287,9 +287,13 @@ class MSGAT(nn.Module):
         self.tpcs = nn.ModuleList(
             TPC(channels=c["channels"], n_nodes=n_nodes, in_timesteps=in_timesteps, out_timesteps=out_timesteps,
                 dilations=c["dilations"]) for c in components)
+        self.stack_components = True   # False: evaluate the components one by one, as the reference does
         self.reset_parameters()
 
     def forward(self, X: torch.Tensor, H: torch.Tensor, D: torch.Tensor) -> torch.Tensor:
+        if self.stack_components and stacked.can_stack(self):
+            # all components in each kernel launch (stacked.py) instead of the reference's loop (msgat.py:204)
+            return stacked.forward(self, X, H, D)
         gates = self.te(H, D).unbind(1) if self.te is not None else self.W.unbind(0)
         out = None
         for tpc, x, gate in zip(self.tpcs, X.unbind(1), gates):

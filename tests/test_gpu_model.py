@@ -171,3 +171,34 @@ def test_cfg1_pemsd4_five_components_forward_matches_the_reference():
         pred = net(torch.from_numpy(g["X"]).float().to(_dev()), torch.from_numpy(g["H"]).to(_dev()),
                    torch.from_numpy(g["D"]).to(_dev()))
     assert rel_err(pred.cpu(), g["pred"]) < TOL
+
+
+@pytest.mark.parametrize("factory,cin,R,use_te", [("msgat72", 3, 3, True), ("msgat96", 1, 2, False), ("msgat48", 3, 4, True)])
+def test_stacked_components_equal_the_component_loop(factory, cin, R, use_te):
+    """stacked.forward (all R components in each launch) against the module-by-module loop of the same model:
+    prediction and every parameter gradient."""
+    import ms_gat_amd
+    from ms_gat_amd import model
+    torch.manual_seed(3)
+    N, T, B = 29, 12, 4
+    adj = ms_gat_amd.synthetic_adjacency(N, 40, seed=9)
+    net = getattr(model, factory)(n_components=R, in_channels=cin, in_timesteps=T, out_timesteps=T, use_te=use_te,
+                                  adj=adj).to(_dev())
+    gen = torch.Generator().manual_seed(5)
+    X = torch.randn(B, R, cin, N, T, generator=gen).to(_dev())
+    H = torch.randint(0, 24, (B,), generator=gen).to(_dev())
+    D = torch.randint(0, 7, (B,), generator=gen).to(_dev())
+    dout = torch.randn(B, N, T, generator=gen).to(_dev())
+    params = [p for p in net.parameters() if p.requires_grad]
+    names = [n for n, p in net.named_parameters() if p.requires_grad]
+    results = []
+    for stack in (True, False):
+        net.stack_components = stack
+        pred = net(X, H, D)
+        results.append((pred, torch.autograd.grad(pred, params, dout, allow_unused=True)))
+    (p1, g1), (p2, g2) = results
+    assert rel_err(p1, p2) < 1e-5
+    for n, a, b in zip(names, g1, g2):
+        assert (a is None) == (b is None), n
+        if a is not None:
+            assert rel_err(a, b) < 2e-5, n
