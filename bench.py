@@ -179,6 +179,7 @@ def full_model_step_ms(wl, dev, dense, steps=6, warmup=5):
     net = model.msgat72(n_components=wl["R"], in_channels=wl["Cin"], in_timesteps=wl["T"], out_timesteps=wl["T"],
                         use_te=True, adj=adj).to(dev)
     if dense:
+        net.stack_components = False   # the reference's loop over components (msgat.py:204)
         for tpc in net.tpcs:
             tpc.tgacns = torch.nn.ModuleList(_EagerMEAM(m) for m in tpc.tgacns)
             tpc.ln = _EagerLayerNorm(tpc.ln)
