@@ -163,3 +163,15 @@ def test_trainer_loop_checkpoint_and_evaluator_roundtrip(tmp_path):
     assert tr2.epoch == ck["epoch"] + 1 and tr2.best["loss"] == ck["best"]["loss"]
     # DataParallel-style prefixes written by the reference (main.py:54) are accepted
     assert list(engine.strip_data_parallel_prefix({"module.a": 1, "module.b": 2})) == ["a", "b"]
+
+
+def test_components_are_stackable_only_when_their_architectures_agree():
+    from ms_gat_amd import model, stacked
+    net = model.msgat72(n_components=3, in_channels=1, in_timesteps=12, out_timesteps=12, use_te=True, adj=torch.eye(6))
+    assert net.stack_components and stacked.can_stack(net)
+    odd = model.MSGAT([{"channels": [1, 48, 48], "dilations": [[1, 2], [2, 4]]},
+                       {"channels": [1, 72, 72], "dilations": [[1, 2], [2, 4]]}], in_timesteps=12, out_timesteps=12,
+                      use_te=True, adj=torch.eye(6))
+    assert not stacked.can_stack(odd)
+    p = torch.arange(6.0).view(2, 3)
+    assert torch.equal(stacked._per_group(p, 2), torch.tensor([[0., 1, 2], [0, 1, 2], [3, 4, 5], [3, 4, 5]]))
