@@ -259,3 +259,41 @@ def test_attention_core_equals_the_graph_attention_on_projected_features():
     g_ref = torch.autograd.grad(z2, [xb, Wb, ab, gb], dz)
     assert rel_err(z, z2) < TOL
     _check(g_mine, [g.double() for g in g_ref], ["dx", "dW", "dalpha", "dWg"])
+
+
+def test_parameter_sets_per_relation_in_one_launch():
+    """R parameter sets evaluated in one launch (the relation count of include/msgat_hip.h) equal R separate calls:
+    LayerNorm, node pooling, channel pooling, time mixing bias and the prediction head, forward and gradients."""
+    from ms_gat_amd import ops
+    gen = torch.Generator().manual_seed(31)
+    R, B, C, N, T, To, Co = 3, 2, 5, 19, 12, 12, 4
+    x = _rand(gen, R * B, C, N, T)
+    lw, lb = _rand(gen, R, T) + 1.0, _rand(gen, R, T)
+    nw, ca = _rand(gen, R, N), _rand(gen, R, C)
+    hw, hb = _rand(gen, R, To, T, 1, C, scale=0.2), _rand(gen, R, To)
+    A, tb = _rand(gen, R * B, 1, T, T, scale=0.3), _rand(gen, R, C)
+
+    def run(stacked):
+        leaves = _leaf(x, lw, lb, nw, ca, hw, hb, A, tb)
+        x_, lw_, lb_, nw_, ca_, hw_, hb_, A_, tb_ = leaves
+        if stacked:
+            y = ops.layer_norm_t(x_, lw_, lb_)
+            outs = [y, ops.node_pool(y, nw_), ops.channel_pool(y, ca_), ops.head(y, hw_, hb_), ops.time_mix(y, A_, tb_)]
+        else:
+            parts = [[], [], [], [], []]
+            for r in range(R):
+                sl = slice(r * B, (r + 1) * B)
+                y = ops.layer_norm_t(x_[sl], lw_[r], lb_[r])
+                for k, v in enumerate((y, ops.node_pool(y, nw_[r]), ops.channel_pool(y, ca_[r]), ops.head(y, hw_[r], hb_[r]),
+                                       ops.time_mix(y, A_[sl], tb_[r]))):
+                    parts[k].append(v)
+            outs = [torch.cat(p, dim=0) for p in parts]
+        gen2 = torch.Generator().manual_seed(77)
+        douts = [_rand(gen2, *o.shape) for o in outs]
+        return outs, torch.autograd.grad(outs, leaves, douts)
+
+    (o1, g1), (o2, g2) = run(True), run(False)
+    for a, b in zip(o1, o2):
+        assert rel_err(a, b) < 1e-5
+    for name, a, b in zip(["dx", "dlnw", "dlnb", "dnw", "dca", "dhw", "dhb", "dA", "dtb"], g1, g2):
+        assert rel_err(a, b) < 2e-5, name
