@@ -112,7 +112,7 @@ def dense_reference_step(hp, device, B, backward=True):
     return outs
 
 
-def time_aggregate_kernel(hp, reps=20):
+def time_aggregate_kernel(hp, reps=40):
     """HIP-event timing of the attention-aggregate kernel alone (second depth: Cu = Co channels of
     the projected features), on torch's current stream -- the stream the kernel is launched on."""
     from ms_gat_amd import _lib
@@ -121,23 +121,45 @@ def time_aggregate_kernel(hp, reps=20):
     L = _lib.lib()
     gs, _keep = hp.graph.on(dev)
     shape = _lib.Shape(wl["R"], wl["B"], wl["hidden"], wl["Co"], N, T)
-    u = torch.randn(G, Cu, N, T, device=dev)
+    # Timed as it runs in the step: right behind its producer.  Two loops of back-to-back launches on the launch
+    # stream, bracketed by HIP events: (projection x -> u, aggregation u -> v) and (projection alone); the
+    # difference per repetition is the aggregation with its input in the state the step leaves it in.
+    # Re-launching the aggregation alone on the same 196 MB would keep its operands in the 256 MB infinity
+    # cache (40 us, 4.9 TB/s); on operands nothing touched recently it takes 51 us (3.8 TB/s).  The rocprofv3
+    # per-grid average of the in-application launches is in profiles/r01/c_final_agg_lds_by_grid.txt.
+    Cin = wl["hidden"]
+    xs = [torch.randn(G, Cin, N, T, device=dev) for _ in range(2)]
+    us = [torch.empty(G, Cu, N, T, device=dev) for _ in range(2)]
+    vs = [torch.empty_like(u) for u in us]
+    qb = torch.empty(G, N, T, device=dev)
+    alpha = torch.randn(wl["R"], Cin, device=dev) * 0.1
+    W = torch.randn(wl["R"], Cu, Cin, device=dev) * 0.1
     E = torch.rand(G, max(hp.graph.nnz, 1), device=dev)
-    v = torch.empty_like(u)
     stream = torch.cuda.current_stream(dev)
 
-    def launch():
-        _lib.check(L.msgat_stage_aggregate(C.byref(shape), C.byref(gs), Cu, u.data_ptr(), E.data_ptr(),
-                                           v.data_ptr(), stream.cuda_stream), "msgat_stage_aggregate")
-    for _ in range(3):
-        launch()
-    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0.record(stream)
-    for _ in range(reps):
-        launch()
-    t1.record(stream)
-    t1.synchronize()
-    sec = t0.elapsed_time(t1) * 1e-3 / reps
+    def produce(i):
+        _lib.check(L.msgat_stage_project(C.byref(shape), xs[i % 2].data_ptr(), alpha.data_ptr(), W.data_ptr(),
+                                         qb.data_ptr(), us[i % 2].data_ptr(), stream.cuda_stream), "msgat_stage_project")
+
+    def launch(i):
+        _lib.check(L.msgat_stage_aggregate(C.byref(shape), C.byref(gs), Cu, us[i % 2].data_ptr(), E.data_ptr(),
+                                           vs[i % 2].data_ptr(), stream.cuda_stream), "msgat_stage_aggregate")
+    def timed(with_aggregate):
+        for i in range(2):
+            produce(i)
+            if with_aggregate:
+                launch(i)
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record(stream)
+        for i in range(reps):
+            produce(i)
+            if with_aggregate:
+                launch(i)
+        t1.record(stream)
+        t1.synchronize()
+        return t0.elapsed_time(t1) * 1e-3 / reps
+
+    sec = timed(True) - timed(False)
     # algorithmic bytes per launch: read u once + write v once + E + CSR
     nnz = hp.graph.nnz
     bytes_ = 2 * 4 * G * Cu * N * T + 4 * G * nnz + 8 * nnz + 4 * (N + 1)
