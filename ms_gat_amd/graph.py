@@ -134,6 +134,10 @@ def graph_of(adjacency: torch.Tensor) -> SparseGraph:
         if ref() is adjacency or torch.equal(snapshot, adjacency.detach()):
             _CACHE.move_to_end(key)
             return g
+    if adjacency.is_cuda and torch.cuda.is_current_stream_capturing():
+        # building the CSR reads the adjacency back to the host, which a stream capture cannot contain
+        raise _lib.MsgatError("the CSR of this adjacency is not cached yet: run one forward outside the HIP-graph "
+                              "capture first (engine.Trainer does this in its warm-up)")
     g = SparseGraph(adjacency)
     _CACHE[key] = (g, weakref.ref(adjacency), adjacency.detach().clone())
     _CACHE.move_to_end(key)
