@@ -15,15 +15,64 @@ component, then LayerNorm -> prediction head (msgat.py:158-160), gate and sum ov
 """
 from __future__ import annotations
 
-from typing import Callable, List
 
 import torch
 
 from . import ops
 
 
-def _stack(mods: List, get: Callable) -> torch.Tensor:
-    return torch.stack([get(m) for m in mods])
+class _StackedView(torch.autograd.Function):
+    """The bank's [R, ...] storage as a differentiable function of the R parameters that are views of it: no kernel
+    forward (the values are already there), no kernel backward (each parameter's gradient is row r of the incoming
+    gradient, handed over as a view)."""
+
+    @staticmethod
+    def forward(ctx, storage, *params):
+        ctx.R = len(params)
+        return storage.view(storage.shape)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return (None, *grad.unbind(0))
+
+
+class ParamBank:
+    """Per-component parameters of identical shape stored back to back, so that "the same parameter of all R
+    components" is one [R, ...] tensor without a stacking kernel.
+
+    Each component keeps its own `nn.Parameter` objects (same names, `state_dict`, optimizer state); their `.data`
+    are re-pointed to rows of the bank's storage.  `model.to(...)` or anything else that re-allocates parameter
+    storage breaks the aliasing; `get` notices (pointer check) and rebuilds the row block, which costs kernels
+    once.  Stacking by `torch.stack` cost ~46 concatenations per step forward and ~140 slice copies backward."""
+
+    def __init__(self, tpcs):
+        self.tpcs = list(tpcs)
+        self.params = [dict(t.named_parameters()) for t in self.tpcs]
+        self.storage = {}
+
+    def get(self, name: str) -> torch.Tensor:
+        ps = [d[name] for d in self.params]
+        st = self.storage.get(name)
+        ok = st is not None and st.device == ps[0].device and all(
+            p.data_ptr() == st[r].data_ptr() and p.shape == st.shape[1:] for r, p in enumerate(ps))
+        if not ok:
+            if ps[0].is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("parameter bank must be built before a HIP-graph capture (run one eager forward)")
+            with torch.no_grad():
+                st = torch.stack([p.detach() for p in ps]).contiguous()
+                for r, p in enumerate(ps):
+                    p.data = st[r]
+            self.storage[name] = st
+        if any(p.requires_grad for p in ps):
+            return _StackedView.apply(st, *ps)
+        return st
+
+
+def _bank(model) -> ParamBank:
+    bank = model.__dict__.get("_param_bank")
+    if bank is None or len(bank.tpcs) != len(model.tpcs) or any(a is not b for a, b in zip(bank.tpcs, model.tpcs)):
+        bank = model.__dict__["_param_bank"] = ParamBank(model.tpcs)
+    return bank
 
 
 def _per_group(p: torch.Tensor, B: int) -> torch.Tensor:
@@ -45,72 +94,73 @@ def can_stack(model) -> bool:
                t.in_timesteps == first.in_timesteps and t.out_timesteps == first.out_timesteps for t in model.tpcs)
 
 
-def _channel_attention(cas, pooled: torch.Tensor, R: int, B: int) -> torch.Tensor:
+def _taps(P, prefix: str, layer: int) -> torch.Tensor:
+    """[R, 2*Co, Ci]: both taps of convolution `layer` of the TACN stacks (model.TACN.stacked_taps), one copy kernel."""
+    w = P(f"{prefix}tacn.seq.{1 + 2 * layer}.weight")                                   # [R,Co,Ci,1,2]
+    R, Co, Ci = w.shape[:3]
+    return w[:, :, :, 0, :].permute(0, 3, 1, 2).reshape(R, 2 * Co, Ci)
+
+
+def _channel_attention(P, prefix: str, pooled: torch.Tensor, R: int, B: int) -> torch.Tensor:
     """pooled [G,C,T] -> att [R,B,C,C]  (attention.py:90-92)."""
     p = pooled.view(R, B, *pooled.shape[1:])
-    return torch.softmax(p @ _stack(cas, lambda m: m.Wc).unsqueeze(1) @ p.transpose(2, 3), dim=-1)
+    return torch.softmax(p @ P(prefix + "cacn.seq.0.Wc").unsqueeze(1) @ p.transpose(2, 3), dim=-1)
 
 
-def _temporal_attention(tas, pooled: torch.Tensor, R: int, B: int) -> torch.Tensor:
+def _temporal_attention(P, prefix: str, pooled: torch.Tensor, R: int, B: int) -> torch.Tensor:
     """pooled [G,N,T] (alpha-weighted channel sum) -> att [G,T,T]  (attention.py:60-64)."""
     per_t = pooled.view(R, B, *pooled.shape[1:]).transpose(2, 3)                      # [R,B,T,N]
-    left = per_t @ _stack(tas, lambda m: m.Wt1).transpose(1, 2).unsqueeze(1)          # [R,B,T,10]
-    right = per_t @ _stack(tas, lambda m: m.Wt2).transpose(1, 2).unsqueeze(1)
+    left = per_t @ P(prefix + "tacn.seq.0.Wt1").transpose(1, 2).unsqueeze(1)          # [R,B,T,10]
+    right = per_t @ P(prefix + "tacn.seq.0.Wt2").transpose(1, 2).unsqueeze(1)
     att = torch.softmax(left @ right.transpose(2, 3), dim=-1)
     return att.reshape(R * B, att.shape[-2], att.shape[-1])
 
 
-def _tacn_finish(tacns, mixed: torch.Tensor, att: torch.Tensor) -> torch.Tensor:
+def _tacn_finish(P, prefix: str, dilations, mixed: torch.Tensor, att: torch.Tensor) -> torch.Tensor:
     """TACN from the channel-mixed input of its first convolution (see model.TACN.finish), R stacks at once."""
     T = att.size(-1)
     h = None
-    for i, d in enumerate(tacns[0].dilations):
-        bias = _stack(tacns, lambda m: m.seq[1 + 2 * i].bias)                          # [R,Co]
+    for i, d in enumerate(dilations):
+        bias = P(f"{prefix}tacn.seq.{1 + 2 * i}.bias")                                 # [R,Co]
         if i == 0:
             taps = torch.stack([_shift_down(att, d), att], dim=1)                      # [G,2,T,T]
         else:
             eye = torch.eye(T, device=att.device, dtype=att.dtype)
             taps = torch.stack([_shift_down(eye, d), eye], dim=0).unsqueeze(0)         # [1,2,T,T]
-            (mixed,) = ops.mix_multi([h], _stack(tacns, lambda m: m.stacked_taps(i)))
+            (mixed,) = ops.mix_multi([h], _taps(P, prefix, i))
         h = ops.time_mix(mixed, taps, bias)
     return h
 
 
-def _meam(meams, x: torch.Tensor, adjacency, R: int, B: int) -> torch.Tensor:
-    m0 = meams[0]
+def _meam(P, prefix: str, m0, x: torch.Tensor, adjacency, R: int, B: int) -> torch.Tensor:
     C, cb = m0.in_channels, m0.out_channels // 3
-    cas = [m.cacn.seq[0] for m in meams]
-    tas = [m.tacn.seq[0] for m in meams]
-    tacns = [m.tacn for m in meams]
-    normed = ops.layer_norm_t(x, _stack(meams, lambda m: m.ln.weight), _stack(meams, lambda m: m.ln.bias), m0.ln.eps)
+    normed = ops.layer_norm_t(x, P(prefix + "ln.weight"), P(prefix + "ln.bias"), m0.ln.eps)
 
-    att_c = _channel_attention(cas, ops.node_pool(normed, _stack(cas, lambda m: m.alpha)), R, B)
-    conv_w = _stack(meams, lambda m: m.cacn.seq[1].weight[:, :, 0, 0])                 # [R,cb,C]
-    conv_b = _stack(meams, lambda m: m.cacn.seq[1].bias)                               # [R,cb]
+    att_c = _channel_attention(P, prefix, ops.node_pool(normed, P(prefix + "cacn.seq.0.alpha")), R, B)
+    conv_w = P(prefix + "cacn.seq.1.weight")[:, :, :, 0, 0]                            # [R,cb,C]
+    conv_b = P(prefix + "cacn.seq.1.bias")                                             # [R,cb]
     Mc = (conv_w.unsqueeze(1) @ att_c).reshape(R * B, cb, C)                           # per-sample matrices
-    Wg = _stack(meams, lambda m: m.gacn.gatt.Wg)
-    alpha_g = _stack(meams, lambda m: m.gacn.gatt.alpha)
-    alpha_t = _stack(tas, lambda m: m.alpha)
-    W_g = _stack(meams, lambda m: m.gacn.W)
+    Wg, alpha_g, W_g = P(prefix + "gacn.gatt.Wg"), P(prefix + "gacn.gatt.alpha"), P(prefix + "gacn.W")
+    alpha_t = P(prefix + "tacn.seq.0.alpha")
 
     if C <= cb or not m0.dilations:
         (cacn,) = ops.mix_multi([normed], Mc, _per_group(conv_b, B))
-        att_t = _temporal_attention(tas, ops.channel_pool(normed, alpha_t), R, B)
+        att_t = _temporal_attention(P, prefix, ops.channel_pool(normed, alpha_t), R, B)
         if m0.dilations:
-            (mixed,) = ops.mix_multi([normed], _stack(tacns, lambda m: m.stacked_taps(0)))
-            tacn = _tacn_finish(tacns, mixed, att_t)
+            (mixed,) = ops.mix_multi([normed], _taps(P, prefix, 0))
+            tacn = _tacn_finish(P, prefix, m0.dilations, mixed, att_t)
         else:
             tacn = ops.time_mix(normed, att_t.unsqueeze(1))
         gacn = ops.gacn(normed, alpha_g, Wg, W_g, adjacency)
     else:
         # every channel mixing of the normalised input as row blocks of one per-sample matrix (model.MEAM._merged_branches)
-        rows = torch.cat([Mc, _per_group(_stack(tacns, lambda m: m.stacked_taps(0)), B), _per_group(W_g, B),
+        rows = torch.cat([Mc, _per_group(_taps(P, prefix, 0), B), _per_group(W_g, B),
                           _per_group(alpha_g.unsqueeze(1), B), _per_group(alpha_t.unsqueeze(1), B)], dim=1)
         bias = _per_group(torch.cat([conv_b, conv_b.new_zeros(R, 3 * cb + 2)], dim=1), B)
         cacn, mixed, u, q, pooled_t = ops.mix_multi([normed], rows, bias, out_channels=[cb, 2 * cb, cb, 1, 1])
-        tacn = _tacn_finish(tacns, mixed, _temporal_attention(tas, pooled_t[:, 0], R, B))
+        tacn = _tacn_finish(P, prefix, m0.dilations, mixed, _temporal_attention(P, prefix, pooled_t[:, 0], R, B))
         gacn = ops.attention_core(u, q[:, 0], Wg, adjacency)
-    return ops.mix_multi([x], _stack(meams, lambda m: m.res.weight[:, :, 0, 0]), _stack(meams, lambda m: m.res.bias),
+    return ops.mix_multi([x], P(prefix + "res.weight")[:, :, :, 0, 0], P(prefix + "res.bias"),
                          adds=[cacn, tacn, gacn], relu=True)[0]
 
 
@@ -118,11 +168,12 @@ def forward(model, X: torch.Tensor, H: torch.Tensor, D: torch.Tensor) -> torch.T
     """X [B,R,C,N,T], H [B], D [B] -> [B,N,T_out]: `MSGAT.forward` with all R components in each kernel."""
     tpcs = list(model.tpcs)
     R, B = len(tpcs), X.shape[0]
+    P = _bank(model).get
     x = X.transpose(0, 1).reshape(R * B, *X.shape[2:])                                 # relation-major groups
-    for level in range(len(tpcs[0].tgacns)):
-        x = _meam([t.tgacns[level] for t in tpcs], x, model.adj, R, B)
-    xn = ops.layer_norm_t(x, _stack(tpcs, lambda t: t.ln.weight), _stack(tpcs, lambda t: t.ln.bias), tpcs[0].ln.eps)
-    pred = ops.head(xn, _stack(tpcs, lambda t: t.fc.weight), _stack(tpcs, lambda t: t.fc.bias))     # [R*B,N,T_out]
+    for level, m0 in enumerate(tpcs[0].tgacns):
+        x = _meam(P, f"tgacns.{level}.", m0, x, model.adj, R, B)
+    xn = ops.layer_norm_t(x, P("ln.weight"), P("ln.bias"), tpcs[0].ln.eps)
+    pred = ops.head(xn, P("fc.weight"), P("fc.bias"))                                  # [R*B,N,T_out]
     pred = pred.view(R, B, *pred.shape[1:])
     gate = model.te(H, D).transpose(0, 1) if model.te is not None else model.W.unsqueeze(1)          # [R,B|1,N,T_out]
     return (pred * gate).sum(dim=0)

@@ -202,3 +202,34 @@ def test_stacked_components_equal_the_component_loop(factory, cin, R, use_te):
         assert (a is None) == (b is None), n
         if a is not None:
             assert rel_err(a, b) < 2e-5, n
+
+
+def test_training_with_the_parameter_bank_tracks_the_component_loop(tmp_path):
+    """The stacked schedule keeps every component's parameters as rows of shared storage (stacked.ParamBank); a
+    few optimizer steps must move them exactly as they move when the components are evaluated one by one."""
+    import copy
+    from ms_gat_amd import data, engine, model
+    torch.manual_seed(0)
+    ds = data.SyntheticPEMS(n_nodes=30, n_edges=40, n_channels=1, in_hours=[1, 2, 3], batch_size=6, days=2)
+    net = model.msgat48(n_components=3, in_channels=1, in_timesteps=12, out_timesteps=12, use_te=True, adj=ds.adj)
+    net.to(_dev())
+    twin = copy.deepcopy(net)
+    twin.stack_components = False
+    batches = [b for _, b in zip(range(4), ds.training)]
+    a = engine.Trainer(net, 50.0, str(tmp_path / "stacked"))
+    b = engine.Trainer(twin, 50.0, str(tmp_path / "loop"))
+    for epoch in (1, 2):
+        la = a.run_epoch(batches, gpu_id=0, epoch=epoch, mode="train")
+        lb = b.run_epoch(batches, gpu_id=0, epoch=epoch, mode="train")
+        assert abs(la - lb) < 1e-4 * abs(lb), (epoch, la, lb)
+    for (name, p), q in zip(net.named_parameters(), twin.parameters()):
+        assert rel_err(p.detach().cpu(), q.detach().cpu()) < 2e-2, name
+    # the bank survives a round trip through state_dict (values are copied in place, aliasing intact)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    net.load_state_dict(state)
+    X, H, D, _ = [t.to(_dev()) for t in batches[0]]
+    with torch.no_grad():
+        p1 = net(X, H, D)
+        net.stack_components = False
+        p2 = net(X, H, D)
+    assert rel_err(p1, p2) < 1e-5
