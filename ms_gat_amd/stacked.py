@@ -5,16 +5,16 @@ loop (msgat.py:204): R independent networks of identical architecture over the s
 B samples.  On an MI355X a single component at B = 32 does not fill the machine -- its dense score kernel
 launches 224 blocks for 768 block slots -- and every one of its ~300 kernel launches is paid R times.  Here
 the components ride on the leading axis instead: activations are [R*B, C, N, T], relation-major, and every
-parameter gets a leading [R] axis (`torch.stack` of the R modules' tensors, so autograd hands each module its
-own gradient and `state_dict` keeps the reference's per-component keys).  The library's entry points take the
-relation count (include/msgat_hip.h), exactly like the graph attention has from the start (`StackedGACN`).
+parameter gets a leading [R] axis -- the R modules' tensors stored back to back (`ParamBank`), so autograd hands
+each module its own gradient and `state_dict` keeps the reference's per-component keys.  The library's entry
+points take the relation count (include/msgat_hip.h), exactly like the graph attention has from the start
+(`StackedGACN`).
 
 `forward(model, X, H, D)` computes what `MSGAT.forward`'s loop computes, block for block:
 LayerNorm -> {channel, temporal, graph} branches -> residual tail (msgat.py:117-131), twice or more per
 component, then LayerNorm -> prediction head (msgat.py:158-160), gate and sum over components (msgat.py:203-204).
 """
 from __future__ import annotations
-
 
 import torch
 
