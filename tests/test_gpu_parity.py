@@ -367,3 +367,19 @@ def test_cpu_tensors_are_refused_not_silently_computed():
     m = ms_gat_amd.GraphAttention(3, 12)
     with pytest.raises(MsgatError):
         m(torch.randn(1, 3, 8, 12), torch.eye(8))
+
+
+def test_randomised_shape_sweep():
+    """Seeded random shapes across every template the library instantiates: T in {4,8,12,16}, 1..1100 nodes,
+    1..130 channels, all three execution modes (Co = 0, C <= Co, C > Co), 1..3 relations, edge counts from none
+    to 8 per node (rows with more than 8 edges take the tail loop of the gather)."""
+    rng = np.random.default_rng(123)
+    for it in range(30):
+        T = int(rng.choice([4, 8, 12, 16]))
+        N = int(rng.choice([1, 2, 3, 5, 9, 17, 33, 64, 100, 257, 500, 1100]))
+        C = int(rng.choice([1, 2, 3, 7, 24, 40, 72, 130]))
+        Co = int(rng.choice([0, 1, 4, 8, 24, 30, 72]))
+        R, Bg = int(rng.choice([1, 2, 3])), int(rng.choice([1, 2, 3]))
+        E = int(min(N * (N - 1) // 2, rng.choice([0, 1, N // 2, N, 3 * N, 8 * N])))
+        prob = random_problem(R, Bg, C, Co, N, T, E, seed=1000 + it)
+        assert_close(run_ours(*prob), oracle_f64(*prob), what=f"T{T} N{N} C{C} Co{Co} R{R} Bg{Bg} E{E}")
