@@ -132,9 +132,13 @@ def time_aggregate_kernel(hp, reps=40):
     E = torch.rand(G, max(hp.graph.nnz, 1), device=dev)
     stream = torch.cuda.current_stream(dev)
 
+    nscratch = int(L.msgat_edge_scratch_floats(C.byref(shape), C.byref(gs)))
+    scratch = torch.empty(nscratch, device=dev) if nscratch else None
+
     def launch(i):
         _lib.check(L.msgat_stage_aggregate(C.byref(shape), C.byref(gs), Cu, us[i].data_ptr(), E.data_ptr(),
-                                           vs[i].data_ptr(), stream.cuda_stream), "msgat_stage_aggregate")
+                                           vs[i].data_ptr(), None if scratch is None else scratch.data_ptr(),
+                                           stream.cuda_stream), "msgat_stage_aggregate")
 
     def timed(nsets):
         for i in range(4):

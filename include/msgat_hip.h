@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MSGAT_ABI_VERSION 2
+#define MSGAT_ABI_VERSION 3
 
 enum {
   MSGAT_OK = 0,
@@ -59,6 +59,25 @@ enum {
   MSGAT_MODE_PROJ_FIRST = 2 /* C >  Co: project to Co channels, then aggregate (3x less gather) */
 };
 
+/* Sliced jagged-diagonal (JDS) form of one sparse structure (rows of the CSR, or columns of the
+ * CSC), used by the aggregate / SDDMM kernels when an [N,T] slab does not fit LDS (N > ~3400 at
+ * T = 12; the N = 8192 stress graph): rows are cut into slices of 64 (one wavefront), sorted by
+ * degree inside a slice, and the k-th edges of a slice's rows are stored back to back, so lane l of
+ * a wave reads entry colstart[k] + l -- coalesced, every byte once, no dependent address.
+ * Built on the host by msgat_graph_jds_build().  n_slices == 0: absent (the CSR kernels run). */
+#define MSGAT_JDS_PAD 8 /* colstart carries this many extra trailing entries, all equal to nnz */
+typedef struct msgat_jds {
+  int32_t n_slices;        /* ceil(N / 64), or 0 when the layout is absent                      */
+  int32_t n_cols;          /* jagged columns in total = sum over slices of the largest degree   */
+  const int32_t* slice;    /* [n_slices+1]  first jagged column of each slice                   */
+  const int32_t* colstart; /* [n_cols+1+MSGAT_JDS_PAD] first position of each jagged column (padded)   */
+  const int32_t* lane_row; /* [64 n_slices] row handled by each lane of a slice, -1 past N      */
+  const int32_t* idx;      /* [nnz]         neighbour node of each position                     */
+  const int32_t* src;      /* [nnz]         position -> CSR edge index (E is permuted by this)  */
+  const int32_t* pos;      /* [nnz]         CSR edge index -> position (row form only)          */
+  int32_t prefer;          /* != 0: use the JDS kernels even when a whole slab fits LDS (tests) */
+} msgat_jds_t;
+
 /* Device-resident sparse adjacency.  Built on the host by msgat_graph_build() and copied
  * to the device by the caller. */
 typedef struct msgat_graph {
@@ -71,6 +90,8 @@ typedef struct msgat_graph {
   const int32_t* colptr; /* [N+1]  CSC column starts                                */
   const int32_t* crow;   /* [nnz]  row of each CSC entry                            */
   const int32_t* cperm;  /* [nnz]  CSC position -> CSR edge index                   */
+  msgat_jds_t jds_rows;  /* JDS of the CSR (forward aggregate, SDDMM); optional      */
+  msgat_jds_t jds_cols;  /* JDS of the CSC (transposed aggregate of backward); opt.  */
 } msgat_graph_t;
 
 typedef struct msgat_shape {
@@ -98,6 +119,8 @@ typedef struct msgat_fwd {
   float* u;           /* out AGG_FIRST: y [G,C,N,T] when need_bwd; PROJ_FIRST: W x [G,Co,N,T];
                              PLAIN: unused (may be NULL)                                  */
   int32_t need_bwd;
+  float* edge_scratch; /* tmp msgat_edge_scratch_floats() floats (0 unless the graph carries a JDS
+                             layout the aggregate will use: E re-ordered for it); may be NULL then */
 } msgat_fwd_t;
 
 typedef struct msgat_bwd {
@@ -138,13 +161,23 @@ int msgat_graph_count(const float* adj, int32_t n, int64_t ld, int32_t* nnz_out)
 int msgat_graph_build(const float* adj, int32_t n, int64_t ld, int32_t nnz,
                       int32_t* rowptr, int32_t* col, float* val, int32_t* erow,
                       int32_t* colptr, int32_t* crow, int32_t* cperm);
-/* Host-side structural check of a (host-resident) graph. */
+/* Host-side structural check of a (host-resident) graph (its JDS forms too, when present). */
 int msgat_graph_validate(const msgat_graph_t* host_graph);
+/* JDS form of a CSR (ptr = rowptr, idx = col, perm = NULL) or CSC (ptr = colptr, idx = crow,
+ * perm = cperm) structure, all HOST pointers: first the sizes, then the arrays (see msgat_jds_t;
+ * jpos may be NULL).  Pure index work: replaces nothing in the reference, it re-orders the
+ * non-zeros of the mask of attention.py:36 for coalesced reads. */
+int msgat_graph_jds_count(const int32_t* ptr, int32_t n, int32_t* n_slices_out, int32_t* n_cols_out);
+int msgat_graph_jds_build(const int32_t* ptr, const int32_t* idx, const int32_t* perm, int32_t n,
+                          int32_t nnz, int32_t n_slices, int32_t n_cols, int32_t* slice,
+                          int32_t* colstart, int32_t* lane_row, int32_t* jidx, int32_t* jsrc,
+                          int32_t* jpos);
 
 /* ---- device: fused entry points --------------------------------------------------
  * msgat_gacn_forward replaces attention.py:33-36 (+ msgat.py:27-28 when Co > 0).
  * msgat_gacn_backward replaces the autograd of those lines (adj gets no gradient,
  * msgat.py:190). */
+size_t msgat_edge_scratch_floats(const msgat_shape_t* shape, const msgat_graph_t* graph);
 int msgat_gacn_forward(const msgat_shape_t* shape, const msgat_graph_t* graph,
                        const msgat_fwd_t* io, void* stream);
 size_t msgat_bwd_workspace_bytes(const msgat_shape_t* shape, int32_t nnz);
@@ -163,9 +196,11 @@ int msgat_stage_project(const msgat_shape_t* shape, const float* x, const float*
 int msgat_stage_scores(const msgat_shape_t* shape, const msgat_graph_t* graph,
                        const float* q, const float* Wg, float* kW, float* lse, float* pq,
                        float* E, void* stream);
-/* attention.py:36: v[g,c,n,:] = sum_{e in row n} E[g,e] u[g,c,col_e,:] over Cu channels. */
+/* attention.py:36: v[g,c,n,:] = sum_{e in row n} E[g,e] u[g,c,col_e,:] over Cu channels.
+ * edge_scratch: msgat_edge_scratch_floats() floats (NULL when that is 0). */
 int msgat_stage_aggregate(const msgat_shape_t* shape, const msgat_graph_t* graph,
-                          int32_t Cu, const float* u, const float* E, float* v, void* stream);
+                          int32_t Cu, const float* u, const float* E, float* v, float* edge_scratch,
+                          void* stream);
 /* attention.py:36 + msgat.py:27-28 for C <= Co: y = aggregate(x) (stored if y != NULL),
  * z[g,o] = sum_c W[r,o,c] y[g,c]. */
 int msgat_stage_aggregate_project(const msgat_shape_t* shape, const msgat_graph_t* graph,

@@ -19,11 +19,24 @@ c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int32)
 
 
+JDS_PAD = 8  # MSGAT_JDS_PAD
+
+
+class Jds(C.Structure):
+    """msgat_jds_t: sliced jagged-diagonal form of the CSR rows / CSC columns (n_slices = 0: absent)."""
+    _fields_ = [
+        ("n_slices", C.c_int32), ("n_cols", C.c_int32),
+        ("slice", C.c_void_p), ("colstart", C.c_void_p), ("lane_row", C.c_void_p), ("idx", C.c_void_p),
+        ("src", C.c_void_p), ("pos", C.c_void_p), ("prefer", C.c_int32),
+    ]
+
+
 class Graph(C.Structure):
     _fields_ = [
         ("n_nodes", C.c_int32), ("nnz", C.c_int32),
         ("rowptr", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p), ("erow", C.c_void_p),
         ("colptr", C.c_void_p), ("crow", C.c_void_p), ("cperm", C.c_void_p),
+        ("jds_rows", Jds), ("jds_cols", Jds),
     ]
 
 
@@ -34,7 +47,7 @@ class Shape(C.Structure):
 
 class Fwd(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x", "alpha", "Wg", "W", "z", "q", "kW", "lse", "pq", "E", "u")] + [
-        ("need_bwd", C.c_int32)]
+        ("need_bwd", C.c_int32), ("edge_scratch", C.c_void_p)]
 
 
 class Bwd(C.Structure):
@@ -54,12 +67,15 @@ _PROTOTYPES = {
     "msgat_graph_count": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, c_int_p]),
     "msgat_graph_build": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32] + [C.c_void_p] * 7),
     "msgat_graph_validate": (C.c_int, [C.POINTER(Graph)]),
+    "msgat_graph_jds_count": (C.c_int, [C.c_void_p, C.c_int32, c_int_p, c_int_p]),
+    "msgat_graph_jds_build": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p] * 6),
+    "msgat_edge_scratch_floats": (C.c_size_t, [C.POINTER(Shape), C.POINTER(Graph)]),
     "msgat_gacn_forward": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph), C.POINTER(Fwd), C.c_void_p]),
     "msgat_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Shape), C.c_int32]),
     "msgat_gacn_backward": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph), C.POINTER(Bwd), C.c_void_p]),
     "msgat_stage_project": (C.c_int, [C.POINTER(Shape)] + [C.c_void_p] * 6),
     "msgat_stage_scores": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)] + [C.c_void_p] * 7),
-    "msgat_stage_aggregate": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph), C.c_int32] + [C.c_void_p] * 4),
+    "msgat_stage_aggregate": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph), C.c_int32] + [C.c_void_p] * 5),
     "msgat_stage_aggregate_project": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)] + [C.c_void_p] * 6),
     "msgat_stage_mix": (C.c_int, [C.POINTER(Shape), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -116,7 +132,7 @@ def lib() -> C.CDLL:
             for name, (res, args) in _PROTOTYPES.items():
                 fn = getattr(h, name)  # AttributeError here = header/library mismatch
                 fn.restype, fn.argtypes = res, args
-            if h.msgat_abi_version() != 2:
+            if h.msgat_abi_version() != 3:
                 raise MsgatError("libmsgat_hip.so ABI version mismatch; rebuild")
             _handle = h
     return _handle

@@ -131,6 +131,95 @@ __global__ __launch_bounds__(kAggBlock) void k_agg_cols(
   }
 }
 
+// ---- column aggregate on the sliced jagged-diagonal edge layout (msgat_jds_t) --------------------------------
+// Same LDS plan as k_agg_cols (one 4-timestep column of the slab per pass) but the edges are read from the
+// JDS form: wave w owns slices w, w+16, ...; for jagged column k of its slice lane l reads neighbour index and
+// coefficient at colstart[k] + l -- one coalesced 4-B-per-lane load each, no dependent address, kJU columns
+// requested per trip and two trips in flight (register double buffer).  Measured at the stress graph
+// (N = 8192, degree 17, G = 256, Cu = 24): see profiles/r02/.  The CSR form it replaces spent its time in
+// ~4 dependent round trips per row (row extent -> window -> window ...) of 16-B pieces at a ~68-B stride.
+constexpr int kJU = MSGAT_JDS_PAD;  // jagged columns per trip; colstart is padded by this many entries
+
+struct JdsTrip {
+  int id[kJU];
+  float e[kJU];
+  int cnt[kJU];  // wave-uniform (SGPRs)
+};
+
+// requests one trip: all loads unconditional at clamped addresses (a load inside a branch costs hipcc's
+// counted vmcnt waits, see mfma.hip); inactive lanes re-read the column's last entry and are masked at use
+__device__ __forceinline__ void jds_issue(const int* __restrict__ colstart, const int* __restrict__ jidx,
+                                          const float* Eg, int k, int k1, int lane, int last,
+                                          JdsTrip& t) {
+  int cs[kJU + 1];
+#pragma unroll
+  for (int u = 0; u <= kJU; ++u) cs[u] = colstart[k + u];  // padded: always in bounds
+#pragma unroll
+  for (int u = 0; u < kJU; ++u) {
+    t.cnt[u] = (k + u < k1) ? cs[u + 1] - cs[u] : 0;
+    const int p = min(cs[u] + min(lane, max(t.cnt[u] - 1, 0)), last);
+    t.id[u] = jidx[p];
+    t.e[u] = Eg[p];
+  }
+}
+
+__device__ __forceinline__ float jds_mask(float e, int lane, int cnt) {
+  // bitwise, not a select or a multiply: a select lets hipcc sink the load into a branch, a multiply would
+  // turn another row's Inf/NaN coefficient into a NaN here
+  return __int_as_float(__float_as_int(e) & -(int)(lane < cnt));
+}
+
+template <int T4>
+__global__ __launch_bounds__(kAggBlock) void k_agg_jds(
+    const int* __restrict__ slice, const int* __restrict__ colstart, const int* __restrict__ lane_row,
+    const int* __restrict__ jidx, const float4* __restrict__ u4, const float* __restrict__ Ej,
+    const float* __restrict__ addvec, const float4* __restrict__ extra4, float4* __restrict__ v4, int Bg,
+    int Cu, int N, int nnz, int n_slices) {
+  extern __shared__ float4 slab[];  // [N]: column j of the [N][T4] slab
+  const int g = blockIdx.y;
+  const int r = g / Bg;
+  const int c = blockIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const size_t base = ((size_t)g * Cu + c) * N * T4;
+  const float* Eg = Ej + (size_t)g * nnz;
+  const float av = (addvec != nullptr) ? addvec[r * Cu + c] : 0.f;
+  const int last = nnz - 1;
+  for (int j = 0; j < T4; ++j) {
+    // stage column j: 8 loads in flight per lane, clamped addresses, masked LDS writes
+    for (int n0 = 0; n0 < N; n0 += 8 * kAggBlock) {
+      float4 t[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = u4[base + (size_t)min(n0 + i * kAggBlock + (int)threadIdx.x, N - 1) * T4 + j];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)  // lanes past N re-write entry N-1 with the value they re-read from it: no branch,
+        slab[min(n0 + i * kAggBlock + (int)threadIdx.x, N - 1)] = t[i];  // so the 8 loads stay in flight together
+    }
+    __syncthreads();
+    for (int s = wave; s < n_slices; s += kAggBlock / 64) {
+      const int k0 = slice[s], k1 = slice[s + 1];
+      const int row = lane_row[64 * s + lane];
+      float4 ex = f4zero();
+      if (addvec != nullptr && row >= 0) ex = extra4[((size_t)g * N + row) * T4 + j];
+      float4 acc = f4zero();
+      JdsTrip a, b;
+      jds_issue(colstart, jidx, Eg, k0, k1, lane, last, a);
+      for (int k = k0; k < k1; k += 2 * kJU) {
+        jds_issue(colstart, jidx, Eg, min(k + kJU, k1), k1, lane, last, b);
+#pragma unroll
+        for (int u = 0; u < kJU; ++u) f4fma(jds_mask(a.e[u], lane, a.cnt[u]), slab[a.id[u]], acc);
+        jds_issue(colstart, jidx, Eg, min(k + 2 * kJU, k1), k1, lane, last, a);
+#pragma unroll
+        for (int u = 0; u < kJU; ++u) f4fma(jds_mask(b.e[u], lane, b.cnt[u]), slab[b.id[u]], acc);
+      }
+      if (row >= 0) {
+        if (addvec != nullptr) f4fma(av, ex, acc);
+        v4[base + (size_t)row * T4 + j] = acc;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- gather-from-L2 aggregate (not even one column fits LDS) ------------------------------------------
 template <int T4>
 __global__ __launch_bounds__(kBlock) void k_agg_glb(
@@ -152,12 +241,22 @@ __global__ __launch_bounds__(kBlock) void k_agg_glb(
 }
 
 template <int T4>
-static int launch_aggregate_t(const int* ptr, const int* idx, int nnz, const float* u, const float* E,
-                              const float* addvec, const float* extra, float* v, int G, int Bg, int Cu,
-                              int N, hipStream_t s) {
+static int launch_aggregate_t(const int* ptr, const int* idx, int nnz, const msgat_jds_t* jds, const float* u,
+                              const float* E, const float* addvec, const float* extra, float* v, int G, int Bg,
+                              int Cu, int N, hipStream_t s) {
   const int T = 4 * T4;
   const int CH = slab_channels(N, T, Cu, kLdsBudget);
-  if (CH >= 1) {
+  if (jds != nullptr) {  // E is in the JDS order of this structure (the caller permuted it by jds->src)
+    const size_t lds = (size_t)N * sizeof(float4);
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_jds<T4>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
+    }
+    hipLaunchKernelGGL(k_agg_jds<T4>, dim3(Cu, G), dim3(kAggBlock), lds, s, jds->slice, jds->colstart,
+                       jds->lane_row, jds->idx, (const float4*)u, E, addvec, (const float4*)extra, (float4*)v, Bg,
+                       Cu, N, nnz, jds->n_slices);
+  } else if (CH >= 1) {
     const size_t lds = (size_t)CH * N * T * sizeof(float);
     if (lds > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_lds<T4>),
@@ -185,14 +284,14 @@ static int launch_aggregate_t(const int* ptr, const int* idx, int nnz, const flo
   return MSGAT_OK;
 }
 
-int launch_aggregate(const int* ptr, const int* idx, int nnz, const float* u, const float* E,
-                     const float* addvec, const float* extra, float* v, int G, int Bg, int Cu, int N,
-                     int T, hipStream_t s) {
+int launch_aggregate(const int* ptr, const int* idx, int nnz, const msgat_jds_t* jds, const float* u,
+                     const float* E, const float* addvec, const float* extra, float* v, int G, int Bg, int Cu,
+                     int N, int T, hipStream_t s) {
   switch (T) {
-    case 4: return launch_aggregate_t<1>(ptr, idx, nnz, u, E, addvec, extra, v, G, Bg, Cu, N, s);
-    case 8: return launch_aggregate_t<2>(ptr, idx, nnz, u, E, addvec, extra, v, G, Bg, Cu, N, s);
-    case 12: return launch_aggregate_t<3>(ptr, idx, nnz, u, E, addvec, extra, v, G, Bg, Cu, N, s);
-    case 16: return launch_aggregate_t<4>(ptr, idx, nnz, u, E, addvec, extra, v, G, Bg, Cu, N, s);
+    case 4: return launch_aggregate_t<1>(ptr, idx, nnz, jds, u, E, addvec, extra, v, G, Bg, Cu, N, s);
+    case 8: return launch_aggregate_t<2>(ptr, idx, nnz, jds, u, E, addvec, extra, v, G, Bg, Cu, N, s);
+    case 12: return launch_aggregate_t<3>(ptr, idx, nnz, jds, u, E, addvec, extra, v, G, Bg, Cu, N, s);
+    case 16: return launch_aggregate_t<4>(ptr, idx, nnz, jds, u, E, addvec, extra, v, G, Bg, Cu, N, s);
   }
   return MSGAT_ERR_UNSUPPORTED;
 }
@@ -334,7 +433,71 @@ __global__ __launch_bounds__(kBlock) void k_sddmm(
   }
 }
 
-int sddmm_chunks(int Cu, int N, int T) {
+// ---- SDDMM on the JDS layout: one 4-timestep column of u in LDS per pass -------------------------------
+// Block (chunk k, group g) walks its channels x T/4 columns; per pass it stages column j of u[c] and every
+// lane (= row, through lane_row) dots its dv[c,row,4j..4j+3] against the staged neighbour entries of its
+// row's edges.  The per-edge partial lives in dEp (JDS order: lane l of jagged column k owns position
+// colstart[k] + l, so the read-modify-write is one coalesced 4-B-per-lane load + store, private to the
+// lane: no atomics, fixed (c, j) summation order).
+template <int T4>
+__global__ __launch_bounds__(kAggBlock) void k_sddmm_jds(
+    const int* __restrict__ slice, const int* __restrict__ colstart, const int* __restrict__ lane_row,
+    const int* __restrict__ jidx, const float4* __restrict__ u4, const float4* __restrict__ dv4,
+    float* __restrict__ dEp, int Cu, int N, int nnz, int n_slices, int CH, int nchunks) {
+  extern __shared__ float4 slab[];  // [N]
+  const int g = blockIdx.y;
+  const int kc = blockIdx.x;
+  const int c0 = kc * CH;
+  const int ch = min(CH, Cu - c0);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  float* out = dEp + ((size_t)g * nchunks + kc) * nnz;
+  const int last = nnz - 1;
+  for (int pass = 0; pass < ch * T4; ++pass) {
+    const int c = pass / T4, j = pass - c * T4;
+    const size_t base = ((size_t)g * Cu + c0 + c) * N * T4;
+    for (int n0 = 0; n0 < N; n0 += 8 * kAggBlock) {
+      float4 t[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = u4[base + (size_t)min(n0 + i * kAggBlock + (int)threadIdx.x, N - 1) * T4 + j];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)  // lanes past N re-write entry N-1 with the value they re-read from it: no branch,
+        slab[min(n0 + i * kAggBlock + (int)threadIdx.x, N - 1)] = t[i];  // so the 8 loads stay in flight together
+    }
+    __syncthreads();
+    for (int s = wave; s < n_slices; s += kAggBlock / 64) {
+      const int k0 = slice[s], k1 = slice[s + 1];
+      const int row = lane_row[64 * s + lane];
+      const float4 a = dv4[base + (size_t)max(row, 0) * T4 + j];  // lanes past N hold no edge: never stored
+      JdsTrip ta, tb;  // .e carries the running partial of the edge (previous passes)
+      jds_issue(colstart, jidx, out, k0, k1, lane, last, ta);
+      for (int k = k0; k < k1; k += 2 * kJU) {
+        jds_issue(colstart, jidx, out, min(k + kJU, k1), k1, lane, last, tb);
+#pragma unroll
+        for (int u = 0; u < kJU; ++u)
+          if (lane < ta.cnt[u]) {  // a store in a branch costs nothing; the loads above stay unconditional
+            const float prev = (pass == 0) ? 0.f : ta.e[u];
+            out[colstart[min(k + u, k1)] + lane] = f4dot(a, slab[ta.id[u]], prev);
+          }
+        jds_issue(colstart, jidx, out, min(k + 2 * kJU, k1), k1, lane, last, ta);
+#pragma unroll
+        for (int u = 0; u < kJU; ++u)
+          if (lane < tb.cnt[u]) {
+            const float prev = (pass == 0) ? 0.f : tb.e[u];
+            out[colstart[min(k + kJU + u, k1)] + lane] = f4dot(a, slab[tb.id[u]], prev);
+          }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// channel chunks of the SDDMM (= partial buffers of [G,nnz]): LDS slab form: as many channels as fit the LDS
+// budget per chunk; JDS form: enough chunks to give every CU a block, at most one per channel
+int sddmm_chunks(int G, int Cu, int N, int T, bool jds) {
+  if (jds) {
+    const int want = max(1, min(Cu, cdiv(256, max(G, 1))));
+    return cdiv(Cu, cdiv(Cu, want));  // every chunk owns at least one channel
+  }
   const int CH = slab_channels(N, T, Cu, kLdsBudget);
   return CH >= 1 ? cdiv(Cu, CH) : 1;
 }
@@ -344,7 +507,19 @@ static int launch_sddmm_t(const msgat_graph_t& gr, const float* u, const float* 
                           int G, int Cu, int N, hipStream_t s) {
   const int T = 4 * T4;
   const int CH = slab_channels(N, T, Cu, kLdsBudget);
-  if (CH >= 1) {
+  if (jds_usable(gr.jds_rows, gr.nnz, N, T)) {  // partials come out in JDS order (k_edge_grad reads them through pos)
+    const msgat_jds_t& jd = gr.jds_rows;
+    const int nch = sddmm_chunks(G, Cu, N, T, true);
+    const int chj = cdiv(Cu, nch);
+    const size_t lds = (size_t)N * sizeof(float4);
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm_jds<T4>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
+    }
+    hipLaunchKernelGGL(k_sddmm_jds<T4>, dim3(nch, G), dim3(kAggBlock), lds, s, jd.slice, jd.colstart, jd.lane_row,
+                       jd.idx, (const float4*)u, (const float4*)dv, dEp, Cu, N, gr.nnz, jd.n_slices, chj, nch);
+  } else if (CH >= 1) {
     const size_t lds = (size_t)CH * N * T * sizeof(float);
     if (lds > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm<T4, true>),

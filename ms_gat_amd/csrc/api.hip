@@ -24,6 +24,13 @@ int check_graph(const msgat_shape_t* sh, const msgat_graph_t* gr) {
   if (gr->n_nodes != sh->N || gr->nnz < 0) return MSGAT_ERR_SHAPE;
   if (!gr->rowptr || !gr->colptr) return MSGAT_ERR_NULL;
   if (gr->nnz > 0 && (!gr->col || !gr->val || !gr->erow || !gr->crow || !gr->cperm)) return MSGAT_ERR_NULL;
+  for (const msgat_jds_t* j : {&gr->jds_rows, &gr->jds_cols}) {
+    if (j->n_slices == 0) continue;
+    if (j->n_slices != cdiv(sh->N, 64) || j->n_cols < 0) return MSGAT_ERR_GRAPH;
+    if (!j->slice || !j->colstart || !j->lane_row) return MSGAT_ERR_NULL;
+    if (gr->nnz > 0 && (!j->idx || !j->src)) return MSGAT_ERR_NULL;
+  }
+  if (gr->jds_rows.n_slices != 0 && gr->nnz > 0 && !gr->jds_rows.pos) return MSGAT_ERR_NULL;
   return MSGAT_OK;
 }
 
@@ -35,12 +42,14 @@ struct BwdPlan {
   size_t off_dEp, off_gE, off_Ec, off_delta, off_dkW, off_dq, off_dv, off_dwg, off_cp, total;
 };
 
-BwdPlan plan_bwd(const msgat_shape_t& sh, int nnz) {
+// jds: 1 = the SDDMM runs on the JDS layout, 0 = on the CSR, -1 = unknown (size query: room for either)
+BwdPlan plan_bwd(const msgat_shape_t& sh, int nnz, int jds) {
   BwdPlan p{};
   p.mode = msgat_gacn_mode(sh.C, sh.Co);
   p.G = sh.R * sh.Bg;
   p.Cu = (p.mode == MSGAT_MODE_PROJ_FIRST) ? sh.Co : sh.C;
-  p.nch = sddmm_chunks(p.Cu, sh.N, sh.T);
+  if (jds < 0) p.nch = max(sddmm_chunks(p.G, p.Cu, sh.N, sh.T, false), sddmm_chunks(p.G, p.Cu, sh.N, sh.T, true));
+  else p.nch = sddmm_chunks(p.G, p.Cu, sh.N, sh.T, jds != 0);
   const size_t G = p.G, N = sh.N, T = sh.T, P = N * T;
   size_t off = 0;
   auto take = [&](size_t floats) {
@@ -119,16 +128,48 @@ extern "C" int msgat_stage_scores(const msgat_shape_t* sh, const msgat_graph_t* 
   return launch_scores(*gr, q, Wg, kW, lse, pq, E, sh->R * sh->Bg, sh->Bg, sh->N, sh->T, (hipStream_t)stream);
 }
 
+// forward aggregate over the CSR: on the JDS layout when the graph carries a usable one (E re-ordered into
+// `scratch` first), on the CSR otherwise
+static int aggregate_rows(const msgat_shape_t* sh, const msgat_graph_t* gr, int Cu, const float* u, const float* E,
+                          float* v, float* scratch, hipStream_t s) {
+  const int G = sh->R * sh->Bg;
+  if (jds_usable(gr->jds_rows, gr->nnz, sh->N, sh->T)) {
+    if (!scratch) return MSGAT_ERR_WORKSPACE;
+    int st = launch_permute_edges(E, gr->jds_rows.src, scratch, G, gr->nnz, s);
+    if (st) return st;
+    return launch_aggregate(gr->rowptr, gr->col, gr->nnz, &gr->jds_rows, u, scratch, nullptr, nullptr, v, G, sh->Bg,
+                            Cu, sh->N, sh->T, s);
+  }
+  return launch_aggregate(gr->rowptr, gr->col, gr->nnz, nullptr, u, E, nullptr, nullptr, v, G, sh->Bg, Cu, sh->N,
+                          sh->T, s);
+}
+
+// transposed aggregate over the CSC (backward): E goes to CSC order -- or to the JDS order of the CSC -- in Ec
+static int aggregate_cols(const msgat_shape_t* sh, const msgat_graph_t* gr, int Cu, const float* dv, const float* E,
+                          float* Ec, const float* addvec, const float* extra, float* out, hipStream_t s) {
+  const int G = sh->R * sh->Bg;
+  const bool jds = jds_usable(gr->jds_cols, gr->nnz, sh->N, sh->T);
+  int st = launch_permute_edges(E, jds ? gr->jds_cols.src : gr->cperm, Ec, G, gr->nnz, s);
+  if (st) return st;
+  return launch_aggregate(gr->colptr, gr->crow, gr->nnz, jds ? &gr->jds_cols : nullptr, dv, Ec, addvec, extra, out, G,
+                          sh->Bg, Cu, sh->N, sh->T, s);
+}
+
+extern "C" size_t msgat_edge_scratch_floats(const msgat_shape_t* sh, const msgat_graph_t* gr) {
+  if (check_shape(sh) != MSGAT_OK || check_graph(sh, gr) != MSGAT_OK) return 0;
+  return jds_usable(gr->jds_rows, gr->nnz, sh->N, sh->T) ? (size_t)sh->R * sh->Bg * gr->nnz : 0;
+}
+
 extern "C" int msgat_stage_aggregate(const msgat_shape_t* sh, const msgat_graph_t* gr, int32_t Cu,
-                                     const float* u, const float* E, float* v, void* stream) {
+                                     const float* u, const float* E, float* v, float* edge_scratch,
+                                     void* stream) {
   int st = check_shape(sh);
   if (st) return st;
   st = check_graph(sh, gr);
   if (st) return st;
   if (!u || !v || (gr->nnz > 0 && !E)) return MSGAT_ERR_NULL;
   if (Cu <= 0 || Cu > kMaxC) return MSGAT_ERR_SHAPE;
-  return launch_aggregate(gr->rowptr, gr->col, gr->nnz, u, E, nullptr, nullptr, v, sh->R * sh->Bg,
-                          sh->Bg, Cu, sh->N, sh->T, (hipStream_t)stream);
+  return aggregate_rows(sh, gr, Cu, u, E, v, edge_scratch, (hipStream_t)stream);
 }
 
 extern "C" int msgat_stage_aggregate_project(const msgat_shape_t* sh, const msgat_graph_t* gr,
@@ -324,7 +365,7 @@ static msgat_shape_t plain_shape(const msgat_shape_t* sh) {
 
 extern "C" size_t msgat_attention_bwd_workspace_bytes(const msgat_shape_t* sh, int32_t nnz) {
   if (check_shape(sh) != MSGAT_OK || nnz < 0) return 0;
-  return plan_bwd(plain_shape(sh), nnz).total;
+  return plan_bwd(plain_shape(sh), nnz, -1).total;
 }
 
 extern "C" int msgat_attention_backward(const msgat_shape_t* shp, const msgat_graph_t* gr, const float* u,
@@ -339,8 +380,9 @@ extern "C" int msgat_attention_backward(const msgat_shape_t* shp, const msgat_gr
   if (st) return st;
   if (!u || !dv || !q || !kW || !lse || !pq || !Wg || !du || !dq || !dWg) return MSGAT_ERR_NULL;
   if (gr->nnz > 0 && !E) return MSGAT_ERR_NULL;
-  const BwdPlan p = plan_bwd(*sh, gr->nnz);
-  if (p.total > 0 && (!workspace || workspace_bytes < p.total)) return MSGAT_ERR_WORKSPACE;
+  const BwdPlan p = plan_bwd(*sh, gr->nnz, jds_usable(gr->jds_rows, gr->nnz, sh->N, sh->T) ? 1 : 0);
+  const size_t need = plan_bwd(*sh, gr->nnz, -1).total;  // what the size query promised to be enough
+  if (need > 0 && (!workspace || workspace_bytes < need)) return MSGAT_ERR_WORKSPACE;
   char* ws = (char*)workspace;
   hipStream_t s = (hipStream_t)stream;
   float* dEp = (float*)(ws + p.off_dEp);
@@ -358,9 +400,7 @@ extern "C" int msgat_attention_backward(const msgat_shape_t* shp, const msgat_gr
   if (st) return st;
   st = launch_dwg(q, dkW, dwgp, dWg, G, Bg, N, T, s);
   if (st) return st;
-  st = launch_permute_edges(E, gr->cperm, Ec, G, gr->nnz, s);
-  if (st) return st;
-  return launch_aggregate(gr->colptr, gr->crow, gr->nnz, dv, Ec, nullptr, nullptr, du, G, Bg, sh->C, N, T, s);
+  return aggregate_cols(sh, gr, sh->C, dv, E, Ec, nullptr, nullptr, du, s);
 }
 
 // ---- prediction head ----------------------------------------------------------------------------------
@@ -462,21 +502,19 @@ extern "C" int msgat_gacn_forward(const msgat_shape_t* sh, const msgat_graph_t* 
 
   switch (mode) {
     case MSGAT_MODE_PLAIN:
-      return launch_aggregate(gr->rowptr, gr->col, gr->nnz, io->x, io->E, nullptr, nullptr, io->z, G,
-                              sh->Bg, sh->C, sh->N, sh->T, s);
+      return aggregate_rows(sh, gr, sh->C, io->x, io->E, io->z, io->edge_scratch, s);
     case MSGAT_MODE_AGG_FIRST:
       return launch_aggregate_project(*gr, io->x, io->E, io->W, io->need_bwd ? io->u : nullptr, io->z, G,
                                       sh->Bg, sh->C, sh->Co, sh->N, sh->T, s);
     default:
-      return launch_aggregate(gr->rowptr, gr->col, gr->nnz, io->u, io->E, nullptr, nullptr, io->z, G,
-                              sh->Bg, sh->Co, sh->N, sh->T, s);
+      return aggregate_rows(sh, gr, sh->Co, io->u, io->E, io->z, io->edge_scratch, s);
   }
 }
 
 // ---- fused backward --------------------------------------------------------------------------------
 extern "C" size_t msgat_bwd_workspace_bytes(const msgat_shape_t* sh, int32_t nnz) {
   if (check_shape(sh) != MSGAT_OK || nnz < 0) return 0;
-  return plan_bwd(*sh, nnz).total;
+  return plan_bwd(*sh, nnz, -1).total;
 }
 
 extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t* gr,
@@ -490,9 +528,9 @@ extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t*
       !io->dx || !io->dalpha || !io->dWg || !io->workspace)
     return MSGAT_ERR_NULL;
   if (gr->nnz > 0 && !io->E) return MSGAT_ERR_NULL;
-  const BwdPlan p = plan_bwd(*sh, gr->nnz);
+  const BwdPlan p = plan_bwd(*sh, gr->nnz, jds_usable(gr->jds_rows, gr->nnz, sh->N, sh->T) ? 1 : 0);
   if (p.mode != MSGAT_MODE_PLAIN && (!io->W || !io->dW || !io->u)) return MSGAT_ERR_NULL;
-  if (io->workspace_bytes < p.total) return MSGAT_ERR_WORKSPACE;
+  if (io->workspace_bytes < plan_bwd(*sh, gr->nnz, -1).total) return MSGAT_ERR_WORKSPACE;
   if (((uintptr_t)io->workspace & 255) != 0) return MSGAT_ERR_WORKSPACE;
 
   hipStream_t s = (hipStream_t)stream;
@@ -529,18 +567,16 @@ extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t*
   st = launch_dwg(io->q, dkW, dwgp, io->dWg, G, Bg, N, T, s);
   if (st) return st;
 
-  st = launch_permute_edges(io->E, gr->cperm, Ec, G, gr->nnz, s);
-  if (st) return st;
   if (p.mode == MSGAT_MODE_PROJ_FIRST) {
     // du = E^T dz;  dx = W^T du + alpha (x) dq;  dW = du x^T;  dalpha = dq . x
-    st = launch_aggregate(gr->colptr, gr->crow, gr->nnz, dv, Ec, nullptr, nullptr, dvb, G, Bg, Co, N, T, s);
+    st = aggregate_cols(sh, gr, Co, dv, io->E, Ec, nullptr, nullptr, dvb, s);
     if (st) return st;
     st = launch_project(dvb, io->W, 1, nullptr, io->alpha, dq, io->dx, nullptr, G, Bg, Co, C, P, s);
     if (st) return st;
     return launch_chanpair(dvb, dq, io->x, cpp, io->dW, Co * C, io->dalpha, C, G, Bg, Co + 1, C, P, s);
   }
   // PLAIN / AGG_FIRST:  dx = E^T dv + alpha (x) dq;  dalpha = dq . x
-  st = launch_aggregate(gr->colptr, gr->crow, gr->nnz, dv, Ec, io->alpha, dq, io->dx, G, Bg, C, N, T, s);
+  st = aggregate_cols(sh, gr, C, dv, io->E, Ec, io->alpha, dq, io->dx, s);
   if (st) return st;
   return launch_chanpair(nullptr, dq, io->x, cpp, nullptr, 0, io->dalpha, C, G, Bg, 1, C, P, s);
 }

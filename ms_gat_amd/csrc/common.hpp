@@ -55,6 +55,13 @@ inline int slab_channels(int N, int T, int Cu, int budget_bytes) {
   return ch;
 }
 
+// the JDS kernels hold one float4 per node in LDS; they take over when no whole [N,T] slab fits (or on request)
+inline bool jds_usable(const msgat_jds_t& j, int nnz, int N, int T) {
+  if (j.n_slices <= 0 || nnz <= 0 || !j.slice || !j.colstart || !j.lane_row || !j.idx || !j.src) return false;
+  if ((size_t)N * 16 > (size_t)kLdsMax - 1024) return false;
+  return j.prefer != 0 || slab_channels(N, T, 1, kLdsBudget) == 0;
+}
+
 // Diagnostic builds only (tools/*_stamps.hip compile a kernel file with -DMSGAT_STAMPS): s_memtime
 // stamps of the phases of a block, written to a buffer nothing else reads.  The product library is
 // built without the macro and contains no stamp.
@@ -184,16 +191,18 @@ int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, i
 int launch_scores(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW, float* lse,
                   float* pq, float* E, int G, int Bg, int N, int T, hipStream_t s);
 // v[g,c,n,:] = sum_{e in ptr[n]..ptr[n+1]} E[g,e] u[g,c,idx[e],:] (+ addvec[r,c]*extra[g,n,:])
-int launch_aggregate(const int* ptr, const int* idx, int nnz, const float* u, const float* E,
-                     const float* addvec, const float* extra, float* v, int G, int Bg, int Cu, int N,
-                     int T, hipStream_t s);
+// jds != nullptr: E is in that layout's position order (permuted by jds->src) and the JDS kernel runs
+int launch_aggregate(const int* ptr, const int* idx, int nnz, const msgat_jds_t* jds, const float* u,
+                     const float* E, const float* addvec, const float* extra, float* v, int G, int Bg, int Cu,
+                     int N, int T, hipStream_t s);
 // Ec[g,k] = E[g, cperm[k]]: edge coefficients in CSC order for the transposed aggregate
 int launch_permute_edges(const float* E, const int* cperm, float* Ec, int G, int nnz, hipStream_t s);
 int launch_aggregate_project(const msgat_graph_t& gr, const float* x, const float* E,
                              const float* W, float* y, float* z, int G, int Bg, int C, int Co,
                              int N, int T, hipStream_t s);
 // dEp[g,k,e] = sum over channel chunk k of <dv[g,c,erow[e],:], u[g,c,col[e],:]>
-int sddmm_chunks(int Cu, int N, int T);
+// (with gr.jds_rows usable the partials are in JDS position order: launch_bwd_edge reads them through pos)
+int sddmm_chunks(int G, int Cu, int N, int T, bool jds);
 int launch_sddmm(const msgat_graph_t& gr, const float* u, const float* dv, float* dEp, int G,
                  int Cu, int N, int T, hipStream_t s);
 int launch_bwd_edge(const msgat_graph_t& gr, const float* dEp, int nchunks, const float* E,

@@ -10,12 +10,13 @@ namespace msgat {
 // k_bwd_row (one lane per row): delta_n = sum_e g_e;  dkW[n] = sum_e g_e (q[col_e] - pq[n]);
 //   dq[n] = dkW[n] Wg^T  (the row-local part of dq).
 __global__ __launch_bounds__(kBlock) void k_edge_grad(const float* __restrict__ dEp, int nchunks,
-                                                      const float* __restrict__ E,
+                                                      const float* __restrict__ E, const int* __restrict__ epos,
                                                       float* __restrict__ gE, int nnz) {
   const int g = blockIdx.y;
   const int e = blockIdx.x * kBlock + threadIdx.x;
   if (e >= nnz) return;
-  const float* p = dEp + (size_t)g * nchunks * nnz + e;
+  // epos: the SDDMM ran on the JDS layout and left its partials in position order
+  const float* p = dEp + (size_t)g * nchunks * nnz + (epos != nullptr ? epos[e] : e);
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int k = 0;
   for (; k + 4 <= nchunks; k += 4) {  // 4 independent loads in flight; fixed summation order
@@ -97,7 +98,8 @@ int launch_bwd_edge(const msgat_graph_t& gr, const float* dEp, int nchunks, cons
                     float* dkW, float* dq, int G, int Bg, int N, int T, hipStream_t s) {
   if (gr.nnz > 0) {
     dim3 ge(cdiv(gr.nnz, kBlock), G);
-    hipLaunchKernelGGL(k_edge_grad, ge, dim3(kBlock), 0, s, dEp, nchunks, E, gE, gr.nnz);
+    const int* epos = jds_usable(gr.jds_rows, gr.nnz, N, T) ? gr.jds_rows.pos : nullptr;
+    hipLaunchKernelGGL(k_edge_grad, ge, dim3(kBlock), 0, s, dEp, nchunks, E, epos, gE, gr.nnz);
     MSGAT_CHECK_LAUNCH();
   }
   dim3 grid(cdiv(N, kBlock), G);

@@ -70,8 +70,10 @@ class _GACNFunction(torch.autograd.Function):
             u = new(G, Cin, N, T)
         else:
             u = None
+        nscratch = int(L.msgat_edge_scratch_floats(C.byref(shape), C.byref(gstruct)))
+        scratch = new(nscratch) if nscratch else None   # E in the order of the JDS layout (large graphs)
         io = _lib.Fwd(_ptr(x), _ptr(alpha), _ptr(Wg), _ptr(W), _ptr(z), _ptr(q), _ptr(kW), _ptr(lse), _ptr(pq),
-                      _ptr(E), _ptr(u), int(need_bwd))
+                      _ptr(E), _ptr(u), int(need_bwd), _ptr(scratch))
         st = L.msgat_gacn_forward(C.byref(shape), C.byref(gstruct), C.byref(io), _stream_handle(dev))
         _lib.check(st, "msgat_gacn_forward")
 
@@ -640,8 +642,10 @@ class _AttentionCoreFunction(torch.autograd.Function):
         stream = _stream_handle(dev)
         _lib.check(L.msgat_stage_scores(C.byref(shape), C.byref(gstruct), _ptr(q), _ptr(Wg), _ptr(kW), _ptr(lse), _ptr(pq),
                                         _ptr(E), stream), "msgat_stage_scores")
-        _lib.check(L.msgat_stage_aggregate(C.byref(shape), C.byref(gstruct), Cu, _ptr(u), _ptr(E), _ptr(z), stream),
-                   "msgat_stage_aggregate")
+        nscratch = int(L.msgat_edge_scratch_floats(C.byref(shape), C.byref(gstruct)))
+        scratch = _new(u, nscratch) if nscratch else None
+        _lib.check(L.msgat_stage_aggregate(C.byref(shape), C.byref(gstruct), Cu, _ptr(u), _ptr(E), _ptr(z), _ptr(scratch),
+                                           stream), "msgat_stage_aggregate")
         if need_bwd:
             ctx.graph, ctx.R = graph, R
             ctx.save_for_backward(u, q, Wg, kW, lse, pq, E)

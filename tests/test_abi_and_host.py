@@ -34,15 +34,31 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(h, n), f"{n} declared in include/msgat_hip.h but not exported"
     assert sorted(_lib.exported_symbols()) == names, "ctypes prototypes and header disagree"
-    assert _lib.lib().msgat_abi_version() == 2
+    assert _lib.lib().msgat_abi_version() == 3
 
 
-def test_struct_layouts_match_the_header():
+def test_struct_layouts_match_the_header(tmp_path):
+    """sizeof / offsetof of every ABI struct as the C compiler lays out include/msgat_hip.h vs the ctypes mirror."""
+    import subprocess
     from ms_gat_amd import _lib
-    assert C.sizeof(_lib.Shape) == 6 * 4
-    assert C.sizeof(_lib.Graph) == 8 + 7 * 8
-    assert C.sizeof(_lib.Fwd) == 11 * 8 + 8       # 11 pointers + int32 (padded)
-    assert C.sizeof(_lib.Bwd) == 16 * 8 + 8
+    structs = {"msgat_shape_t": _lib.Shape, "msgat_jds_t": _lib.Jds, "msgat_graph_t": _lib.Graph,
+               "msgat_fwd_t": _lib.Fwd, "msgat_bwd_t": _lib.Bwd, "msgat_seg_t": _lib.Seg}
+    lines = []
+    for cname, cls in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for field, *_ in cls._fields_:
+            lines.append(f'printf("{cname}.{field} %zu\\n", offsetof({cname}, {field}));')
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "msgat_hip.h"\nint main(void) {\n' + "\n".join(lines)
+                   + "\nreturn 0; }\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for field, *_ in cls._fields_:
+            assert int(got[f"{cname}.{field}"]) == getattr(cls, field).offset, f"{cname}.{field}"
+    assert _lib.JDS_PAD == 8 and "#define MSGAT_JDS_PAD 8" in open(os.path.join(ROOT, "include", "msgat_hip.h")).read()
 
 
 def test_mode_selection_and_status_strings():
@@ -119,6 +135,66 @@ def test_graph_validate_rejects_corruption():
     g.col[3] = 99
     with pytest.raises(_lib.MsgatError):
         g.validate()
+
+
+def _numpy_jds(ptr, idx, ids):
+    """Restatement of msgat_graph_jds_build: slices of 64 rows, stable sort by degree (descending) inside a
+    slice, k-th entries of a slice's rows back to back."""
+    n = len(ptr) - 1
+    slices, colstart, lane_row, jidx, jsrc = [0], [], [], [], []
+    for r0 in range(0, n, 64):
+        rows = list(range(r0, min(r0 + 64, n)))
+        deg = {r: int(ptr[r + 1] - ptr[r]) for r in rows}
+        order = sorted(rows, key=lambda r: -deg[r])          # Python's sort is stable
+        lane_row += order + [-1] * (64 - len(order))
+        for k in range(deg[order[0]] if order else 0):
+            colstart.append(len(jidx))
+            for r in order:
+                if deg[r] > k:
+                    jidx.append(int(idx[ptr[r] + k]))
+                    jsrc.append(int(ids[ptr[r] + k]))
+        slices.append(len(colstart))
+    return np.array(slices), np.array(colstart + [len(jidx)] * 9), np.array(lane_row), np.array(jidx), np.array(jsrc)
+
+
+@pytest.mark.parametrize("n,e,seed", [(1, 0, 0), (7, 5, 1), (64, 300, 2), (65, 70, 3), (200, 1500, 4), (883, 866, 5)])
+def test_native_jds_build_matches_numpy(n, e, seed):
+    """The sliced jagged-diagonal edge layout of the large-graph kernels (msgat_jds_t): pure index work, bit-exact."""
+    import ms_gat_amd
+    g = ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(n, e, seed), jds="always")
+    assert g.has_jds
+    g.validate()
+    nnz = g.nnz
+    for form, ptr, idx, ids in (("jds_rows", g.rowptr, g.col, np.arange(nnz)), ("jds_cols", g.colptr, g.crow, g.cperm.numpy())):
+        j = g._jds[form]
+        sl, cs, lr, ji, js = _numpy_jds(ptr.numpy(), idx.numpy(), ids)
+        assert j["n_slices"] == (n + 63) // 64 and j["n_cols"] == len(cs) - 9
+        assert np.array_equal(j["slice"].numpy(), sl)
+        assert np.array_equal(j["colstart"].numpy(), cs)
+        assert np.array_equal(j["lane_row"].numpy(), lr)
+        assert np.array_equal(j["idx"].numpy(), ji)
+        assert np.array_equal(j["src"].numpy(), js)
+        assert sorted(js.tolist()) == list(range(nnz))      # a permutation of the CSR edges
+        if "pos" in j:
+            assert np.array_equal(j["pos"].numpy()[js], np.arange(nnz))
+
+
+def test_jds_is_built_for_large_graphs_only_and_validate_catches_corruption():
+    import ms_gat_amd
+    from ms_gat_amd import _lib
+    assert not ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(300, 340, 0)).has_jds       # a slab fits LDS
+    assert not ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(2100, 3000, 0), jds="never").has_jds
+    big = ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(2100, 3000, 0))
+    assert big.has_jds and not big.jds_prefer
+    big.validate()
+    hs = big.host_struct()
+    assert hs.jds_rows.n_slices == 33 and hs.jds_cols.n_slices == 33 and hs.jds_rows.prefer == 0
+    for field, at in (("idx", 5), ("src", 7), ("lane_row", 3), ("colstart", 2)):
+        g = ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(100, 300, 1), jds="always")
+        t = g._jds["jds_cols"][field]
+        t[at] = t[at] + 1
+        with pytest.raises(_lib.MsgatError):
+            g.validate()
 
 
 def test_sym_norm_adjacency_matches_reference_and_oracle():

@@ -24,15 +24,17 @@ def _cuda(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(_dev())
 
 
-def run_ours(x, adj, Wg, alpha, W, dz):
+def run_ours(x, adj, Wg, alpha, W, dz, jds=None):
     """One fwd+bwd through ms_gat_amd.ops.gacn with R stacked relations.
-    x [G,C,N,T]; Wg [R,T,T]; alpha [R,C]; W [R,Co,C] or None; dz like the output."""
+    x [G,C,N,T]; Wg [R,T,T]; alpha [R,C]; W [R,Co,C] or None; dz like the output.
+    jds: None = the library's own choice of edge layout; "always" / "never" force it (SparseGraph)."""
     import ms_gat_amd
     xt = _cuda(x).requires_grad_(True)
     Wgt = _cuda(Wg).requires_grad_(True)
     at = _cuda(alpha).requires_grad_(True)
     Wt = None if W is None else _cuda(W).requires_grad_(True)
-    z = ms_gat_amd.gacn(xt, at, Wgt, Wt, _cuda(adj))
+    graph = _cuda(adj) if jds is None else ms_gat_amd.SparseGraph(torch.from_numpy(np.ascontiguousarray(adj)), jds=jds)
+    z = ms_gat_amd.gacn(xt, at, Wgt, Wt, graph)
     z.backward(_cuda(dz))
     torch.cuda.synchronize()
     out = dict(z=z.detach().cpu().numpy(), dx=xt.grad.cpu().numpy(), dWg=Wgt.grad.cpu().numpy(),
@@ -341,6 +343,30 @@ def test_stress_graph_uses_the_large_n_path():
     assert_close(got, want, what="N=4000 AGG_FIRST")
     prob = random_problem(1, 1, 40, 8, 3500, 12, 7000, seed=62)
     assert_close(run_ours(*prob), _dense_oracle_gpu(*prob), what="N=3500 PROJ_FIRST")
+
+
+@pytest.mark.parametrize("R,Bg,C,Co,N,E,seed", [
+    (1, 2, 5, 0, 50, 60, 70),        # PLAIN, one partial slice
+    (2, 2, 3, 24, 130, 400, 71),     # AGG_FIRST: backward aggregate with the alpha (x) dq epilogue, SDDMM on C channels
+    (1, 3, 40, 8, 200, 2500, 72),    # PROJ_FIRST, degrees ~26: several trips of 8 jagged columns per slice
+    (3, 1, 72, 24, 64, 600, 73),     # exactly one slice, dense-ish rows, R relations
+    (1, 1, 12, 4, 333, 300, 74),     # sparse: most rows have 1-2 edges
+])
+def test_jds_edge_layout_agrees_with_the_csr_kernels_and_the_oracle(R, Bg, C, Co, N, E, seed):
+    """The large-graph kernels (k_agg_jds, k_sddmm_jds: one column of a slab in LDS, edges in the sliced
+    jagged-diagonal layout) forced onto small graphs, against the fp64 oracle and against the CSR kernels."""
+    prob = random_problem(R, Bg, C, Co, N, 12, E, seed)
+    got = run_ours(*prob, jds="always")
+    assert_close(got, oracle_f64(*prob), what=f"JDS N={N} C={C}->{Co}")
+    ref = run_ours(*prob, jds="never")
+    assert np.array_equal(got["z"], ref["z"]), "the aggregate sums a row's edges in CSR order in both layouts"
+    assert_close(got, ref, tol=2e-6, what="JDS vs CSR kernels")
+
+
+def test_jds_with_other_timestep_counts():
+    for T, seed in ((4, 80), (8, 81), (16, 82)):
+        prob = random_problem(1, 2, 6, 3, 150, T, 500, seed)
+        assert_close(run_ours(*prob, jds="always"), oracle_f64(*prob), what=f"JDS T={T}")
 
 
 def test_mid_size_graph_uses_a_large_lds_slab():

@@ -87,6 +87,8 @@ def main():
     sp = C.byref(shape)
     gp = C.byref(gs)
     ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    nscr = int(L.msgat_edge_scratch_floats(sp, gp))
+    escr = torch.empty(nscr, device=dev) if nscr else None
     stages = {}
 
     def reg(name, nbytes, fn):
@@ -99,7 +101,7 @@ def main():
     reg("scores_nopq  q->kW,lse,E", 4 * G * P * 3,
         lambda: _lib.check(L.msgat_stage_scores(sp, gp, ptr(q), ptr(Wg), ptr(kW), ptr(lse), None, ptr(E), st()), "s"))
     reg("aggregate    u->z (Cu=Co)", 8 * G * Co * P,
-        lambda: _lib.check(L.msgat_stage_aggregate(sp, gp, Co, ptr(u), ptr(E), ptr(out_u), st()), "a"))
+        lambda: _lib.check(L.msgat_stage_aggregate(sp, gp, Co, ptr(u), ptr(E), ptr(out_u), ptr(escr), st()), "a"))
     reg("mix_bwd      du,dq->dx", 4 * G * P * (Co + 1 + Cc),
         lambda: _lib.check(L.msgat_stage_mix(sp, Co, Cc, ptr(u), ptr(W), 1, ptr(alpha), ptr(dq), ptr(out_x), st()), "m"))
     nfl = L.msgat_contract_partial_floats(sp, Co + 1, Cc)

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Times the edge kernels of the N = 8192 stress graph (BASELINE.json configs[4]: degree 16, R = 4, B = 64,
+C = 72 -> 24) with HIP events: forward aggregate, backward (transposed) aggregate and SDDMM through the fused
+backward is not separable, so the stages are called directly.
+
+    python tools/stress_kernels.py [--B 64] [--reps 5] [--jds auto|never]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ms_gat_amd  # noqa: E402
+from ms_gat_amd import _lib  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=64)
+    ap.add_argument("--R", type=int, default=4)
+    ap.add_argument("--N", type=int, default=8192)
+    ap.add_argument("--E", type=int, default=65536)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--jds", default="auto")
+    a = ap.parse_args()
+    N, T, R, B, Cc, Co = a.N, 12, a.R, a.B, 72, 24
+    G = R * B
+    dev = torch.device("cuda:0")
+    L = _lib.lib()
+    graph = ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(N, a.E, 0), jds=a.jds)
+    gs, _keep = graph.on(dev)
+    nnz = graph.nnz
+    shape = _lib.Shape(R, B, Cc, Co, N, T)
+    sp, gp = C.byref(shape), C.byref(gs)
+    u = torch.randn(G, Co, N, T, device=dev)
+    v = torch.empty_like(u)
+    E = torch.rand(G, nnz, device=dev)
+    nscr = int(L.msgat_edge_scratch_floats(sp, gp))
+    scr = torch.empty(max(nscr, 1), device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        for _ in range(a.reps):
+            fn()
+        t1.record()
+        t1.synchronize()
+        return t0.elapsed_time(t1) / a.reps
+
+    alg = 2 * 4 * G * Co * N * T + 4 * G * nnz + 8 * nnz + 4 * (N + 1)
+    ms = timed(lambda: _lib.check(L.msgat_stage_aggregate(sp, gp, Co, u.data_ptr(), E.data_ptr(), v.data_ptr(),
+                                                          scr.data_ptr() if nscr else None, st), "agg"))
+    print(f"aggregate (incl. edge permute)  {ms:8.3f} ms   {alg / ms / 1e6:8.1f} GB/s algorithmic  jds={graph.has_jds} nnz={nnz}",
+          flush=True)
+
+    # attention backward on the projected features: SDDMM + edge/row passes + dense column pass + transposed aggregate
+    shp = _lib.Shape(R, B, Co, 0, N, T)
+    q, kW, pq = (torch.randn(G, N, T, device=dev) * 0.3 for _ in range(3))
+    lse = torch.randn(G, N, device=dev) + 12.0
+    Wg = torch.randn(R, T, T, device=dev) * 0.3
+    dv = torch.randn(G, Co, N, T, device=dev)
+    du, dq, dWg = torch.empty_like(u), torch.empty(G, N, T, device=dev), torch.empty(R, T, T, device=dev)
+    nb = int(L.msgat_attention_bwd_workspace_bytes(C.byref(shp), nnz))
+    ws = torch.empty(nb, device=dev, dtype=torch.uint8)
+    ms = timed(lambda: _lib.check(L.msgat_attention_backward(C.byref(shp), gp, u.data_ptr(), dv.data_ptr(), q.data_ptr(),
+                                                             kW.data_ptr(), lse.data_ptr(), pq.data_ptr(), E.data_ptr(),
+                                                             Wg.data_ptr(), du.data_ptr(), dq.data_ptr(), dWg.data_ptr(),
+                                                             ws.data_ptr(), ws.numel(), st), "bwd"))
+    print(f"attention backward (all stages) {ms:8.3f} ms", flush=True)
+
+
+if __name__ == "__main__":
+    main()
