@@ -59,24 +59,34 @@ enum {
   MSGAT_MODE_PROJ_FIRST = 2 /* C >  Co: project to Co channels, then aggregate (3x less gather) */
 };
 
-/* Sliced jagged-diagonal (JDS) form of one sparse structure (rows of the CSR, or columns of the
- * CSC), used by the aggregate / SDDMM kernels when an [N,T] slab does not fit LDS (N > ~3400 at
- * T = 12; the N = 8192 stress graph): rows are cut into slices of 64 (one wavefront), sorted by
- * degree inside a slice, and the k-th edges of a slice's rows are stored back to back, so lane l of
- * a wave reads entry colstart[k] + l -- coalesced, every byte once, no dependent address.
- * Built on the host by msgat_graph_jds_build().  n_slices == 0: absent (the CSR kernels run). */
-#define MSGAT_JDS_PAD 8 /* colstart carries this many extra trailing entries, all equal to nnz */
-typedef struct msgat_jds {
-  int32_t n_slices;        /* ceil(N / 64), or 0 when the layout is absent                      */
-  int32_t n_cols;          /* jagged columns in total = sum over slices of the largest degree   */
-  const int32_t* slice;    /* [n_slices+1]  first jagged column of each slice                   */
-  const int32_t* colstart; /* [n_cols+1+MSGAT_JDS_PAD] first position of each jagged column (padded)   */
-  const int32_t* lane_row; /* [64 n_slices] row handled by each lane of a slice, -1 past N      */
-  const int32_t* idx;      /* [nnz]         neighbour node of each position                     */
-  const int32_t* src;      /* [nnz]         position -> CSR edge index (E is permuted by this)  */
-  const int32_t* pos;      /* [nnz]         CSR edge index -> position (row form only)          */
-  int32_t prefer;          /* != 0: use the JDS kernels even when a whole slab fits LDS (tests) */
-} msgat_jds_t;
+/* Sliced ELLPACK form (SELL-64, rows sorted by degree) of one sparse structure -- the rows of the
+ * CSR, or the columns of the CSC -- used by the aggregate / SDDMM kernels when an [N,T] slab does
+ * not fit LDS (N > ~3400 at T = 12; the N = 8192 stress graph).  Those kernels keep ONE 4-timestep
+ * column of a slab in LDS per pass, so the edge lists are re-read once per (group, channel, column):
+ * several times the bytes of the features themselves, and through the CSR that is dependent round
+ * trips of 16-B pieces at a ~68-B stride plus a dozen address instructions per edge.  Here the rows
+ * are sorted by degree (descending, stable), cut into slices of 64 (one wavefront) and every slice
+ * is padded to its largest degree rounded up to a multiple of 4 and stored in "trips" of 4 edges
+ * per row, lane-interleaved:
+ *     entry (slice s, k-th edge, lane l)  at position  slice_off[s] + 256 (k / 4) + 4 l + k % 4
+ * so lane l reads its edges 4t .. 4t+3 with ONE coalesced 16-B-per-lane load per array (1 KiB per
+ * wave instruction): no dependent address, no mask (padding entries carry coefficient 0).
+ * Sorting makes the degrees inside a slice nearly equal, so the padding is a few percent.
+ * Built on the host by msgat_graph_sell_build().  n_slices == 0: absent (the CSR kernels run). */
+#define MSGAT_SELL_SLACK 512 /* idx (and every per-position buffer) carries this many readable trailing entries */
+typedef struct msgat_sell {
+  int32_t n_slices;         /* ceil(N / 64), or 0 when the layout is absent                          */
+  int32_t n_pos;            /* positions in total = slice_off[n_slices] (>= nnz: padding included)    */
+  const int32_t* slice_off; /* [n_slices+1]  first position of each slice; width = difference / 64    */
+  const int32_t* lane_row;  /* [64 n_slices] row handled by each lane of a slice, -1 past N           */
+  const uint16_t* idx;      /* [n_pos+SLACK] neighbour node of each position (0 at padding); the layout
+                               is only built for N <= 10176 (one float4 per node must fit LDS)         */
+  const int32_t* src;       /* [n_pos]       position -> CSR edge index, -1 at padding                */
+  const int32_t* pos;       /* [nnz]         CSR edge index -> position (row form only)               */
+  int32_t prefer;           /* != 0: use the SELL kernels even when a whole slab fits LDS (tests)     */
+  int32_t pair_trips;       /* max over i of trips(slice i) + trips(slice n_slices-1-i), a trip = 4
+                               columns: the SDDMM keeps a wave's slice PAIR in registers when it fits    */
+} msgat_sell_t;
 
 /* Device-resident sparse adjacency.  Built on the host by msgat_graph_build() and copied
  * to the device by the caller. */
@@ -90,8 +100,8 @@ typedef struct msgat_graph {
   const int32_t* colptr; /* [N+1]  CSC column starts                                */
   const int32_t* crow;   /* [nnz]  row of each CSC entry                            */
   const int32_t* cperm;  /* [nnz]  CSC position -> CSR edge index                   */
-  msgat_jds_t jds_rows;  /* JDS of the CSR (forward aggregate, SDDMM); optional      */
-  msgat_jds_t jds_cols;  /* JDS of the CSC (transposed aggregate of backward); opt.  */
+  msgat_sell_t sell_rows; /* SELL of the CSR (forward aggregate, SDDMM); optional     */
+  msgat_sell_t sell_cols; /* SELL of the CSC (transposed aggregate of backward); opt. */
 } msgat_graph_t;
 
 typedef struct msgat_shape {
@@ -119,7 +129,7 @@ typedef struct msgat_fwd {
   float* u;           /* out AGG_FIRST: y [G,C,N,T] when need_bwd; PROJ_FIRST: W x [G,Co,N,T];
                              PLAIN: unused (may be NULL)                                  */
   int32_t need_bwd;
-  float* edge_scratch; /* tmp msgat_edge_scratch_floats() floats (0 unless the graph carries a JDS
+  float* edge_scratch; /* tmp msgat_edge_scratch_floats() floats (0 unless the graph carries a SELL
                              layout the aggregate will use: E re-ordered for it); may be NULL then */
 } msgat_fwd_t;
 
@@ -161,17 +171,18 @@ int msgat_graph_count(const float* adj, int32_t n, int64_t ld, int32_t* nnz_out)
 int msgat_graph_build(const float* adj, int32_t n, int64_t ld, int32_t nnz,
                       int32_t* rowptr, int32_t* col, float* val, int32_t* erow,
                       int32_t* colptr, int32_t* crow, int32_t* cperm);
-/* Host-side structural check of a (host-resident) graph (its JDS forms too, when present). */
+/* Host-side structural check of a (host-resident) graph (its SELL forms too, when present). */
 int msgat_graph_validate(const msgat_graph_t* host_graph);
-/* JDS form of a CSR (ptr = rowptr, idx = col, perm = NULL) or CSC (ptr = colptr, idx = crow,
- * perm = cperm) structure, all HOST pointers: first the sizes, then the arrays (see msgat_jds_t;
- * jpos may be NULL).  Pure index work: replaces nothing in the reference, it re-orders the
- * non-zeros of the mask of attention.py:36 for coalesced reads. */
-int msgat_graph_jds_count(const int32_t* ptr, int32_t n, int32_t* n_slices_out, int32_t* n_cols_out);
-int msgat_graph_jds_build(const int32_t* ptr, const int32_t* idx, const int32_t* perm, int32_t n,
-                          int32_t nnz, int32_t n_slices, int32_t n_cols, int32_t* slice,
-                          int32_t* colstart, int32_t* lane_row, int32_t* jidx, int32_t* jsrc,
-                          int32_t* jpos);
+/* SELL form of a CSR (ptr = rowptr, idx = col, perm = NULL) or CSC (ptr = colptr, idx = crow,
+ * perm = cperm) structure, all HOST pointers: first the sizes, then the arrays (see msgat_sell_t;
+ * spos may be NULL; sidx must have n_pos + MSGAT_SELL_SLACK entries; n <= 65535).  Pure index work: replaces
+ * nothing in the reference, it re-orders the non-zeros of the mask of attention.py:36 for
+ * coalesced reads. */
+int msgat_graph_sell_count(const int32_t* ptr, int32_t n, int32_t* n_slices_out, int32_t* n_pos_out,
+                           int32_t* pair_trips_out);
+int msgat_graph_sell_build(const int32_t* ptr, const int32_t* idx, const int32_t* perm, int32_t n,
+                           int32_t nnz, int32_t n_slices, int32_t n_pos, int32_t* slice_off,
+                           int32_t* lane_row, uint16_t* sidx, int32_t* ssrc, int32_t* spos);
 
 /* ---- device: fused entry points --------------------------------------------------
  * msgat_gacn_forward replaces attention.py:33-36 (+ msgat.py:27-28 when Co > 0).
@@ -180,7 +191,7 @@ int msgat_graph_jds_build(const int32_t* ptr, const int32_t* idx, const int32_t*
 size_t msgat_edge_scratch_floats(const msgat_shape_t* shape, const msgat_graph_t* graph);
 int msgat_gacn_forward(const msgat_shape_t* shape, const msgat_graph_t* graph,
                        const msgat_fwd_t* io, void* stream);
-size_t msgat_bwd_workspace_bytes(const msgat_shape_t* shape, int32_t nnz);
+size_t msgat_bwd_workspace_bytes(const msgat_shape_t* shape, const msgat_graph_t* graph);
 int msgat_gacn_backward(const msgat_shape_t* shape, const msgat_graph_t* graph,
                         const msgat_bwd_t* io, void* stream);
 
@@ -310,7 +321,7 @@ int msgat_contract_segments(int32_t R, int32_t Bg, int32_t N, int32_t T, const m
  * callers that produced u and q themselves (e.g. in a merged channel-mixing pass):
  *   du = E^T dv  [G,Cu,N,T],   dq = total gradient at q  [G,N,T],   dWg [R,T,T].
  * shape->C is Cu (the channels of u), shape->Co is ignored. */
-size_t msgat_attention_bwd_workspace_bytes(const msgat_shape_t* shape, int32_t nnz);
+size_t msgat_attention_bwd_workspace_bytes(const msgat_shape_t* shape, const msgat_graph_t* graph);
 int msgat_attention_backward(const msgat_shape_t* shape, const msgat_graph_t* graph, const float* u,
                              const float* dv, const float* q, const float* kW, const float* lse,
                              const float* pq, const float* E, const float* Wg, float* du, float* dq,

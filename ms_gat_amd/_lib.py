@@ -19,15 +19,15 @@ c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int32)
 
 
-JDS_PAD = 8  # MSGAT_JDS_PAD
+SELL_SLACK = 512  # MSGAT_SELL_SLACK
 
 
-class Jds(C.Structure):
-    """msgat_jds_t: sliced jagged-diagonal form of the CSR rows / CSC columns (n_slices = 0: absent)."""
+class Sell(C.Structure):
+    """msgat_sell_t: degree-sorted sliced-ELLPACK form of the CSR rows / CSC columns (n_slices = 0: absent)."""
     _fields_ = [
-        ("n_slices", C.c_int32), ("n_cols", C.c_int32),
-        ("slice", C.c_void_p), ("colstart", C.c_void_p), ("lane_row", C.c_void_p), ("idx", C.c_void_p),
-        ("src", C.c_void_p), ("pos", C.c_void_p), ("prefer", C.c_int32),
+        ("n_slices", C.c_int32), ("n_pos", C.c_int32),
+        ("slice_off", C.c_void_p), ("lane_row", C.c_void_p), ("idx", C.c_void_p), ("src", C.c_void_p),
+        ("pos", C.c_void_p), ("prefer", C.c_int32), ("pair_trips", C.c_int32),
     ]
 
 
@@ -36,7 +36,7 @@ class Graph(C.Structure):
         ("n_nodes", C.c_int32), ("nnz", C.c_int32),
         ("rowptr", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p), ("erow", C.c_void_p),
         ("colptr", C.c_void_p), ("crow", C.c_void_p), ("cperm", C.c_void_p),
-        ("jds_rows", Jds), ("jds_cols", Jds),
+        ("sell_rows", Sell), ("sell_cols", Sell),
     ]
 
 
@@ -67,11 +67,11 @@ _PROTOTYPES = {
     "msgat_graph_count": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, c_int_p]),
     "msgat_graph_build": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32] + [C.c_void_p] * 7),
     "msgat_graph_validate": (C.c_int, [C.POINTER(Graph)]),
-    "msgat_graph_jds_count": (C.c_int, [C.c_void_p, C.c_int32, c_int_p, c_int_p]),
-    "msgat_graph_jds_build": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p] * 6),
+    "msgat_graph_sell_count": (C.c_int, [C.c_void_p, C.c_int32, c_int_p, c_int_p, c_int_p]),
+    "msgat_graph_sell_build": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p] * 5),
     "msgat_edge_scratch_floats": (C.c_size_t, [C.POINTER(Shape), C.POINTER(Graph)]),
     "msgat_gacn_forward": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph), C.POINTER(Fwd), C.c_void_p]),
-    "msgat_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Shape), C.c_int32]),
+    "msgat_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Shape), C.POINTER(Graph)]),
     "msgat_gacn_backward": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph), C.POINTER(Bwd), C.c_void_p]),
     "msgat_stage_project": (C.c_int, [C.POINTER(Shape)] + [C.c_void_p] * 6),
     "msgat_stage_scores": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)] + [C.c_void_p] * 7),
@@ -97,7 +97,7 @@ _PROTOTYPES = {
     "msgat_contract_segments_partial_floats": (C.c_size_t, [C.c_int32] * 3),
     "msgat_contract_segments": (C.c_int, [C.c_int32] * 4 + [C.POINTER(Seg), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                           C.c_void_p, C.c_void_p]),
-    "msgat_attention_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Shape), C.c_int32]),
+    "msgat_attention_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Shape), C.POINTER(Graph)]),
     "msgat_attention_backward": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)] + [C.c_void_p] * 12 + [C.c_size_t, C.c_void_p]),
     "msgat_head_forward_partial_floats": (C.c_size_t, [C.c_int32] * 4),
     "msgat_head_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p]),

@@ -12,6 +12,7 @@
 // gather-from-L2 kernel.  Either way the kernel is HBM-bound: algorithmic bytes =
 // read u once + write v once.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace msgat {
 
@@ -131,92 +132,151 @@ __global__ __launch_bounds__(kAggBlock) void k_agg_cols(
   }
 }
 
-// ---- column aggregate on the sliced jagged-diagonal edge layout (msgat_jds_t) --------------------------------
-// Same LDS plan as k_agg_cols (one 4-timestep column of the slab per pass) but the edges are read from the
-// JDS form: wave w owns slices w, w+16, ...; for jagged column k of its slice lane l reads neighbour index and
-// coefficient at colstart[k] + l -- one coalesced 4-B-per-lane load each, no dependent address, kJU columns
-// requested per trip and two trips in flight (register double buffer).  Measured at the stress graph
-// (N = 8192, degree 17, G = 256, Cu = 24): see profiles/r02/.  The CSR form it replaces spent its time in
-// ~4 dependent round trips per row (row extent -> window -> window ...) of 16-B pieces at a ~68-B stride.
-constexpr int kJU = MSGAT_JDS_PAD;  // jagged columns per trip; colstart is padded by this many entries
+// ---- column aggregate on the SELL-64 edge layout (msgat_sell_t) ----------------------------------------------
+// Same LDS plan as k_agg_cols (one 4-timestep column of the slab in LDS), but the edges come from the degree-sorted
+// sliced-ELLPACK form: wave w owns slices w, w+16, ...; edges 4t .. 4t+3 of a slice's 64 rows ("trip" t) sit at
+// slice_off + 256 t + 4 lane, so a trip is ONE coalesced 16-B-per-lane load per array (neighbour indices,
+// coefficients) with no address arithmetic and no mask (padding carries coefficient 0), several trips in flight.
+// Per edge that leaves 4 FMAs, one shift and one LDS read.  The CSR form spent ~16 vector + ~9 scalar
+// instructions and ~4 dependent global round trips per row on the same work (profiles/r02/stress_*).
+constexpr int kSD = 4;  // trips (of 4 edges per row) in flight per wave
+constexpr int kSellMaxSlices = 10;  // slices per wave: ceil(ceil(10176 / 64) / 16), 10176 = the most nodes whose float4 column fits LDS
 
-struct JdsTrip {
-  int id[kJU];
-  float e[kJU];
-  int cnt[kJU];  // wave-uniform (SGPRs)
+struct SellTrip {
+  uint2 id;  // 4 neighbour indices, 16 bits each
+  float4 e;
 };
 
-// requests one trip: all loads unconditional at clamped addresses (a load inside a branch costs hipcc's
-// counted vmcnt waits, see mfma.hip); inactive lanes re-read the column's last entry and are masked at use
-__device__ __forceinline__ void jds_issue(const int* __restrict__ colstart, const int* __restrict__ jidx,
-                                          const float* Eg, int k, int k1, int lane, int last,
-                                          JdsTrip& t) {
-  int cs[kJU + 1];
+// Requests trip min(t, ntrip-1) of a slice: unconditional, so hipcc keeps counted vmcnt waits; a trip index past
+// the slice re-reads its last trip (the lines are in L2) and is simply not consumed.  pi2 / pe4 point at this
+// lane's entry of trip 0.
+__device__ __forceinline__ void sell_issue(const uint2* __restrict__ pi2, const float4* pe4, int t, int ntrip,
+                                           SellTrip& x) {
+  const int tc = min(t, ntrip - 1);
+  x.id = pi2[64 * tc];
+  x.e = pe4[64 * tc];
+}
+// lab: the same trip without global loads
+__device__ __forceinline__ void sell_fake(int t, SellTrip& x) {
+  const unsigned l = threadIdx.x & 63;
+  x.id = make_uint2(((l * 37 + t * 101) & 8191) | (((l * 53 + t * 211) & 8191) << 16),
+                    ((l * 71 + t * 307) & 8191) | (((l * 89 + t * 401) & 8191) << 16));
+  x.e = make_float4(1.f, 0.5f, 0.25f, 0.125f);
+}
+__device__ __forceinline__ int4 sell_unpack(uint2 v) {
+  return make_int4((int)(v.x & 0xffffu), (int)(v.x >> 16), (int)(v.y & 0xffffu), (int)(v.y >> 16));
+}
+
+template <int LAB = 0>
+__device__ __forceinline__ void sell_gather(const SellTrip& x, const float4* slab, float4& acc) {
+  const int4 id = sell_unpack(x.id);
+  if (LAB == 1) {  // lab: conflict-free LDS reads that still depend on the loaded indices
+    const int l = threadIdx.x & 63;
+    f4fma(x.e.x, slab[(id.x & 0) + l], acc);
+    f4fma(x.e.y, slab[(id.y & 0) + l + 64], acc);
+    f4fma(x.e.z, slab[(id.z & 0) + l + 128], acc);
+    f4fma(x.e.w, slab[(id.w & 0) + l + 192], acc);
+    return;
+  }
+  f4fma(x.e.x, slab[id.x], acc);
+  f4fma(x.e.y, slab[id.y], acc);
+  f4fma(x.e.z, slab[id.z], acc);
+  f4fma(x.e.w, slab[id.w], acc);
+}
+
+// stage column j of the [N][T4] slab at `src`: NB loads in flight per lane; lanes past N re-write entry N-1 with
+// the value they re-read from it (no branch, so the loads stay in flight together)
+template <int T4, int NB = 8>
+__device__ __forceinline__ void stage_column(float4* slab, const float4* __restrict__ src, int j, int N) {
+  for (int n0 = 0; n0 < N; n0 += NB * kAggBlock) {
+    float4 t[NB];
 #pragma unroll
-  for (int u = 0; u <= kJU; ++u) cs[u] = colstart[k + u];  // padded: always in bounds
+    for (int i = 0; i < NB; ++i) t[i] = src[(size_t)min(n0 + i * kAggBlock + (int)threadIdx.x, N - 1) * T4 + j];
 #pragma unroll
-  for (int u = 0; u < kJU; ++u) {
-    t.cnt[u] = (k + u < k1) ? cs[u + 1] - cs[u] : 0;
-    const int p = min(cs[u] + min(lane, max(t.cnt[u] - 1, 0)), last);
-    t.id[u] = jidx[p];
-    t.e[u] = Eg[p];
+    for (int i = 0; i < NB; ++i) slab[min(n0 + i * kAggBlock + (int)threadIdx.x, N - 1)] = t[i];
   }
 }
 
-__device__ __forceinline__ float jds_mask(float e, int lane, int cnt) {
-  // bitwise, not a select or a multiply: a select lets hipcc sink the load into a branch, a multiply would
-  // turn another row's Inf/NaN coefficient into a NaN here
-  return __int_as_float(__float_as_int(e) & -(int)(lane < cnt));
-}
-
-template <int T4>
-__global__ __launch_bounds__(kAggBlock) void k_agg_jds(
-    const int* __restrict__ slice, const int* __restrict__ colstart, const int* __restrict__ lane_row,
-    const int* __restrict__ jidx, const float4* __restrict__ u4, const float* __restrict__ Ej,
-    const float* __restrict__ addvec, const float4* __restrict__ extra4, float4* __restrict__ v4, int Bg,
-    int Cu, int N, int nnz, int n_slices) {
+template <int T4, int LAB = 0>
+__global__ __launch_bounds__(kAggBlock) void k_agg_sell(
+    const int* __restrict__ slice_off, const int* __restrict__ lane_row, const uint16_t* __restrict__ sidx,
+    const float4* __restrict__ u4, const float* __restrict__ Es, const float* __restrict__ addvec,
+    const float4* __restrict__ extra4, float4* __restrict__ v4, int G, int Bg, int Cu, int N, int n_pos,
+    int n_slices) {
   extern __shared__ float4 slab[];  // [N]: column j of the [N][T4] slab
-  const int g = blockIdx.y;
+  // XCD-aware block -> (group, channel, column) map.  Workgroups are dealt round-robin over the 8 XCDs (block b
+  // runs on XCD b % 8), each with its own 4 MB L2.  Two things must meet in ONE L2 at the same time:
+  //   - the Cu x T/4 blocks of a group all read the same E[g] (0.6 MB at the stress graph): group g is pinned to
+  //     XCD g % 8, so an L2 serves one or two groups' coefficients instead of eleven;
+  //   - the T/4 column blocks of one (group, channel) slab touch the same 128-B lines (a column is 16 B of every
+  //     48-B row) for reading u and for writing v: they take consecutive slots of the XCD, run side by side, and
+  //     the fabric sees every line once instead of T/4 times, the partial-line stores merging in L2.
+  // Without either the kernel moved 3-5x its algorithmic bytes over the fabric and ran at the same 4.2 ms
+  // whatever its instruction count (profiles/r02/stress_*).
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int j = slot % T4;
+  const int c = (slot / T4) % Cu;
+  const int g = (slot / (T4 * Cu)) * 8 + xcd;
+  if (g >= G) return;  // grid is padded to a multiple of 8 groups
   const int r = g / Bg;
-  const int c = blockIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const size_t base = ((size_t)g * Cu + c) * N * T4;
-  const float* Eg = Ej + (size_t)g * nnz;
+  const float* Eg = Es + (size_t)g * n_pos;
   const float av = (addvec != nullptr) ? addvec[r * Cu + c] : 0.f;
-  const int last = nnz - 1;
-  for (int j = 0; j < T4; ++j) {
-    // stage column j: 8 loads in flight per lane, clamped addresses, masked LDS writes
-    for (int n0 = 0; n0 < N; n0 += 8 * kAggBlock) {
-      float4 t[8];
+  if (LAB != 3) stage_column<T4>(slab, u4 + base, j, N);
+  __syncthreads();
+  // The rows of a slice are scattered over N (the layout is sorted by degree), so results are not stored from
+  // here: 64 lanes x 16 B to 64 different 128-B lines per instruction cost 1.07 of the kernel's 2.95 ms (lab
+  // variants, profiles/r02/stress_agg_sell_lab.txt).  They wait in registers until every wave is done with the
+  // staged column, go back into its LDS space at their row, and leave in row order: consecutive lanes write
+  // consecutive rows (and read `extra` the same way).
+  float4 accs[kSellMaxSlices];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) t[i] = u4[base + (size_t)min(n0 + i * kAggBlock + (int)threadIdx.x, N - 1) * T4 + j];
-#pragma unroll
-      for (int i = 0; i < 8; ++i)  // lanes past N re-write entry N-1 with the value they re-read from it: no branch,
-        slab[min(n0 + i * kAggBlock + (int)threadIdx.x, N - 1)] = t[i];  // so the 8 loads stay in flight together
-    }
-    __syncthreads();
-    for (int s = wave; s < n_slices; s += kAggBlock / 64) {
-      const int k0 = slice[s], k1 = slice[s + 1];
-      const int row = lane_row[64 * s + lane];
-      float4 ex = f4zero();
-      if (addvec != nullptr && row >= 0) ex = extra4[((size_t)g * N + row) * T4 + j];
+  for (int i = 0; i < kSellMaxSlices; ++i) {
+    accs[i] = f4zero();
+    const int s = wave + i * (kAggBlock / 64);
+    if (s < n_slices) {  // wave-uniform
+      const int off = slice_off[s];
+      const int ntrip = (slice_off[s + 1] - off) >> 8;  // 256 entries per trip
+      const uint2* pi4 = reinterpret_cast<const uint2*>(sidx + off) + lane;
+      const float4* pe4 = reinterpret_cast<const float4*>(Eg + off) + lane;
       float4 acc = f4zero();
-      JdsTrip a, b;
-      jds_issue(colstart, jidx, Eg, k0, k1, lane, last, a);
-      for (int k = k0; k < k1; k += 2 * kJU) {
-        jds_issue(colstart, jidx, Eg, min(k + kJU, k1), k1, lane, last, b);
-#pragma unroll
-        for (int u = 0; u < kJU; ++u) f4fma(jds_mask(a.e[u], lane, a.cnt[u]), slab[a.id[u]], acc);
-        jds_issue(colstart, jidx, Eg, min(k + 2 * kJU, k1), k1, lane, last, a);
-#pragma unroll
-        for (int u = 0; u < kJU; ++u) f4fma(jds_mask(b.e[u], lane, b.cnt[u]), slab[b.id[u]], acc);
+      if (ntrip > 0) {  // wave-uniform (a slice of rows without edges has no trips)
+        // kSD trips in flight, rotating through four register sets; consumption is guarded by wave-uniform
+        // branches that contain no load
+        SellTrip a, b, c4, d;
+        if (LAB == 2) sell_fake(0, a); else sell_issue(pi4, pe4, 0, ntrip, a);
+        if (LAB == 2) sell_fake(1, b); else sell_issue(pi4, pe4, 1, ntrip, b);
+        if (LAB == 2) sell_fake(2, c4); else sell_issue(pi4, pe4, 2, ntrip, c4);
+        if (LAB == 2) sell_fake(3, d); else sell_issue(pi4, pe4, 3, ntrip, d);
+        for (int t = 0; t < ntrip; t += kSD) {
+          sell_gather<LAB>(a, slab, acc);
+          if (LAB == 2) sell_fake(t + 4, a); else sell_issue(pi4, pe4, t + 4, ntrip, a);
+          if (t + 1 < ntrip) sell_gather<LAB>(b, slab, acc);
+          if (LAB == 2) sell_fake(t + 5, b); else sell_issue(pi4, pe4, t + 5, ntrip, b);
+          if (t + 2 < ntrip) sell_gather<LAB>(c4, slab, acc);
+          if (LAB == 2) sell_fake(t + 6, c4); else sell_issue(pi4, pe4, t + 6, ntrip, c4);
+          if (t + 3 < ntrip) sell_gather<LAB>(d, slab, acc);
+          if (LAB == 2) sell_fake(t + 7, d); else sell_issue(pi4, pe4, t + 7, ntrip, d);
+        }
       }
-      if (row >= 0) {
-        if (addvec != nullptr) f4fma(av, ex, acc);
-        v4[base + (size_t)row * T4 + j] = acc;
-      }
+      accs[i] = acc;
     }
-    __syncthreads();
+  }
+  __syncthreads();  // every wave is done reading the staged column
+#pragma unroll
+  for (int i = 0; i < kSellMaxSlices; ++i) {
+    const int s = wave + i * (kAggBlock / 64);
+    if (s < n_slices) {
+      const int row = lane_row[64 * s + lane];
+      if (row >= 0) slab[row] = accs[i];
+    }
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += kAggBlock) {
+    float4 acc = slab[n];
+    if (addvec != nullptr) f4fma(av, extra4[((size_t)g * N + n) * T4 + j], acc);
+    if (LAB != 4 || acc.x == 12345.678f) v4[base + (size_t)n * T4 + j] = acc;
   }
 }
 
@@ -241,21 +301,33 @@ __global__ __launch_bounds__(kBlock) void k_agg_glb(
 }
 
 template <int T4>
-static int launch_aggregate_t(const int* ptr, const int* idx, int nnz, const msgat_jds_t* jds, const float* u,
+static int launch_aggregate_t(const int* ptr, const int* idx, int nnz, const msgat_sell_t* sell, const float* u,
                               const float* E, const float* addvec, const float* extra, float* v, int G, int Bg,
                               int Cu, int N, hipStream_t s) {
   const int T = 4 * T4;
   const int CH = slab_channels(N, T, Cu, kLdsBudget);
-  if (jds != nullptr) {  // E is in the JDS order of this structure (the caller permuted it by jds->src)
+  if (sell != nullptr) {  // E is in the position order of this layout (the caller permuted it by sell->src)
     const size_t lds = (size_t)N * sizeof(float4);
     if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_jds<T4>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_sell<T4>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
     }
-    hipLaunchKernelGGL(k_agg_jds<T4>, dim3(Cu, G), dim3(kAggBlock), lds, s, jds->slice, jds->colstart,
-                       jds->lane_row, jds->idx, (const float4*)u, E, addvec, (const float4*)extra, (float4*)v, Bg,
-                       Cu, N, nnz, jds->n_slices);
+#define MSGAT_AGG_SELL(LAB)                                                                                          \
+  hipLaunchKernelGGL((k_agg_sell<T4, LAB>), dim3((unsigned)cdiv(G, 8) * 8 * Cu * T4), dim3(kAggBlock), lds, s,       \
+                     sell->slice_off, sell->lane_row, sell->idx, (const float4*)u, E, addvec, (const float4*)extra, \
+                     (float4*)v, G, Bg, Cu, N, sell->n_pos, sell->n_slices)
+#ifdef MSGAT_LAB  // diagnostic builds only (tools/_lab.sh): time the kernel with one phase removed
+    const char* lab = getenv("MSGAT_AGG_LAB");
+    const int labv = (lab && T4 == 3) ? atoi(lab) : 0;
+    if (labv == 1) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_sell<T4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); MSGAT_AGG_SELL(1); }
+    else if (labv == 2) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_sell<T4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); MSGAT_AGG_SELL(2); }
+    else if (labv == 3) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_sell<T4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); MSGAT_AGG_SELL(3); }
+    else if (labv == 4) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_sell<T4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); MSGAT_AGG_SELL(4); }
+    else
+#endif
+    MSGAT_AGG_SELL(0);
+#undef MSGAT_AGG_SELL
   } else if (CH >= 1) {
     const size_t lds = (size_t)CH * N * T * sizeof(float);
     if (lds > 64 * 1024) {
@@ -284,31 +356,34 @@ static int launch_aggregate_t(const int* ptr, const int* idx, int nnz, const msg
   return MSGAT_OK;
 }
 
-int launch_aggregate(const int* ptr, const int* idx, int nnz, const msgat_jds_t* jds, const float* u,
+int launch_aggregate(const int* ptr, const int* idx, int nnz, const msgat_sell_t* sell, const float* u,
                      const float* E, const float* addvec, const float* extra, float* v, int G, int Bg, int Cu,
                      int N, int T, hipStream_t s) {
   switch (T) {
-    case 4: return launch_aggregate_t<1>(ptr, idx, nnz, jds, u, E, addvec, extra, v, G, Bg, Cu, N, s);
-    case 8: return launch_aggregate_t<2>(ptr, idx, nnz, jds, u, E, addvec, extra, v, G, Bg, Cu, N, s);
-    case 12: return launch_aggregate_t<3>(ptr, idx, nnz, jds, u, E, addvec, extra, v, G, Bg, Cu, N, s);
-    case 16: return launch_aggregate_t<4>(ptr, idx, nnz, jds, u, E, addvec, extra, v, G, Bg, Cu, N, s);
+    case 4: return launch_aggregate_t<1>(ptr, idx, nnz, sell, u, E, addvec, extra, v, G, Bg, Cu, N, s);
+    case 8: return launch_aggregate_t<2>(ptr, idx, nnz, sell, u, E, addvec, extra, v, G, Bg, Cu, N, s);
+    case 12: return launch_aggregate_t<3>(ptr, idx, nnz, sell, u, E, addvec, extra, v, G, Bg, Cu, N, s);
+    case 16: return launch_aggregate_t<4>(ptr, idx, nnz, sell, u, E, addvec, extra, v, G, Bg, Cu, N, s);
   }
   return MSGAT_ERR_UNSUPPORTED;
 }
 
-// E in CSC order for the transposed aggregate of the backward pass: Ec[g,k] = E[g, cperm[k]]
+// E re-ordered for a gather: Eo[g,k] = E[g, perm[k]] (CSC order: perm = cperm; SELL position order: perm =
+// sell.src, whose padding entries are -1 and get coefficient 0).  The output row stride may exceed n (SELL).
 __global__ __launch_bounds__(kBlock) void k_permute_edges(const float* __restrict__ E,
-                                                          const int* __restrict__ cperm,
-                                                          float* __restrict__ Ec, int nnz) {
+                                                          const int* __restrict__ perm,
+                                                          float* __restrict__ Eo, int nnz, int n) {
   const int g = blockIdx.y;
   const int k = blockIdx.x * kBlock + threadIdx.x;
-  if (k < nnz) Ec[(size_t)g * nnz + k] = E[(size_t)g * nnz + cperm[k]];
+  if (k >= n) return;
+  const int e = perm[k];
+  Eo[(size_t)g * n + k] = (e >= 0) ? E[(size_t)g * nnz + e] : 0.f;
 }
 
-int launch_permute_edges(const float* E, const int* cperm, float* Ec, int G, int nnz, hipStream_t s) {
-  if (nnz == 0) return MSGAT_OK;
-  dim3 grid(cdiv(nnz, kBlock), G);
-  hipLaunchKernelGGL(k_permute_edges, grid, dim3(kBlock), 0, s, E, cperm, Ec, nnz);
+int launch_permute_edges(const float* E, const int* perm, float* Eo, int G, int nnz, int n, hipStream_t s) {
+  if (n == 0) return MSGAT_OK;
+  dim3 grid(cdiv(n, kBlock), G);
+  hipLaunchKernelGGL(k_permute_edges, grid, dim3(kBlock), 0, s, E, perm, Eo, nnz, n);
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
@@ -433,68 +508,143 @@ __global__ __launch_bounds__(kBlock) void k_sddmm(
   }
 }
 
-// ---- SDDMM on the JDS layout: one 4-timestep column of u in LDS per pass -------------------------------
-// Block (chunk k, group g) walks its channels x T/4 columns; per pass it stages column j of u[c] and every
-// lane (= row, through lane_row) dots its dv[c,row,4j..4j+3] against the staged neighbour entries of its
-// row's edges.  The per-edge partial lives in dEp (JDS order: lane l of jagged column k owns position
-// colstart[k] + l, so the read-modify-write is one coalesced 4-B-per-lane load + store, private to the
-// lane: no atomics, fixed (c, j) summation order).
+// ---- SDDMM on the SELL layout: one 4-timestep column of u in LDS per pass -------------------------------------
+// Block (chunk kc, group g) walks its channels x T/4 columns; per pass it stages column j of u[c] and every
+// lane (= row, through lane_row) dots its dv[c,row,4j..4j+3] against the staged entries of its row's
+// neighbours.  The per-edge partial lives in dEp in SELL position order, so the read-modify-write is one
+// coalesced 4-B-per-lane load + store, private to the lane: no atomics, fixed (c, j) summation order.
+// Padding positions accumulate garbage nobody reads (k_edge_grad goes through sell.pos).
 template <int T4>
-__global__ __launch_bounds__(kAggBlock) void k_sddmm_jds(
-    const int* __restrict__ slice, const int* __restrict__ colstart, const int* __restrict__ lane_row,
-    const int* __restrict__ jidx, const float4* __restrict__ u4, const float4* __restrict__ dv4,
-    float* __restrict__ dEp, int Cu, int N, int nnz, int n_slices, int CH, int nchunks) {
+__global__ __launch_bounds__(kAggBlock) void k_sddmm_sell(
+    const int* __restrict__ slice_off, const int* __restrict__ lane_row, const uint16_t* __restrict__ sidx,
+    const float4* __restrict__ u4, const float4* __restrict__ dv4, float* dEp, int Cu, int N, int n_pos,
+    int n_slices, int CH, int nchunks) {
   extern __shared__ float4 slab[];  // [N]
   const int g = blockIdx.y;
   const int kc = blockIdx.x;
   const int c0 = kc * CH;
   const int ch = min(CH, Cu - c0);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  float* out = dEp + ((size_t)g * nchunks + kc) * nnz;
-  const int last = nnz - 1;
+  float* out = dEp + ((size_t)g * nchunks + kc) * n_pos;
   for (int pass = 0; pass < ch * T4; ++pass) {
     const int c = pass / T4, j = pass - c * T4;
     const size_t base = ((size_t)g * Cu + c0 + c) * N * T4;
-    for (int n0 = 0; n0 < N; n0 += 8 * kAggBlock) {
-      float4 t[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) t[i] = u4[base + (size_t)min(n0 + i * kAggBlock + (int)threadIdx.x, N - 1) * T4 + j];
-#pragma unroll
-      for (int i = 0; i < 8; ++i)  // lanes past N re-write entry N-1 with the value they re-read from it: no branch,
-        slab[min(n0 + i * kAggBlock + (int)threadIdx.x, N - 1)] = t[i];  // so the 8 loads stay in flight together
-    }
+    stage_column<T4>(slab, u4 + base, j, N);
     __syncthreads();
     for (int s = wave; s < n_slices; s += kAggBlock / 64) {
-      const int k0 = slice[s], k1 = slice[s + 1];
+      const int off = slice_off[s];
+      const int ntrip = (slice_off[s + 1] - off) >> 8;
+      if (ntrip == 0) continue;  // wave-uniform
       const int row = lane_row[64 * s + lane];
-      const float4 a = dv4[base + (size_t)max(row, 0) * T4 + j];  // lanes past N hold no edge: never stored
-      JdsTrip ta, tb;  // .e carries the running partial of the edge (previous passes)
-      jds_issue(colstart, jidx, out, k0, k1, lane, last, ta);
-      for (int k = k0; k < k1; k += 2 * kJU) {
-        jds_issue(colstart, jidx, out, min(k + kJU, k1), k1, lane, last, tb);
-#pragma unroll
-        for (int u = 0; u < kJU; ++u)
-          if (lane < ta.cnt[u]) {  // a store in a branch costs nothing; the loads above stay unconditional
-            const float prev = (pass == 0) ? 0.f : ta.e[u];
-            out[colstart[min(k + u, k1)] + lane] = f4dot(a, slab[ta.id[u]], prev);
-          }
-        jds_issue(colstart, jidx, out, min(k + 2 * kJU, k1), k1, lane, last, ta);
-#pragma unroll
-        for (int u = 0; u < kJU; ++u)
-          if (lane < tb.cnt[u]) {
-            const float prev = (pass == 0) ? 0.f : tb.e[u];
-            out[colstart[min(k + kJU + u, k1)] + lane] = f4dot(a, slab[tb.id[u]], prev);
-          }
+      const uint2* pi4 = reinterpret_cast<const uint2*>(sidx + off) + lane;
+      float4* po4 = reinterpret_cast<float4*>(out + off) + lane;
+      const float4 a = dv4[base + (size_t)max(row, 0) * T4 + j];  // lanes past N own padding only
+      auto finish = [&](const SellTrip& x, int t) {  // .e carries the running partials of the trip's 4 edges
+        const int4 id = sell_unpack(x.id);
+        float4 o;
+        o.x = f4dot(a, slab[id.x], pass == 0 ? 0.f : x.e.x);
+        o.y = f4dot(a, slab[id.y], pass == 0 ? 0.f : x.e.y);
+        o.z = f4dot(a, slab[id.z], pass == 0 ? 0.f : x.e.z);
+        o.w = f4dot(a, slab[id.w], pass == 0 ? 0.f : x.e.w);
+        po4[64 * t] = o;
+      };
+      SellTrip ta, tb;
+      sell_issue(pi4, po4, 0, ntrip, ta);
+      for (int t = 0; t < ntrip; t += 2) {
+        sell_issue(pi4, po4, t + 1, ntrip, tb);
+        finish(ta, t);
+        sell_issue(pi4, po4, t + 2, ntrip, ta);  // clamped past the end: re-reads the last trip, not consumed
+        if (t + 1 < ntrip) finish(tb, t + 1);    // wave-uniform; only stores inside
       }
     }
     __syncthreads();
   }
 }
 
+// ---- SDDMM on the SELL layout with the per-edge sums in registers ------------------------------------------------
+// The read-modify-write of k_sddmm_sell moves every partial through L2 once per (channel, column) pass -- 72 times
+// at the stress graph, 1.2 MB per pass and block, far more than an XCD's L2 holds for its 32 blocks: it ran at
+// 6.7 ms, no faster than the CSR kernel it replaced.  Here the sums never leave the registers: the slices of a
+// group are dealt to Q = ceil(n_slices / 32) blocks, each wave owning ONE PAIR of slices -- slice i from the
+// wide end of the degree-sorted order and slice n_slices-1-i from the narrow end, so every pair needs about the
+// same ~2 x (mean degree) / 4 trips -- whose neighbour indices (16-bit) are loaded once and whose sums live in
+// kRegTrips float4 accumulators across all Cu x T/4 passes.  A pass is: stage column j of u[c] (every block of the
+// group stages the same column; they share an XCD, so L2 serves the repeats), one dv value per slice, then LDS
+// gathers and FMAs only.  Usable when sell.pair_trips <= kRegTrips (host-checked); k_sddmm_sell otherwise.
+constexpr int kRegTrips = 12;
+
+template <int T4>
+__global__ __launch_bounds__(kAggBlock) void k_sddmm_sellreg(
+    const int* __restrict__ slice_off, const int* __restrict__ lane_row, const uint16_t* __restrict__ sidx,
+    const float4* __restrict__ u4, const float4* __restrict__ dv4, float* __restrict__ dE, int G, int Cu, int N,
+    int n_pos, int n_slices, int Q) {
+  extern __shared__ float4 slab[];  // [N]
+  // XCD-aware map (see k_agg_sell): the Q blocks of a group sit in consecutive slots of XCD g % 8
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int q = slot % Q;
+  const int g = (slot / Q) * 8 + xcd;
+  if (g >= G) return;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int W = q * (kAggBlock / 64) + wave;  // pair index
+  const int sA = W, sB = n_slices - 1 - W;
+  const bool hasA = sA < n_slices && sA <= sB, hasB = hasA && sB > sA;  // wave-uniform
+  const int sAc = hasA ? sA : 0, sBc = hasB ? sB : 0;
+  const int offA = slice_off[sAc], offB = slice_off[sBc];
+  const int ntA = hasA ? (slice_off[sAc + 1] - offA) >> 8 : 0;
+  const int ntB = hasB ? (slice_off[sBc + 1] - offB) >> 8 : 0;
+  const int nt = ntA + ntB;
+  const int rowA = max(lane_row[64 * sAc + lane], 0), rowB = max(lane_row[64 * sBc + lane], 0);  // lanes past N: padding only
+
+  // this wave's neighbour indices, for the whole kernel: trips 0 .. ntA-1 of slice A, then those of slice B
+  const uint2* piA = reinterpret_cast<const uint2*>(sidx + offA) + lane;
+  const uint2* piB = reinterpret_cast<const uint2*>(sidx + offB) + lane;
+  uint2 ids[kRegTrips];
+  float4 acc[kRegTrips];
+#pragma unroll
+  for (int t = 0; t < kRegTrips; ++t) {
+    const int tt = min(t, max(nt - 1, 0));
+    const uint2* p = (tt < ntA) ? piA + 64 * tt : piB + 64 * (tt - ntA);  // wave-uniform choice, load unconditional
+    ids[t] = (nt > 0) ? *p : make_uint2(0u, 0u);
+    acc[t] = f4zero();
+  }
+
+  for (int pass = 0; pass < Cu * T4; ++pass) {
+    const int c = pass / T4, j = pass - c * T4;
+    const size_t base = ((size_t)g * Cu + c) * N * T4;
+    const float4 aA = dv4[base + (size_t)rowA * T4 + j];
+    const float4 aB = dv4[base + (size_t)rowB * T4 + j];
+    stage_column<T4, 4>(slab, u4 + base, j, N);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < kRegTrips; ++t) {
+      if (t < nt) {  // wave-uniform; LDS reads and FMAs only
+        const bool inA = t < ntA;
+        const float4 a = make_float4(inA ? aA.x : aB.x, inA ? aA.y : aB.y, inA ? aA.z : aB.z, inA ? aA.w : aB.w);
+        const int4 id = sell_unpack(ids[t]);
+        acc[t].x = f4dot(a, slab[id.x], acc[t].x);
+        acc[t].y = f4dot(a, slab[id.y], acc[t].y);
+        acc[t].z = f4dot(a, slab[id.z], acc[t].z);
+        acc[t].w = f4dot(a, slab[id.w], acc[t].w);
+      }
+    }
+    __syncthreads();
+  }
+
+  float* out = dE + (size_t)g * n_pos;
+  float4* poA = reinterpret_cast<float4*>(out + offA) + lane;
+  float4* poB = reinterpret_cast<float4*>(out + offB) + lane;
+#pragma unroll
+  for (int t = 0; t < kRegTrips; ++t)
+    if (t < nt) *((t < ntA) ? poA + 64 * t : poB + 64 * (t - ntA)) = acc[t];
+}
+
+static bool sddmm_in_registers(const msgat_sell_t& sl) { return sl.pair_trips > 0 && sl.pair_trips <= kRegTrips; }
+
 // channel chunks of the SDDMM (= partial buffers of [G,nnz]): LDS slab form: as many channels as fit the LDS
-// budget per chunk; JDS form: enough chunks to give every CU a block, at most one per channel
-int sddmm_chunks(int G, int Cu, int N, int T, bool jds) {
-  if (jds) {
+// budget per chunk; SELL form: enough chunks to give every CU a block, at most one per channel
+int sddmm_chunks(int G, int Cu, int N, int T, const msgat_sell_t* sell) {
+  if (sell != nullptr) {
+    if (sddmm_in_registers(*sell)) return 1;  // the sums leave the registers once, complete
     const int want = max(1, min(Cu, cdiv(256, max(G, 1))));
     return cdiv(Cu, cdiv(Cu, want));  // every chunk owns at least one channel
   }
@@ -507,18 +657,30 @@ static int launch_sddmm_t(const msgat_graph_t& gr, const float* u, const float* 
                           int G, int Cu, int N, hipStream_t s) {
   const int T = 4 * T4;
   const int CH = slab_channels(N, T, Cu, kLdsBudget);
-  if (jds_usable(gr.jds_rows, gr.nnz, N, T)) {  // partials come out in JDS order (k_edge_grad reads them through pos)
-    const msgat_jds_t& jd = gr.jds_rows;
-    const int nch = sddmm_chunks(G, Cu, N, T, true);
+  if (sell_usable(gr.sell_rows, gr.nnz, N, T)) {  // partials come out in SELL position order (k_edge_grad: pos)
+    const msgat_sell_t& sl = gr.sell_rows;
+    const int nch = sddmm_chunks(G, Cu, N, T, &sl);
     const int chj = cdiv(Cu, nch);
     const size_t lds = (size_t)N * sizeof(float4);
+    if (sddmm_in_registers(sl)) {
+      if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm_sellreg<T4>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
+      }
+      const int Q = cdiv(sl.n_slices, 2 * (kAggBlock / 64));
+      hipLaunchKernelGGL(k_sddmm_sellreg<T4>, dim3((unsigned)cdiv(G, 8) * 8 * Q), dim3(kAggBlock), lds, s, sl.slice_off,
+                         sl.lane_row, sl.idx, (const float4*)u, (const float4*)dv, dEp, G, Cu, N, sl.n_pos, sl.n_slices, Q);
+      MSGAT_CHECK_LAUNCH();
+      return MSGAT_OK;
+    }
     if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm_jds<T4>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm_sell<T4>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
     }
-    hipLaunchKernelGGL(k_sddmm_jds<T4>, dim3(nch, G), dim3(kAggBlock), lds, s, jd.slice, jd.colstart, jd.lane_row,
-                       jd.idx, (const float4*)u, (const float4*)dv, dEp, Cu, N, gr.nnz, jd.n_slices, chj, nch);
+    hipLaunchKernelGGL(k_sddmm_sell<T4>, dim3(nch, G), dim3(kAggBlock), lds, s, sl.slice_off, sl.lane_row, sl.idx,
+                       (const float4*)u, (const float4*)dv, dEp, Cu, N, sl.n_pos, sl.n_slices, chj, nch);
   } else if (CH >= 1) {
     const size_t lds = (size_t)CH * N * T * sizeof(float);
     if (lds > 64 * 1024) {

@@ -24,13 +24,13 @@ int check_graph(const msgat_shape_t* sh, const msgat_graph_t* gr) {
   if (gr->n_nodes != sh->N || gr->nnz < 0) return MSGAT_ERR_SHAPE;
   if (!gr->rowptr || !gr->colptr) return MSGAT_ERR_NULL;
   if (gr->nnz > 0 && (!gr->col || !gr->val || !gr->erow || !gr->crow || !gr->cperm)) return MSGAT_ERR_NULL;
-  for (const msgat_jds_t* j : {&gr->jds_rows, &gr->jds_cols}) {
+  for (const msgat_sell_t* j : {&gr->sell_rows, &gr->sell_cols}) {
     if (j->n_slices == 0) continue;
-    if (j->n_slices != cdiv(sh->N, 64) || j->n_cols < 0) return MSGAT_ERR_GRAPH;
-    if (!j->slice || !j->colstart || !j->lane_row) return MSGAT_ERR_NULL;
+    if (j->n_slices != cdiv(sh->N, 64) || j->n_pos < gr->nnz) return MSGAT_ERR_GRAPH;
+    if (!j->slice_off || !j->lane_row) return MSGAT_ERR_NULL;
     if (gr->nnz > 0 && (!j->idx || !j->src)) return MSGAT_ERR_NULL;
   }
-  if (gr->jds_rows.n_slices != 0 && gr->nnz > 0 && !gr->jds_rows.pos) return MSGAT_ERR_NULL;
+  if (gr->sell_rows.n_slices != 0 && gr->nnz > 0 && !gr->sell_rows.pos) return MSGAT_ERR_NULL;
   return MSGAT_OK;
 }
 
@@ -42,14 +42,15 @@ struct BwdPlan {
   size_t off_dEp, off_gE, off_Ec, off_delta, off_dkW, off_dq, off_dv, off_dwg, off_cp, total;
 };
 
-// jds: 1 = the SDDMM runs on the JDS layout, 0 = on the CSR, -1 = unknown (size query: room for either)
-BwdPlan plan_bwd(const msgat_shape_t& sh, int nnz, int jds) {
+// the graph decides the edge layout (CSR, or SELL for large N) and with it the size of the per-edge buffers
+BwdPlan plan_bwd(const msgat_shape_t& sh, const msgat_graph_t& gr) {
   BwdPlan p{};
+  const int nnz = gr.nnz;
   p.mode = msgat_gacn_mode(sh.C, sh.Co);
   p.G = sh.R * sh.Bg;
   p.Cu = (p.mode == MSGAT_MODE_PROJ_FIRST) ? sh.Co : sh.C;
-  if (jds < 0) p.nch = max(sddmm_chunks(p.G, p.Cu, sh.N, sh.T, false), sddmm_chunks(p.G, p.Cu, sh.N, sh.T, true));
-  else p.nch = sddmm_chunks(p.G, p.Cu, sh.N, sh.T, jds != 0);
+  const bool sell_r = sell_usable(gr.sell_rows, nnz, sh.N, sh.T), sell_c = sell_usable(gr.sell_cols, nnz, sh.N, sh.T);
+  p.nch = sddmm_chunks(p.G, p.Cu, sh.N, sh.T, sell_r ? &gr.sell_rows : nullptr);
   const size_t G = p.G, N = sh.N, T = sh.T, P = N * T;
   size_t off = 0;
   auto take = [&](size_t floats) {
@@ -57,9 +58,9 @@ BwdPlan plan_bwd(const msgat_shape_t& sh, int nnz, int jds) {
     off += align256(floats * sizeof(float));
     return o;
   };
-  p.off_dEp = take(G * p.nch * (size_t)nnz);
+  p.off_dEp = take(sell_r ? G * p.nch * (size_t)gr.sell_rows.n_pos + MSGAT_SELL_SLACK : G * p.nch * (size_t)nnz);
   p.off_gE = take(G * (size_t)nnz);
-  p.off_Ec = take(G * (size_t)nnz);
+  p.off_Ec = take(sell_c ? G * (size_t)gr.sell_cols.n_pos + MSGAT_SELL_SLACK : G * (size_t)nnz);
   p.off_delta = take(G * N);
   p.off_dkW = take(G * P);
   p.off_dq = take(G * P);
@@ -128,36 +129,38 @@ extern "C" int msgat_stage_scores(const msgat_shape_t* sh, const msgat_graph_t* 
   return launch_scores(*gr, q, Wg, kW, lse, pq, E, sh->R * sh->Bg, sh->Bg, sh->N, sh->T, (hipStream_t)stream);
 }
 
-// forward aggregate over the CSR: on the JDS layout when the graph carries a usable one (E re-ordered into
+// forward aggregate over the CSR: on the SELL layout when the graph carries a usable one (E re-ordered into
 // `scratch` first), on the CSR otherwise
 static int aggregate_rows(const msgat_shape_t* sh, const msgat_graph_t* gr, int Cu, const float* u, const float* E,
                           float* v, float* scratch, hipStream_t s) {
   const int G = sh->R * sh->Bg;
-  if (jds_usable(gr->jds_rows, gr->nnz, sh->N, sh->T)) {
+  if (sell_usable(gr->sell_rows, gr->nnz, sh->N, sh->T)) {
     if (!scratch) return MSGAT_ERR_WORKSPACE;
-    int st = launch_permute_edges(E, gr->jds_rows.src, scratch, G, gr->nnz, s);
+    int st = launch_permute_edges(E, gr->sell_rows.src, scratch, G, gr->nnz, gr->sell_rows.n_pos, s);
     if (st) return st;
-    return launch_aggregate(gr->rowptr, gr->col, gr->nnz, &gr->jds_rows, u, scratch, nullptr, nullptr, v, G, sh->Bg,
+    return launch_aggregate(gr->rowptr, gr->col, gr->nnz, &gr->sell_rows, u, scratch, nullptr, nullptr, v, G, sh->Bg,
                             Cu, sh->N, sh->T, s);
   }
   return launch_aggregate(gr->rowptr, gr->col, gr->nnz, nullptr, u, E, nullptr, nullptr, v, G, sh->Bg, Cu, sh->N,
                           sh->T, s);
 }
 
-// transposed aggregate over the CSC (backward): E goes to CSC order -- or to the JDS order of the CSC -- in Ec
+// transposed aggregate over the CSC (backward): E goes to CSC order -- or to the SELL order of the CSC -- in Ec
 static int aggregate_cols(const msgat_shape_t* sh, const msgat_graph_t* gr, int Cu, const float* dv, const float* E,
                           float* Ec, const float* addvec, const float* extra, float* out, hipStream_t s) {
   const int G = sh->R * sh->Bg;
-  const bool jds = jds_usable(gr->jds_cols, gr->nnz, sh->N, sh->T);
-  int st = launch_permute_edges(E, jds ? gr->jds_cols.src : gr->cperm, Ec, G, gr->nnz, s);
+  const bool sell = sell_usable(gr->sell_cols, gr->nnz, sh->N, sh->T);
+  int st = launch_permute_edges(E, sell ? gr->sell_cols.src : gr->cperm, Ec, G, gr->nnz,
+                                sell ? gr->sell_cols.n_pos : gr->nnz, s);
   if (st) return st;
-  return launch_aggregate(gr->colptr, gr->crow, gr->nnz, jds ? &gr->jds_cols : nullptr, dv, Ec, addvec, extra, out, G,
-                          sh->Bg, Cu, sh->N, sh->T, s);
+  return launch_aggregate(gr->colptr, gr->crow, gr->nnz, sell ? &gr->sell_cols : nullptr, dv, Ec, addvec, extra, out,
+                          G, sh->Bg, Cu, sh->N, sh->T, s);
 }
 
 extern "C" size_t msgat_edge_scratch_floats(const msgat_shape_t* sh, const msgat_graph_t* gr) {
   if (check_shape(sh) != MSGAT_OK || check_graph(sh, gr) != MSGAT_OK) return 0;
-  return jds_usable(gr->jds_rows, gr->nnz, sh->N, sh->T) ? (size_t)sh->R * sh->Bg * gr->nnz : 0;
+  if (!sell_usable(gr->sell_rows, gr->nnz, sh->N, sh->T)) return 0;
+  return (size_t)sh->R * sh->Bg * gr->sell_rows.n_pos + MSGAT_SELL_SLACK;
 }
 
 extern "C" int msgat_stage_aggregate(const msgat_shape_t* sh, const msgat_graph_t* gr, int32_t Cu,
@@ -363,9 +366,9 @@ static msgat_shape_t plain_shape(const msgat_shape_t* sh) {
   return s;
 }
 
-extern "C" size_t msgat_attention_bwd_workspace_bytes(const msgat_shape_t* sh, int32_t nnz) {
-  if (check_shape(sh) != MSGAT_OK || nnz < 0) return 0;
-  return plan_bwd(plain_shape(sh), nnz, -1).total;
+extern "C" size_t msgat_attention_bwd_workspace_bytes(const msgat_shape_t* sh, const msgat_graph_t* gr) {
+  if (check_shape(sh) != MSGAT_OK || check_graph(sh, gr) != MSGAT_OK) return 0;
+  return plan_bwd(plain_shape(sh), *gr).total;
 }
 
 extern "C" int msgat_attention_backward(const msgat_shape_t* shp, const msgat_graph_t* gr, const float* u,
@@ -380,9 +383,8 @@ extern "C" int msgat_attention_backward(const msgat_shape_t* shp, const msgat_gr
   if (st) return st;
   if (!u || !dv || !q || !kW || !lse || !pq || !Wg || !du || !dq || !dWg) return MSGAT_ERR_NULL;
   if (gr->nnz > 0 && !E) return MSGAT_ERR_NULL;
-  const BwdPlan p = plan_bwd(*sh, gr->nnz, jds_usable(gr->jds_rows, gr->nnz, sh->N, sh->T) ? 1 : 0);
-  const size_t need = plan_bwd(*sh, gr->nnz, -1).total;  // what the size query promised to be enough
-  if (need > 0 && (!workspace || workspace_bytes < need)) return MSGAT_ERR_WORKSPACE;
+  const BwdPlan p = plan_bwd(*sh, *gr);
+  if (p.total > 0 && (!workspace || workspace_bytes < p.total)) return MSGAT_ERR_WORKSPACE;
   char* ws = (char*)workspace;
   hipStream_t s = (hipStream_t)stream;
   float* dEp = (float*)(ws + p.off_dEp);
@@ -512,9 +514,9 @@ extern "C" int msgat_gacn_forward(const msgat_shape_t* sh, const msgat_graph_t* 
 }
 
 // ---- fused backward --------------------------------------------------------------------------------
-extern "C" size_t msgat_bwd_workspace_bytes(const msgat_shape_t* sh, int32_t nnz) {
-  if (check_shape(sh) != MSGAT_OK || nnz < 0) return 0;
-  return plan_bwd(*sh, nnz, -1).total;
+extern "C" size_t msgat_bwd_workspace_bytes(const msgat_shape_t* sh, const msgat_graph_t* gr) {
+  if (check_shape(sh) != MSGAT_OK || check_graph(sh, gr) != MSGAT_OK) return 0;
+  return plan_bwd(*sh, *gr).total;
 }
 
 extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t* gr,
@@ -528,9 +530,9 @@ extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t*
       !io->dx || !io->dalpha || !io->dWg || !io->workspace)
     return MSGAT_ERR_NULL;
   if (gr->nnz > 0 && !io->E) return MSGAT_ERR_NULL;
-  const BwdPlan p = plan_bwd(*sh, gr->nnz, jds_usable(gr->jds_rows, gr->nnz, sh->N, sh->T) ? 1 : 0);
+  const BwdPlan p = plan_bwd(*sh, *gr);
   if (p.mode != MSGAT_MODE_PLAIN && (!io->W || !io->dW || !io->u)) return MSGAT_ERR_NULL;
-  if (io->workspace_bytes < plan_bwd(*sh, gr->nnz, -1).total) return MSGAT_ERR_WORKSPACE;
+  if (io->workspace_bytes < p.total) return MSGAT_ERR_WORKSPACE;
   if (((uintptr_t)io->workspace & 255) != 0) return MSGAT_ERR_WORKSPACE;
 
   hipStream_t s = (hipStream_t)stream;

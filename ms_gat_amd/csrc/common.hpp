@@ -55,10 +55,10 @@ inline int slab_channels(int N, int T, int Cu, int budget_bytes) {
   return ch;
 }
 
-// the JDS kernels hold one float4 per node in LDS; they take over when no whole [N,T] slab fits (or on request)
-inline bool jds_usable(const msgat_jds_t& j, int nnz, int N, int T) {
-  if (j.n_slices <= 0 || nnz <= 0 || !j.slice || !j.colstart || !j.lane_row || !j.idx || !j.src) return false;
-  if ((size_t)N * 16 > (size_t)kLdsMax - 1024) return false;
+// the SELL kernels hold one float4 per node in LDS; they take over when no whole [N,T] slab fits (or on request)
+inline bool sell_usable(const msgat_sell_t& j, int nnz, int N, int T) {
+  if (j.n_slices <= 0 || nnz <= 0 || !j.slice_off || !j.lane_row || !j.idx || !j.src) return false;
+  if ((size_t)N * 16 > (size_t)kLdsMax - 1024) return false;  // <= 10176 nodes = 159 slices = 10 per wave (kSellMaxSlices)
   return j.prefer != 0 || slab_channels(N, T, 1, kLdsBudget) == 0;
 }
 
@@ -191,18 +191,20 @@ int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, i
 int launch_scores(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW, float* lse,
                   float* pq, float* E, int G, int Bg, int N, int T, hipStream_t s);
 // v[g,c,n,:] = sum_{e in ptr[n]..ptr[n+1]} E[g,e] u[g,c,idx[e],:] (+ addvec[r,c]*extra[g,n,:])
-// jds != nullptr: E is in that layout's position order (permuted by jds->src) and the JDS kernel runs
-int launch_aggregate(const int* ptr, const int* idx, int nnz, const msgat_jds_t* jds, const float* u,
+// sell != nullptr: E is in that layout's position order (permuted by sell->src, row stride sell->n_pos, with
+// MSGAT_SELL_SLACK readable floats behind the last row) and the SELL kernel runs
+int launch_aggregate(const int* ptr, const int* idx, int nnz, const msgat_sell_t* sell, const float* u,
                      const float* E, const float* addvec, const float* extra, float* v, int G, int Bg, int Cu,
                      int N, int T, hipStream_t s);
-// Ec[g,k] = E[g, cperm[k]]: edge coefficients in CSC order for the transposed aggregate
-int launch_permute_edges(const float* E, const int* cperm, float* Ec, int G, int nnz, hipStream_t s);
+// Eo[g,k] = E[g, perm[k]] for k < n (0 where perm[k] < 0): edge coefficients in CSC or SELL position order
+int launch_permute_edges(const float* E, const int* perm, float* Eo, int G, int nnz, int n, hipStream_t s);
 int launch_aggregate_project(const msgat_graph_t& gr, const float* x, const float* E,
                              const float* W, float* y, float* z, int G, int Bg, int C, int Co,
                              int N, int T, hipStream_t s);
 // dEp[g,k,e] = sum over channel chunk k of <dv[g,c,erow[e],:], u[g,c,col[e],:]>
-// (with gr.jds_rows usable the partials are in JDS position order: launch_bwd_edge reads them through pos)
-int sddmm_chunks(int G, int Cu, int N, int T, bool jds);
+// (with gr.sell_rows usable the partials are [G,chunks,n_pos] in SELL position order + MSGAT_SELL_SLACK floats
+// of slack, and launch_bwd_edge reads them through sell.pos)
+int sddmm_chunks(int G, int Cu, int N, int T, const msgat_sell_t* sell);
 int launch_sddmm(const msgat_graph_t& gr, const float* u, const float* dv, float* dEp, int G,
                  int Cu, int N, int T, hipStream_t s);
 int launch_bwd_edge(const msgat_graph_t& gr, const float* dEp, int nchunks, const float* E,

@@ -5,6 +5,8 @@
 // (attention.py:36).  Only its non-zeros matter to that product, so the kernels walk
 // them: CSR for the forward gather, CSC (+ the CSC->CSR permutation) for the transposed
 // gather of the backward pass.
+#include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -87,113 +89,142 @@ extern "C" int msgat_graph_validate(const msgat_graph_t* g) {
       if (g->col[p] != j || g->erow[p] != g->crow[k]) return MSGAT_ERR_GRAPH;
     }
   }
-  // JDS forms: every position belongs to exactly one CSR edge, owned by the lane whose row the edge starts from
-  // (rows form) or ends in (columns form), and holds the node at the edge's other end
+  // SELL forms: every CSR edge sits at exactly one position, in the lane that owns the row the edge starts from
+  // (rows form) or the column it ends in (columns form), as that lane's k-th entry in CSR / CSC order, and holds
+  // the node at the edge's other end; everything else is padding
   for (int form = 0; form < 2; ++form) {
-    const msgat_jds_t& j = form == 0 ? g->jds_rows : g->jds_cols;
+    const msgat_sell_t& j = form == 0 ? g->sell_rows : g->sell_cols;
     if (j.n_slices == 0) continue;
-    if (j.n_slices != (n + 63) / 64 || j.n_cols < 0 || !j.slice || !j.colstart || !j.lane_row) return MSGAT_ERR_GRAPH;
-    if (nnz > 0 && (!j.idx || !j.src)) return MSGAT_ERR_GRAPH;
-    if (j.slice[0] != 0 || j.slice[j.n_slices] != j.n_cols || j.colstart[0] != 0) return MSGAT_ERR_GRAPH;
-    for (int32_t c = j.n_cols; c <= j.n_cols + MSGAT_JDS_PAD; ++c)
-      if (j.colstart[c] != nnz) return MSGAT_ERR_GRAPH;
-    std::vector<char> used((size_t)nnz, 0);
+    if (j.n_slices != (n + 63) / 64 || j.n_pos < nnz || !j.slice_off || !j.lane_row) return MSGAT_ERR_GRAPH;
+    if (j.n_pos > 0 && (!j.idx || !j.src)) return MSGAT_ERR_GRAPH;
+    if (j.slice_off[0] != 0 || j.slice_off[j.n_slices] != j.n_pos) return MSGAT_ERR_GRAPH;
+    const int32_t* ptr = form == 0 ? g->rowptr : g->colptr;
+    std::vector<char> used((size_t)nnz, 0), seen_row((size_t)n, 0);
+    int32_t prev_deg = INT32_MAX;
     for (int32_t s = 0; s < j.n_slices; ++s) {
-      if (j.slice[s + 1] < j.slice[s]) return MSGAT_ERR_GRAPH;
-      int32_t prev = 64;
-      for (int32_t c = j.slice[s]; c < j.slice[s + 1]; ++c) {
-        const int32_t cnt = j.colstart[c + 1] - j.colstart[c];
-        if (cnt <= 0 || cnt > prev) return MSGAT_ERR_GRAPH;  // active lanes form a shrinking prefix
-        prev = cnt;
-        for (int32_t l = 0; l < cnt; ++l) {
-          const int32_t p = j.colstart[c] + l, e = j.src[p], owner = j.lane_row[64 * s + l];
-          if (e < 0 || e >= nnz || used[(size_t)e] || owner < 0 || owner >= n) return MSGAT_ERR_GRAPH;
+      const int32_t span = j.slice_off[s + 1] - j.slice_off[s];
+      if (span < 0 || span % 256 != 0) return MSGAT_ERR_GRAPH;  // 64 lanes x a multiple of 4 columns
+      const int32_t width = span / 64;
+      for (int32_t l = 0; l < 64; ++l) {
+        const int32_t owner = j.lane_row[64 * s + l];
+        if (owner < -1 || owner >= n) return MSGAT_ERR_GRAPH;
+        int32_t deg = 0;
+        if (owner >= 0) {
+          if (seen_row[(size_t)owner]) return MSGAT_ERR_GRAPH;
+          seen_row[(size_t)owner] = 1;
+          deg = ptr[owner + 1] - ptr[owner];
+          if (deg > prev_deg || deg > width) return MSGAT_ERR_GRAPH;  // sorted by degree, descending
+          prev_deg = deg;
+        }
+        for (int32_t k = 0; k < width; ++k) {
+          const int32_t p = j.slice_off[s] + 256 * (k >> 2) + 4 * l + (k & 3), e = j.src[p];
+          if (k >= deg) {
+            if (e != -1 || j.idx[p] >= n) return MSGAT_ERR_GRAPH;
+            continue;
+          }
+          if (e < 0 || e >= nnz || used[(size_t)e]) return MSGAT_ERR_GRAPH;
           used[(size_t)e] = 1;
-          const int32_t from = form == 0 ? g->erow[e] : g->col[e], to = form == 0 ? g->col[e] : g->erow[e];
-          if (owner != from || j.idx[p] != to) return MSGAT_ERR_GRAPH;
+          const int32_t want = form == 0 ? ptr[owner] + k : g->cperm[ptr[owner] + k];
+          const int32_t to = form == 0 ? g->col[e] : g->erow[e];
+          if (e != want || j.idx[p] != to) return MSGAT_ERR_GRAPH;
           if (j.pos && j.pos[e] != p) return MSGAT_ERR_GRAPH;
         }
       }
     }
+    int32_t pair = 0;
+    for (int32_t i = 0; 2 * i < j.n_slices; ++i) {
+      const int32_t o = j.n_slices - 1 - i;
+      pair = std::max(pair, (j.slice_off[i + 1] - j.slice_off[i]) / 256 + (o > i ? (j.slice_off[o + 1] - j.slice_off[o]) / 256 : 0));
+    }
+    if (j.pair_trips != pair) return MSGAT_ERR_GRAPH;
+    for (int32_t i = 0; i < n; ++i)
+      if (!seen_row[(size_t)i]) return MSGAT_ERR_GRAPH;
     for (int32_t e = 0; e < nnz; ++e)
       if (!used[(size_t)e]) return MSGAT_ERR_GRAPH;
+    for (int32_t p = j.n_pos; p < j.n_pos + MSGAT_SELL_SLACK; ++p)
+      if (j.idx[p] >= n) return MSGAT_ERR_GRAPH;  // the slack is read (and ignored) by the kernels
   }
   return MSGAT_OK;
 }
 
-// ---- sliced jagged-diagonal (JDS) layout of one sparse structure ---------------------------------------------
-// For graphs whose [N,T] slab exceeds LDS the aggregate keeps ONE 4-timestep column of a slab in LDS per pass,
-// so the edge lists are re-read once per (group, channel, column) -- 8x more bytes than the features themselves
-// at the N = 8192 / degree 16 stress graph.  Read through the CSR (lane = row, a window of the row's edges per
-// trip) those reads are dependent round trips of 16-B pieces at a ~68-B stride.  The JDS form makes them
-// contiguous and address-independent: rows are cut into slices of 64 (one wavefront), sorted by degree inside
-// the slice (descending, stable), and the k-th edges of all rows of a slice that have one are stored back to
-// back ("jagged column" k).  Lane l of the wave then reads entry colstart[k] + l for l < count_k: one coalesced
-// 4-B-per-lane load per array and k, every byte read once, and all addresses known up front.
-//
-//   slice[s] .. slice[s+1]        jagged columns of slice s (width = its largest degree)
-//   colstart[c] .. colstart[c+1]  positions of jagged column c
-//   lane_row[64 s + l]            row handled by lane l of slice s (-1 past the last row)
-//   idx[p]                        neighbour of position p;  src[p] = edge id (in the caller's edge numbering,
-//                                 through `perm` when given);  pos[e] = inverse of src (optional)
-extern "C" int msgat_graph_jds_count(const int32_t* ptr, int32_t n, int32_t* n_slices_out, int32_t* n_cols_out) {
-  if (!ptr || !n_slices_out || !n_cols_out) return MSGAT_ERR_NULL;
+// ---- sliced ELLPACK (SELL-64, degree-sorted) layout of one sparse structure: see msgat_sell_t ---------------------
+// order = rows by degree, descending, stable (counting sort); slice s = order[64 s .. 64 s + 63]; its width is the
+// degree of its first row rounded up to a multiple of 4; a "trip" = 4 consecutive columns, stored lane-interleaved
+// (lane l owns entries 4 l .. 4 l + 3 of the trip's 256) so one 16-B-per-lane load fetches a lane's 4 edges.
+static void sell_order(const int32_t* ptr, int32_t n, std::vector<int32_t>& order) {
+  int32_t maxdeg = 0;
+  for (int32_t i = 0; i < n; ++i) maxdeg = std::max(maxdeg, ptr[i + 1] - ptr[i]);
+  std::vector<int32_t> start((size_t)maxdeg + 2, 0);
+  for (int32_t i = 0; i < n; ++i) start[(size_t)(maxdeg - (ptr[i + 1] - ptr[i])) + 1]++;
+  for (int32_t d = 0; d <= maxdeg; ++d) start[(size_t)d + 1] += start[(size_t)d];
+  order.assign((size_t)n, 0);
+  for (int32_t i = 0; i < n; ++i) order[(size_t)start[(size_t)(maxdeg - (ptr[i + 1] - ptr[i]))]++] = i;
+}
+
+extern "C" int msgat_graph_sell_count(const int32_t* ptr, int32_t n, int32_t* n_slices_out, int32_t* n_pos_out,
+                                      int32_t* pair_trips_out) {
+  if (!ptr || !n_slices_out || !n_pos_out || !pair_trips_out) return MSGAT_ERR_NULL;
   if (n <= 0) return MSGAT_ERR_SHAPE;
+  for (int32_t i = 0; i < n; ++i)
+    if (ptr[i + 1] < ptr[i]) return MSGAT_ERR_GRAPH;
+  std::vector<int32_t> order;
+  sell_order(ptr, n, order);
   const int32_t ns = (n + 63) / 64;
-  int64_t cols = 0;
+  int64_t total = 0;
+  std::vector<int32_t> trips((size_t)ns, 0);
   for (int32_t s = 0; s < ns; ++s) {
-    int32_t w = 0;
-    for (int32_t i = 64 * s; i < n && i < 64 * s + 64; ++i) {
-      const int32_t d = ptr[i + 1] - ptr[i];
-      if (d < 0) return MSGAT_ERR_GRAPH;
-      if (d > w) w = d;
-    }
-    cols += w;
+    const int32_t first = order[(size_t)64 * s];
+    trips[(size_t)s] = (ptr[first + 1] - ptr[first] + 3) / 4;
+    total += (int64_t)256 * trips[(size_t)s];
   }
-  if (cols > INT32_MAX) return MSGAT_ERR_SHAPE;
+  if (total > INT32_MAX - MSGAT_SELL_SLACK) return MSGAT_ERR_SHAPE;
+  int32_t pair = 0;
+  for (int32_t i = 0; 2 * i < ns; ++i)
+    pair = std::max(pair, trips[(size_t)i] + (ns - 1 - i > i ? trips[(size_t)(ns - 1 - i)] : 0));
   *n_slices_out = ns;
-  *n_cols_out = (int32_t)cols;
+  *n_pos_out = (int32_t)total;
+  *pair_trips_out = pair;
   return MSGAT_OK;
 }
 
-extern "C" int msgat_graph_jds_build(const int32_t* ptr, const int32_t* idx, const int32_t* perm, int32_t n,
-                                     int32_t nnz, int32_t n_slices, int32_t n_cols, int32_t* slice,
-                                     int32_t* colstart, int32_t* lane_row, int32_t* jidx, int32_t* jsrc,
-                                     int32_t* jpos) {
-  if (!ptr || !slice || !colstart || !lane_row) return MSGAT_ERR_NULL;
-  if (nnz > 0 && (!idx || !jidx || !jsrc)) return MSGAT_ERR_NULL;
-  if (n <= 0 || nnz < 0 || n_slices != (n + 63) / 64 || ptr[n] != nnz) return MSGAT_ERR_SHAPE;
-  int32_t c = 0, p = 0;
+extern "C" int msgat_graph_sell_build(const int32_t* ptr, const int32_t* idx, const int32_t* perm, int32_t n,
+                                      int32_t nnz, int32_t n_slices, int32_t n_pos, int32_t* slice_off,
+                                      int32_t* lane_row, uint16_t* sidx, int32_t* ssrc, int32_t* spos) {
+  if (!ptr || !slice_off || !lane_row || !sidx) return MSGAT_ERR_NULL;
+  if (n_pos > 0 && !ssrc) return MSGAT_ERR_NULL;
+  if (nnz > 0 && !idx) return MSGAT_ERR_NULL;
+  if (n <= 0 || n > 65535 || nnz < 0 || n_slices != (n + 63) / 64 || ptr[n] != nnz || n_pos < nnz) return MSGAT_ERR_SHAPE;
+  std::vector<int32_t> order;
+  sell_order(ptr, n, order);
+  int64_t off = 0;
   for (int32_t s = 0; s < n_slices; ++s) {
-    const int32_t r0 = 64 * s, rows = (n - r0 < 64) ? n - r0 : 64;
-    int32_t order[64], deg[64];
-    for (int32_t i = 0; i < rows; ++i) { order[i] = i; deg[i] = ptr[r0 + i + 1] - ptr[r0 + i]; }
-    // stable insertion sort by degree, descending: the active lanes of every jagged column are a prefix
-    for (int32_t i = 1; i < rows; ++i) {
-      const int32_t o = order[i];
-      int32_t j = i;
-      while (j > 0 && deg[order[j - 1]] < deg[o]) { order[j] = order[j - 1]; --j; }
-      order[j] = o;
-    }
-    for (int32_t l = 0; l < 64; ++l) lane_row[64 * s + l] = (l < rows) ? r0 + order[l] : -1;
-    slice[s] = c;
-    const int32_t width = rows > 0 ? deg[order[0]] : 0;
-    for (int32_t k = 0; k < width; ++k) {
-      if (c >= n_cols) return MSGAT_ERR_SHAPE;
-      colstart[c++] = p;
-      for (int32_t l = 0; l < rows && deg[order[l]] > k; ++l) {
-        const int32_t e = ptr[r0 + order[l]] + k;
-        if (p >= nnz) return MSGAT_ERR_SHAPE;
-        jidx[p] = idx[e];
-        const int32_t id = perm ? perm[e] : e;
-        jsrc[p] = id;
-        if (jpos) jpos[id] = p;
-        ++p;
+    const int32_t first = order[(size_t)64 * s];
+    const int32_t width = (ptr[first + 1] - ptr[first] + 3) / 4 * 4;
+    if (off + (int64_t)64 * width > n_pos) return MSGAT_ERR_SHAPE;  // caller's count is stale
+    slice_off[s] = (int32_t)off;
+    for (int32_t l = 0; l < 64; ++l) {
+      const int32_t i = 64 * s + l;
+      const int32_t row = i < n ? order[(size_t)i] : -1;
+      lane_row[i] = row;
+      const int32_t deg = row >= 0 ? ptr[row + 1] - ptr[row] : 0;
+      for (int32_t k = 0; k < width; ++k) {
+        const int32_t p = (int32_t)off + 256 * (k >> 2) + 4 * l + (k & 3);
+        if (k < deg) {
+          const int32_t e = ptr[row] + k;
+          const int32_t id = perm ? perm[e] : e;
+          sidx[p] = (uint16_t)idx[e];
+          ssrc[p] = id;
+          if (spos) spos[id] = p;
+        } else {
+          sidx[p] = 0;  // padding: coefficient 0 times node 0
+          ssrc[p] = -1;
+        }
       }
     }
+    off += (int64_t)64 * width;
   }
-  if (c != n_cols || p != nnz) return MSGAT_ERR_SHAPE;
-  slice[n_slices] = c;
-  for (int32_t i = 0; i <= MSGAT_JDS_PAD; ++i) colstart[c + i] = p;  // end marker + padding, all = nnz
+  if (off != n_pos) return MSGAT_ERR_SHAPE;
+  slice_off[n_slices] = n_pos;
+  for (int32_t p = n_pos; p < n_pos + MSGAT_SELL_SLACK; ++p) sidx[p] = 0;
   return MSGAT_OK;
 }

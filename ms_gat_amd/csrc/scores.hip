@@ -11,21 +11,21 @@ namespace msgat {
 //   dq[n] = dkW[n] Wg^T  (the row-local part of dq).
 __global__ __launch_bounds__(kBlock) void k_edge_grad(const float* __restrict__ dEp, int nchunks,
                                                       const float* __restrict__ E, const int* __restrict__ epos,
-                                                      float* __restrict__ gE, int nnz) {
+                                                      int stride, float* __restrict__ gE, int nnz) {
   const int g = blockIdx.y;
   const int e = blockIdx.x * kBlock + threadIdx.x;
   if (e >= nnz) return;
-  // epos: the SDDMM ran on the JDS layout and left its partials in position order
-  const float* p = dEp + (size_t)g * nchunks * nnz + (epos != nullptr ? epos[e] : e);
+  // epos: the SDDMM ran on the SELL layout and left its partials in position order (chunk stride = n_pos)
+  const float* p = dEp + (size_t)g * nchunks * stride + (epos != nullptr ? epos[e] : e);
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int k = 0;
   for (; k + 4 <= nchunks; k += 4) {  // 4 independent loads in flight; fixed summation order
-    a0 += p[(size_t)(k + 0) * nnz];
-    a1 += p[(size_t)(k + 1) * nnz];
-    a2 += p[(size_t)(k + 2) * nnz];
-    a3 += p[(size_t)(k + 3) * nnz];
+    a0 += p[(size_t)(k + 0) * stride];
+    a1 += p[(size_t)(k + 1) * stride];
+    a2 += p[(size_t)(k + 2) * stride];
+    a3 += p[(size_t)(k + 3) * stride];
   }
-  for (; k < nchunks; ++k) a0 += p[(size_t)k * nnz];
+  for (; k < nchunks; ++k) a0 += p[(size_t)k * stride];
   gE[(size_t)g * nnz + e] = E[(size_t)g * nnz + e] * ((a0 + a1) + (a2 + a3));
 }
 
@@ -98,8 +98,9 @@ int launch_bwd_edge(const msgat_graph_t& gr, const float* dEp, int nchunks, cons
                     float* dkW, float* dq, int G, int Bg, int N, int T, hipStream_t s) {
   if (gr.nnz > 0) {
     dim3 ge(cdiv(gr.nnz, kBlock), G);
-    const int* epos = jds_usable(gr.jds_rows, gr.nnz, N, T) ? gr.jds_rows.pos : nullptr;
-    hipLaunchKernelGGL(k_edge_grad, ge, dim3(kBlock), 0, s, dEp, nchunks, E, epos, gE, gr.nnz);
+    const bool sell = sell_usable(gr.sell_rows, gr.nnz, N, T);
+    hipLaunchKernelGGL(k_edge_grad, ge, dim3(kBlock), 0, s, dEp, nchunks, E, sell ? gr.sell_rows.pos : nullptr,
+                       sell ? gr.sell_rows.n_pos : gr.nnz, gE, gr.nnz);
     MSGAT_CHECK_LAUNCH();
   }
   dim3 grid(cdiv(N, kBlock), G);

@@ -59,20 +59,20 @@ def synthetic_adjacency(n_nodes: int, n_edges: int, seed: int = 0) -> torch.Tens
     return sym_norm_adjacency(n_nodes, random_edges(n_nodes, n_edges, seed))
 
 
-# one float4 per node must fit LDS for the JDS kernels (csrc/common.hpp: kLdsMax - 1024); below _JDS_AUTO_MIN
+# one float4 per node must fit LDS for the SELL kernels (csrc/common.hpp: kLdsMax - 1024); below _SELL_AUTO_MIN
 # nodes a whole [N,T] slab fits LDS for every supported T, so the layout would never be used
-_JDS_MAX_NODES = (160 * 1024 - 1024) // 16
-_JDS_AUTO_MIN = 2048
+_SELL_MAX_NODES = (160 * 1024 - 1024) // 16
+_SELL_AUTO_MIN = 2048
 
 
 class SparseGraph:
     """CSR + CSC of a dense adjacency, host arrays plus (lazily) device copies.
 
-    `jds`: "auto" also builds the sliced jagged-diagonal layouts (include/msgat_hip.h, msgat_jds_t) for graphs
-    large enough that an [N,T] slab may not fit LDS; "always" builds them and makes the library prefer the JDS
-    kernels (tests exercise them on small graphs this way); "never" omits them."""
+    `sell`: "auto" also builds the degree-sorted sliced-ELLPACK layouts (include/msgat_hip.h, msgat_sell_t) for
+    graphs large enough that an [N,T] slab may not fit LDS; "always" builds them and makes the library prefer the
+    SELL kernels (tests exercise them on small graphs this way); "never" omits them."""
 
-    def __init__(self, adjacency: torch.Tensor, jds: str = "auto"):
+    def __init__(self, adjacency: torch.Tensor, sell: str = "auto"):
         if adjacency.dim() != 2 or adjacency.size(0) != adjacency.size(1):
             raise ValueError(f"adjacency must be [N,N], got {tuple(adjacency.shape)}")
         a = adjacency.detach().to(device="cpu", dtype=torch.float32).contiguous()
@@ -93,56 +93,56 @@ class SparseGraph:
                                        self.val.data_ptr(), self.erow.data_ptr(), self.colptr.data_ptr(),
                                        self.crow.data_ptr(), self.cperm.data_ptr()), "msgat_graph_build")
         self._dev = {}
-        if jds not in ("auto", "always", "never"):
-            raise ValueError(f"jds must be 'auto', 'always' or 'never', got {jds!r}")
-        self.jds_prefer = jds == "always"
-        self._jds = {}
-        if jds != "never" and self.nnz > 0 and n <= _JDS_MAX_NODES and (self.jds_prefer or n >= _JDS_AUTO_MIN):
-            self._jds["jds_rows"] = self._build_jds(self.rowptr, self.col, None, with_pos=True)
-            self._jds["jds_cols"] = self._build_jds(self.colptr, self.crow, self.cperm, with_pos=False)
+        if sell not in ("auto", "always", "never"):
+            raise ValueError(f"sell must be 'auto', 'always' or 'never', got {sell!r}")
+        self.sell_prefer = sell == "always"
+        self._sell = {}
+        if sell != "never" and self.nnz > 0 and n <= _SELL_MAX_NODES and (self.sell_prefer or n >= _SELL_AUTO_MIN):
+            self._sell["sell_rows"] = self._build_sell(self.rowptr, self.col, None, with_pos=True)
+            self._sell["sell_cols"] = self._build_sell(self.colptr, self.crow, self.cperm, with_pos=False)
 
     _FIELDS = ("rowptr", "col", "val", "erow", "colptr", "crow", "cperm")
-    _JDS_FIELDS = ("slice", "colstart", "lane_row", "idx", "src", "pos")
+    _SELL_FIELDS = ("slice_off", "lane_row", "idx", "src", "pos")
 
-    def _build_jds(self, ptr, idx, perm, with_pos: bool):
+    def _build_sell(self, ptr, idx, perm, with_pos: bool):
         L = _lib.lib()
-        ns, nc = C.c_int32(0), C.c_int32(0)
-        _lib.check(L.msgat_graph_jds_count(ptr.data_ptr(), self.n_nodes, C.byref(ns), C.byref(nc)), "msgat_graph_jds_count")
-        ns, nc = int(ns.value), int(nc.value)
-        t = dict(slice=torch.zeros(ns + 1, dtype=torch.int32),
-                 colstart=torch.zeros(nc + 1 + _lib.JDS_PAD, dtype=torch.int32),
-                 lane_row=torch.zeros(64 * ns, dtype=torch.int32),
-                 idx=torch.zeros(self.nnz, dtype=torch.int32), src=torch.zeros(self.nnz, dtype=torch.int32))
+        ns, npos, pair = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        _lib.check(L.msgat_graph_sell_count(ptr.data_ptr(), self.n_nodes, C.byref(ns), C.byref(npos), C.byref(pair)),
+                   "msgat_graph_sell_count")
+        ns, npos = int(ns.value), int(npos.value)
+        t = dict(slice_off=torch.zeros(ns + 1, dtype=torch.int32), lane_row=torch.zeros(64 * ns, dtype=torch.int32),
+                 idx=torch.zeros(npos + _lib.SELL_SLACK, dtype=torch.int16), src=torch.zeros(max(npos, 1), dtype=torch.int32))
         if with_pos:
             t["pos"] = torch.zeros(self.nnz, dtype=torch.int32)
-        _lib.check(L.msgat_graph_jds_build(ptr.data_ptr(), idx.data_ptr(), None if perm is None else perm.data_ptr(),
-                                           self.n_nodes, self.nnz, ns, nc, t["slice"].data_ptr(), t["colstart"].data_ptr(),
-                                           t["lane_row"].data_ptr(), t["idx"].data_ptr(), t["src"].data_ptr(),
-                                           t["pos"].data_ptr() if with_pos else None), "msgat_graph_jds_build")
-        t["n_slices"], t["n_cols"] = ns, nc
+        _lib.check(L.msgat_graph_sell_build(ptr.data_ptr(), idx.data_ptr(), None if perm is None else perm.data_ptr(),
+                                            self.n_nodes, self.nnz, ns, npos, t["slice_off"].data_ptr(),
+                                            t["lane_row"].data_ptr(), t["idx"].data_ptr(), t["src"].data_ptr(),
+                                            t["pos"].data_ptr() if with_pos else None), "msgat_graph_sell_build")
+        t["n_slices"], t["n_pos"], t["pair_trips"] = ns, npos, int(pair.value)
         return t
 
     @property
-    def has_jds(self) -> bool:
-        return bool(self._jds)
+    def has_sell(self) -> bool:
+        return bool(self._sell)
 
     def _struct(self, tensors) -> _lib.Graph:
         g = _lib.Graph()
         g.n_nodes, g.nnz = self.n_nodes, self.nnz
         for name in self._FIELDS:
             setattr(g, name, tensors[name].data_ptr())
-        for form, host in self._jds.items():
+        for form, host in self._sell.items():
             j = getattr(g, form)
-            j.n_slices, j.n_cols, j.prefer = host["n_slices"], host["n_cols"], int(self.jds_prefer)
-            for name in self._JDS_FIELDS:
+            j.n_slices, j.n_pos, j.prefer = host["n_slices"], host["n_pos"], int(self.sell_prefer)
+            j.pair_trips = host["pair_trips"]
+            for name in self._SELL_FIELDS:
                 if name in host:
                     setattr(j, name, tensors[f"{form}.{name}"].data_ptr())
         return g
 
     def _host_tensors(self):
         t = {k: getattr(self, k) for k in self._FIELDS}
-        for form, host in self._jds.items():
-            for name in self._JDS_FIELDS:
+        for form, host in self._sell.items():
+            for name in self._SELL_FIELDS:
                 if name in host:
                     t[f"{form}.{name}"] = host[name]
         return t

@@ -71,7 +71,7 @@ class _GACNFunction(torch.autograd.Function):
         else:
             u = None
         nscratch = int(L.msgat_edge_scratch_floats(C.byref(shape), C.byref(gstruct)))
-        scratch = new(nscratch) if nscratch else None   # E in the order of the JDS layout (large graphs)
+        scratch = new(nscratch) if nscratch else None   # E in the order of the SELL layout (large graphs)
         io = _lib.Fwd(_ptr(x), _ptr(alpha), _ptr(Wg), _ptr(W), _ptr(z), _ptr(q), _ptr(kW), _ptr(lse), _ptr(pq),
                       _ptr(E), _ptr(u), int(need_bwd), _ptr(scratch))
         st = L.msgat_gacn_forward(C.byref(shape), C.byref(gstruct), C.byref(io), _stream_handle(dev))
@@ -106,7 +106,7 @@ class _GACNFunction(torch.autograd.Function):
         dalpha = torch.empty_like(alpha)
         dWg = torch.empty_like(Wg)
         dW = None if W is None else torch.empty_like(W)
-        nbytes = L.msgat_bwd_workspace_bytes(C.byref(shape), ctx.graph.nnz)
+        nbytes = L.msgat_bwd_workspace_bytes(C.byref(shape), C.byref(gstruct))
         ws = torch.empty(max(int(nbytes), 256), device=dev, dtype=torch.uint8)
         io = _lib.Bwd(_ptr(x), _ptr(alpha), _ptr(Wg), _ptr(W), _ptr(q), _ptr(kW), _ptr(lse), _ptr(pq), _ptr(E),
                       _ptr(u), _ptr(dz), _ptr(dx), _ptr(dalpha), _ptr(dWg), _ptr(dW), _ptr(ws), ws.numel())
@@ -661,7 +661,7 @@ class _AttentionCoreFunction(torch.autograd.Function):
         gstruct, _keep = ctx.graph.on(dev)
         dz = dz.contiguous()
         du, dq, dWg = torch.empty_like(u), torch.empty_like(q), torch.empty_like(Wg)
-        nbytes = L.msgat_attention_bwd_workspace_bytes(C.byref(shape), ctx.graph.nnz)
+        nbytes = L.msgat_attention_bwd_workspace_bytes(C.byref(shape), C.byref(gstruct))
         ws = torch.empty(max(int(nbytes), 256), device=dev, dtype=torch.uint8)
         st = L.msgat_attention_backward(C.byref(shape), C.byref(gstruct), _ptr(u), _ptr(dz), _ptr(q), _ptr(kW), _ptr(lse),
                                         _ptr(pq), _ptr(E), _ptr(Wg), _ptr(du), _ptr(dq), _ptr(dWg), _ptr(ws), ws.numel(),

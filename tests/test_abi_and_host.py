@@ -41,7 +41,7 @@ def test_struct_layouts_match_the_header(tmp_path):
     """sizeof / offsetof of every ABI struct as the C compiler lays out include/msgat_hip.h vs the ctypes mirror."""
     import subprocess
     from ms_gat_amd import _lib
-    structs = {"msgat_shape_t": _lib.Shape, "msgat_jds_t": _lib.Jds, "msgat_graph_t": _lib.Graph,
+    structs = {"msgat_shape_t": _lib.Shape, "msgat_sell_t": _lib.Sell, "msgat_graph_t": _lib.Graph,
                "msgat_fwd_t": _lib.Fwd, "msgat_bwd_t": _lib.Bwd, "msgat_seg_t": _lib.Seg}
     lines = []
     for cname, cls in structs.items():
@@ -58,7 +58,7 @@ def test_struct_layouts_match_the_header(tmp_path):
         assert int(got[cname]) == C.sizeof(cls), cname
         for field, *_ in cls._fields_:
             assert int(got[f"{cname}.{field}"]) == getattr(cls, field).offset, f"{cname}.{field}"
-    assert _lib.JDS_PAD == 8 and "#define MSGAT_JDS_PAD 8" in open(os.path.join(ROOT, "include", "msgat_hip.h")).read()
+    assert f"#define MSGAT_SELL_SLACK {_lib.SELL_SLACK} " in open(os.path.join(ROOT, "include", "msgat_hip.h")).read()
 
 
 def test_mode_selection_and_status_strings():
@@ -85,8 +85,11 @@ def test_bad_arguments_come_back_as_status_codes():
     assert L.msgat_gacn_forward(C.byref(_lib.Shape(0, 2, 3, 24, 16, 12)), C.byref(g), None, None) == -2
     g.n_nodes = 15
     assert L.msgat_gacn_forward(C.byref(shape), C.byref(g), None, None) == -2    # graph/shape mismatch
-    assert L.msgat_bwd_workspace_bytes(C.byref(bad_t), 10) == 0
-    assert L.msgat_bwd_workspace_bytes(C.byref(shape), 40) > 0
+    import ms_gat_amd
+    hs = ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(16, 12, 0)).host_struct()
+    assert L.msgat_bwd_workspace_bytes(C.byref(bad_t), C.byref(hs)) == 0
+    assert L.msgat_bwd_workspace_bytes(C.byref(shape), None) == 0
+    assert L.msgat_bwd_workspace_bytes(C.byref(shape), C.byref(hs)) > 0
     with pytest.raises(_lib.MsgatError):
         _lib.check(-4, "x")
 
@@ -137,61 +140,81 @@ def test_graph_validate_rejects_corruption():
         g.validate()
 
 
-def _numpy_jds(ptr, idx, ids):
-    """Restatement of msgat_graph_jds_build: slices of 64 rows, stable sort by degree (descending) inside a
-    slice, k-th entries of a slice's rows back to back."""
+def _numpy_sell(ptr, idx, ids):
+    """Restatement of msgat_graph_sell_build: rows sorted by degree (descending, stable), slices of 64, every
+    slice padded to its first row's degree rounded up to a multiple of 4 and stored in lane-interleaved trips."""
     n = len(ptr) - 1
-    slices, colstart, lane_row, jidx, jsrc = [0], [], [], [], []
-    for r0 in range(0, n, 64):
-        rows = list(range(r0, min(r0 + 64, n)))
-        deg = {r: int(ptr[r + 1] - ptr[r]) for r in rows}
-        order = sorted(rows, key=lambda r: -deg[r])          # Python's sort is stable
-        lane_row += order + [-1] * (64 - len(order))
-        for k in range(deg[order[0]] if order else 0):
-            colstart.append(len(jidx))
-            for r in order:
-                if deg[r] > k:
-                    jidx.append(int(idx[ptr[r] + k]))
-                    jsrc.append(int(ids[ptr[r] + k]))
-        slices.append(len(colstart))
-    return np.array(slices), np.array(colstart + [len(jidx)] * 9), np.array(lane_row), np.array(jidx), np.array(jsrc)
+    deg = np.diff(ptr)
+    order = np.argsort(-deg, kind="stable")
+    ns = (n + 63) // 64
+    off, lane_row, sidx, ssrc = [0], [], [], []
+    for s in range(ns):
+        rows = order[64 * s: 64 * s + 64]
+        width = (int(deg[rows[0]]) + 3) // 4 * 4
+        lane_row += rows.tolist() + [-1] * (64 - len(rows))
+        for trip in range(width // 4):                       # a trip = 4 columns, lane-interleaved
+            for lane in range(64):
+                r = rows[lane] if lane < len(rows) else -1
+                for k in range(4 * trip, 4 * trip + 4):
+                    live = r >= 0 and k < deg[r]
+                    sidx.append(int(idx[ptr[r] + k]) if live else 0)
+                    ssrc.append(int(ids[ptr[r] + k]) if live else -1)
+        off.append(len(sidx))
+    return np.array(off), np.array(lane_row), np.array(sidx, dtype=np.int64), np.array(ssrc, dtype=np.int64)
 
 
 @pytest.mark.parametrize("n,e,seed", [(1, 0, 0), (7, 5, 1), (64, 300, 2), (65, 70, 3), (200, 1500, 4), (883, 866, 5)])
-def test_native_jds_build_matches_numpy(n, e, seed):
-    """The sliced jagged-diagonal edge layout of the large-graph kernels (msgat_jds_t): pure index work, bit-exact."""
-    import ms_gat_amd
-    g = ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(n, e, seed), jds="always")
-    assert g.has_jds
-    g.validate()
-    nnz = g.nnz
-    for form, ptr, idx, ids in (("jds_rows", g.rowptr, g.col, np.arange(nnz)), ("jds_cols", g.colptr, g.crow, g.cperm.numpy())):
-        j = g._jds[form]
-        sl, cs, lr, ji, js = _numpy_jds(ptr.numpy(), idx.numpy(), ids)
-        assert j["n_slices"] == (n + 63) // 64 and j["n_cols"] == len(cs) - 9
-        assert np.array_equal(j["slice"].numpy(), sl)
-        assert np.array_equal(j["colstart"].numpy(), cs)
-        assert np.array_equal(j["lane_row"].numpy(), lr)
-        assert np.array_equal(j["idx"].numpy(), ji)
-        assert np.array_equal(j["src"].numpy(), js)
-        assert sorted(js.tolist()) == list(range(nnz))      # a permutation of the CSR edges
-        if "pos" in j:
-            assert np.array_equal(j["pos"].numpy()[js], np.arange(nnz))
-
-
-def test_jds_is_built_for_large_graphs_only_and_validate_catches_corruption():
+def test_native_sell_build_matches_numpy(n, e, seed):
+    """The degree-sorted sliced-ELLPACK edge layout of the large-graph kernels (msgat_sell_t): pure index work,
+    bit-exact."""
     import ms_gat_amd
     from ms_gat_amd import _lib
-    assert not ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(300, 340, 0)).has_jds       # a slab fits LDS
-    assert not ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(2100, 3000, 0), jds="never").has_jds
+    g = ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(n, e, seed), sell="always")
+    assert g.has_sell
+    g.validate()
+    nnz = g.nnz
+    for form, ptr, idx, ids in (("sell_rows", g.rowptr, g.col, np.arange(nnz)), ("sell_cols", g.colptr, g.crow, g.cperm.numpy())):
+        j = g._sell[form]
+        off, lr, si, ss = _numpy_sell(ptr.numpy(), idx.numpy(), ids)
+        assert j["n_slices"] == (n + 63) // 64 and j["n_pos"] == off[-1] and j["n_pos"] % 256 == 0
+        trips = np.diff(off) // 256
+        ns = len(trips)
+        assert j["pair_trips"] == max(trips[i] + (trips[ns - 1 - i] if ns - 1 - i > i else 0) for i in range((ns + 1) // 2))
+        assert np.array_equal(j["slice_off"].numpy(), off)
+        assert np.array_equal(j["lane_row"].numpy(), lr)
+        assert j["idx"].dtype == torch.int16 and np.array_equal(j["idx"].numpy()[: j["n_pos"]], si)
+        assert not j["idx"].numpy()[j["n_pos"]:].any() and len(j["idx"]) == j["n_pos"] + _lib.SELL_SLACK
+        assert np.array_equal(j["src"].numpy()[: j["n_pos"]], ss)
+        assert sorted(ss[ss >= 0].tolist()) == list(range(nnz))      # every CSR edge exactly once
+        if "pos" in j:
+            assert np.array_equal(ss[j["pos"].numpy()], np.arange(nnz))
+
+
+def test_sell_padding_stays_small_on_the_stress_graph_shape():
+    """Sorting by degree keeps the slices homogeneous: Poisson-like degrees (the BASELINE stress graph's shape,
+    scaled down) pad by a few percent, not by the max/mean degree ratio an unsorted sliced layout would."""
+    import ms_gat_amd
+    g = ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(2048, 16384, 0))
+    assert g.has_sell and g.nnz == 2048 + 2 * 16384
+    assert g._sell["sell_rows"]["n_pos"] < 1.12 * g.nnz
+    deg = np.diff(g.rowptr.numpy())
+    unsorted = sum(64 * int(deg[i:i + 64].max()) for i in range(0, 2048, 64))
+    assert unsorted > 1.4 * g.nnz
+
+
+def test_sell_is_built_for_large_graphs_only_and_validate_catches_corruption():
+    import ms_gat_amd
+    from ms_gat_amd import _lib
+    assert not ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(300, 340, 0)).has_sell       # a slab fits LDS
+    assert not ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(2100, 3000, 0), sell="never").has_sell
     big = ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(2100, 3000, 0))
-    assert big.has_jds and not big.jds_prefer
+    assert big.has_sell and not big.sell_prefer
     big.validate()
     hs = big.host_struct()
-    assert hs.jds_rows.n_slices == 33 and hs.jds_cols.n_slices == 33 and hs.jds_rows.prefer == 0
-    for field, at in (("idx", 5), ("src", 7), ("lane_row", 3), ("colstart", 2)):
-        g = ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(100, 300, 1), jds="always")
-        t = g._jds["jds_cols"][field]
+    assert hs.sell_rows.n_slices == 33 and hs.sell_cols.n_slices == 33 and hs.sell_rows.prefer == 0
+    for field, at in (("idx", 5), ("src", 7), ("lane_row", 3), ("slice_off", 1)):
+        g = ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(100, 300, 1), sell="always")
+        t = g._sell["sell_cols"][field]
         t[at] = t[at] + 1
         with pytest.raises(_lib.MsgatError):
             g.validate()

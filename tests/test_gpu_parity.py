@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_err
+from conftest import load_golden, record_err, rel_err
 from oracle import dense_torch, gat_oracle
 
 pytestmark = pytest.mark.gpu
@@ -24,16 +24,16 @@ def _cuda(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(_dev())
 
 
-def run_ours(x, adj, Wg, alpha, W, dz, jds=None):
+def run_ours(x, adj, Wg, alpha, W, dz, sell=None):
     """One fwd+bwd through ms_gat_amd.ops.gacn with R stacked relations.
     x [G,C,N,T]; Wg [R,T,T]; alpha [R,C]; W [R,Co,C] or None; dz like the output.
-    jds: None = the library's own choice of edge layout; "always" / "never" force it (SparseGraph)."""
+    sell: None = the library's own choice of edge layout; "always" / "never" force it (SparseGraph)."""
     import ms_gat_amd
     xt = _cuda(x).requires_grad_(True)
     Wgt = _cuda(Wg).requires_grad_(True)
     at = _cuda(alpha).requires_grad_(True)
     Wt = None if W is None else _cuda(W).requires_grad_(True)
-    graph = _cuda(adj) if jds is None else ms_gat_amd.SparseGraph(torch.from_numpy(np.ascontiguousarray(adj)), jds=jds)
+    graph = _cuda(adj) if sell is None else ms_gat_amd.SparseGraph(torch.from_numpy(np.ascontiguousarray(adj)), sell=sell)
     z = ms_gat_amd.gacn(xt, at, Wgt, Wt, graph)
     z.backward(_cuda(dz))
     torch.cuda.synchronize()
@@ -72,6 +72,7 @@ def assert_close(got, want, tol=TOL, what="", floor=0.0):
         e = rel_err(got[k], want[k])
         if floor > 0.0:
             e = min(e, float(np.abs(np.asarray(got[k], dtype=np.float64) - want[k]).max()) / floor)
+        record_err(what, k, e, tol)
         assert e < tol, f"{what} {k}: rel err {e:.3e} >= {tol}"
 
 
@@ -348,25 +349,98 @@ def test_stress_graph_uses_the_large_n_path():
 @pytest.mark.parametrize("R,Bg,C,Co,N,E,seed", [
     (1, 2, 5, 0, 50, 60, 70),        # PLAIN, one partial slice
     (2, 2, 3, 24, 130, 400, 71),     # AGG_FIRST: backward aggregate with the alpha (x) dq epilogue, SDDMM on C channels
-    (1, 3, 40, 8, 200, 2500, 72),    # PROJ_FIRST, degrees ~26: several trips of 8 jagged columns per slice
+    (1, 3, 40, 8, 200, 2500, 72),    # PROJ_FIRST, degrees ~26: several trips of 4 columns per slice
     (3, 1, 72, 24, 64, 600, 73),     # exactly one slice, dense-ish rows, R relations
     (1, 1, 12, 4, 333, 300, 74),     # sparse: most rows have 1-2 edges
 ])
-def test_jds_edge_layout_agrees_with_the_csr_kernels_and_the_oracle(R, Bg, C, Co, N, E, seed):
-    """The large-graph kernels (k_agg_jds, k_sddmm_jds: one column of a slab in LDS, edges in the sliced
-    jagged-diagonal layout) forced onto small graphs, against the fp64 oracle and against the CSR kernels."""
+def test_sell_edge_layout_agrees_with_the_csr_kernels_and_the_oracle(R, Bg, C, Co, N, E, seed):
+    """The large-graph kernels (k_agg_sell, k_sddmm_sell: one column of a slab in LDS, edges in the degree-sorted
+    sliced-ELLPACK layout) forced onto small graphs, against the fp64 oracle and against the CSR kernels."""
     prob = random_problem(R, Bg, C, Co, N, 12, E, seed)
-    got = run_ours(*prob, jds="always")
-    assert_close(got, oracle_f64(*prob), what=f"JDS N={N} C={C}->{Co}")
-    ref = run_ours(*prob, jds="never")
-    assert np.array_equal(got["z"], ref["z"]), "the aggregate sums a row's edges in CSR order in both layouts"
-    assert_close(got, ref, tol=2e-6, what="JDS vs CSR kernels")
+    got = run_ours(*prob, sell="always")
+    assert_close(got, oracle_f64(*prob), what=f"SELL N={N} C={C}->{Co}")
+    assert_close(got, run_ours(*prob, sell="never"), tol=5e-6, what="SELL vs CSR kernels")
 
 
-def test_jds_with_other_timestep_counts():
+def test_sell_with_other_timestep_counts():
     for T, seed in ((4, 80), (8, 81), (16, 82)):
         prob = random_problem(1, 2, 6, 3, 150, T, 500, seed)
-        assert_close(run_ours(*prob, jds="always"), oracle_f64(*prob), what=f"JDS T={T}")
+        assert_close(run_ours(*prob, sell="always"), oracle_f64(*prob), what=f"SELL T={T}")
+
+
+def _stress_setup(R, Bg, seed):
+    """BASELINE.json configs[4]: N = 8192 sensors, average degree 16 (+ self loops), T = 12, msgat72's second-MEAM
+    widths C = 72 -> 24.  Everything stays on the device (x alone is 7.2 GB at R = 4, B = 64)."""
+    import ms_gat_amd
+    dev = _dev()
+    N, T, C, Co = 8192, 12, 72, 24
+    graph = ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(N, 65536, 0))
+    assert graph.has_sell and graph.nnz == N + 2 * 65536
+    g = torch.Generator(device=dev).manual_seed(seed)
+    x = torch.nn.functional.layer_norm(torch.randn(R * Bg, C, N, T, device=dev, generator=g), (T,))
+    Wg = torch.randn(R, T, T, device=dev, generator=g) * (1.0 / T) ** 0.5
+    alpha = (torch.rand(R, C, device=dev, generator=g) * 2 - 1) * C ** -0.5
+    W = torch.randn(R, Co, C, device=dev, generator=g) * (2.0 / (Co + C)) ** 0.5
+    return graph, x, Wg, alpha, W, g
+
+
+def _terr(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def test_stress_config_full_size_properties():
+    """configs[4] at its full size (R = 4, B = 64: G = 256 groups) through size-independent properties:
+    determinism, z linear in W, every gradient linear in the cotangent, and the closed form of Wg = 0 (uniform
+    softmax: E = adj / N, so z = W (adj x) / N) against a sparse fp64 product."""
+    import ms_gat_amd
+    R, Bg, N = 4, 64, 8192
+    graph, x, Wg, alpha, W, gen = _stress_setup(R, Bg, 123)
+    dev = x.device
+    with torch.no_grad():
+        z1 = ms_gat_amd.gacn(x, alpha, Wg, W, graph)
+        assert torch.equal(z1, ms_gat_amd.gacn(x, alpha, Wg, W, graph)), "no atomics anywhere: bitwise reproducible"
+        W2 = torch.randn(W.shape, device=dev, generator=gen) * 0.1
+        z2 = ms_gat_amd.gacn(x, alpha, Wg, W2, graph)
+        z12 = ms_gat_amd.gacn(x, alpha, Wg, W + W2, graph)
+        e = _terr(z1 + z2, z12)
+        record_err("stress full size: z linear in W", "z", e, 1e-5)
+        assert e < 1e-5
+        del z2, z12
+
+        # Wg = 0: scores are 0, softmax is uniform, lse = log2 N exactly
+        z0 = ms_gat_amd.gacn(x, alpha, torch.zeros_like(Wg), W, graph)
+        A = torch.sparse_coo_tensor(torch.stack([graph.erow.long(), graph.col.long()]), graph.val.double(), (N, N)).to(dev)
+        for grp in (0, 77, 130, 255):
+            r = grp // Bg
+            xg = x[grp].double().permute(1, 0, 2).reshape(N, -1)                   # [N, C*T]
+            y = (torch.sparse.mm(A, xg) / N).reshape(N, x.shape[1], -1)             # [N, C, T]
+            want = torch.einsum("oc,nct->ont", W[r].double(), y)
+            e = _terr(z0[grp].double(), want)
+            record_err("stress full size: Wg = 0 closed form", f"z[group {grp}]", e, TOL)
+            assert e < TOL
+        del z0, z1
+
+    def grads(dz):
+        xt = x.detach().requires_grad_(True)
+        ps = [p.detach().clone().requires_grad_(True) for p in (alpha, Wg, W)]
+        ms_gat_amd.gacn(xt, ps[0], ps[1], ps[2], graph).backward(dz)
+        return [xt.grad] + [p.grad for p in ps]
+
+    dz1 = torch.randn(R * Bg, 24, N, 12, device=dev, generator=gen)
+    dz2 = torch.randn(R * Bg, 24, N, 12, device=dev, generator=gen)
+    g1, g2 = grads(dz1), grads(dz2)
+    g12 = grads(dz1 + dz2)
+    for name, a, b, c in zip(("dx", "dalpha", "dWg", "dW"), g1, g2, g12):
+        e = _terr(a + b, c)
+        record_err("stress full size: gradients linear in dz", name, e, 2e-5)
+        assert e < 2e-5, name
+
+
+def test_stress_config_widths_against_the_dense_oracle():
+    """configs[4]'s graph and widths (C = 72 -> 24, R = 4) at the largest batch the dense [B,N,N] oracle handles
+    comfortably on the same GPU (2 samples per relation)."""
+    prob = random_problem(4, 2, 72, 24, 8192, 12, 65536, seed=167)
+    assert_close(run_ours(*prob), _dense_oracle_gpu(*prob), what="stress widths N=8192 R=4 C=72->24 vs dense eager")
 
 
 def test_mid_size_graph_uses_a_large_lds_slab():

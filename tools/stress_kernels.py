@@ -3,7 +3,7 @@
 C = 72 -> 24) with HIP events: forward aggregate, backward (transposed) aggregate and SDDMM through the fused
 backward is not separable, so the stages are called directly.
 
-    python tools/stress_kernels.py [--B 64] [--reps 5] [--jds auto|never]
+    python tools/stress_kernels.py [--B 64] [--reps 5] [--sell auto|never]
 """
 import argparse
 import ctypes as C
@@ -24,13 +24,13 @@ def main():
     ap.add_argument("--N", type=int, default=8192)
     ap.add_argument("--E", type=int, default=65536)
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--jds", default="auto")
+    ap.add_argument("--sell", default="auto")
     a = ap.parse_args()
     N, T, R, B, Cc, Co = a.N, 12, a.R, a.B, 72, 24
     G = R * B
     dev = torch.device("cuda:0")
     L = _lib.lib()
-    graph = ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(N, a.E, 0), jds=a.jds)
+    graph = ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(N, a.E, 0), sell=a.sell)
     gs, _keep = graph.on(dev)
     nnz = graph.nnz
     shape = _lib.Shape(R, B, Cc, Co, N, T)
@@ -56,7 +56,7 @@ def main():
     alg = 2 * 4 * G * Co * N * T + 4 * G * nnz + 8 * nnz + 4 * (N + 1)
     ms = timed(lambda: _lib.check(L.msgat_stage_aggregate(sp, gp, Co, u.data_ptr(), E.data_ptr(), v.data_ptr(),
                                                           scr.data_ptr() if nscr else None, st), "agg"))
-    print(f"aggregate (incl. edge permute)  {ms:8.3f} ms   {alg / ms / 1e6:8.1f} GB/s algorithmic  jds={graph.has_jds} nnz={nnz}",
+    print(f"aggregate (incl. edge permute)  {ms:8.3f} ms   {alg / ms / 1e6:8.1f} GB/s algorithmic  sell={graph.has_sell} nnz={nnz}",
           flush=True)
 
     # attention backward on the projected features: SDDMM + edge/row passes + dense column pass + transposed aggregate
@@ -66,7 +66,7 @@ def main():
     Wg = torch.randn(R, T, T, device=dev) * 0.3
     dv = torch.randn(G, Co, N, T, device=dev)
     du, dq, dWg = torch.empty_like(u), torch.empty(G, N, T, device=dev), torch.empty(R, T, T, device=dev)
-    nb = int(L.msgat_attention_bwd_workspace_bytes(C.byref(shp), nnz))
+    nb = int(L.msgat_attention_bwd_workspace_bytes(C.byref(shp), gp))
     ws = torch.empty(nb, device=dev, dtype=torch.uint8)
     ms = timed(lambda: _lib.check(L.msgat_attention_backward(C.byref(shp), gp, u.data_ptr(), dv.data_ptr(), q.data_ptr(),
                                                              kW.data_ptr(), lse.data_ptr(), pq.data_ptr(), E.data_ptr(),
