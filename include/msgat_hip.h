@@ -342,6 +342,32 @@ size_t msgat_head_grad_weight_partial_floats(int32_t C, int32_t T, int32_t T_out
 int msgat_head_grad_weight(const float* dout, const float* x, float* dWc, float* partials, int32_t B, int32_t C,
                            int32_t N, int32_t T, int32_t T_out, int32_t R, void* stream);
 
+/* ---- device: the tail of a training step ----
+ * msgat_huber_metrics: one pass over the prediction replaces engine.py:56 (HuberLoss, loss.py:51-52) and the
+ *     metric sums of engine.py:70 / metrics.py:20-35, with nothing read back to the host:
+ *       loss[0]  = mean over n of (|e| <= delta ? e^2 / 2 : delta |e| - delta^2 / 2),  e = pred - truth   (fp32)
+ *       sums[0] += sum |e|;  sums[1] += 100 sum_{truth > mask_value} |e / truth|;  sums[2] += sum e^2;
+ *       sums[3] += loss[0]                                                         (fp64 [4], running totals
+ *     the caller zeroes per epoch; may be NULL).  `partials`: msgat_huber_partial_doubles(n)
+ *     doubles.  Fixed summation order: bitwise reproducible.
+ * msgat_huber_grad: dpred = dloss[0] * clamp(e, -delta, delta) / n  -- the backward of the loss above.
+ * msgat_adam_step: torch.optim.Adam's update (engine.py:106: lr 1e-3, weight_decay 5e-4 as L2 on the gradient,
+ *     betas, eps outside the square root, bias correction) for ALL parameter tensors in one launch.  The
+ *     gradients and both moments are flat fp32 buffers; the parameters stay where they are and are reached
+ *     through a chunk table (device arrays): chunk c = chunk_len[c] <= msgat_adam_chunk_elems() elements at
+ *     chunk_param[c], whose gradient / moments start at element chunk_off[c] of the flat buffers.
+ *     state[0] = step count (advanced by this call), state[1] = learning rate: device memory, so a captured
+ *     launch follows the scheduler. */
+size_t msgat_huber_partial_doubles(int64_t n);
+int msgat_huber_metrics(const float* pred, const float* truth, int64_t n, float delta, float mask_value,
+                        double* partials, float* loss, double* sums, void* stream);
+int msgat_huber_grad(const float* pred, const float* truth, const float* dloss, int64_t n, float delta,
+                     float* dpred, void* stream);
+int msgat_adam_chunk_elems(void);
+int msgat_adam_step(float* const* chunk_param, const int64_t* chunk_off, const int32_t* chunk_len,
+                    int32_t n_chunks, const float* grad, float* exp_avg, float* exp_avg_sq, float* state,
+                    float beta1, float beta2, float eps, float weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

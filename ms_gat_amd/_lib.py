@@ -107,6 +107,11 @@ _PROTOTYPES = {
     "msgat_layernorm_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "msgat_layernorm_partial_floats": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "msgat_layernorm_backward": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
+    "msgat_huber_partial_doubles": (C.c_size_t, [C.c_int64]),
+    "msgat_huber_metrics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float] + [C.c_void_p] * 4),
+    "msgat_huber_grad": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
+    "msgat_adam_chunk_elems": (C.c_int, []),
+    "msgat_adam_step": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] + [C.c_void_p] * 4 + [C.c_float] * 4 + [C.c_void_p]),
 }
 
 _lock = threading.Lock()

@@ -582,3 +582,32 @@ extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t*
   if (st) return st;
   return launch_chanpair(nullptr, dq, io->x, cpp, nullptr, 0, io->dalpha, C, G, Bg, 1, C, P, s);
 }
+
+// ---- step tail: fused Huber loss + metric sums, flat Adam ------------------------------------------------------
+extern "C" size_t msgat_huber_partial_doubles(int64_t n) { return n > 0 ? huber_partial_doubles(n) : 0; }
+
+extern "C" int msgat_huber_metrics(const float* pred, const float* truth, int64_t n, float delta, float mask_value,
+                                   double* partials, float* loss, double* sums, void* stream) {
+  if (!pred || !truth || !partials || !loss) return MSGAT_ERR_NULL;
+  if (n <= 0 || !(delta > 0.f)) return MSGAT_ERR_SHAPE;
+  return launch_huber_metrics(pred, truth, n, delta, mask_value, partials, loss, sums, (hipStream_t)stream);
+}
+
+extern "C" int msgat_huber_grad(const float* pred, const float* truth, const float* dloss, int64_t n, float delta,
+                                float* dpred, void* stream) {
+  if (!pred || !truth || !dloss || !dpred) return MSGAT_ERR_NULL;
+  if (n <= 0 || !(delta > 0.f)) return MSGAT_ERR_SHAPE;
+  return launch_huber_grad(pred, truth, dloss, n, delta, dpred, (hipStream_t)stream);
+}
+
+extern "C" int msgat_adam_chunk_elems(void) { return adam_chunk_elems(); }
+
+extern "C" int msgat_adam_step(float* const* chunk_param, const int64_t* chunk_off, const int32_t* chunk_len,
+                               int32_t n_chunks, const float* grad, float* exp_avg, float* exp_avg_sq, float* state,
+                               float beta1, float beta2, float eps, float weight_decay, void* stream) {
+  if (!state || n_chunks < 0) return n_chunks < 0 ? MSGAT_ERR_SHAPE : MSGAT_ERR_NULL;
+  if (n_chunks > 0 && (!chunk_param || !chunk_off || !chunk_len || !grad || !exp_avg || !exp_avg_sq)) return MSGAT_ERR_NULL;
+  if (!(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f && weight_decay >= 0.f)) return MSGAT_ERR_SHAPE;
+  return launch_adam(chunk_param, (const long long*)chunk_off, chunk_len, n_chunks, grad, exp_avg, exp_avg_sq, state,
+                     beta1, beta2, eps, weight_decay, (hipStream_t)stream);
+}

@@ -259,4 +259,15 @@ int launch_layernorm_fwd(const float* x, const float* w, const float* b, float* 
 int launch_layernorm_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
                          float* part, long long rows, int T, float eps, int R, hipStream_t s);
 
+// step tail (tail.hip)
+size_t huber_partial_doubles(long long n);
+int launch_huber_metrics(const float* pred, const float* truth, long long n, float delta, float mask_value,
+                         double* part, float* loss, double* sums, hipStream_t s);
+int launch_huber_grad(const float* pred, const float* truth, const float* dloss, long long n, float delta,
+                      float* dpred, hipStream_t s);
+int adam_chunk_elems();
+int launch_adam(float* const* chunk_param, const long long* chunk_off, const int* chunk_len, int nchunks,
+                const float* grad, float* m, float* v, float* state, float beta1, float beta2, float eps,
+                float weight_decay, hipStream_t s);
+
 }  // namespace msgat

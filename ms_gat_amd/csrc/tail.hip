@@ -1,0 +1,161 @@
+// The tail of a training step: loss + metric sums in one pass over the prediction, and
+// Adam over flat state buffers in one launch.
+//
+//   reference            engine.py:56 HuberLoss (loss.py:51-52: mean of 0.5 e^2 inside delta, delta |e| - 0.5 delta^2
+//                        beyond), engine.py:66-70 + metrics.py:20-35: per batch `loss.item()` and three more `.item()`
+//                        sums (|e|, 100 |e / y| where y > mask, e^2) -- four host syncs and ~10 elementwise / reduce
+//                        launches; engine.py:106 optim.Adam(lr 1e-3, weight_decay 5e-4).
+//   here                 k_huber_metrics: every block folds its elements into four double partials (fixed order inside
+//                        the block), k_huber_finish adds the partials in block order: deterministic, nothing read back.
+//                        k_huber_grad: the loss gradient.  k_adam: torch.optim.Adam's update (L2 decay folded into the
+//                        gradient, bias correction, eps outside the square root) for every parameter tensor at once,
+//                        driven by a chunk table; the step counter and the learning rate live in device memory so the
+//                        launch is capturable in a HIP graph.
+#include "common.hpp"
+
+namespace msgat {
+
+constexpr int kTailBlock = 256;
+constexpr int kTailPerThread = 8;  // elements per lane per block trip
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ __launch_bounds__(kTailBlock) void k_huber_metrics(const float* __restrict__ pred,
+                                                              const float* __restrict__ truth, long long n,
+                                                              float delta, float mask_value,
+                                                              double* __restrict__ part) {
+  __shared__ double red[4][kTailBlock / 64];
+  double s[4] = {0.0, 0.0, 0.0, 0.0};  // huber, |e|, 100 |e / y| (y > mask), e^2
+  const long long stride = (long long)gridDim.x * kTailBlock;
+  for (long long i = (long long)blockIdx.x * kTailBlock + threadIdx.x; i < n; i += stride) {
+    const float p = pred[i], y = truth[i];
+    const float e = p - y, a = fabsf(e);
+    s[0] += (a <= delta) ? 0.5f * a * a : delta * a - 0.5f * delta * delta;
+    s[1] += a;
+    if (y > mask_value) s[2] += 100.0 * (double)fabsf(e / y);
+    s[3] += (double)e * (double)e;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double w = wave_sum(s[k]);
+    if (lane == 0) red[k][wave] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < kTailBlock / 64; ++w) t += red[threadIdx.x][w];
+    part[(size_t)blockIdx.x * 4 + threadIdx.x] = t;
+  }
+}
+
+// loss[0] = mean Huber loss (fp32, what the reference's loss tensor holds); sums[0..2] += AE, APE, SE and
+// sums[3] += that mean (the epoch's running total of batch losses), all double
+__global__ void k_huber_finish(const double* __restrict__ part, int nblocks, long long n, float* __restrict__ loss,
+                               double* __restrict__ sums) {
+  const int k = threadIdx.x;
+  if (k >= 4) return;
+  double t = 0.0;
+  for (int b = 0; b < nblocks; ++b) t += part[(size_t)b * 4 + k];
+  if (k == 0) {
+    loss[0] = (float)(t / (double)n);
+    if (sums != nullptr) sums[3] += t / (double)n;
+  } else if (sums != nullptr) {
+    sums[k - 1] += t;
+  }
+}
+
+__global__ __launch_bounds__(kTailBlock) void k_huber_grad(const float* __restrict__ pred,
+                                                           const float* __restrict__ truth,
+                                                           const float* __restrict__ dloss, long long n, float delta,
+                                                           float* __restrict__ dpred) {
+  const long long i = (long long)blockIdx.x * kTailBlock + threadIdx.x;
+  if (i >= n) return;
+  const float e = pred[i] - truth[i];
+  const float g = fminf(fmaxf(e, -delta), delta);  // d/de of the Huber function
+  dpred[i] = g * (dloss[0] / (float)n);
+}
+
+static int huber_blocks(long long n) {
+  const long long want = (n + (long long)kTailBlock * kTailPerThread - 1) / ((long long)kTailBlock * kTailPerThread);
+  return (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+}
+
+size_t huber_partial_doubles(long long n) { return (size_t)huber_blocks(n) * 4; }
+
+int launch_huber_metrics(const float* pred, const float* truth, long long n, float delta, float mask_value,
+                         double* part, float* loss, double* sums, hipStream_t s) {
+  const int nb = huber_blocks(n);
+  hipLaunchKernelGGL(k_huber_metrics, dim3(nb), dim3(kTailBlock), 0, s, pred, truth, n, delta, mask_value, part);
+  MSGAT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_huber_finish, dim3(1), dim3(64), 0, s, part, nb, n, loss, sums);
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
+}
+
+int launch_huber_grad(const float* pred, const float* truth, const float* dloss, long long n, float delta,
+                      float* dpred, hipStream_t s) {
+  hipLaunchKernelGGL(k_huber_grad, dim3((unsigned)((n + kTailBlock - 1) / kTailBlock)), dim3(kTailBlock), 0, s, pred,
+                     truth, dloss, n, delta, dpred);
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
+}
+
+// ---- Adam ---------------------------------------------------------------------------------------------------------
+// state[0] = step count t (float, advanced by the launch), state[1] = learning rate.  Chunk c covers
+// chunk_len[c] <= kAdamChunk elements of one parameter tensor starting at chunk_param[c]; its gradient and moments
+// sit at chunk_off[c] of the flat buffers.
+constexpr int kAdamChunk = 2048;
+
+__global__ void k_adam_advance(float* __restrict__ state) { state[0] += 1.0f; }
+
+__global__ __launch_bounds__(kTailBlock) void k_adam(float* const* __restrict__ chunk_param,
+                                                     const long long* __restrict__ chunk_off,
+                                                     const int* __restrict__ chunk_len,
+                                                     const float* __restrict__ grad, float* __restrict__ m,
+                                                     float* __restrict__ v, const float* __restrict__ state,
+                                                     float beta1, float beta2, float eps, float weight_decay) {
+  const int c = blockIdx.x;
+  float* p = chunk_param[c];
+  const long long off = chunk_off[c];
+  const int len = chunk_len[c];
+  const float t = state[0], lr = state[1];
+  // torch.optim.Adam (_single_tensor_adam): bias_correction = 1 - beta^t; step_size = lr / bc1;
+  // denom = sqrt(v) / sqrt(bc2) + eps; p -= step_size * m / denom
+  // (in double, as the host-side Python floats of the reference optimizer are: 1 - 0.999^t cancels badly in fp32)
+  const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+  const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  for (int i = threadIdx.x; i < len; i += kTailBlock) {
+    const float w = p[i];
+    const float g = fmaf(weight_decay, w, grad[off + i]);
+    float mi = m[off + i], vi = v[off + i];
+    mi = fmaf(g - mi, 1.0f - beta1, mi);              // exp_avg.lerp_(grad, 1 - beta1)
+    vi = fmaf(g * g, 1.0f - beta2, vi * beta2);       // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    m[off + i] = mi;
+    v[off + i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = w - step_size * (mi / denom);
+  }
+}
+
+int launch_adam(float* const* chunk_param, const long long* chunk_off, const int* chunk_len, int nchunks,
+                const float* grad, float* m, float* v, float* state, float beta1, float beta2, float eps,
+                float weight_decay, hipStream_t s) {
+  hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(1), 0, s, state);
+  MSGAT_CHECK_LAUNCH();
+  if (nchunks > 0) {
+    hipLaunchKernelGGL(k_adam, dim3(nchunks), dim3(kTailBlock), 0, s, chunk_param, chunk_off, chunk_len, grad, m, v,
+                       state, beta1, beta2, eps, weight_decay);
+    MSGAT_CHECK_LAUNCH();
+  }
+  return MSGAT_OK;
+}
+
+int adam_chunk_elems() { return kAdamChunk; }
+
+}  // namespace msgat

@@ -15,7 +15,7 @@ from typing import List, Sequence, Tuple
 import numpy as np
 import torch
 import yaml
-from torch.utils.data import DataLoader, Dataset
+from torch.utils.data import DataLoader, Dataset, Sampler
 
 from .graph import sym_norm_adjacency, synthetic_adjacency
 
@@ -91,13 +91,68 @@ class MSGATData:
             raw, self.in_hours, out_timesteps, self.timesteps_per_hour, batch_size, num_workers)
 
 
-def make_loaders(raw: torch.Tensor, in_hours, out_timesteps, tau, batch_size, num_workers=0, pin_memory=True):
-    """raw [C,N,T_total] -> (training, validation, evaluation) loaders; only training shuffles (data_loader.py:80-89)."""
+class ShardedBatchSampler(Sampler):
+    """This rank's samples of every GLOBAL batch, for one-process-per-GPU data parallelism.
+
+    `nn.DataParallel` (main.py:52-55) loads a batch in one process and scatters it on dim 0.  Here all ranks
+    walk the same sequence of global batches of `batch_size` samples -- the same per-epoch permutation, drawn
+    from `seed + epoch` on every rank -- and each yields only its contiguous shard (`parallel.shard_bounds`), so
+    a rank loads 1/world of the data and the shards partition the epoch.  A last global batch with fewer samples
+    than ranks is dropped on every rank alike (an empty shard would leave a rank out of the gradient collective).
+    `set_epoch(e)` re-seeds the permutation; `Engine.run_epoch` calls it."""
+
+    def __init__(self, n: int, batch_size: int, shuffle: bool, rank: int, world: int, seed: int = 0):
+        if not 0 <= rank < world or batch_size < 1:
+            raise ValueError(f"bad shard: rank {rank} of {world}, batch {batch_size}")
+        self.n, self.batch_size, self.shuffle, self.rank, self.world, self.seed = n, batch_size, shuffle, rank, world, seed
+        self.epoch = 0
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = int(epoch)
+
+    def _starts(self):
+        return [b for b in range(0, self.n, self.batch_size) if min(self.batch_size, self.n - b) >= self.world]
+
+    def __len__(self) -> int:
+        return len(self._starts())
+
+    def __iter__(self):
+        from .parallel import shard_bounds
+        if self.shuffle:
+            order = torch.randperm(self.n, generator=torch.Generator().manual_seed(self.seed + self.epoch)).tolist()
+        else:
+            order = list(range(self.n))
+        for b in self._starts():
+            size = min(self.batch_size, self.n - b)
+            lo, hi = shard_bounds(size, self.rank, self.world)
+            yield order[b + lo: b + hi]
+
+
+def make_loaders(raw: torch.Tensor, in_hours, out_timesteps, tau, batch_size, num_workers=0, pin_memory=True,
+                 rank: int | None = None, world: int | None = None, seed: int = 0):
+    """raw [C,N,T_total] -> (training, validation, evaluation) loaders; only training shuffles (data_loader.py:80-89).
+
+    `batch_size` is the GLOBAL batch (the reference's `-b`).  Under an initialised process group (or explicit
+    `rank` / `world`) the loaders are sharded (`ShardedBatchSampler`, attribute `msgat_sharded`): every rank loads
+    only its part of each global batch."""
+    import torch.distributed as dist
+    if world is None:
+        on = dist.is_available() and dist.is_initialized()
+        rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
     intervals, train_end = split_intervals(raw.size(-1), in_hours, out_timesteps, tau)
     normed = zscore(raw, split=train_end)
-    return [DataLoader(PeriodicWindows(normed, raw[0], iv, in_hours, out_timesteps, tau), batch_size,
-                       shuffle=(i == 0), pin_memory=pin_memory and torch.cuda.is_available(),
-                       num_workers=num_workers) for i, iv in enumerate(intervals)]
+    pin = pin_memory and torch.cuda.is_available()
+    loaders = []
+    for i, iv in enumerate(intervals):
+        ds = PeriodicWindows(normed, raw[0], iv, in_hours, out_timesteps, tau)
+        if world > 1:
+            loader = DataLoader(ds, batch_sampler=ShardedBatchSampler(len(ds), batch_size, i == 0, rank, world, seed),
+                                pin_memory=pin, num_workers=num_workers)
+            loader.msgat_sharded = True
+        else:
+            loader = DataLoader(ds, batch_size, shuffle=(i == 0), pin_memory=pin, num_workers=num_workers)
+        loaders.append(loader)
+    return loaders
 
 
 class SyntheticPEMS:

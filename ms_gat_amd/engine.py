@@ -7,22 +7,24 @@ src/loss.py:51-52 (Huber), src/metrics.py:20-35 (MAE / MAPE / RMSE).
 
 Differences that are the point of this build:
   * fp32 end to end (the reference wraps the forward in CUDA AMP, engine.py:54; the parity bar of
-    the hot path is fp32), so there is no GradScaler; checkpoints keep the reference's keys and
-    carry an empty `grad_scaler` entry so either side can load the other's files.
-  * loss and metric sums stay on the device; the host reads them once per epoch instead of four
-    `.item()` syncs per batch (engine.py:66, metrics.py:24,30,34).
-  * under `torch.distributed` every rank runs its batch shard and gradients are averaged with one
-    flat all-reduce (`parallel.FlatGradAllReduce`); `nn.DataParallel` (main.py:52-55) is not used.
-  * `hip_graph=True` captures one training step (forward, loss, backward, Adam) per batch shape in a
-    HIP graph and replays it: a step is ~1100 kernel launches whose host-side issue cost otherwise
-    exceeds the GPU time of the small kernels.  The library never allocates or synchronises, so its
-    launches are capturable as they are.
+    the hot path is fp32).  No loss scaling is needed, but checkpoints carry the state dict of a
+    default `GradScaler` under the reference's key so that either side loads the other's files.
+  * the step tail runs in the library: ONE pass over the prediction gives the
+    Huber loss and the metric sums (`ops.huber_metrics`), which stay on the device -- the host reads them
+    once per epoch instead of four `.item()` syncs per batch (engine.py:66, metrics.py:24,30,34) -- and
+    Adam updates every parameter in one launch over flat state buffers (`FlatAdam`).
+  * under `torch.distributed` every rank runs its batch shard and the gradients are averaged with ONE
+    flat all-reduce of the buffer Adam reads (`nn.DataParallel`, main.py:52-55, is not used).
+  * `hip_graph=True` captures one training step per batch shape in a HIP graph and replays it.
+CPU tensors (the host-logic tests run a small CPU `nn.Module` through this loop) take plain PyTorch
+ops for loss and optimizer; the library has no CPU path.
 """
 from __future__ import annotations
 
+import ctypes as C
 from pathlib import Path
 from time import localtime, strftime
-from typing import Optional, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -44,36 +46,56 @@ class HuberLoss(nn.Module):
         self.delta = delta
 
     def forward(self, output: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        if output.is_cuda:
+            from . import ops
+            return ops.huber_metrics(output, target, self.delta)
         return huber_loss(output, target, self.delta)
 
 
 class Metrics:
     """Running MAE / MAPE / RMSE with the reference's definitions (metrics.py:11-38): MAPE sums
     |err/y| over entries with y > mask_value but divides by ALL entries, like the reference.
-    Sums accumulate on the device in float64; properties synchronise when read."""
+    Totals [AE, APE, SE, sum of batch losses] accumulate on the device in float64; properties synchronise
+    when read."""
 
     def __init__(self, mask_value: float = 0.0):
         self.mask_value = mask_value
         self.n = 0
-        self._sums: Optional[torch.Tensor] = None  # [AE, APE, SE]
+        self.batches = 0
+        self._sums: Optional[torch.Tensor] = None
 
-    def update(self, y_pred: torch.Tensor, y_true: torch.Tensor) -> None:
+    def totals(self, device) -> torch.Tensor:
+        if self._sums is None:
+            self._sums = torch.zeros(4, device=device, dtype=torch.float64)
+        return self._sums
+
+    def count(self, y_true: torch.Tensor) -> None:
+        """A batch whose sums went into `totals` inside the fused loss kernel."""
+        self.n += y_true.numel()
+        self.batches += 1
+
+    def update(self, y_pred: torch.Tensor, y_true: torch.Tensor, loss: Optional[torch.Tensor] = None,
+               count: bool = True) -> None:
         err = (y_pred.detach() - y_true).double()
         truth = y_true.double()
         mask = truth > self.mask_value
         ape = torch.where(mask, (err / torch.where(mask, truth, torch.ones_like(truth))).abs(), torch.zeros_like(err))
-        s = torch.stack([err.abs().sum(), 100.0 * ape.sum(), (err * err).sum()])
-        self._sums = s if self._sums is None else self._sums + s
-        self.n += y_true.numel()
+        zero = err.new_zeros(())
+        s = torch.stack([err.abs().sum(), 100.0 * ape.sum(), (err * err).sum(),
+                         zero if loss is None else loss.detach().double()])
+        self.totals(y_pred.device).add_(s)
+        if count:
+            self.count(y_true)
 
     def _get(self, i: int) -> float:
         return 0.0 if self._sums is None else float(self._sums[i].item())
 
     def all_reduce(self) -> None:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and self._sums is not None:
-            buf = torch.cat([self._sums, self._sums.new_tensor([float(self.n)])])
+            buf = torch.cat([self._sums, self._sums.new_tensor([float(self.n), float(self.batches)])])
             dist.all_reduce(buf)
-            self._sums, self.n = buf[:3], int(buf[3].item())
+            self._sums, self.n = buf[:4].clone(), int(buf[4].item())
+            self._loss_batches = float(buf[5].item())
 
     @property
     def MAE(self) -> float:
@@ -87,8 +109,158 @@ class Metrics:
     def RMSE(self) -> float:
         return (self._get(2) / max(self.n, 1)) ** 0.5
 
+    @property
+    def loss(self) -> float:
+        """Mean of the batch losses (over all ranks' batches after `all_reduce`)."""
+        return self._get(3) / max(getattr(self, "_loss_batches", self.batches), 1)
+
     def todict(self):
         return {"MAE": self.MAE, "MAPE": self.MAPE, "RMSE": self.RMSE}
+
+
+class FlatAdam(optim.Optimizer):
+    """`torch.optim.Adam` (engine.py:106; L2 weight decay on the gradient, bias correction, eps outside the
+    square root) as ONE launch over flat state buffers (`msgat_adam_step`, csrc/tail.hip).
+
+    The gradients are gathered into one flat fp32 buffer (the buffer a multi-rank step all-reduces, so the
+    collective and the update share it), both moments are flat, and the parameters stay where they are -- views
+    of the parameter bank (`stacked.ParamBank`) -- reached through a device table of 2048-element chunks.  The
+    step count and the learning rate live in device memory: a captured launch follows `StepLR`.
+    `state_dict()` / `load_state_dict()` speak torch.optim.Adam's format (per-parameter `step`, `exp_avg`,
+    `exp_avg_sq`), so checkpoints interchange with the reference's optimizer."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) != 1:
+            raise ValueError("FlatAdam takes one parameter group (the reference trains with one, engine.py:106)")
+        self._params: List[nn.Parameter] = []
+        self._steps = 0
+        self._tables: Dict[tuple, tuple] = {}
+        self._lr_on_device = None
+
+    # -- flat buffers ----------------------------------------------------------------------------------------
+    def _build(self) -> None:
+        self._params = [p for p in self.param_groups[0]["params"] if p.requires_grad]
+        if not self._params:
+            raise ValueError("no trainable parameters")
+        dev = self._params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FlatAdam runs in libmsgat_hip.so on the GPU; use torch.optim.Adam for CPU parameters")
+        self._offsets, off = [], 0
+        for p in self._params:
+            self._offsets.append(off)
+            off += p.numel()
+        self.numel = off
+        self.flat_grad = torch.zeros(off + 1, device=dev, dtype=torch.float32)   # + the rank's weight (all-reduce)
+        self.exp_avg = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(off, device=dev, dtype=torch.float32)
+        self._grad_views = [self.flat_grad[o:o + p.numel()].view_as(p) for p, o in zip(self._params, self._offsets)]
+        self._dev_state = torch.tensor([float(self._steps), float(self.param_groups[0]["lr"])], device=dev)
+        self._lr_on_device = float(self.param_groups[0]["lr"])
+        for p, o in zip(self._params, self._offsets):
+            old = self.state.get(p, {})
+            m, v = self.exp_avg[o:o + p.numel()].view_as(p), self.exp_avg_sq[o:o + p.numel()].view_as(p)
+            if "exp_avg" in old:      # state that arrived through load_state_dict: move it into the flat buffers
+                m.copy_(old["exp_avg"])
+                v.copy_(old["exp_avg_sq"])
+            self.state[p] = {"step": torch.tensor(float(self._steps)), "exp_avg": m, "exp_avg_sq": v}
+        self._tables.clear()
+
+    def _table(self, active: tuple):
+        """Device chunk table of the parameters that have a gradient (torch's Adam skips the others)."""
+        key = (active, tuple(p.data_ptr() for p in self._params))
+        hit = self._tables.get(key)
+        if hit is None:
+            from . import _lib
+            chunk = int(_lib.lib().msgat_adam_chunk_elems())
+            ptrs, offs, lens = [], [], []
+            for p, o, on in zip(self._params, self._offsets, active):
+                if not on:
+                    continue
+                if not p.is_contiguous():
+                    raise RuntimeError("FlatAdam needs contiguous parameters")
+                for s in range(0, p.numel(), chunk):
+                    ptrs.append(p.data_ptr() + 4 * s)
+                    offs.append(o + s)
+                    lens.append(min(chunk, p.numel() - s))
+            dev = self.flat_grad.device
+            hit = (torch.tensor(ptrs, dtype=torch.int64).to(dev), torch.tensor(offs, dtype=torch.int64).to(dev),
+                   torch.tensor(lens, dtype=torch.int32).to(dev), len(ptrs))
+            self._tables = {key: hit}     # parameter storage moved or the gradient pattern changed: one table alive
+        return hit
+
+    def sync_lr(self) -> None:
+        """Write the group's learning rate (a host float the scheduler edits) into device memory when it changed."""
+        lr = float(self.param_groups[0]["lr"])
+        if self._lr_on_device is not None and lr != self._lr_on_device:
+            self._dev_state[1].fill_(lr)
+            self._lr_on_device = lr
+
+    def note_replayed_step(self) -> None:
+        """A HIP-graph replay ran the captured update: advance the host-side mirror of the step count."""
+        self._steps += 1
+
+    @torch.no_grad()
+    def step(self, closure=None, rank_weight: Optional[float] = None):
+        """One update.  `rank_weight` (this rank's sample count) makes it a data-parallel step: the flat gradient
+        buffer is all-reduced as sum(w g) / sum(w) -- the gradient of the mean loss over the global batch, also for
+        uneven shards -- before the update, in the one collective of the step."""
+        from . import _lib
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if not self._params or self._params[0].device != self.flat_grad.device:
+            self._build()
+        active = tuple(p.grad is not None for p in self._params)
+        grads = [p.grad for p in self._params if p.grad is not None]
+        if grads:
+            torch._foreach_copy_([v for v, on in zip(self._grad_views, active) if on], grads)
+        if rank_weight is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self.flat_grad[: self.numel].mul_(float(rank_weight))
+            self.flat_grad[self.numel:].fill_(float(rank_weight))
+            dist.all_reduce(self.flat_grad)
+            self.flat_grad[: self.numel].div_(self.flat_grad[self.numel])
+        self.sync_lr()
+        ptrs, offs, lens, n = self._table(active)
+        g = self.param_groups[0]
+        st = _lib.lib().msgat_adam_step(ptrs.data_ptr(), offs.data_ptr(), lens.data_ptr(), n, self.flat_grad.data_ptr(),
+                                        self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self._dev_state.data_ptr(),
+                                        float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                        float(g["weight_decay"]), torch.cuda.current_stream(self.flat_grad.device).cuda_stream)
+        _lib.check(st, "msgat_adam_step")
+        if not torch.cuda.is_current_stream_capturing():
+            self._steps += 1
+        return loss
+
+    @property
+    def allreduce_bytes(self) -> int:
+        if not self._params:
+            self._build()
+        return self.flat_grad.numel() * 4
+
+    # -- torch.optim.Adam's checkpoint format ------------------------------------------------------------------
+    def state_dict(self):
+        for st in self.state.values():
+            if "step" in st:
+                st["step"] = torch.tensor(float(self._steps))
+        sd = super().state_dict()
+        for group in sd["param_groups"]:            # the keys torch.optim.Adam writes, so the reference's loader accepts it
+            group.setdefault("amsgrad", False)
+            group.setdefault("maximize", False)
+            group.setdefault("foreach", None)
+            group.setdefault("capturable", False)
+            group.setdefault("differentiable", False)
+            group.setdefault("fused", None)
+            group["lr"] = float(group["lr"])
+        return sd
+
+    def load_state_dict(self, state_dict) -> None:
+        super().load_state_dict(state_dict)
+        steps = [float(st["step"]) for st in self.state.values() if "step" in st]
+        self._steps = int(max(steps)) if steps else 0
+        if self.param_groups[0]["params"] and self.param_groups[0]["params"][0].is_cuda:
+            self._build()                             # moves the loaded moments into the flat buffers
 
 
 class _GraphedStep:
@@ -97,27 +269,29 @@ class _GraphedStep:
     Training steps are captured whole (forward, loss, backward and, on a single GPU, the optimizer
     step); with several ranks the graph ends after backward and the all-reduce and the optimizer run
     eagerly.  Capture follows PyTorch's whole-network recipe: warm-up iterations on a side stream
-    (they initialise Adam's lazy state), then capture -- with parameters and optimizer state put back
+    (they initialise the optimizer's lazy state), then capture -- with parameters and optimizer state put back
     afterwards, so the captured run starts from exactly the state an eager run would."""
 
     def __init__(self, engine: "Engine", batch, training: bool, step_in_graph: bool):
-        model, loss_fn, opt = engine.model, engine.loss_fn, engine.optimizer
+        model, opt = engine.model, engine.optimizer
         self.static = [t.clone() for t in batch]
         *inputs, truth = self.static
         self.training = training
-        saved_params = saved_state = None
+        self.grads = None
+        trained = saved_params = saved_state = None
         if training:
             trained = [p for group in opt.param_groups for p in group["params"] if p.requires_grad]
             saved_params = [p.detach().clone() for p in trained]
             saved_state = {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state.get(p, {}).items()}
                            for group in opt.param_groups for p in group["params"]}
+            saved_steps = getattr(opt, "_steps", None)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
                 if training:
                     opt.zero_grad(set_to_none=True)
-                    loss_fn(model(*inputs), truth).backward()
+                    engine._loss(model(*inputs), truth, None).backward()
                     if step_in_graph:
                         opt.step()
                 else:
@@ -130,27 +304,37 @@ class _GraphedStep:
                     p.copy_(old)
                 for p, st in opt.state.items():
                     for k, v in st.items():
-                        if torch.is_tensor(v):
+                        if torch.is_tensor(v) and v.is_cuda:
                             old = saved_state.get(p, {}).get(k)
                             v.copy_(old) if old is not None else v.zero_()
+                if isinstance(opt, FlatAdam) and step_in_graph:
+                    opt._steps = saved_steps
+                    opt._dev_state[0].fill_(float(saved_steps))
             opt.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             if training:
                 self.pred = model(*inputs)
-                self.loss = loss_fn(self.pred, truth)
+                self.loss = engine._loss(self.pred, truth, engine._graph_metrics)
                 self.loss.backward()
                 if step_in_graph:
                     opt.step()
             else:
                 with torch.no_grad():
                     self.pred = model(*inputs)
-                    self.loss = loss_fn(self.pred, truth)
+                    self.loss = engine._loss(self.pred, truth, engine._graph_metrics)
+        if training:
+            # the gradients of THIS capture live in its private pool: whoever reads p.grad after a replay (the eager
+            # all-reduce + optimizer of a multi-rank step) must see these tensors, not those of a later capture
+            self.grads = [(p, p.grad) for p in trained]
 
     def replay(self, batch):
         for dst, src in zip(self.static, batch):
             dst.copy_(src, non_blocking=True)
         self.graph.replay()
+        if self.grads is not None:
+            for p, g in self.grads:
+                p.grad = g
         return self.pred, self.loss, self.static[-1]
 
 
@@ -166,6 +350,7 @@ class Engine:
         self._grad_sync = None
         self.hip_graph = False
         self._graphs = {}
+        self._graph_metrics = None   # the Metrics whose device totals the captured loss kernels add to
 
     # -- helpers -------------------------------------------------------------------------
     def _device(self, gpu_id):
@@ -179,18 +364,57 @@ class Engine:
             return dist.get_rank(), dist.get_world_size()
         return 0, 1
 
+    def _loss(self, pred: torch.Tensor, truth: torch.Tensor, metrics: Optional[Metrics]) -> torch.Tensor:
+        """Huber loss of a batch; feeds `metrics` (engine.py:56,66-70).  On the GPU one library pass does both."""
+        if pred.is_cuda:
+            from . import ops
+            sums = None if metrics is None else metrics.totals(pred.device)
+            return ops.huber_metrics(pred, truth, self.loss_fn.delta, 0.0 if metrics is None else metrics.mask_value, sums)
+        loss = huber_loss(pred, truth, self.loss_fn.delta)
+        if metrics is not None:
+            metrics.update(pred, truth, loss, count=False)   # counted by the caller, as for the fused path
+        return loss
+
+    def _optimizer_step(self, n_samples: int, world: int) -> None:
+        if isinstance(self.optimizer, FlatAdam):
+            self.optimizer.step(rank_weight=float(n_samples) if world > 1 else None)
+            return
+        if world > 1:
+            if self._grad_sync is None:
+                self._grad_sync = parallel.FlatGradAllReduce(self.model.parameters())
+            self._grad_sync(weight=float(n_samples))
+        self.optimizer.step()
+
     def run_epoch(self, data, gpu_id=None, epoch=None, mode: str = "train") -> float:
-        """One pass over `data` (an iterable of (X, H, D, Y) batches).  Returns the mean batch loss."""
+        """One pass over `data` (an iterable of (X, H, D, Y) batches).  Returns the mean batch loss.
+
+        Under torch.distributed every rank must see the SAME sequence of global batches and takes its dim-0 shard
+        (`parallel.shard_batch`) -- loaders built by `data.make_loaders` under a process group are already sharded
+        (`msgat_sharded`), each rank loading only its own samples of a shared per-epoch permutation.  Global batches
+        with fewer samples than ranks are skipped on every rank alike."""
         training = mode == "train"
         self.model.train(training)
         device = self._device(gpu_id)
         rank, world = self._world()
-        metrics = Metrics()
-        loss_sum = torch.zeros((), device=device, dtype=torch.float64)
-        n_batches = 0
-        with torch.set_grad_enabled(training):
+        presharded = bool(getattr(data, "msgat_sharded", False))
+        sampler = getattr(data, "batch_sampler", None)
+        if hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(0 if epoch is None else int(epoch))
+        if self._graph_metrics is None or not self.hip_graph:
+            metrics = Metrics()
+        else:
+            metrics = self._graph_metrics       # captured kernels hold its totals buffer: re-use it, zeroed
+            metrics.totals(device).zero_()
+            metrics.n = metrics.batches = 0
+        if self.hip_graph and device.type == "cuda":
+            self._graph_metrics = metrics
+            metrics.totals(device)
+        guard = torch.cuda.device(device) if device.type == "cuda" else _NullContext()
+        with guard, torch.set_grad_enabled(training):
             for batch in data:
-                if world > 1:
+                if world > 1 and not presharded:
+                    if batch[0].shape[0] < world:
+                        continue
                     batch = parallel.shard_batch(batch, rank, world)
                 batch = [t.to(device, non_blocking=True) for t in batch]
                 *inputs, truth = batch
@@ -201,26 +425,22 @@ class Engine:
                         with torch.enable_grad():
                             graphed = self._graphs[key] = _GraphedStep(self, batch, training, step_in_graph=world == 1)
                     pred, loss, truth = graphed.replay(batch)
+                    if training and world == 1 and isinstance(self.optimizer, FlatAdam):
+                        self.optimizer.note_replayed_step()
                 else:
                     pred = self.model(*inputs)
-                    loss = self.loss_fn(pred, truth)
+                    loss = self._loss(pred, truth, metrics)
                     if training:
                         self.optimizer.zero_grad(set_to_none=True)
                         loss.backward()
                 if training and (world > 1 or not self.hip_graph):
-                    if world > 1:
-                        if self._grad_sync is None:
-                            self._grad_sync = parallel.FlatGradAllReduce(self.model.parameters())
-                        self._grad_sync(weight=float(truth.shape[0]))
-                    self.optimizer.step()
-                loss_sum += loss.detach().double()
-                metrics.update(pred, truth)
-                n_batches += 1
+                    self._optimizer_step(truth.shape[0], world)
+                metrics.count(truth)
         if world > 1:
-            dist.all_reduce(loss_sum)
-            loss_sum /= world
+            if metrics._sums is None:
+                metrics.totals(device)
             metrics.all_reduce()
-        loss_ave = float(loss_sum.item()) / max(n_batches, 1)
+        loss_ave = metrics.loss
         stats = {"loss": loss_ave, **metrics.todict()}
         if rank == 0:
             if mode == "evaluate":
@@ -238,21 +458,27 @@ class Engine:
             f.write(" - " + ",".join(f"{k}={v}" for k, v in kwargs.items()) + "\n")
 
 
+class _NullContext:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
 class Trainer(Engine):
     """Adam(lr 1e-3, wd 5e-4), StepLR(30, 0.1), early stopping after 20 stale epochs, best-val checkpoints
-    after epoch 20 (engine.py:104-133)."""
+    after epoch 20 (engine.py:104-133).  GPU parameters train with `FlatAdam` (one launch), CPU parameters (host-logic
+    tests) with torch.optim.Adam -- same update, same checkpoint format."""
 
     def __init__(self, model: nn.Module, loss_delta: float, out_dir: str, hip_graph: bool = False):
         super().__init__(model, loss_delta=loss_delta, out_dir=out_dir)
         self.hip_graph = hip_graph
-        if hip_graph:
-            # a captured Adam reads its learning rate from device memory: keep ONE tensor alive and write
-            # the scheduler's value into it (`_sync_lr`), or replays would keep the captured rate
-            dev = next(model.parameters()).device
-            self._lr = torch.tensor(1e-3, device=dev)
-            self.optimizer = optim.Adam(model.parameters(), lr=self._lr, weight_decay=5e-4, capturable=True)
-        else:
-            self.optimizer = optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4)
+        on_gpu = next(model.parameters()).is_cuda
+        if hip_graph and not on_gpu:
+            raise ValueError("hip_graph=True needs the model on the GPU")
+        adam = FlatAdam if on_gpu else optim.Adam
+        self.optimizer = adam(model.parameters(), lr=1e-3, weight_decay=5e-4)
         self.scheduler = lr_scheduler.StepLR(self.optimizer, step_size=30, gamma=0.1)
         self.best = {"epoch": 0, "loss": float("inf"), "ckpt": ""}
         self.epoch = 1
@@ -276,16 +502,16 @@ class Trainer(Engine):
             self.epoch += 1
 
     def _sync_lr(self) -> None:
-        if self.hip_graph:
-            for group in self.optimizer.param_groups:
-                if group["lr"] is not self._lr:
-                    self._lr.fill_(float(group["lr"]))
-                    group["lr"] = self._lr
+        if isinstance(self.optimizer, FlatAdam):
+            self.optimizer.sync_lr()   # a captured update reads the rate from device memory
 
     def save(self, ckpt) -> None:
+        """The reference's five keys (engine.py:135-146).  `grad_scaler` holds the state of a default-constructed,
+        enabled GradScaler -- this build trains in fp32 and never scales, but the reference's `load` feeds that entry
+        to `GradScaler.load_state_dict`, which rejects an empty dict (engine.py:155)."""
         torch.save(dict(best=self.best, epoch=self.epoch, model=self.model.state_dict(),
                         optimizer=self.optimizer.state_dict(), scheduler=self.scheduler.state_dict(),
-                        grad_scaler={}), ckpt)
+                        grad_scaler=default_grad_scaler_state()), ckpt)
 
     def load(self, ckpt) -> None:
         states = torch.load(ckpt, map_location=next(self.model.parameters()).device, weights_only=False)
@@ -295,6 +521,11 @@ class Trainer(Engine):
         self.optimizer.load_state_dict(states["optimizer"])
         self.scheduler.load_state_dict(states["scheduler"])
         self._sync_lr()
+
+
+def default_grad_scaler_state() -> dict:
+    """`torch.cuda.amp.GradScaler().state_dict()` of an enabled, never-stepped scaler (its constructor defaults)."""
+    return {"scale": 65536.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000, "_growth_tracker": 0}
 
 
 class Evaluator(Engine):

@@ -26,7 +26,9 @@ def _require_device_tensor(name: str, t: torch.Tensor, device=None):
         raise _lib.MsgatError(
             f"{name} is on {t.device}: ms_gat_amd runs on MI355X (PyTorch-ROCm 'cuda' device) only; "
             "there is no CPU path -- the CPU oracle lives under oracle/ and is test infrastructure.")
-    if t.dtype != torch.float32:
+    if t.dtype != torch.float32 and not (t.dtype in (torch.float16, torch.bfloat16) and torch.is_autocast_enabled("cuda")):
+        # inside an autocast region (the reference's engine.py:54) half-precision outputs of neighbouring matmuls are
+        # accepted and cast back to float32 at the op boundary (see _guard below)
         raise TypeError(f"{name} must be float32 (the reference arithmetic type), got {t.dtype}")
     if device is not None and t.device != device:
         raise ValueError(f"{name} is on {t.device}, expected {device}")
@@ -682,3 +684,74 @@ def attention_core(u: torch.Tensor, q: torch.Tensor, Wg: torch.Tensor, adjacency
     if graph.n_nodes != N:
         raise ValueError(f"adjacency has {graph.n_nodes} nodes, signals have {N}")
     return _AttentionCoreFunction.apply(u, q, Wg, graph)
+
+
+# ---- step tail: fused Huber loss + metric sums ---------------------------------------
+
+class _HuberMetricsFunction(torch.autograd.Function):
+    """pred, truth (same shape) -> mean Huber loss (0-dim); adds |e|, 100|e/y| (y > mask) and e^2 sums plus the loss
+    itself to the running fp64 totals `sums` [4] on the device (engine.py:56,66-70; loss.py:51-52; metrics.py:20-35)."""
+
+    @staticmethod
+    def forward(ctx, pred, truth, delta: float, mask_value: float, sums):
+        L = _lib.lib()
+        pred_c, truth_c = pred.contiguous(), truth.contiguous()
+        n = pred_c.numel()
+        part = torch.empty(max(int(L.msgat_huber_partial_doubles(n)), 1), device=pred.device, dtype=torch.float64)
+        loss = torch.empty((), device=pred.device, dtype=torch.float32)
+        st = L.msgat_huber_metrics(_ptr(pred_c), _ptr(truth_c), n, float(delta), float(mask_value), _ptr(part), _ptr(loss),
+                                   _ptr(sums), _stream_handle(pred.device))
+        _lib.check(st, "msgat_huber_metrics")
+        ctx.delta = float(delta)
+        ctx.save_for_backward(pred_c, truth_c)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        pred, truth = ctx.saved_tensors
+        dpred = torch.empty_like(pred)
+        st = _lib.lib().msgat_huber_grad(_ptr(pred), _ptr(truth), _ptr(dloss.contiguous()), pred.numel(), ctx.delta,
+                                         _ptr(dpred), _stream_handle(pred.device))
+        _lib.check(st, "msgat_huber_grad")
+        return dpred, None, None, None, None
+
+
+def huber_metrics(pred: torch.Tensor, truth: torch.Tensor, delta: float, mask_value: float = 0.0,
+                  sums: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Mean Huber loss of `pred` against `truth` in one pass that also feeds the epoch's metric totals."""
+    _require_device_tensor("prediction", pred)
+    _require_device_tensor("target", truth, pred.device)
+    if pred.shape != truth.shape or pred.numel() == 0:
+        raise ValueError(f"prediction {tuple(pred.shape)} and target {tuple(truth.shape)} must match and be non-empty")
+    if sums is not None and (sums.dtype != torch.float64 or sums.numel() != 4 or sums.device != pred.device):
+        raise ValueError("sums must be a float64 [4] tensor on the prediction's device")
+    return _HuberMetricsFunction.apply(pred, truth, delta, mask_value, sums)
+
+
+# ---- boundary hygiene for every autograd.Function above -----------------------------------------------------------
+# (a) the library's launches act on the CURRENT HIP device (hipFuncSetAttribute for > 64 KB LDS, occupancy queries),
+#     while the reference's API lets the caller name any device (`run_epoch(..., gpu_id=k)`, engine.py:40,50):
+#     make the tensors' device current for the duration of the call;
+# (b) the reference runs the forward under CUDA AMP (engine.py:54): inside an autocast region these ops receive
+#     half-precision outputs of neighbouring matmuls -- cast them back to fp32 (the parity type) and switch
+#     autocast off inside, as torch.amp.custom_fwd(cast_inputs=torch.float32) does.
+def _guard(fn, is_forward: bool):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(ctx, *args):
+        dev = next((a.device for a in args if torch.is_tensor(a) and a.is_cuda), None)
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(ctx, *args)
+        with torch.cuda.device(dev):
+            return fn(ctx, *args)
+
+    if is_forward:
+        return torch.amp.custom_fwd(wrapped, device_type="cuda", cast_inputs=torch.float32)
+    return torch.amp.custom_bwd(wrapped, device_type="cuda")
+
+
+for _name, _cls in list(globals().items()):
+    if isinstance(_cls, type) and issubclass(_cls, torch.autograd.Function) and _cls is not torch.autograd.Function:
+        _cls.forward = staticmethod(_guard(_cls.forward, True))
+        _cls.backward = staticmethod(_guard(_cls.backward, False))

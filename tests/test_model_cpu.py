@@ -175,3 +175,47 @@ def test_components_are_stackable_only_when_their_architectures_agree():
     assert not stacked.can_stack(odd)
     p = torch.arange(6.0).view(2, 3)
     assert torch.equal(stacked._per_group(p, 2), torch.tensor([[0., 1, 2], [0, 1, 2], [3, 4, 5], [3, 4, 5]]))
+
+
+def test_checkpoints_interchange_with_the_reference_loader(tmp_path):
+    """What /root/reference/src/engine.py:148-157 does with a checkpoint: GradScaler.load_state_dict on the
+    `grad_scaler` entry (an empty dict raises there), Adam.load_state_dict on `optimizer`, StepLR on `scheduler`;
+    and the other direction: a checkpoint written through nn.DataParallel (`module.` keys, main.py:54,60) loads here."""
+    from torch import optim
+    from ms_gat_amd import data, engine
+    torch.manual_seed(1)
+    ds = data.SyntheticPEMS(n_nodes=6, n_edges=6, n_channels=2, in_hours=[1, 2], batch_size=16, days=2)
+    model = _TinyModel(2, 2, 12)
+    tr = engine.Trainer(model, 50.0, str(tmp_path))
+    tr.run_epoch(ds.training, epoch=1, mode="train")
+    ckpt = tmp_path / "a.pkl"
+    tr.save(ckpt)
+    states = torch.load(ckpt, weights_only=False)
+
+    # the reference's load sequence, object for object
+    ref_model = _TinyModel(2, 2, 12)
+    ref_opt = optim.Adam(ref_model.parameters(), lr=1e-3, weight_decay=5e-4)
+    ref_sched = optim.lr_scheduler.StepLR(ref_opt, step_size=30, gamma=0.1)
+    scaler = torch.amp.GradScaler("cuda", enabled=True)
+    fresh = torch.amp.GradScaler("cuda", enabled=True).state_dict() if torch.cuda.is_available() else None
+    if scaler.is_enabled():                                  # on a CUDA-less host torch disables the scaler with a warning
+        scaler.load_state_dict(states["grad_scaler"])
+        assert states["grad_scaler"] == fresh
+    assert set(states["grad_scaler"]) == {"scale", "growth_factor", "backoff_factor", "growth_interval", "_growth_tracker"}
+    assert states["grad_scaler"] == engine.default_grad_scaler_state() and states["grad_scaler"]["scale"] == 65536.0
+    ref_model.load_state_dict(states["model"])
+    ref_opt.load_state_dict(states["optimizer"])
+    ref_sched.load_state_dict(states["scheduler"])
+    assert isinstance(states["optimizer"]["param_groups"][0]["lr"], float)
+    st = ref_opt.state[next(iter(ref_model.parameters()))]
+    assert set(st) == {"step", "exp_avg", "exp_avg_sq"} and float(st["step"]) > 0
+
+    # a DataParallel-written checkpoint: every model key prefixed with `module.`
+    states["model"] = {"module." + k: v for k, v in states["model"].items()}
+    torch.save(states, tmp_path / "dp.pkl")
+    tr2 = engine.Trainer(_TinyModel(2, 2, 12), 50.0, str(tmp_path / "resume"))
+    tr2.load(tmp_path / "dp.pkl")
+    m3 = _TinyModel(2, 2, 12)
+    engine.Evaluator(m3, 50.0, str(tmp_path / "eval"), tmp_path / "dp.pkl")
+    for a, b, c in zip(model.state_dict().values(), tr2.model.state_dict().values(), m3.state_dict().values()):
+        assert torch.equal(a, b) and torch.equal(a, c)
