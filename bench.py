@@ -3,20 +3,21 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload pemsd7|pemsd4|stress]
 
-N > 1 is launched by the driver as one process per GPU:
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+Two launch modes, one JSON line each (rank 0 prints it; see the repo prompt for the contract):
 
-One *step* = one forward + backward pass of the hot path over one synthetic batch:
-both GACN depths of every MS-GAT component (reference msgat.py:25-28 called from
-msgat.py:127, twice per TPC, R components), i.e. for msgat72 on PEMSD7
-GACN(1->24) and GACN(72->24), R = 3 relations stacked into one launch sequence,
-B = 32 samples per GPU.  With N > 1 the batch axis is sharded (weak scaling: B per GPU is
-fixed) and the parameter gradients are all-reduced over RCCL once per step.
+* plain `python bench.py` (one GPU) -- BASELINE.json's headline configuration, configs[2]: one *step* = forward +
+  backward of the hot path over one synthetic batch: both GACN depths of every MS-GAT component (reference
+  msgat.py:25-28 called from msgat.py:127, twice per TPC), i.e. for msgat72 on PEMSD7 GACN(1->24) and GACN(72->24),
+  R = 3 relations stacked into one launch sequence, B = 32 samples.  The line carries `roofline` (attention-aggregate
+  kernel, HIP-event timed on the launch stream), `cpu_baseline` (oracle/dense_torch.py -- the reference's op sequence --
+  on the host cores, all of them and one), the eager PyTorch-ROCm baselines, the whole-model training step
+  (`full_step_cfg4`: what the multi-GPU mode times, at one GPU) and `stress` (configs[4]: N = 8192).
 
-Rank 0 prints ONE JSON line (see the repo prompt for the contract) carrying
-`roofline` (attention-aggregate kernel, HIP-event timed on the launch stream) and
-`cpu_baseline` (oracle/dense_torch.py -- the reference's op sequence -- on the host cores).
+* under torch.distributed.run (the driver's N > 1 launch; any N >= 1) or MSGAT_BENCH_FORCE_DIST=1 -- configs[3]: one
+  *step* = one whole msgat72 TRAINING step through `engine.Trainer`: forward of all R = 5 components, Huber loss,
+  backward, ONE flat RCCL all-reduce of every gradient (1.96 M parameters, 7.8 MB) and Adam, B = 32 samples per GPU
+  (weak scaling).  It replaces the reference's `nn.DataParallel` loop (main.py:52-55, engine.py:49-63).  The hot-path
+  step of the plain mode is reported beside it as `hot_path`.
 """
 from __future__ import annotations
 
@@ -24,6 +25,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -36,8 +38,8 @@ sys.path.insert(0, ROOT)
 METRIC = "MS-GAT fwd+bwd samples/sec (B×T node-updates/s), PEMSD7 N=883 T=12"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
 
-# rehearsal switch: run the RCCL path (process group, gradient all-reduce, MAX over ranks) even with one rank,
-# so the multi-GPU code is exercised on a one-GPU box:  MSGAT_BENCH_FORCE_DIST=1 python -m torch.distributed.run ...
+# rehearsal switch: the multi-GPU mode (process group, flat gradient all-reduce, MAX over ranks) with one rank on a
+# one-GPU box:  MSGAT_BENCH_FORCE_DIST=1 python bench.py
 FORCE_DIST = os.environ.get("MSGAT_BENCH_FORCE_DIST") == "1"
 
 WORKLOADS = {
@@ -46,6 +48,7 @@ WORKLOADS = {
     "pemsd4": dict(N=307, E=340, B=64, R=1, Cin=3, hidden=72, Co=24, T=12),
     "stress": dict(N=8192, E=65536, B=64, R=4, Cin=1, hidden=72, Co=24, T=12),
 }
+CFG4 = dict(N=883, E=866, B=32, R=5, Cin=1, T=12)   # configs[3]: per-GPU workload of the 1/2/4/8 scaling curve
 
 
 def layer_norm_t(x):
@@ -71,29 +74,50 @@ class HotPath:
                     torch.nn.init.xavier_normal_(m.W[r], generator=g)
                     m.alpha[r].uniform_(-cin ** -0.5, cin ** -0.5, generator=g)
             self.layers.append(m.to(device))
-        gx = torch.Generator().manual_seed(1000 + seed)
+        big = R * B * wl["hidden"] * N * T > (1 << 28)     # the stress inputs are generated on the device
+        gdev = device if big else torch.device("cpu")
+        gx = torch.Generator(device=gdev).manual_seed(1000 + seed)
         self.xs, self.dzs = [], []
         for cin in (wl["Cin"], wl["hidden"]):
-            x = layer_norm_t(torch.randn(R, B, cin, N, T, generator=gx))  # msgat.py:122: GACN sees LayerNorm output
+            x = layer_norm_t(torch.randn(R, B, cin, N, T, generator=gx, device=gdev))  # msgat.py:122: GACN sees LayerNorm output
             self.xs.append(x.to(device).requires_grad_(True))
-            self.dzs.append(torch.randn(R, B, wl["Co"], N, T, generator=gx).to(device))
+            self.dzs.append(torch.randn(R, B, wl["Co"], N, T, generator=gx, device=gdev).to(device))
         from ms_gat_amd import parallel
         self.params = [p for m in self.layers for p in m.parameters()]
         self.sync = parallel.FlatGradAllReduce(self.params)
 
-    def step(self, world):
+    def step(self, allreduce=False):
         for m, x, dz in zip(self.layers, self.xs, self.dzs):
             x.grad = None
             for p in m.parameters():
                 p.grad = None
             z = m(x, self.graph)
             z.backward(dz)
-        if world > 1 or FORCE_DIST:  # one flat bucket: the payload is KBs, the collective is latency-bound
+        if allreduce:  # one flat bucket: the payload is KBs, the collective is latency-bound
             self.sync(weight=float(self.wl["B"]))
 
     def forward_only(self):
         with torch.no_grad():
             return [m(x, self.graph) for m, x in zip(self.layers, self.xs)]
+
+
+def timed_steps(fn, steps, warmup, device, barrier):
+    """`warmup` untimed calls, then EXACTLY `steps` timed ones bracketed by barrier + synchronize (the contract's
+    wall clock), with a HIP event between consecutive steps on the launch stream for the per-step distribution."""
+    for _ in range(warmup):
+        fn()
+    barrier()
+    stream = torch.cuda.current_stream(device)
+    events = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    events[0].record(stream)
+    for i in range(steps):
+        fn()
+        events[i + 1].record(stream)
+    barrier()
+    wall = time.perf_counter() - t0
+    per_step = [events[i].elapsed_time(events[i + 1]) for i in range(steps)]
+    return wall, per_step
 
 
 def dense_reference_step(hp, device, B, backward=True):
@@ -112,26 +136,34 @@ def dense_reference_step(hp, device, B, backward=True):
     return outs
 
 
+def aggregate_kernel_name(wl):
+    """The library picks the aggregate variant by slab size (aggregate.hip): whole [N,T] slab in LDS; one
+    4-timestep column of it with the edges in the SELL layout; or gather from L2."""
+    if wl["N"] * wl["T"] * 4 <= 159 * 1024:
+        return "k_agg_lds"
+    return "k_agg_sell" if wl["N"] * 16 <= 159 * 1024 else "k_agg_glb"
+
+
 def time_aggregate_kernel(hp, reps=40):
-    """HIP-event timing of the attention-aggregate kernel alone (second depth: Cu = Co channels of
-    the projected features), on torch's current stream -- the stream the kernel is launched on."""
+    """HIP-event timing of the attention-aggregate kernel alone (second depth: Cu = Co channels of the projected
+    features), on torch's current stream -- the stream the kernel is launched on.  Returns (seconds per launch on
+    operands that are NOT cache-resident, seconds per launch re-using one operand set, algorithmic bytes)."""
     from ms_gat_amd import _lib
     wl, dev = hp.wl, hp.device
     G, Cu, N, T = wl["R"] * wl["B"], wl["Co"], wl["N"], wl["T"]
     L = _lib.lib()
     gs, _keep = hp.graph.on(dev)
     shape = _lib.Shape(wl["R"], wl["B"], wl["hidden"], wl["Co"], N, T)
-    # Timed on operands that are NOT cache-resident: one launch touches 196 MB, which would sit in the 256 MB
-    # infinity cache from one repetition to the next if the same buffers were re-used (40 us, 4.9 TB/s -- reported
-    # beside it as `us_per_launch_cached_operands`).  Four operand sets used in turn (784 MB) keep every launch on
-    # HBM: the conservative figure, and the one the roofline fraction is computed from.  In the step the kernel
-    # sits between the two (its input was just written by the projection): 43.8 us in the rocprofv3 per-grid
-    # average of the in-application launches (profiles/r01/c_final_agg_lds_by_grid.txt).
-    us = [torch.randn(G, Cu, N, T, device=dev) for _ in range(4)]
+    # One launch touches 196 MB at the PEMSD7 workload, which would sit in the 256 MB infinity cache from one
+    # repetition to the next if the same buffers were re-used (`us_per_launch_cached_operands`).  Four operand sets
+    # used in turn (784 MB) keep every launch on HBM: the conservative figure, and the one the roofline fraction is
+    # computed from.  (At the stress workload one set is 4.8 GB: two sets, far beyond any cache.)
+    small = G * Cu * N * T * 4 < (1 << 30)
+    nsets = 4 if small else 2
+    us = [torch.randn(G, Cu, N, T, device=dev) for _ in range(nsets)]
     vs = [torch.empty_like(u) for u in us]
     E = torch.rand(G, max(hp.graph.nnz, 1), device=dev)
     stream = torch.cuda.current_stream(dev)
-
     nscratch = int(L.msgat_edge_scratch_floats(C.byref(shape), C.byref(gs)))
     scratch = torch.empty(nscratch, device=dev) if nscratch else None
 
@@ -140,23 +172,57 @@ def time_aggregate_kernel(hp, reps=40):
                                            vs[i].data_ptr(), None if scratch is None else scratch.data_ptr(),
                                            stream.cuda_stream), "msgat_stage_aggregate")
 
-    def timed(nsets):
+    def timed(sets, n):
         for i in range(4):
-            launch(i % nsets)
+            launch(i % sets)
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0.record(stream)
-        for i in range(reps):
-            launch(i % nsets)
+        for i in range(n):
+            launch(i % sets)
         t1.record(stream)
         t1.synchronize()
-        return t0.elapsed_time(t1) * 1e-3 / reps
+        return t0.elapsed_time(t1) * 1e-3 / n
 
-    sec = timed(4)
-    time_aggregate_kernel.cached_sec = timed(1)
+    reps = reps if small else 8
+    cold = timed(nsets, reps)
+    cached = timed(1, reps)
     # algorithmic bytes per launch: read u once + write v once + E + CSR
     nnz = hp.graph.nnz
-    bytes_ = 2 * 4 * G * Cu * N * T + 4 * G * nnz + 8 * nnz + 4 * (N + 1)
-    return sec, bytes_
+    nbytes = 2 * 4 * G * Cu * N * T + 4 * G * nnz + 8 * nnz + 4 * (N + 1)
+    return cold, cached, nbytes
+
+
+def recorded_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE
+    collected in separate rocprofv3 passes, gfx950 x2 correction on the fetch side; see profiles/*/hbm_traffic*.json).
+    PMC counters cannot be collected from inside this process, so the newest committed record is quoted -- with its
+    source file, so the figure is never mistaken for something measured in this run."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_traffic*.json")), reverse=True):
+        try:
+            with open(path) as f:
+                k = json.load(f)["kernels"]
+            for name, v in k.items():
+                if kernel in name:
+                    return {"bytes_per_launch": int(v["hbm_bytes_per_launch"]), "source": os.path.relpath(path, ROOT)}
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
+def roofline_object(hp):
+    cold, cached, nbytes = time_aggregate_kernel(hp)
+    kernel = aggregate_kernel_name(hp.wl)
+    rec = recorded_traffic(kernel)
+    return {
+        "kernel": kernel + " (attention-aggregate, second GACN depth)", "bound": "hbm",
+        "achieved": round(nbytes / cold / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(nbytes / cold / 1e9 / HBM_PEAK_GBS, 4),
+        "traffic": None if rec is None else rec["bytes_per_launch"],   # recorded, not measured in this run:
+        "traffic_recorded": rec,                                       # ... this names the committed PMC summary
+        "us_per_launch": round(cold * 1e6, 2), "us_per_launch_cached_operands": round(cached * 1e6, 2),
+        "algorithmic_bytes": nbytes,
+    }
 
 
 class _EagerMEAM(torch.nn.Module):
@@ -184,82 +250,121 @@ class _EagerLayerNorm(torch.nn.Module):
                                               self.inner.eps)
 
 
-def full_model_step_ms(wl, dev, dense, steps=6, warmup=5):
-    """One training step (forward, Huber loss, backward, Adam) of the whole msgat72 model: MEAM blocks in the
-    library (LayerNorm, the three branches, the tail), or -- `dense=True` -- the reference's eager op sequence."""
-    from ms_gat_amd import engine, model
-    import ms_gat_amd
-    torch.manual_seed(0)
-    adj = ms_gat_amd.synthetic_adjacency(wl["N"], wl["E"], seed=0)
-    net = model.msgat72(n_components=wl["R"], in_channels=wl["Cin"], in_timesteps=wl["T"], out_timesteps=wl["T"],
-                        use_te=True, adj=adj).to(dev)
-    if dense:
-        net.stack_components = False   # the reference's loop over components (msgat.py:204)
-        for tpc in net.tpcs:
-            tpc.tgacns = torch.nn.ModuleList(_EagerMEAM(m) for m in tpc.tgacns)
-            tpc.ln = _EagerLayerNorm(tpc.ln)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=5e-4)
-    loss_fn = engine.HuberLoss(50.0)
-    g = torch.Generator().manual_seed(3)
-    X = torch.randn(wl["B"], wl["R"], wl["Cin"], wl["N"], wl["T"], generator=g).to(dev)
-    H = torch.randint(0, 24, (wl["B"],), generator=g).to(dev)
-    D = torch.randint(0, 7, (wl["B"],), generator=g).to(dev)
-    Y = (torch.randn(wl["B"], wl["N"], wl["T"], generator=g) * 30).to(dev)
+class _Recording:
+    """Batches that are already this rank's shard (`msgat_sharded`: `Engine.run_epoch` must not slice them again),
+    with a HIP event recorded on the launch stream before each one and after the last."""
+    msgat_sharded = True
 
-    def step():
-        opt.zero_grad(set_to_none=True)
-        loss_fn(net(X, H, D), Y).backward()
-        opt.step()
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize(dev)
+    def __init__(self, batches, events, dev):
+        self.batches, self.events, self.dev = batches, events, dev
+
+    def _mark(self):
+        if self.events is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream(self.dev))
+            self.events.append(e)
+
+    def __iter__(self):
+        for b in self.batches:
+            self._mark()
+            yield b
+        self._mark()
+
+
+class TrainStep:
+    """One whole msgat72 training step through `engine.Trainer` on synthetic data: forward, Huber loss + metrics,
+    backward, (with several ranks) ONE flat all-reduce of all gradients, Adam.  `dense=True` swaps every block for
+    the reference's eager op sequence (the PyTorch-ROCm baseline of the same step)."""
+
+    def __init__(self, cfg, dev, seed=0, dense=False, hip_graph=False):
+        import tempfile
+        import ms_gat_amd
+        from ms_gat_amd import engine, model
+        torch.manual_seed(0)
+        self.cfg, self.dev = cfg, dev
+        adj = ms_gat_amd.synthetic_adjacency(cfg["N"], cfg["E"], seed=0)
+        net = model.msgat72(n_components=cfg["R"], in_channels=cfg["Cin"], in_timesteps=cfg["T"],
+                            out_timesteps=cfg["T"], use_te=True, adj=adj).to(dev)
+        if dense:
+            net.stack_components = False   # the reference's loop over components (msgat.py:204)
+            for tpc in net.tpcs:
+                tpc.tgacns = torch.nn.ModuleList(_EagerMEAM(m) for m in tpc.tgacns)
+                tpc.ln = _EagerLayerNorm(tpc.ln)
+        self.net = net
+        self._tmp = tempfile.TemporaryDirectory()
+        self.trainer = engine.Trainer(net, 50.0, self._tmp.name, hip_graph=hip_graph)
+        g = torch.Generator().manual_seed(3 + seed)
+        B = cfg["B"]
+        self.batch = [torch.randn(B, cfg["R"], cfg["Cin"], cfg["N"], cfg["T"], generator=g).to(dev),
+                      torch.randint(0, 24, (B,), generator=g).to(dev), torch.randint(0, 7, (B,), generator=g).to(dev),
+                      (torch.randn(B, cfg["N"], cfg["T"], generator=g) * 30).to(dev)]
+        self.n_params = sum(p.numel() for p in net.parameters() if p.requires_grad)
+
+    def run(self, steps, record=None):
+        """`steps` training steps in one `run_epoch` (one host read at its end, like an epoch of the engine)."""
+        return self.trainer.run_epoch(_Recording([self.batch] * steps, record, self.dev), gpu_id=self.dev.index,
+                                      epoch=1, mode="train")
+
+    @property
+    def allreduce_bytes(self):
+        opt = self.trainer.optimizer
+        return int(opt.allreduce_bytes) if hasattr(opt, "allreduce_bytes") else 4 * (self.n_params + 1)
+
+
+def time_train_step(ts, steps, warmup, barrier):
+    ts.run(warmup)
+    barrier()
+    events = []
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize(dev)
-    return (time.perf_counter() - t0) / steps * 1e3
+    ts.run(steps, record=events)
+    barrier()
+    wall = time.perf_counter() - t0
+    per_step = [events[i].elapsed_time(events[i + 1]) for i in range(steps)]
+    return wall, per_step
 
 
-def full_model_graph_step_ms(wl, dev, steps=10):
-    """The same training step through `engine.Trainer(hip_graph=True)`: one HIP-graph replay per batch."""
-    import tempfile
-    import ms_gat_amd
-    from ms_gat_amd import engine, model
-    torch.manual_seed(0)
-    adj = ms_gat_amd.synthetic_adjacency(wl["N"], wl["E"], seed=0)
-    net = model.msgat72(n_components=wl["R"], in_channels=wl["Cin"], in_timesteps=wl["T"], out_timesteps=wl["T"],
-                        use_te=True, adj=adj).to(dev)
-    g = torch.Generator().manual_seed(3)
-    batch = [torch.randn(wl["B"], wl["R"], wl["Cin"], wl["N"], wl["T"], generator=g).to(dev),
-             torch.randint(0, 24, (wl["B"],), generator=g).to(dev), torch.randint(0, 7, (wl["B"],), generator=g).to(dev),
-             (torch.randn(wl["B"], wl["N"], wl["T"], generator=g) * 30).to(dev)]
-    with tempfile.TemporaryDirectory() as tmp:
-        tr = engine.Trainer(net, 50.0, tmp, hip_graph=True)
-        tr.run_epoch([batch] * 2, gpu_id=dev.index, epoch=0, mode="train")   # captures
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        tr.run_epoch([batch] * steps, gpu_id=dev.index, epoch=1, mode="train")
-        torch.cuda.synchronize(dev)
-        return (time.perf_counter() - t0) / steps * 1e3
+def cpu_baseline(hp, wl):
+    """oracle/dense_torch.py on the host cores: all of them (torch threads = the process's CPU share, at most 16 --
+    a GPU box gives one GPU a 16-core share) and ONE thread, on a bounded sample of the same workload."""
+    out = {}
+    cpu = torch.device("cpu")
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    for key, threads, budget, frac in (("cpu_baseline", cores, 12.0, 1), ("cpu_baseline_1thread", 1, 10.0, 4)):
+        torch.set_num_threads(threads)
+        Bs = max(1, (wl["B"] if wl["N"] <= 1024 else max(1, wl["B"] // 8)) // frac)
+        dense_reference_step(hp, cpu, Bs)  # warm-up
+        t0, n = time.perf_counter(), 0
+        while n < 2 or (time.perf_counter() - t0 < budget and n < 40):
+            dense_reference_step(hp, cpu, Bs)
+            n += 1
+        dt = (time.perf_counter() - t0) / n
+        out[key] = {
+            "value": round(Bs / dt, 3), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": (f"{n} fwd+bwd passes of oracle/dense_torch.py (the reference's dense op sequence) on "
+                       f"{Bs} of the {wl['B']} samples per relation, all {wl['R']} relations and both GACN depths, "
+                       f"same graph and widths, {threads} torch thread{'s' if threads > 1 else ''}"),
+        }
+    torch.set_num_threads(cores)
+    return out
 
 
-def recorded_traffic(workload):
-    """HBM bytes per launch of k_agg_lds from the PMC passes committed under profiles/ (FETCH_SIZE and
-    WRITE_SIZE collected separately, gfx950 x2 correction on the fetch side; see profiles/*/hbm_traffic.json).
-    PMC counters cannot be collected from inside this process, so the newest committed record is quoted."""
-    import glob
-    if workload != "pemsd7":
-        return None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_traffic.json")), reverse=True):
-        try:
-            with open(path) as f:
-                k = json.load(f)["kernels"]
-            for name, v in k.items():
-                if "k_agg_lds" in name:
-                    return int(v["hbm_bytes_per_launch"])
-        except (OSError, KeyError, ValueError):
-            continue
-    return None
+def stress_object(dev):
+    """configs[4] (N = 8192, degree 16, R = 4, B = 64, C = 72 -> 24): the hot-path step and the aggregate kernel's
+    roofline at full size, for the default bench line (the full-size parity properties are tests/test_gpu_parity.py)."""
+    wl = WORKLOADS["stress"]
+    hp = HotPath(wl, dev, seed=0)
+    wall, per_step = timed_steps(hp.step, 5, 2, dev, lambda: torch.cuda.synchronize(dev))
+    obj = {
+        "workload": (f"stress: N={wl['N']} nodes, {wl['E']} undirected edges (+self loops), T={wl['T']}, B={wl['B']}, "
+                     f"R={wl['R']} relations, GACN {wl['Cin']}->{wl['Co']} and {wl['hidden']}->{wl['Co']}, forward+backward "
+                     "of the hot path"),
+        "ms_per_step": round(wall / 5 * 1e3, 3), "ms_per_step_median_hip_events": round(statistics.median(per_step), 3),
+        "samples_per_s": round(wl["B"] / (wall / 5), 2),
+        "roofline": roofline_object(hp),
+    }
+    del hp
+    torch.cuda.empty_cache()
+    return obj
 
 
 def main():
@@ -268,12 +373,13 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="pemsd7", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-baselines", action="store_true", help="skip the CPU / eager baselines")
+    ap.add_argument("--no-baselines", action="store_true", help="skip the CPU / eager baselines and the secondary objects")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ     # under torch.distributed.run
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
@@ -281,110 +387,119 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    multi = world > 1 or FORCE_DIST
+    multi = launched or FORCE_DIST
     if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
-
-    wl = WORKLOADS[args.workload]
-    hp = HotPath(wl, dev, seed=rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     def barrier():
         if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        hp.step(world)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        hp.step(world)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if multi:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    def max_over_ranks(x):
+        if not multi:
+            return x
+        t = torch.tensor([x], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    samples = wl["B"] * world  # samples per step over all ranks
-    value = samples / (elapsed / args.steps)
+        return float(t.item())
 
-    out = {
-        "metric": METRIC, "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {
-            "workload": (f"{args.workload}: N={wl['N']} nodes, {wl['E']} undirected edges (+self loops, sym-normalised), "
-                         f"T={wl['T']}, B={wl['B']}/GPU, R={wl['R']} relations, GACN {wl['Cin']}->{wl['Co']} and "
-                         f"{wl['hidden']}->{wl['Co']} (msgat72 widths), forward+backward of the hot path"),
-            "global_batch": samples, "parallelism": f"batch-sharded x{world}, RCCL all-reduce of parameter grads",
-        },
-        "node_updates_per_s": round(value * wl["R"] * wl["T"] * wl["N"], 1),
+    wl = WORKLOADS[args.workload]
+    hp = HotPath(wl, dev, seed=rank)
+    hot_wall, hot_steps = timed_steps(lambda: hp.step(allreduce=multi), args.steps, args.warmup, dev, barrier)
+    hot_wall = max_over_ranks(hot_wall)
+    hot = {
+        "workload": (f"{args.workload}: N={wl['N']} nodes, {wl['E']} undirected edges (+self loops, sym-normalised), "
+                     f"T={wl['T']}, B={wl['B']}/GPU, R={wl['R']} relations, GACN {wl['Cin']}->{wl['Co']} and "
+                     f"{wl['hidden']}->{wl['Co']} (msgat72 widths), forward+backward of the hot path"),
+        "ms_per_step": round(hot_wall / args.steps * 1e3, 4),
+        "ms_per_step_median_hip_events": round(statistics.median(hot_steps), 4),
+        "value": round(wl["B"] * world / (hot_wall / args.steps), 2),
     }
 
+    out = {"metric": METRIC, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+
+    if multi:
+        # configs[3]: the whole training step, B = 32 per GPU, all gradients in one flat RCCL all-reduce
+        ts = TrainStep(CFG4, dev, seed=rank)
+        steps = max(5, min(args.steps, 30))
+        wall, per_step = time_train_step(ts, steps, max(2, min(args.warmup, 5)), barrier)
+        wall = max_over_ranks(wall)
+        out.update({
+            "steps": steps, "value": round(CFG4["B"] * world / (wall / steps), 2),
+            "ms_per_step": round(wall / steps * 1e3, 4),
+            "ms_per_step_median_hip_events": round(statistics.median(per_step), 4),
+            "config": {
+                "workload": (f"configs[3] per-GPU workload: msgat72 TRAINING step through engine.Trainer -- forward of "
+                             f"R={CFG4['R']} components, Huber loss + metrics, backward, one flat RCCL all-reduce of "
+                             f"{ts.n_params} gradients ({ts.allreduce_bytes} bytes), Adam; PEMSD7-like N={CFG4['N']}, "
+                             f"{CFG4['E']} edges, T={CFG4['T']}, B={CFG4['B']}/GPU"),
+                "global_batch": CFG4["B"] * world,
+                "parallelism": f"batch-sharded x{world}, one flat RCCL all-reduce of all gradients per step",
+            },
+            "allreduce_bytes_per_step": ts.allreduce_bytes if world > 1 else 0,
+            "allreduce_bytes_per_step_when_sharded": ts.allreduce_bytes,
+            "trainable_parameters": ts.n_params,
+            "hot_path": hot,
+        })
+    else:
+        out.update({
+            "value": hot["value"], "ms_per_step": hot["ms_per_step"],
+            "ms_per_step_median_hip_events": hot["ms_per_step_median_hip_events"],
+            "config": {"workload": hot["workload"], "global_batch": wl["B"],
+                       "parallelism": "single GPU (batch-sharded x1)"},
+            "node_updates_per_s": round(hot["value"] * wl["R"] * wl["T"] * wl["N"], 1),
+        })
+
     if rank == 0:
-        sec, nbytes = time_aggregate_kernel(hp)
-        out["roofline"] = {
-            # the library picks the variant by slab size: whole [N,T] slab in LDS, one 4-timestep column of it,
-            # or gather from L2 (aggregate.hip)
-            "kernel": ("k_agg_lds" if wl["N"] * wl["T"] * 4 <= 159 * 1024 else
-                       "k_agg_cols" if wl["N"] * 16 <= 159 * 1024 else "k_agg_glb")
-                      + " (attention-aggregate, second GACN depth)", "bound": "hbm",
-            "achieved": round(nbytes / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": recorded_traffic(args.workload),
-            "us_per_launch": round(sec * 1e6, 2),
-            "us_per_launch_cached_operands": round(time_aggregate_kernel.cached_sec * 1e6, 2), "algorithmic_bytes": nbytes,
-        }
-    if rank == 0 and world == 1 and not args.no_baselines:
-        # PyTorch-ROCm eager on the same GPU: the reference's dense op sequence
+        out["roofline"] = roofline_object(hp)
+    if rank == 0 and not multi and not args.no_baselines:
+        sync = lambda: torch.cuda.synchronize(dev)  # noqa: E731
+        ms_per_step = out["ms_per_step_median_hip_events"]
+        # PyTorch-ROCm eager on the same GPU: the reference's dense op sequence, median of 10 event-timed passes
         for bw, key in ((False, "eager_rocm_forward"), (True, "eager_rocm_fwd_bwd")):
-            for _ in range(2):
-                dense_reference_step(hp, dev, wl["B"], backward=bw)
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            reps = 3
-            for _ in range(reps):
-                dense_reference_step(hp, dev, wl["B"], backward=bw)
-            torch.cuda.synchronize(dev)
-            out[key + "_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 3)
-        for _ in range(3):
-            hp.forward_only()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(20):
-            hp.forward_only()
-        torch.cuda.synchronize(dev)
-        out["forward_ms"] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
+            _, per = timed_steps(lambda: dense_reference_step(hp, dev, wl["B"], backward=bw), 10, 2, dev, sync)
+            out[key + "_ms"] = round(statistics.median(per), 3)
+        _, per = timed_steps(hp.forward_only, 30, 5, dev, sync)
+        out["forward_ms"] = round(statistics.median(per), 4)
         out["speedup_vs_eager_rocm_forward"] = round(out["eager_rocm_forward_ms"] / out["forward_ms"], 2)
         out["speedup_vs_eager_rocm_fwd_bwd"] = round(out["eager_rocm_fwd_bwd_ms"] / ms_per_step, 2)
 
-        # secondary: the whole msgat72 training step, HIP graph branch vs the reference's dense eager one
+        # secondary: the whole msgat72 training step (engine.Trainer: fused loss + metrics, FlatAdam)
         try:
-            out["full_model_step_ms"] = round(full_model_step_ms(wl, dev, dense=False), 3)
-            out["full_model_hip_graph_step_ms"] = round(full_model_graph_step_ms(wl, dev), 3)
-            out["full_model_eager_rocm_step_ms"] = round(full_model_step_ms(wl, dev, dense=True), 3)
-        except RuntimeError as e:  # e.g. the dense [B,N,N] tensors of the stress graph do not fit
-            out["full_model_error"] = str(e).splitlines()[0][:120]
+            cfg3 = dict(CFG4, R=wl["R"])
+            for key, cfg in (("full_step_cfg4", CFG4), ("full_step_cfg3", cfg3)):
+                ts = TrainStep(cfg, dev)
+                wall, per = time_train_step(ts, 20, 5, sync)
+                out[key] = {
+                    "workload": f"msgat72 training step (engine.Trainer), N={cfg['N']}, R={cfg['R']}, B={cfg['B']}, T={cfg['T']}",
+                    "ms_per_step": round(wall / 20 * 1e3, 3), "ms_per_step_median_hip_events": round(statistics.median(per), 3),
+                    "value": round(cfg["B"] / (wall / 20), 2), "unit": "samples/s",
+                    "trainable_parameters": ts.n_params, "allreduce_bytes_per_step_when_sharded": ts.allreduce_bytes,
+                }
+                del ts
+            out["full_model_samples_per_s"] = out["full_step_cfg3"]["value"]
+            ts = TrainStep(cfg3, dev, hip_graph=True)
+            wall, per = time_train_step(ts, 20, 5, sync)
+            out["full_step_cfg3"]["hip_graph_replay_ms_per_step"] = round(wall / 20 * 1e3, 3)
+            del ts
+            ts = TrainStep(cfg3, dev, dense=True)
+            wall, per = time_train_step(ts, 10, 3, sync)
+            out["full_step_cfg3"]["eager_rocm_ms_per_step"] = round(wall / 10 * 1e3, 3)
+            del ts
+            torch.cuda.empty_cache()
+        except RuntimeError as e:
+            out["full_model_error"] = str(e).splitlines()[0][:160]
 
-        # CPU baseline: same op sequence on the host cores, bounded sample of the same workload
-        cores = min(len(os.sched_getaffinity(0)), 16)  # the GPU box gives one GPU a 16-core share
-        torch.set_num_threads(cores)
-        cpu = torch.device("cpu")
-        Bs = wl["B"] if wl["N"] <= 1024 else max(1, wl["B"] // 8)  # bounded: ~10-20 s of host time
-        dense_reference_step(hp, cpu, Bs)  # warm-up
-        t0 = time.perf_counter()
-        n = 0
-        while n < 3 or (time.perf_counter() - t0 < 12.0 and n < 40):
-            dense_reference_step(hp, cpu, Bs)
-            n += 1
-        dt = (time.perf_counter() - t0) / n
-        out["cpu_baseline"] = {
-            "value": round(Bs / dt, 3), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": (f"{n} fwd+bwd passes of oracle/dense_torch.py (the reference's dense op sequence) on "
-                       f"{Bs} of the {wl['B']} samples per relation, all {wl['R']} relations and both GACN depths, "
-                       f"same graph and widths, {cores} torch threads"),
-        }
+        if args.workload == "pemsd7":
+            try:
+                out["stress"] = stress_object(dev)
+            except RuntimeError as e:
+                out["stress"] = {"error": str(e).splitlines()[0][:160]}
+        out.update(cpu_baseline(hp, wl))
     if rank == 0:
         print(json.dumps(out), flush=True)
     if multi:

@@ -354,10 +354,13 @@ int msgat_head_grad_weight(const float* dout, const float* x, float* dWc, float*
  * msgat_adam_step: torch.optim.Adam's update (engine.py:106: lr 1e-3, weight_decay 5e-4 as L2 on the gradient,
  *     betas, eps outside the square root, bias correction) for ALL parameter tensors in one launch.  The
  *     gradients and both moments are flat fp32 buffers; the parameters stay where they are and are reached
- *     through a chunk table (device arrays): chunk c = chunk_len[c] <= msgat_adam_chunk_elems() elements at
- *     chunk_param[c], whose gradient / moments start at element chunk_off[c] of the flat buffers.
- *     state[0] = step count (advanced by this call), state[1] = learning rate: device memory, so a captured
- *     launch follows the scheduler. */
+ *     through a chunk table (device arrays): chunk c = chunk_len[c] <= msgat_adam_chunk_elems() elements of
+ *     tensor chunk_tensor[c] at chunk_param[c], whose gradient / moments start at element chunk_off[c] of the
+ *     flat buffers.  steps[t] = updates tensor t has received so far, advanced by this call for the n_active
+ *     tensors listed in active_tensors (torch keeps one step count per parameter and skips parameters without a
+ *     gradient); lr[0] = learning rate.  Both are device memory, so a captured launch follows the scheduler.
+ *     The hyper-parameters are doubles, like the Python floats the reference's optimizer holds: 1 - beta2 must
+ *     be rounded to fp32 once, not computed from an fp32 beta2. */
 size_t msgat_huber_partial_doubles(int64_t n);
 int msgat_huber_metrics(const float* pred, const float* truth, int64_t n, float delta, float mask_value,
                         double* partials, float* loss, double* sums, void* stream);
@@ -365,8 +368,9 @@ int msgat_huber_grad(const float* pred, const float* truth, const float* dloss, 
                      float* dpred, void* stream);
 int msgat_adam_chunk_elems(void);
 int msgat_adam_step(float* const* chunk_param, const int64_t* chunk_off, const int32_t* chunk_len,
-                    int32_t n_chunks, const float* grad, float* exp_avg, float* exp_avg_sq, float* state,
-                    float beta1, float beta2, float eps, float weight_decay, void* stream);
+                    const int32_t* chunk_tensor, int32_t n_chunks, const int32_t* active_tensors, int32_t n_active,
+                    const float* grad, float* exp_avg, float* exp_avg_sq, float* steps, const float* lr,
+                    double beta1, double beta2, double eps, double weight_decay, void* stream);
 
 #ifdef __cplusplus
 }

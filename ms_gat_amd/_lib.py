@@ -111,7 +111,7 @@ _PROTOTYPES = {
     "msgat_huber_metrics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float] + [C.c_void_p] * 4),
     "msgat_huber_grad": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
     "msgat_adam_chunk_elems": (C.c_int, []),
-    "msgat_adam_step": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] + [C.c_void_p] * 4 + [C.c_float] * 4 + [C.c_void_p]),
+    "msgat_adam_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int32, C.c_void_p, C.c_int32] + [C.c_void_p] * 5 + [C.c_double] * 4 + [C.c_void_p]),
 }
 
 _lock = threading.Lock()

@@ -603,11 +603,15 @@ extern "C" int msgat_huber_grad(const float* pred, const float* truth, const flo
 extern "C" int msgat_adam_chunk_elems(void) { return adam_chunk_elems(); }
 
 extern "C" int msgat_adam_step(float* const* chunk_param, const int64_t* chunk_off, const int32_t* chunk_len,
-                               int32_t n_chunks, const float* grad, float* exp_avg, float* exp_avg_sq, float* state,
-                               float beta1, float beta2, float eps, float weight_decay, void* stream) {
-  if (!state || n_chunks < 0) return n_chunks < 0 ? MSGAT_ERR_SHAPE : MSGAT_ERR_NULL;
-  if (n_chunks > 0 && (!chunk_param || !chunk_off || !chunk_len || !grad || !exp_avg || !exp_avg_sq)) return MSGAT_ERR_NULL;
-  if (!(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f && weight_decay >= 0.f)) return MSGAT_ERR_SHAPE;
-  return launch_adam(chunk_param, (const long long*)chunk_off, chunk_len, n_chunks, grad, exp_avg, exp_avg_sq, state,
-                     beta1, beta2, eps, weight_decay, (hipStream_t)stream);
+                               const int32_t* chunk_tensor, int32_t n_chunks, const int32_t* active_tensors,
+                               int32_t n_active, const float* grad, float* exp_avg, float* exp_avg_sq, float* steps,
+                               const float* lr, double beta1, double beta2, double eps, double weight_decay,
+                               void* stream) {
+  if (n_chunks < 0 || n_active < 0) return MSGAT_ERR_SHAPE;
+  if (!steps || !lr) return MSGAT_ERR_NULL;
+  if (n_active > 0 && !active_tensors) return MSGAT_ERR_NULL;
+  if (n_chunks > 0 && (!chunk_param || !chunk_off || !chunk_len || !chunk_tensor || !grad || !exp_avg || !exp_avg_sq)) return MSGAT_ERR_NULL;
+  if (!(beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1. && eps >= 0. && weight_decay >= 0.)) return MSGAT_ERR_SHAPE;
+  return launch_adam(chunk_param, (const long long*)chunk_off, chunk_len, chunk_tensor, n_chunks, active_tensors, n_active,
+                     grad, exp_avg, exp_avg_sq, steps, lr, beta1, beta2, eps, weight_decay, (hipStream_t)stream);
 }

@@ -266,8 +266,8 @@ int launch_huber_metrics(const float* pred, const float* truth, long long n, flo
 int launch_huber_grad(const float* pred, const float* truth, const float* dloss, long long n, float delta,
                       float* dpred, hipStream_t s);
 int adam_chunk_elems();
-int launch_adam(float* const* chunk_param, const long long* chunk_off, const int* chunk_len, int nchunks,
-                const float* grad, float* m, float* v, float* state, float beta1, float beta2, float eps,
-                float weight_decay, hipStream_t s);
+int launch_adam(float* const* chunk_param, const long long* chunk_off, const int* chunk_len, const int* chunk_tensor,
+                int nchunks, const int* active, int n_active, const float* grad, float* m, float* v, float* steps,
+                const float* lr, double beta1, double beta2, double eps, double weight_decay, hipStream_t s);
 
 }  // namespace msgat

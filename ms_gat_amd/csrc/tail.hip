@@ -107,35 +107,42 @@ int launch_huber_grad(const float* pred, const float* truth, const float* dloss,
 }
 
 // ---- Adam ---------------------------------------------------------------------------------------------------------
-// state[0] = step count t (float, advanced by the launch), state[1] = learning rate.  Chunk c covers
-// chunk_len[c] <= kAdamChunk elements of one parameter tensor starting at chunk_param[c]; its gradient and moments
-// sit at chunk_off[c] of the flat buffers.
+// Chunk c covers chunk_len[c] <= kAdamChunk elements of parameter tensor chunk_tensor[c], starting at chunk_param[c];
+// its gradient and moments sit at chunk_off[c] of the flat buffers.  steps[t] = updates tensor t has received (torch
+// keeps one step count per parameter: a parameter without a gradient is skipped and its bias correction lags);
+// lr[0] = learning rate.  Both live in device memory, so a captured launch follows the scheduler.
 constexpr int kAdamChunk = 2048;
 
-__global__ void k_adam_advance(float* __restrict__ state) { state[0] += 1.0f; }
+__global__ void k_adam_advance(float* __restrict__ steps, const int* __restrict__ active, int n_active) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_active) steps[active[i]] += 1.0f;
+}
 
 __global__ __launch_bounds__(kTailBlock) void k_adam(float* const* __restrict__ chunk_param,
                                                      const long long* __restrict__ chunk_off,
                                                      const int* __restrict__ chunk_len,
+                                                     const int* __restrict__ chunk_tensor,
                                                      const float* __restrict__ grad, float* __restrict__ m,
-                                                     float* __restrict__ v, const float* __restrict__ state,
-                                                     float beta1, float beta2, float eps, float weight_decay) {
+                                                     float* __restrict__ v, const float* __restrict__ steps,
+                                                     const float* __restrict__ lrp, double beta1d, double beta2d,
+                                                     float eps, float weight_decay) {
   const int c = blockIdx.x;
   float* p = chunk_param[c];
   const long long off = chunk_off[c];
   const int len = chunk_len[c];
-  const float t = state[0], lr = state[1];
+  const float t = steps[chunk_tensor[c]], lr = lrp[0];
   // torch.optim.Adam (_single_tensor_adam): bias_correction = 1 - beta^t; step_size = lr / bc1;
   // denom = sqrt(v) / sqrt(bc2) + eps; p -= step_size * m / denom
   // (in double, as the host-side Python floats of the reference optimizer are: 1 - 0.999^t cancels badly in fp32)
-  const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+  const double bc1 = 1.0 - pow(beta1d, (double)t), bc2 = 1.0 - pow(beta2d, (double)t);
+  const float beta2 = (float)beta2d, omb1 = (float)(1.0 - beta1d), omb2 = (float)(1.0 - beta2d);  // 1 - beta rounded once
   const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
   for (int i = threadIdx.x; i < len; i += kTailBlock) {
     const float w = p[i];
     const float g = fmaf(weight_decay, w, grad[off + i]);
     float mi = m[off + i], vi = v[off + i];
-    mi = fmaf(g - mi, 1.0f - beta1, mi);              // exp_avg.lerp_(grad, 1 - beta1)
-    vi = fmaf(g * g, 1.0f - beta2, vi * beta2);       // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    mi = fmaf(g - mi, omb1, mi);                      // exp_avg.lerp_(grad, 1 - beta1)
+    vi = fmaf(g * g, omb2, vi * beta2);               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
     m[off + i] = mi;
     v[off + i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
@@ -143,14 +150,16 @@ __global__ __launch_bounds__(kTailBlock) void k_adam(float* const* __restrict__ 
   }
 }
 
-int launch_adam(float* const* chunk_param, const long long* chunk_off, const int* chunk_len, int nchunks,
-                const float* grad, float* m, float* v, float* state, float beta1, float beta2, float eps,
-                float weight_decay, hipStream_t s) {
-  hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(1), 0, s, state);
-  MSGAT_CHECK_LAUNCH();
+int launch_adam(float* const* chunk_param, const long long* chunk_off, const int* chunk_len, const int* chunk_tensor,
+                int nchunks, const int* active, int n_active, const float* grad, float* m, float* v, float* steps,
+                const float* lr, double beta1, double beta2, double eps, double weight_decay, hipStream_t s) {
+  if (n_active > 0) {
+    hipLaunchKernelGGL(k_adam_advance, dim3(cdiv(n_active, kTailBlock)), dim3(kTailBlock), 0, s, steps, active, n_active);
+    MSGAT_CHECK_LAUNCH();
+  }
   if (nchunks > 0) {
-    hipLaunchKernelGGL(k_adam, dim3(nchunks), dim3(kTailBlock), 0, s, chunk_param, chunk_off, chunk_len, grad, m, v,
-                       state, beta1, beta2, eps, weight_decay);
+    hipLaunchKernelGGL(k_adam, dim3(nchunks), dim3(kTailBlock), 0, s, chunk_param, chunk_off, chunk_len, chunk_tensor,
+                       grad, m, v, steps, lr, beta1, beta2, (float)eps, (float)weight_decay);
     MSGAT_CHECK_LAUNCH();
   }
   return MSGAT_OK;

@@ -134,7 +134,9 @@ class FlatAdam(optim.Optimizer):
         if len(self.param_groups) != 1:
             raise ValueError("FlatAdam takes one parameter group (the reference trains with one, engine.py:106)")
         self._params: List[nn.Parameter] = []
-        self._steps = 0
+        self._loaded_steps: Dict[int, float] = {}    # steps that arrived through load_state_dict, by id(param)
+        self._host_steps: List[int] = []             # host mirror of the per-parameter step counts
+        self._captured_active: Optional[tuple] = None
         self._tables: Dict[tuple, tuple] = {}
         self._lr_on_device = None
 
@@ -155,15 +157,17 @@ class FlatAdam(optim.Optimizer):
         self.exp_avg = torch.zeros(off, device=dev, dtype=torch.float32)
         self.exp_avg_sq = torch.zeros(off, device=dev, dtype=torch.float32)
         self._grad_views = [self.flat_grad[o:o + p.numel()].view_as(p) for p, o in zip(self._params, self._offsets)]
-        self._dev_state = torch.tensor([float(self._steps), float(self.param_groups[0]["lr"])], device=dev)
+        self._host_steps = [int(self._loaded_steps.get(id(p), 0)) for p in self._params]
+        self._dev_steps = torch.tensor([float(t) for t in self._host_steps], device=dev)
+        self._dev_lr = torch.tensor([float(self.param_groups[0]["lr"])], device=dev)
         self._lr_on_device = float(self.param_groups[0]["lr"])
-        for p, o in zip(self._params, self._offsets):
+        for i, (p, o) in enumerate(zip(self._params, self._offsets)):
             old = self.state.get(p, {})
             m, v = self.exp_avg[o:o + p.numel()].view_as(p), self.exp_avg_sq[o:o + p.numel()].view_as(p)
             if "exp_avg" in old:      # state that arrived through load_state_dict: move it into the flat buffers
                 m.copy_(old["exp_avg"])
                 v.copy_(old["exp_avg_sq"])
-            self.state[p] = {"step": torch.tensor(float(self._steps)), "exp_avg": m, "exp_avg_sq": v}
+            self.state[p] = {"step": torch.tensor(float(self._host_steps[i])), "exp_avg": m, "exp_avg_sq": v}
         self._tables.clear()
 
     def _table(self, active: tuple):
@@ -173,19 +177,22 @@ class FlatAdam(optim.Optimizer):
         if hit is None:
             from . import _lib
             chunk = int(_lib.lib().msgat_adam_chunk_elems())
-            ptrs, offs, lens = [], [], []
-            for p, o, on in zip(self._params, self._offsets, active):
+            ptrs, offs, lens, tens, act = [], [], [], [], []
+            for i, (p, o, on) in enumerate(zip(self._params, self._offsets, active)):
                 if not on:
                     continue
                 if not p.is_contiguous():
                     raise RuntimeError("FlatAdam needs contiguous parameters")
+                act.append(i)
                 for s in range(0, p.numel(), chunk):
                     ptrs.append(p.data_ptr() + 4 * s)
                     offs.append(o + s)
                     lens.append(min(chunk, p.numel() - s))
+                    tens.append(i)
             dev = self.flat_grad.device
             hit = (torch.tensor(ptrs, dtype=torch.int64).to(dev), torch.tensor(offs, dtype=torch.int64).to(dev),
-                   torch.tensor(lens, dtype=torch.int32).to(dev), len(ptrs))
+                   torch.tensor(lens, dtype=torch.int32).to(dev), torch.tensor(tens, dtype=torch.int32).to(dev),
+                   torch.tensor(act, dtype=torch.int32).to(dev), len(ptrs), len(act))
             self._tables = {key: hit}     # parameter storage moved or the gradient pattern changed: one table alive
         return hit
 
@@ -193,12 +200,13 @@ class FlatAdam(optim.Optimizer):
         """Write the group's learning rate (a host float the scheduler edits) into device memory when it changed."""
         lr = float(self.param_groups[0]["lr"])
         if self._lr_on_device is not None and lr != self._lr_on_device:
-            self._dev_state[1].fill_(lr)
+            self._dev_lr.fill_(lr)
             self._lr_on_device = lr
 
     def note_replayed_step(self) -> None:
-        """A HIP-graph replay ran the captured update: advance the host-side mirror of the step count."""
-        self._steps += 1
+        """A HIP-graph replay ran the captured update: advance the host-side mirror of the step counts."""
+        for i, on in enumerate(self._captured_active or ()):
+            self._host_steps[i] += int(on)
 
     @torch.no_grad()
     def step(self, closure=None, rank_weight: Optional[float] = None):
@@ -222,15 +230,19 @@ class FlatAdam(optim.Optimizer):
             dist.all_reduce(self.flat_grad)
             self.flat_grad[: self.numel].div_(self.flat_grad[self.numel])
         self.sync_lr()
-        ptrs, offs, lens, n = self._table(active)
+        ptrs, offs, lens, tens, act, n, n_act = self._table(active)
         g = self.param_groups[0]
-        st = _lib.lib().msgat_adam_step(ptrs.data_ptr(), offs.data_ptr(), lens.data_ptr(), n, self.flat_grad.data_ptr(),
-                                        self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self._dev_state.data_ptr(),
-                                        float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                                        float(g["weight_decay"]), torch.cuda.current_stream(self.flat_grad.device).cuda_stream)
+        st = _lib.lib().msgat_adam_step(ptrs.data_ptr(), offs.data_ptr(), lens.data_ptr(), tens.data_ptr(), n, act.data_ptr(),
+                                        n_act, self.flat_grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                        self._dev_steps.data_ptr(), self._dev_lr.data_ptr(), float(g["betas"][0]),
+                                        float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+                                        torch.cuda.current_stream(self.flat_grad.device).cuda_stream)
         _lib.check(st, "msgat_adam_step")
-        if not torch.cuda.is_current_stream_capturing():
-            self._steps += 1
+        if torch.cuda.is_current_stream_capturing():
+            self._captured_active = active
+        else:
+            for i, on in enumerate(active):
+                self._host_steps[i] += int(on)
         return loss
 
     @property
@@ -241,9 +253,8 @@ class FlatAdam(optim.Optimizer):
 
     # -- torch.optim.Adam's checkpoint format ------------------------------------------------------------------
     def state_dict(self):
-        for st in self.state.values():
-            if "step" in st:
-                st["step"] = torch.tensor(float(self._steps))
+        for p, t in zip(self._params, self._host_steps):
+            self.state[p]["step"] = torch.tensor(float(t))
         sd = super().state_dict()
         for group in sd["param_groups"]:            # the keys torch.optim.Adam writes, so the reference's loader accepts it
             group.setdefault("amsgrad", False)
@@ -257,10 +268,14 @@ class FlatAdam(optim.Optimizer):
 
     def load_state_dict(self, state_dict) -> None:
         super().load_state_dict(state_dict)
-        steps = [float(st["step"]) for st in self.state.values() if "step" in st]
-        self._steps = int(max(steps)) if steps else 0
+        self._loaded_steps = {id(p): float(st["step"]) for p, st in self.state.items() if "step" in st}
         if self.param_groups[0]["params"] and self.param_groups[0]["params"][0].is_cuda:
-            self._build()                             # moves the loaded moments into the flat buffers
+            self._build()                             # moves the loaded moments and step counts into the flat buffers
+
+    def set_steps(self, steps: List[int]) -> None:
+        """Put the step counts (host mirror and device) back, e.g. after the warm-up iterations of a graph capture."""
+        self._host_steps = list(steps)
+        self._dev_steps.copy_(torch.tensor([float(t) for t in steps]))
 
 
 class _GraphedStep:
@@ -284,7 +299,7 @@ class _GraphedStep:
             saved_params = [p.detach().clone() for p in trained]
             saved_state = {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state.get(p, {}).items()}
                            for group in opt.param_groups for p in group["params"]}
-            saved_steps = getattr(opt, "_steps", None)
+            saved_steps = list(getattr(opt, "_host_steps", []))
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -308,8 +323,7 @@ class _GraphedStep:
                             old = saved_state.get(p, {}).get(k)
                             v.copy_(old) if old is not None else v.zero_()
                 if isinstance(opt, FlatAdam) and step_in_graph:
-                    opt._steps = saved_steps
-                    opt._dev_state[0].fill_(float(saved_steps))
+                    opt.set_steps(saved_steps if saved_steps else [0] * len(opt._host_steps))
             opt.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
