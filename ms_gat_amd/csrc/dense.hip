@@ -39,6 +39,9 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // the nested fmaxf into v_max3_f32 by itself.
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
+// 8 waves = 2 per SIMD.  Tried (round 2): 7 waves per block, which makes the PEMSD7 grid (N = 883, G = 96) exactly
+// 3.0 blocks per CU instead of 2.6 (3 rounds of 112 rows instead of 3 of 128): k_scores 60.7 -> 63.7 us,
+// k_bwd_dense_col 60.2 -> 61.0 us -- 7 waves spread 2,2,2,1 over the SIMDs, and the matrix pipe is per SIMD.
 constexpr int kDWaves = 8;             // the whole grid must be resident at once: leftover blocks run as a second round
 constexpr int kDBlock = 64 * kDWaves;
 constexpr int kDRows = 16 * kDWaves;   // own rows (forward) / columns (backward) per block

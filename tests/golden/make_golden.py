@@ -16,6 +16,7 @@ Fixtures:
   msgat72_n32.npz  msgat72 fwd + HuberLoss(50) + all grads (msgat.py:166-229, loss.py:51-52)
   adj_n12.npz  sym-normalised adjacency from a csv edge list (data_loader.py:49-66)
   slices_*.npz TimeSeriesSlice / normalize (data_loader.py:92-120)
+  loader_tiny.npz  DataLoaderForMSGAT on csv + npz + meta.yaml files (data_loader.py:29-89)
   msgat72_cfg1_pemsd4.npz  BASELINE.json configs[0]: msgat72 forward, N=307, 3 features, B=4, five components
 """
 import os
@@ -209,6 +210,51 @@ def slices_case(seed):
          d=torch.stack([it[2] for it in items]), y=torch.stack([it[3] for it in items]))
 
 
+def loader_case(seed):
+    """The reference's file-based loader end to end (data_loader.py:29-89): a tiny csv edge list (`from,to,cost`
+    with a header), an npz series (key `data`, [T_total, N, C]) and a `data/meta.yaml` entry are written to a
+    temp directory, `DataLoaderForMSGAT` runs there (it opens the relative path `data/meta.yaml`), and the
+    adjacency plus the first batch of every split are stored next to the INPUTS (edges, series, meta values) so
+    the test can re-create the files.  The training split is read in dataset order (its loader shuffles)."""
+    rng = np.random.default_rng(seed)
+    n, c, tau, q, hours, bs = 7, 2, 12, 12, [1, 2, 24], 4
+    total = 24 * 12 * 2 + 40
+    series = (rng.standard_normal((total, n, c)) * 12 + 60).astype(np.float32)
+    edges = [(0, 1), (1, 2), (2, 0), (3, 4), (5, 6), (6, 3), (4, 0)]
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "data"))
+        with open(os.path.join(tmp, "data", "tiny.csv"), "w") as f:
+            f.write("from,to,cost\n")
+            for s, d in edges:
+                f.write(f"{s},{d},{rng.uniform(0.5, 3.0):.3f}\n")
+        np.savez(os.path.join(tmp, "data", "tiny.npz"), data=series)
+        with open(os.path.join(tmp, "data", "meta.yaml"), "w") as f:
+            f.write("tiny:\n    adj-file: data/tiny.csv\n    data-file: data/tiny.npz\n"
+                    f"    num-nodes: {n}\n    num-channels: {c}\n    timesteps-per-hour: {tau}\n")
+        os.chdir(tmp)
+        try:
+            dl = ref_dl.DataLoaderForMSGAT("tiny", hours, q, bs, 0)
+            arrays = dict(edges=np.asarray(edges, dtype=np.int64), series=series, n=np.int64(n), c=np.int64(c),
+                          tau=np.int64(tau), q=np.int64(q), hours=np.asarray(hours), batch_size=np.int64(bs), adj=dl.adj,
+                          lengths=np.asarray([len(dl.training.dataset), len(dl.validation.dataset), len(dl.evaluation.dataset)]),
+                          n_batches=np.asarray([len(dl.training), len(dl.validation), len(dl.evaluation)]))
+            items = [dl.training.dataset[i] for i in range(bs)]
+            for k, name in enumerate("xhdy"):
+                arrays[f"train_{name}"] = torch.stack([it[k] for it in items])
+            for split, loader in (("val", dl.validation), ("eval", dl.evaluation)):
+                first = next(iter(loader))
+                last = None
+                for last in loader:
+                    pass
+                for k, name in enumerate("xhdy"):
+                    arrays[f"{split}_{name}"] = first[k]
+                    arrays[f"{split}_last_{name}"] = last[k]
+        finally:
+            os.chdir(cwd)
+    save("loader_tiny.npz", **arrays)
+
+
 if __name__ == "__main__":
     gatt_case("b2c3n16", 2, 3, 16, 12, 20, 100)
     gatt_case("b2c1n64", 2, 1, 64, 12, 70, 200)
@@ -220,3 +266,4 @@ if __name__ == "__main__":
     adjacency_case()
     slices_case(800)
     cfg1_case(900)
+    loader_case(1000)

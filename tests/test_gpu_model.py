@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_err
+from conftest import load_golden, record_err, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -236,3 +236,60 @@ def test_training_with_the_parameter_bank_tracks_the_component_loop(tmp_path):
         net.stack_components = False
         p2 = net(X, H, D)
     assert rel_err(p1, p2) < 1e-5
+
+
+def test_cfg4_per_rank_workload_full_training_step(tmp_path):
+    """BASELINE.json configs[3], the per-GPU workload of the 1/2/4/8 scaling curve: msgat72 with the reference's default
+    R = 5 components on the PEMSD7-like graph (N = 883), B = 32, one whole training step.  No 8-GPU node is needed to
+    pin it: the stacked launch sequence against the reference's loop over components, both against the reference's
+    dense op sequence on the same GPU, and one step through engine.Trainer with the 7.8 MB flat gradient buffer."""
+    import copy
+    import bench
+    from ms_gat_amd import engine
+    dev = _dev()
+    ts = bench.TrainStep(bench.CFG4, dev)
+    net = ts.net
+    assert len(net.tpcs) == 5 and ts.n_params == 1957960                      # SURVEY section 5: 1 957 960 trainable parameters
+    X, H, D, Y = ts.batch
+    assert tuple(X.shape) == (32, 5, 1, 883, 12)
+
+    def fwd_bwd(model, n):
+        model.zero_grad(set_to_none=True)
+        pred = model(X[:n], H[:n], D[:n])
+        loss = engine.HuberLoss(50.0)(pred, Y[:n])
+        loss.backward()
+        return pred.detach(), float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    loop = copy.deepcopy(net)
+    loop.stack_components = False                                              # msgat.py:204: one component at a time
+    p_s, l_s, g_s = fwd_bwd(net, 32)
+    p_l, l_l, g_l = fwd_bwd(loop, 32)
+    e = rel_err(p_s, p_l)
+    record_err("cfg4 R=5 N=883 B=32: stacked vs component loop", "pred", e, 1e-5)
+    assert e < 1e-5 and abs(l_s - l_l) < 1e-5 * abs(l_l)
+    assert set(g_s) == set(g_l)
+    worst = max(rel_err(g_s[k], g_l[k]) for k in g_l)
+    record_err("cfg4 R=5 N=883 B=32: stacked vs component loop", "all gradients (worst)", worst, TOL)
+    assert worst < TOL
+
+    dense = copy.deepcopy(loop)                                                # the reference's eager op sequence, block by block
+    for tpc in dense.tpcs:
+        tpc.tgacns = torch.nn.ModuleList(bench._EagerMEAM(m) for m in tpc.tgacns)
+        tpc.ln = bench._EagerLayerNorm(tpc.ln)
+    n = 8
+    p_d, l_d, g_d = fwd_bwd(dense, n)
+    p_8, l_8, g_8 = fwd_bwd(net, n)
+    e = rel_err(p_8, p_d)
+    record_err("cfg4 R=5 N=883 B=8: library vs dense eager ops", "pred", e, TOL)
+    assert e < TOL and abs(l_8 - l_d) < TOL * abs(l_d)
+    named = {k.replace(".inner", ""): v for k, v in g_d.items()}
+    worst = max(rel_err(g_8[k], named[k]) for k in g_8)
+    record_err("cfg4 R=5 N=883 B=8: library vs dense eager ops", "all gradients (worst)", worst, TOL)
+    assert set(named) == set(g_8) and worst < TOL
+
+    before = [p.detach().clone() for p in net.parameters() if p.requires_grad]
+    loss = ts.run(1)
+    assert np.isfinite(loss) and ts.allreduce_bytes == 4 * (1957960 + 1)
+    assert isinstance(ts.trainer.optimizer, engine.FlatAdam) and set(ts.trainer.optimizer._host_steps) == {1}
+    moved = sum(int(not torch.equal(a, b)) for a, b in zip(before, (p for p in net.parameters() if p.requires_grad)))
+    assert moved == len(before)

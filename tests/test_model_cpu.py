@@ -219,3 +219,37 @@ def test_checkpoints_interchange_with_the_reference_loader(tmp_path):
     engine.Evaluator(m3, 50.0, str(tmp_path / "eval"), tmp_path / "dp.pkl")
     for a, b, c in zip(model.state_dict().values(), tr2.model.state_dict().values(), m3.state_dict().values()):
         assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_file_based_loader_matches_the_reference_loader(tmp_path):
+    """`MSGATData` on the on-disk formats of the reference -- csv `from,to,cost` with a header
+    (data_loader.py:60-63), npz key `data` [T_total,N,C] (:71), a `data/meta.yaml` entry (:37-43) -- against what
+    `DataLoaderForMSGAT` itself produced from the same files (tests/golden/make_golden.py loader_case): adjacency,
+    split sizes, and the first / last batch of every split, bit for bit."""
+    from ms_gat_amd import data
+    g = load_golden("loader_tiny.npz")
+    (tmp_path / "data").mkdir()
+    with open(tmp_path / "data" / "tiny.csv", "w") as f:
+        f.write("from,to,cost\n")
+        for s, d in g["edges"].tolist():
+            f.write(f"{s},{d},1.250\n")                    # the cost column is ignored (data_loader.py:61)
+    np.savez(tmp_path / "data" / "tiny.npz", data=g["series"])
+    meta = tmp_path / "data" / "meta.yaml"
+    meta.write_text(f"tiny:\n    adj-file: {tmp_path}/data/tiny.csv\n    data-file: {tmp_path}/data/tiny.npz\n"
+                    f"    num-nodes: {int(g['n'])}\n    num-channels: {int(g['c'])}\n    timesteps-per-hour: {int(g['tau'])}\n")
+    ds = data.MSGATData("tiny", g["hours"].tolist(), int(g["q"]), int(g["batch_size"]), num_workers=0, meta_file=str(meta))
+    assert (ds.num_nodes, ds.num_channels, ds.timesteps_per_hour) == (int(g["n"]), int(g["c"]), int(g["tau"]))
+    assert torch.allclose(ds.adj, torch.from_numpy(g["adj"]), atol=1e-7)        # D^-1/2 (A+I) D^-1/2 (:59-66)
+    loaders = (ds.training, ds.validation, ds.evaluation)
+    assert [len(l.dataset) for l in loaders] == g["lengths"].tolist()
+    assert [len(l) for l in loaders] == g["n_batches"].tolist()
+    items = [ds.training.dataset[i] for i in range(int(g["batch_size"]))]      # the training loader shuffles: dataset order
+    for k, name in enumerate("xhdy"):
+        assert torch.equal(torch.stack([it[k] for it in items]), torch.from_numpy(g[f"train_{name}"])), name
+    for split, loader in (("val", ds.validation), ("eval", ds.evaluation)):
+        batches = list(loader)
+        for k, name in enumerate("xhdy"):
+            assert torch.equal(batches[0][k], torch.from_numpy(g[f"{split}_{name}"])), (split, name)
+            assert torch.equal(batches[-1][k], torch.from_numpy(g[f"{split}_last_{name}"])), (split, name)
+    x, h, d, y = next(iter(ds.training))                                       # and the training loader does deliver batches
+    assert tuple(x.shape) == (4, 3, 2, 7, 12) and tuple(y.shape) == (4, 7, 12) and h.dtype == torch.int64
