@@ -238,11 +238,43 @@ def test_training_with_the_parameter_bank_tracks_the_component_loop(tmp_path):
     assert rel_err(p1, p2) < 1e-5
 
 
+def _dense_restatement(net, X, H, D, Y, dtype):
+    """The whole model as the reference's dense op sequence (oracle/dense_torch.py) in `dtype`, with `net`'s parameters:
+    prediction, Huber(50) loss and the gradient of every trainable parameter."""
+    from ms_gat_amd import engine
+    from oracle import dense_torch
+    R, B = len(net.tpcs), X.shape[0]
+    N, T = X.shape[-2], X.shape[-1]
+    P = {k: v.detach().to(dtype) for k, v in net.state_dict().items()}
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items() if k != "adj"}
+    gate = (leaves["te.h_ebd.weight"][H] + leaves["te.d_ebd.weight"][D]).view(B, R, N, T)
+    out = 0
+    for r in range(R):
+        x = X[:, r].to(dtype)
+        for l, meam in enumerate(net.tpcs[r].tgacns):
+            sub = {k[len(f"tpcs.{r}.tgacns.{l}."):]: v for k, v in leaves.items() if k.startswith(f"tpcs.{r}.tgacns.{l}.")}
+            x = dense_torch.meam_dense(x, P["adj"], sub, meam.dilations)
+        x = torch.nn.functional.layer_norm(x, [T], leaves[f"tpcs.{r}.ln.weight"], leaves[f"tpcs.{r}.ln.bias"], 1e-5)
+        y = torch.nn.functional.conv2d(x.transpose(1, 3), leaves[f"tpcs.{r}.fc.weight"], leaves[f"tpcs.{r}.fc.bias"])
+        out = out + y[..., 0].transpose(1, 2) * gate[:, r]
+    loss = engine.huber_loss(out, Y.to(dtype), 50.0)
+    names = [k for k, p in net.named_parameters() if p.requires_grad]
+    grads = torch.autograd.grad(loss, [leaves[k] for k in names])
+    return out.detach(), float(loss), dict(zip(names, grads))
+
+
 def test_cfg4_per_rank_workload_full_training_step(tmp_path):
     """BASELINE.json configs[3], the per-GPU workload of the 1/2/4/8 scaling curve: msgat72 with the reference's default
     R = 5 components on the PEMSD7-like graph (N = 883), B = 32, one whole training step.  No 8-GPU node is needed to
-    pin it: the stacked launch sequence against the reference's loop over components, both against the reference's
-    dense op sequence on the same GPU, and one step through engine.Trainer with the 7.8 MB flat gradient buffer."""
+    pin it:
+      * the stacked launch sequence against the reference's loop over components (msgat.py:204) through the same library;
+      * both against the reference's dense op sequence on the same GPU, in float64 AND in float32.  At this size the
+        gradients of a ReLU network are not smooth functions of rounding: a handful of the 2.4e8 pre-activations sit
+        within an ulp of zero, and any two fp32 implementations mask them differently.  The reference's own fp32
+        arithmetic is up to 2e-2 (max-norm, per tensor) away from float64 here, so the bar for the gradients is
+        "no further from float64 than the reference's fp32 run", recorded per run in the parity log; the prediction
+        and the loss -- smooth -- keep the 1e-4 bar;
+      * one step through engine.Trainer with the 7.8 MB flat gradient buffer Adam and the all-reduce share."""
     import copy
     import bench
     from ms_gat_amd import engine
@@ -253,39 +285,48 @@ def test_cfg4_per_rank_workload_full_training_step(tmp_path):
     X, H, D, Y = ts.batch
     assert tuple(X.shape) == (32, 5, 1, 883, 12)
 
-    def fwd_bwd(model, n):
+    def fwd_bwd(model):
         model.zero_grad(set_to_none=True)
-        pred = model(X[:n], H[:n], D[:n])
-        loss = engine.HuberLoss(50.0)(pred, Y[:n])
+        pred = model(X, H, D)
+        loss = engine.HuberLoss(50.0)(pred, Y)
         loss.backward()
-        return pred.detach(), float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        return pred.detach(), float(loss.detach()), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
 
     loop = copy.deepcopy(net)
     loop.stack_components = False                                              # msgat.py:204: one component at a time
-    p_s, l_s, g_s = fwd_bwd(net, 32)
-    p_l, l_l, g_l = fwd_bwd(loop, 32)
+    p_s, l_s, g_s = fwd_bwd(net)
+    p_l, l_l, g_l = fwd_bwd(loop)
+    what = "cfg4 R=5 N=883 B=32: stacked vs component loop"
     e = rel_err(p_s, p_l)
-    record_err("cfg4 R=5 N=883 B=32: stacked vs component loop", "pred", e, 1e-5)
-    assert e < 1e-5 and abs(l_s - l_l) < 1e-5 * abs(l_l)
-    assert set(g_s) == set(g_l)
-    worst = max(rel_err(g_s[k], g_l[k]) for k in g_l)
-    record_err("cfg4 R=5 N=883 B=32: stacked vs component loop", "all gradients (worst)", worst, TOL)
-    assert worst < TOL
+    record_err(what, "pred", e, 1e-5)
+    assert e < 1e-5 and abs(l_s - l_l) < 1e-5 * abs(l_l) and set(g_s) == set(g_l)
+    gscale = max(float(g.abs().max()) for g in g_l.values())                   # tensors > 100x smaller than the largest gradient
+    errs = []                                                                  # (e.g. the lone alpha of a 1-channel attention:
+    for k in g_l:                                                              # 3e-7) are judged on that scale
+        scale = max(float(g_l[k].abs().max()), 1e-2 * gscale)
+        errs.append(float((g_s[k] - g_l[k]).abs().max()) / scale)
+    # measured: every tensor agrees to ~1e-6 except those downstream of ONE borderline ReLU -- e.g. a single one of the
+    # 72 channels of tpcs.3.tgacns.1.res.bias is off by 3.5e-4, its neighbours by < 1.4e-6 (a mask flip, see docstring)
+    record_err(what, "gradients, worst tensor", max(errs), 1e-3)
+    record_err(what, "gradients, median tensor", float(np.median(errs)), 1e-5)
+    assert max(errs) < 1e-3 and float(np.median(errs)) < 1e-5
 
-    dense = copy.deepcopy(loop)                                                # the reference's eager op sequence, block by block
-    for tpc in dense.tpcs:
-        tpc.tgacns = torch.nn.ModuleList(bench._EagerMEAM(m) for m in tpc.tgacns)
-        tpc.ln = bench._EagerLayerNorm(tpc.ln)
-    n = 8
-    p_d, l_d, g_d = fwd_bwd(dense, n)
-    p_8, l_8, g_8 = fwd_bwd(net, n)
-    e = rel_err(p_8, p_d)
-    record_err("cfg4 R=5 N=883 B=8: library vs dense eager ops", "pred", e, TOL)
-    assert e < TOL and abs(l_8 - l_d) < TOL * abs(l_d)
-    named = {k.replace(".inner", ""): v for k, v in g_d.items()}
-    worst = max(rel_err(g_8[k], named[k]) for k in g_8)
-    record_err("cfg4 R=5 N=883 B=8: library vs dense eager ops", "all gradients (worst)", worst, TOL)
-    assert set(named) == set(g_8) and worst < TOL
+    p64, l64, g64 = _dense_restatement(net, X, H, D, Y, torch.float64)
+    p32, l32, g32 = _dense_restatement(net, X, H, D, Y, torch.float32)
+    what = "cfg4 R=5 N=883 B=32 vs dense float64 ops"
+    e_lib, e_ref = rel_err(p_s.double(), p64), rel_err(p32.double(), p64)
+    record_err(what, "pred (library)", e_lib, TOL)
+    record_err(what, "pred (dense fp32 eager ops)", e_ref, TOL)
+    assert e_lib < TOL and abs(l_s - l64) < TOL * abs(l64)
+    assert set(g64) == set(g_s)
+    lib = {k: rel_err(g_s[k].double(), g64[k]) for k in g64}
+    ref = {k: rel_err(g32[k].double(), g64[k]) for k in g64}
+    record_err(what, "gradients, worst tensor (library)", max(lib.values()), max(2e-3, max(ref.values())))
+    record_err(what, "gradients, worst tensor (dense fp32 eager ops)", max(ref.values()), max(2e-3, max(ref.values())))
+    record_err(what, "gradients, median tensor (library)", float(np.median(list(lib.values()))), TOL)
+    record_err(what, "gradients, median tensor (dense fp32 eager ops)", float(np.median(list(ref.values()))), TOL)
+    assert max(lib.values()) <= max(2e-3, max(ref.values()))
+    assert float(np.median(list(lib.values()))) < TOL
 
     before = [p.detach().clone() for p in net.parameters() if p.requires_grad]
     loss = ts.run(1)
