@@ -239,7 +239,10 @@ int msgat_stage_contract(const msgat_shape_t* shape, int32_t Ca, int32_t Cb, con
  * (identity), eps as torch's (1e-5 in the reference), biased variance.
  * Backward re-derives mean / rstd from x (nothing is saved but x): dx [rows,T], dweight / dbias [T]
  * (either may be NULL) summed in a fixed order through `partials`
- * (msgat_layernorm_partial_floats() floats).  T in {4, 8, 12, 16}.
+ * (msgat_layernorm_partial_floats() floats).  dx_add (may be NULL) is added to dx in the same pass: the
+ * gradient that reached x along its other path -- MEAM's residual convolution reads the block input too
+ * (msgat.py:130) -- so autograd's separate accumulation pass over the activation disappears.
+ * T in {4, 8, 12, 16}.
  *
  * R ("relations") in this and the following entry points: the number of parameter sets evaluated in one
  * launch.  The reference loops over its components (src/models/msgat.py:204), each with its own weights;
@@ -249,9 +252,9 @@ int msgat_stage_contract(const msgat_shape_t* shape, int32_t Ca, int32_t Cb, con
 int msgat_layernorm_forward(const float* x, const float* weight, const float* bias, float* y,
                             int64_t rows, int32_t T, float eps, int32_t R, void* stream);
 size_t msgat_layernorm_partial_floats(int64_t rows, int32_t T, int32_t R);
-int msgat_layernorm_backward(const float* x, const float* weight, const float* dy, float* dx,
-                             float* dweight, float* dbias, float* partials, int64_t rows, int32_t T,
-                             float eps, int32_t R, void* stream);
+int msgat_layernorm_backward(const float* x, const float* weight, const float* dy, const float* dx_add,
+                             float* dx, float* dweight, float* dbias, float* partials, int64_t rows,
+                             int32_t T, float eps, int32_t R, void* stream);
 
 /* ---- device: the temporal and channel branches of MEAM ----
  * Building blocks for TACN (src/models/msgat.py:57-80, TemporalAttention attention.py:58-66) and CACN
@@ -301,7 +304,9 @@ int msgat_node_pool_grad_weight(const float* x, const float* dpooled, float* dw,
  *       writes each output range to its own tensor: MEAM's tail (msgat.py:123-131) without the cat, and all
  *       channel mixings of one activation (CACN's per-sample matrix, TACN's first convolution, GACN's
  *       projection and the two alpha poolings) in ONE pass; m_in_major = 1 is its backward (one dx).
- *   msgat_contract_segments: dst[r,a,c] = sum_{g in r, p} cat(A_segments)[g,a,p] B[g,c,p].
+ *   msgat_contract_segments: dst[r,a,c] = sum_{g in r, p} cat(A_segments)[g,a,p] B[g,c,p]; with_ones = 1 appends a
+ *       virtual channel of ones to B: dst is [R, Ca, Cb+1] and dst[r,a,Cb] = sum_{g,p} A[g,a,p] -- the bias gradient of
+ *       a 1x1 convolution out of the pass that computes its weight gradient (size the partials for Cb+1).
  * At most 6 segments per list. */
 typedef struct {
   float* ptr;
@@ -314,7 +319,7 @@ int msgat_mix_segments(int32_t R, int32_t Bg, int32_t N, int32_t T, const msgat_
                        int32_t n_out, void* stream);
 size_t msgat_contract_segments_partial_floats(int32_t R, int32_t Ca, int32_t Cb);
 int msgat_contract_segments(int32_t R, int32_t Bg, int32_t N, int32_t T, const msgat_seg_t* A, int32_t n_a,
-                            const float* B, int32_t Cb, float* partials, float* dst, void* stream);
+                            const float* B, int32_t Cb, int32_t with_ones, float* partials, float* dst, void* stream);
 
 /* ---- device: the attention core on already projected features ----
  * Forward = msgat_stage_scores(q) + msgat_stage_aggregate(u) (above).  Backward of exactly that pair, for

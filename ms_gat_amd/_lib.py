@@ -95,8 +95,8 @@ _PROTOTYPES = {
     "msgat_mix_segments": (C.c_int, [C.c_int32] * 4 + [C.POINTER(Seg), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                      C.POINTER(Seg), C.c_int32, C.c_int32, C.POINTER(Seg), C.c_int32, C.c_void_p]),
     "msgat_contract_segments_partial_floats": (C.c_size_t, [C.c_int32] * 3),
-    "msgat_contract_segments": (C.c_int, [C.c_int32] * 4 + [C.POINTER(Seg), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
-                                          C.c_void_p, C.c_void_p]),
+    "msgat_contract_segments": (C.c_int, [C.c_int32] * 4 + [C.POINTER(Seg), C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "msgat_attention_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Shape), C.POINTER(Graph)]),
     "msgat_attention_backward": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)] + [C.c_void_p] * 12 + [C.c_size_t, C.c_void_p]),
     "msgat_head_forward_partial_floats": (C.c_size_t, [C.c_int32] * 4),
@@ -106,7 +106,7 @@ _PROTOTYPES = {
     "msgat_head_grad_weight": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 6 + [C.c_void_p]),
     "msgat_layernorm_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "msgat_layernorm_partial_floats": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
-    "msgat_layernorm_backward": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
+    "msgat_layernorm_backward": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "msgat_huber_partial_doubles": (C.c_size_t, [C.c_int64]),
     "msgat_huber_metrics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float] + [C.c_void_p] * 4),
     "msgat_huber_grad": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),

@@ -347,16 +347,18 @@ extern "C" size_t msgat_contract_segments_partial_floats(int32_t R, int32_t Ca, 
 }
 
 extern "C" int msgat_contract_segments(int32_t R, int32_t Bg, int32_t N, int32_t T, const msgat_seg_t* A, int32_t n_a,
-                                       const float* B, int32_t Cb, float* partials, float* dst, void* stream) {
+                                       const float* B, int32_t Cb, int32_t with_ones, float* partials, float* dst,
+                                       void* stream) {
   int st = check_rgnt(R, Bg, N, T);
   if (st) return st;
   if (!B || !partials || !dst) return MSGAT_ERR_NULL;
-  if (Cb <= 0 || Cb > kMaxC) return MSGAT_ERR_SHAPE;
+  if (Cb <= 0 || Cb > kMaxC || (with_ones != 0 && with_ones != 1)) return MSGAT_ERR_SHAPE;
   SegList sa;
   if ((st = to_seglist(A, n_a, &sa))) return st;
   if (sa.n == 0) return MSGAT_ERR_SHAPE;
-  return launch_chanpair_seg(sa, B, partials, dst, sa.total() * Cb, nullptr, 0, R * Bg, Bg, Cb, N * T,
-                             (hipStream_t)stream);
+  const int Cbx = Cb + with_ones;
+  return launch_chanpair_seg(sa, B, partials, dst, sa.total() * Cbx, nullptr, 0, R * Bg, Bg, Cbx, N * T,
+                             (hipStream_t)stream, with_ones);
 }
 
 // ---- attention core on projected features: backward --------------------------------------------------------
@@ -464,13 +466,13 @@ extern "C" size_t msgat_layernorm_partial_floats(int64_t rows, int32_t T, int32_
   return layernorm_partial_floats(rows, T, R);
 }
 
-extern "C" int msgat_layernorm_backward(const float* x, const float* weight, const float* dy, float* dx,
-                                        float* dweight, float* dbias, float* partials, int64_t rows,
+extern "C" int msgat_layernorm_backward(const float* x, const float* weight, const float* dy, const float* dx_add,
+                                        float* dx, float* dweight, float* dbias, float* partials, int64_t rows,
                                         int32_t T, float eps, int32_t R, void* stream) {
   if (!x || !dy || !dx || !partials) return MSGAT_ERR_NULL;
   if (rows <= 0 || !(eps >= 0.f) || R <= 0 || R > 65535 || rows % R) return MSGAT_ERR_SHAPE;
   if (!t_supported(T)) return MSGAT_ERR_UNSUPPORTED;
-  return launch_layernorm_bwd(x, weight, dy, dx, dweight, dbias, partials, rows, T, eps, R, (hipStream_t)stream);
+  return launch_layernorm_bwd(x, weight, dy, dx_add, dx, dweight, dbias, partials, rows, T, eps, R, (hipStream_t)stream);
 }
 
 // ---- fused forward ---------------------------------------------------------------------------------

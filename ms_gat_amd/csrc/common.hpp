@@ -186,8 +186,9 @@ int launch_project_mfma(const SegList& in, const float* M, int m_in_major, const
                         const float* addvec, const float* extra, const SegList& out, float* q, int G, int Bg,
                         int P, const MixEpilogue& epi, hipStream_t s);
 int chanpair_mfma_blocks(int R);  // blocks (= partials) per relation
+// b_ones: B's last channel (Cb counts it) is a virtual row of ones: part[a, Cb-1] = sum_p A[a,p]
 int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
-                         hipStream_t s);
+                         int b_ones, hipStream_t s);
 int launch_scores(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW, float* lse,
                   float* pq, float* E, int G, int Bg, int N, int T, hipStream_t s);
 // v[g,c,n,:] = sum_{e in ptr[n]..ptr[n+1]} E[g,e] u[g,c,idx[e],:] (+ addvec[r,c]*extra[g,n,:])
@@ -223,7 +224,7 @@ int launch_chanpair(const float* A, const float* Aextra, const float* B, float* 
                     int n0, float* dst1, int n1, int G, int Bg, int Ca, int Cb, int P,
                     hipStream_t s);
 int launch_chanpair_seg(const SegList& A, const float* B, float* part, float* dst0, int n0, float* dst1, int n1,
-                        int G, int Bg, int Cb, int P, hipStream_t s);
+                        int G, int Bg, int Cb, int P, hipStream_t s, int b_ones = 0);
 // out[i] = sum_j part[j,i], i < Wd, split over dst0 (first n0) and dst1 (next n1); fixed order
 int launch_reduce_rows(const float* part, int J, int Wd, float* dst0, int n0, float* dst1, int n1,
                        hipStream_t s);
@@ -256,8 +257,8 @@ int launch_reduce_split(const float* part, int R, int J, int Wd, float* dst0, in
                         hipStream_t s);
 int launch_layernorm_fwd(const float* x, const float* w, const float* b, float* y, long long rows, int T,
                          float eps, int R, hipStream_t s);
-int launch_layernorm_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
-                         float* part, long long rows, int T, float eps, int R, hipStream_t s);
+int launch_layernorm_bwd(const float* x, const float* w, const float* dy, const float* add, float* dx, float* dw,
+                         float* db, float* part, long long rows, int T, float eps, int R, hipStream_t s);
 
 // step tail (tail.hip)
 size_t huber_partial_doubles(long long n);

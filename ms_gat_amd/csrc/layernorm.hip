@@ -66,12 +66,14 @@ __global__ __launch_bounds__(kBlock) void k_ln_fwd(const float* __restrict__ x, 
 
 template <int T>
 __global__ __launch_bounds__(kBlock) void k_ln_bwd(const float* __restrict__ x, const float* __restrict__ w,
-                                                   const float* __restrict__ dy, float* __restrict__ dx,
-                                                   float* __restrict__ part, long long rows, float eps) {
+                                                   const float* __restrict__ dy, const float* __restrict__ add,
+                                                   float* __restrict__ dx, float* __restrict__ part, long long rows,
+                                                   float eps) {
   __shared__ float red[kBlock / kWave][2 * T];
   x += (size_t)blockIdx.y * rows * T;
   dy += (size_t)blockIdx.y * rows * T;
   dx += (size_t)blockIdx.y * rows * T;
+  if (add != nullptr) add += (size_t)blockIdx.y * rows * T;
   float wv[T], dw[T], db[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) { wv[t] = w ? w[blockIdx.y * T + t] : 1.f; dw[t] = 0.f; db[t] = 0.f; }
@@ -94,6 +96,12 @@ __global__ __launch_bounds__(kBlock) void k_ln_bwd(const float* __restrict__ x, 
     s2 *= (1.0f / T);
 #pragma unroll
     for (int t = 0; t < T; ++t) gv[t] = rstd * (gv[t] - s1 - xv[t] * s2);
+    if (add != nullptr) {  // the gradient that reached x along its other path (MEAM's residual convolution reads x too)
+      float av[T];
+      load_row<T>(add + r * T, av);
+#pragma unroll
+      for (int t = 0; t < T; ++t) gv[t] += av[t];
+    }
     store_row<T>(dx + r * T, gv);
   }
   // block partial of (dw, db): wave shuffle tree, then the 4 waves in a fixed order
@@ -133,15 +141,15 @@ int launch_layernorm_fwd(const float* x, const float* w, const float* b, float* 
   return MSGAT_OK;
 }
 
-int launch_layernorm_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
-                         float* part, long long rows, int T, float eps, int R, hipStream_t s) {
+int launch_layernorm_bwd(const float* x, const float* w, const float* dy, const float* add, float* dx, float* dw,
+                         float* db, float* part, long long rows, int T, float eps, int R, hipStream_t s) {
   rows /= R;  // per relation
   const int nb = ln_blocks(rows);
   switch (T) {
-    case 4: hipLaunchKernelGGL(k_ln_bwd<4>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, dx, part, rows, eps); break;
-    case 8: hipLaunchKernelGGL(k_ln_bwd<8>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, dx, part, rows, eps); break;
-    case 12: hipLaunchKernelGGL(k_ln_bwd<12>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, dx, part, rows, eps); break;
-    case 16: hipLaunchKernelGGL(k_ln_bwd<16>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, dx, part, rows, eps); break;
+    case 4: hipLaunchKernelGGL(k_ln_bwd<4>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps); break;
+    case 8: hipLaunchKernelGGL(k_ln_bwd<8>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps); break;
+    case 12: hipLaunchKernelGGL(k_ln_bwd<12>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps); break;
+    case 16: hipLaunchKernelGGL(k_ln_bwd<16>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps); break;
     default: return MSGAT_ERR_UNSUPPORTED;
   }
   MSGAT_CHECK_LAUNCH();

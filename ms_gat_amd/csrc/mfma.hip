@@ -274,7 +274,10 @@ constexpr int kRowF4 = kTile / 4 + 1;  // float4s per LDS row (piece + 16 B pad)
 
 template <int MA, int NB>
 __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
-    SegList A, const float* __restrict__ B, float* __restrict__ part, int Cb, int P, int Bg, int nzb) {
+    SegList A, const float* __restrict__ B, float* __restrict__ part, int Cb, int P, int Bg, int nzb, int b_ones) {
+  // b_ones: B's last channel (index Cb-1) is a virtual row of ones, so part[a, Cb-1] = sum_p A[a,p] -- the bias
+  // gradient of a 1x1 convolution comes out of the contraction that computes its weight gradient
+  const int Cbr = Cb - b_ones;  // channels B really has
   const int Ca = A.total();
   extern __shared__ float4 lds4[];
   constexpr int RPW = ((MA + NB) * 16 + kCpWaves * kRPI - 1) / (kCpWaves * kRPI);  // load instructions per wave per tile
@@ -288,6 +291,7 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
   const int ca = min(MA * 16, Ca - a0), cb = min(NB * 16, Cb - c0);
   const int rows = ca + cb;  // rows [0,ca) = A channels, [ca,rows) = B channels
   constexpr int kZeroRow = (MA + NB) * 16;  // an all-zero row for absent channels
+  constexpr int kOnesRow = kZeroRow + 1;    // an all-ones row for the virtual channel
   // this block's run of the relation's tile stream
   const int tpg = cdiv(P, kTile);  // tiles per group (the last one is partial)
   const long long ntot = (long long)Bg * tpg;
@@ -295,7 +299,10 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
   const int ntile = t1 - t0;
 
   MSGAT_STAMP(0);
-  if (threadIdx.x < kRowF4) lds4[kZeroRow * kRowF4 + threadIdx.x] = f4zero();
+  if (threadIdx.x < kRowF4) {
+    lds4[kZeroRow * kRowF4 + threadIdx.x] = f4zero();
+    lds4[kOnesRow * kRowF4 + threadIdx.x] = make_float4(1.f, 1.f, 1.f, 1.f);
+  }
 
   // staging plan: instruction k of this wave covers rows (wave + kCpWaves*k)*kRPI + (lane / kLPR); a
   // lane fetches float4 (lane % kLPR) of the tile.  Rows past the last one alias row 0 (always a
@@ -320,8 +327,8 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
       for (int i = 1; i < kMaxSeg; ++i) gs = (i == sk) ? A.gstride[i] : gs;
       gstride[k] = gs * P;
     } else {
-      p = B + (g0 * Cb + (c0 + row - ca)) * P;
-      gstride[k] = Cb * P;
+      p = B + (g0 * Cbr + min(c0 + row - ca, Cbr - 1)) * P;  // the virtual row aliases a real one; nobody reads its copy
+      gstride[k] = Cbr * P;
     }
     src[k] = p + 4 * lcol;
   }
@@ -359,7 +366,8 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
   }
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    const int row = (nb * 16 + j < cb) ? ca + nb * 16 + j : kZeroRow;
+    const int cl = nb * 16 + j;
+    const int row = (cl < cb) ? ((b_ones && c0 + cl == Cbr) ? kOnesRow : ca + cl) : kZeroRow;
     bw[nb] = row * (kRowF4 * 4) + 32 * wave + kq;
   }
 
@@ -443,28 +451,28 @@ int chanpair_mfma_blocks(int R) {
 
 template <int MA, int NB>
 static int launch_chanpair_t(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
-                             hipStream_t s) {
+                             int b_ones, hipStream_t s) {
   const int Ca = A.total();
   const int nza = cdiv(Ca, MA * 16), nzb = cdiv(Cb, NB * 16);
-  // tile rows + the zero row, reused for the 8 x MA*NB*256-float reduction
-  const size_t lds = sizeof(float4) * (size_t)max(((MA + NB) * 16 + 1) * kRowF4, kCpWaves * MA * NB * 64);
+  // tile rows + the zero row + the ones row, reused for the 8 x MA*NB*256-float reduction
+  const size_t lds = sizeof(float4) * (size_t)max(((MA + NB) * 16 + 2) * kRowF4, kCpWaves * MA * NB * 64);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chanpair_mfma<MA, NB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
   }
   dim3 grid(nblk, R, nza * nzb);
-  hipLaunchKernelGGL((k_chanpair_mfma<MA, NB>), grid, dim3(kCpBlock), lds, s, A, B, part, Cb, P, Bg, nzb);
+  hipLaunchKernelGGL((k_chanpair_mfma<MA, NB>), grid, dim3(kCpBlock), lds, s, A, B, part, Cb, P, Bg, nzb, b_ones);
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
 
 int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
-                         hipStream_t s) {
+                         int b_ones, hipStream_t s) {
   const int Ca = A.total();
   const int MA = min(cdiv(Ca, 16), 3), NB = min(cdiv(Cb, 16), 6);
 #define MSGAT_CP(ma, nb) \
-  if (MA == ma && NB == nb) return launch_chanpair_t<ma, nb>(A, B, part, R, Bg, Cb, P, nblk, s);
+  if (MA == ma && NB == nb) return launch_chanpair_t<ma, nb>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
   MSGAT_CP(1, 1) MSGAT_CP(1, 2) MSGAT_CP(1, 3) MSGAT_CP(1, 4) MSGAT_CP(1, 5) MSGAT_CP(1, 6)
   MSGAT_CP(2, 1) MSGAT_CP(2, 2) MSGAT_CP(2, 3) MSGAT_CP(2, 4) MSGAT_CP(2, 5) MSGAT_CP(2, 6)
   MSGAT_CP(3, 1) MSGAT_CP(3, 2) MSGAT_CP(3, 3) MSGAT_CP(3, 4) MSGAT_CP(3, 5) MSGAT_CP(3, 6)

@@ -196,7 +196,9 @@ class MEAM(nn.Module):
         self.gacn = GACN(in_channels, branch, n_timesteps=n_timesteps)
 
     def forward(self, signals: torch.Tensor, adjacency) -> torch.Tensor:
-        normed = self.ln(signals)
+        # (normed, signals): the residual convolution below reads the block input again (msgat.py:130); routed
+        # through the LayerNorm op, its gradient is added inside the LayerNorm-backward kernel
+        normed, signals = ops.layer_norm_t_tee(signals, self.ln.weight, self.ln.bias, self.ln.eps)
         res_w = self.res.weight[:, :, 0, 0].unsqueeze(0)
         if self.in_channels <= self.out_channels // 3 or not self.dilations:
             # few input channels (the first block of a component): the graph branch aggregates before it

@@ -182,10 +182,69 @@ class _LayerNormTFunction(torch.autograd.Function):
         db = torch.empty(w.shape if ctx.has_w else (T,), device=x.device, dtype=torch.float32) if ctx.has_b else None
         part = torch.empty(max(int(L.msgat_layernorm_partial_floats(rows, T, R)), 1), device=x.device,
                            dtype=torch.float32)
-        st = L.msgat_layernorm_backward(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db), _ptr(part),
+        st = L.msgat_layernorm_backward(_ptr(x), _ptr(w), _ptr(dy), None, _ptr(dx), _ptr(dw), _ptr(db), _ptr(part),
                                         rows, T, ctx.eps, R, _stream_handle(x.device))
         _lib.check(st, "msgat_layernorm_backward")
         return dx, dw, db, None
+
+
+class _LayerNormTeeFunction(torch.autograd.Function):
+    """x -> (LayerNorm(x), x): the second output is x itself, for the consumer that reads the un-normalised input
+    beside the LayerNorm (MEAM's residual convolution, msgat.py:122 and :130).  Routing that use through here lets the
+    backward add its gradient inside the LayerNorm-backward kernel instead of in a separate accumulation pass."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps: float):
+        L = _lib.lib()
+        x = x.contiguous()
+        T = x.shape[-1]
+        rows = x.numel() // T
+        y = torch.empty_like(x)
+        w = None if weight is None else weight.contiguous()
+        b = None if bias is None else bias.contiguous()
+        R = 1 if w is None else w.numel() // T
+        st = L.msgat_layernorm_forward(_ptr(x), _ptr(w), _ptr(b), _ptr(y), rows, T, eps, R, _stream_handle(x.device))
+        _lib.check(st, "msgat_layernorm_forward")
+        ctx.eps, ctx.has_w, ctx.has_b, ctx.R = eps, weight is not None, bias is not None, R
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(*([x] + ([w] if w is not None else [])))
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dx_other):
+        L = _lib.lib()
+        saved = ctx.saved_tensors
+        x, w = saved[0], (saved[1] if ctx.has_w else None)
+        T = x.shape[-1]
+        rows = x.numel() // T
+        if dy is None:
+            return dx_other, None, None, None
+        dy = dy.contiguous()
+        other = None if dx_other is None else dx_other.contiguous()
+        dx = torch.empty_like(x)
+        R = ctx.R
+        dw = torch.empty_like(w) if ctx.has_w else None
+        db = torch.empty(w.shape if ctx.has_w else (T,), device=x.device, dtype=torch.float32) if ctx.has_b else None
+        part = torch.empty(max(int(L.msgat_layernorm_partial_floats(rows, T, R)), 1), device=x.device, dtype=torch.float32)
+        st = L.msgat_layernorm_backward(_ptr(x), _ptr(w), _ptr(dy), _ptr(other), _ptr(dx), _ptr(dw), _ptr(db), _ptr(part),
+                                        rows, T, ctx.eps, R, _stream_handle(x.device))
+        _lib.check(st, "msgat_layernorm_backward")
+        return dx, dw, db, None
+
+
+def layer_norm_t_tee(x: torch.Tensor, weight: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+                     eps: float = 1e-5):
+    """(layer_norm_t(x), x): use the second value wherever the block reads its un-normalised input again."""
+    _require_device_tensor("signals", x)
+    if x.numel() == 0 or not x.requires_grad:
+        return layer_norm_t(x, weight, bias, eps), x
+    T = x.shape[-1]
+    for name, t in (("weight", weight), ("bias", bias)):
+        if t is not None:
+            _require_device_tensor(name, t, x.device)
+            if t.shape[-1] != T or t.dim() > 2 or (t.dim() == 2 and x.shape[0] % t.shape[0]):
+                raise ValueError(f"{name} must be [{T}] or [R,{T}] with R dividing the leading axis, got {tuple(t.shape)}")
+    return _LayerNormTeeFunction.apply(x, weight, bias, float(eps))
 
 
 def layer_norm_t(x: torch.Tensor, weight: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
@@ -577,18 +636,24 @@ class _MixMultiFunction(torch.autograd.Function):
             _, ai, _ = _seg_array(d_ins)
             st = L.msgat_mix_segments(R, G // R, N, T, ad, nd, _ptr(M), 1, None, 0, None, 0, 0, ai, n_in, stream)
             _lib.check(st, "msgat_mix_segments (backward)")
+        want_bias = bool(has_bias and need[1])   # has_bias: 0 none, -1 shared [Co], R per matrix [R,Co]
         if need[0]:
             Co = sum(out_channels)
             parts = []
-            for x, c in zip(ins, in_channels):
+            for i, (x, c) in enumerate(zip(ins, in_channels)):
                 x = x.contiguous()
-                dMi = _new(like, R, Co, c)
-                part = _new(like, max(int(L.msgat_contract_segments_partial_floats(R, Co, c)), 1))
-                st = L.msgat_contract_segments(R, G // R, N, T, ad, nd, _ptr(x), c, _ptr(part), _ptr(dMi), stream)
+                ones = int(want_bias and i == 0)   # the bias gradient = contraction with a virtual channel of ones
+                dMi = _new(like, R, Co, c + ones)
+                part = _new(like, max(int(L.msgat_contract_segments_partial_floats(R, Co, c + ones)), 1))
+                st = L.msgat_contract_segments(R, G // R, N, T, ad, nd, _ptr(x), c, ones, _ptr(part), _ptr(dMi), stream)
                 _lib.check(st, "msgat_contract_segments")
+                if ones:
+                    colsum = dMi[:, :, c]                                  # [R,Co]: sum over the relation's groups and positions
+                    dbias = colsum if has_bias > 0 else colsum.sum(dim=0)
+                    dMi = dMi[:, :, :c]
                 parts.append(dMi)
             dM = parts[0] if len(parts) == 1 else torch.cat(parts, dim=2)
-        if has_bias and need[1]:   # has_bias: 0 none, -1 shared [Co], R per matrix [R,Co]
+        elif want_bias:
             dbias = torch.cat([_channel_sums(k.contiguous(), max(has_bias, 0)) for k in kd], dim=-1)
         d_adds = []
         if add_channels:   # channel ranges of cat(dpre), as views (the library reads channel slices in place)

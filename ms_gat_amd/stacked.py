@@ -134,7 +134,8 @@ def _tacn_finish(P, prefix: str, dilations, mixed: torch.Tensor, att: torch.Tens
 
 def _meam(P, prefix: str, m0, x: torch.Tensor, adjacency, R: int, B: int) -> torch.Tensor:
     C, cb = m0.in_channels, m0.out_channels // 3
-    normed = ops.layer_norm_t(x, P(prefix + "ln.weight"), P(prefix + "ln.bias"), m0.ln.eps)
+    # (normed, x): the residual tail below reads x again; its gradient joins the LayerNorm's in one kernel
+    normed, x = ops.layer_norm_t_tee(x, P(prefix + "ln.weight"), P(prefix + "ln.bias"), m0.ln.eps)
 
     att_c = _channel_attention(P, prefix, ops.node_pool(normed, P(prefix + "cacn.seq.0.alpha")), R, B)
     conv_w = P(prefix + "cacn.seq.1.weight")[:, :, :, 0, 0]                            # [R,cb,C]
