@@ -347,6 +347,34 @@ size_t msgat_head_grad_weight_partial_floats(int32_t C, int32_t T, int32_t T_out
 int msgat_head_grad_weight(const float* dout, const float* x, float* dWc, float* partials, int32_t B, int32_t C,
                            int32_t N, int32_t T, int32_t T_out, int32_t R, void* stream);
 
+/* ---- device: the tiny attention matrices of a MEAM block, one launch each way ----
+ * In the reference each is a chain of batched [T x T] / [C x C] matmuls, a softmax, transposes, pads and stacks
+ * (~20 eager launches forward, ~30 backward per block).  One workgroup per (relation, sample) group here;
+ * parameter gradients are summed over a relation's groups in a fixed order through `partials`.
+ *   channel attention (attention.py:88-94) folded with CACN's 1x1 convolution (msgat.py:93-94):
+ *       att[g] = softmax_rows((p_g Wc_r) p_g^T) [C,C],  Mc[g] = conv_r att[g] [cb,C];   p = pooled [G,C,T]
+ *       (the node-weighted sums of msgat_node_pool), Wc [R,T,T], conv [R,cb,C].  Mc is the per-sample channel
+ *       matrix msgat_mix_segments applies.  Backward: dpooled [G,C,T], dWc [R,T,T], dconv [R,cb,C] from dMc.
+ *   temporal attention (attention.py:58-66) as the taps of TACN's first causal convolution (msgat.py:66-74):
+ *       left = q_g^T Wt1_r^T, right = q_g^T Wt2_r^T [T,K] (saved in lr [G,2,T,K]),  att[g] = softmax_rows(left right^T),
+ *       taps[g,1] = att[g],  taps[g,0] = att[g] shifted down by `dilation` rows (rows < dilation zero);
+ *       q = pooled [G,N,T] (the alpha-weighted channel sums), Wt1 / Wt2 [R,K,N], 2 T K <= 256.  taps [G,2,T,T] is what
+ *       msgat_time_mix applies (K = 2).  Backward: dpooled [G,N,T], dWt1 / dWt2 [R,K,N] from dtaps. */
+int msgat_channel_attention_forward(const float* pooled, const float* Wc, const float* conv, float* att, float* Mc,
+                                    int32_t G, int32_t R, int32_t C, int32_t cb, int32_t T, void* stream);
+size_t msgat_channel_attention_partial_floats(int32_t G, int32_t C, int32_t cb, int32_t T);
+int msgat_channel_attention_backward(const float* dMc, const float* att, const float* pooled, const float* Wc,
+                                     const float* conv, float* dpooled, float* dWc, float* dconv, float* partials,
+                                     int32_t G, int32_t R, int32_t C, int32_t cb, int32_t T, void* stream);
+int msgat_temporal_attention_forward(const float* pooled, const float* Wt1, const float* Wt2, float* lr, float* att,
+                                     float* taps, int32_t G, int32_t R, int32_t N, int32_t K, int32_t T,
+                                     int32_t dilation, void* stream);
+size_t msgat_temporal_attention_partial_floats(int32_t G, int32_t K, int32_t N);
+int msgat_temporal_attention_backward(const float* dtaps, const float* att, const float* lr, const float* pooled,
+                                      const float* Wt1, const float* Wt2, float* dpooled, float* dWt1, float* dWt2,
+                                      float* partials, int32_t G, int32_t R, int32_t N, int32_t K, int32_t T,
+                                      int32_t dilation, void* stream);
+
 /* ---- device: the tail of a training step ----
  * msgat_huber_metrics: one pass over the prediction replaces engine.py:56 (HuberLoss, loss.py:51-52) and the
  *     metric sums of engine.py:70 / metrics.py:20-35, with nothing read back to the host:

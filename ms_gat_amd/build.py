@@ -21,7 +21,7 @@ INCLUDE = os.path.join(ROOT, "include")
 OBJDIR = os.path.join(ROOT, "build", "obj")
 LIB = os.path.join(PKG, "libmsgat_hip.so")
 
-SOURCES = ["api.hip", "project.hip", "mfma.hip", "dense.hip", "scores.hip", "aggregate.hip", "reduce.hip", "layernorm.hip", "branches.hip", "tail.hip", "graph_host.cpp"]
+SOURCES = ["api.hip", "project.hip", "mfma.hip", "dense.hip", "scores.hip", "aggregate.hip", "reduce.hip", "layernorm.hip", "branches.hip", "smallatt.hip", "tail.hip", "graph_host.cpp"]
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(INCLUDE, "msgat_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize",

@@ -617,3 +617,64 @@ extern "C" int msgat_adam_step(float* const* chunk_param, const int64_t* chunk_o
   return launch_adam(chunk_param, (const long long*)chunk_off, chunk_len, chunk_tensor, n_chunks, active_tensors, n_active,
                      grad, exp_avg, exp_avg_sq, steps, lr, beta1, beta2, eps, weight_decay, (hipStream_t)stream);
 }
+
+// ---- the tiny attention matrices of a MEAM block ----------------------------------------------------------------
+static int check_small(int32_t G, int32_t R, int32_t T) {
+  if (G <= 0 || R <= 0 || G % R) return MSGAT_ERR_SHAPE;
+  if (!t_supported(T)) return MSGAT_ERR_UNSUPPORTED;
+  return MSGAT_OK;
+}
+
+extern "C" int msgat_channel_attention_forward(const float* pooled, const float* Wc, const float* conv, float* att,
+                                               float* Mc, int32_t G, int32_t R, int32_t C, int32_t cb, int32_t T,
+                                               void* stream) {
+  if (!pooled || !Wc || !conv || !att || !Mc) return MSGAT_ERR_NULL;
+  int st = check_small(G, R, T);
+  if (st) return st;
+  if (C <= 0 || C > kMaxC || cb <= 0 || cb > kMaxC) return MSGAT_ERR_SHAPE;
+  return launch_chanatt_fwd(pooled, Wc, conv, att, Mc, G, R, C, cb, T, (hipStream_t)stream);
+}
+
+extern "C" size_t msgat_channel_attention_partial_floats(int32_t G, int32_t C, int32_t cb, int32_t T) {
+  if (G <= 0 || C <= 0 || cb <= 0 || !t_supported(T)) return 0;
+  return chanatt_partial_floats(G, C, cb, T);
+}
+
+extern "C" int msgat_channel_attention_backward(const float* dMc, const float* att, const float* pooled,
+                                                const float* Wc, const float* conv, float* dpooled, float* dWc,
+                                                float* dconv, float* partials, int32_t G, int32_t R, int32_t C,
+                                                int32_t cb, int32_t T, void* stream) {
+  if (!dMc || !att || !pooled || !Wc || !conv || !dpooled || !dWc || !dconv || !partials) return MSGAT_ERR_NULL;
+  int st = check_small(G, R, T);
+  if (st) return st;
+  if (C <= 0 || C > kMaxC || cb <= 0 || cb > kMaxC) return MSGAT_ERR_SHAPE;
+  return launch_chanatt_bwd(dMc, att, pooled, Wc, conv, dpooled, dWc, dconv, partials, G, R, C, cb, T, (hipStream_t)stream);
+}
+
+extern "C" int msgat_temporal_attention_forward(const float* pooled, const float* Wt1, const float* Wt2, float* lr,
+                                                float* att, float* taps, int32_t G, int32_t R, int32_t N, int32_t K,
+                                                int32_t T, int32_t dilation, void* stream) {
+  if (!pooled || !Wt1 || !Wt2 || !lr || !att || !taps) return MSGAT_ERR_NULL;
+  int st = check_small(G, R, T);
+  if (st) return st;
+  if (N <= 0 || K <= 0 || dilation < 0) return MSGAT_ERR_SHAPE;
+  return launch_tempatt_fwd(pooled, Wt1, Wt2, lr, att, taps, G, R, N, K, T, dilation, (hipStream_t)stream);
+}
+
+extern "C" size_t msgat_temporal_attention_partial_floats(int32_t G, int32_t K, int32_t N) {
+  if (G <= 0 || K <= 0 || N <= 0) return 0;
+  return tempatt_partial_floats(G, K, N);
+}
+
+extern "C" int msgat_temporal_attention_backward(const float* dtaps, const float* att, const float* lr,
+                                                 const float* pooled, const float* Wt1, const float* Wt2,
+                                                 float* dpooled, float* dWt1, float* dWt2, float* partials, int32_t G,
+                                                 int32_t R, int32_t N, int32_t K, int32_t T, int32_t dilation,
+                                                 void* stream) {
+  if (!dtaps || !att || !lr || !pooled || !Wt1 || !Wt2 || !dpooled || !dWt1 || !dWt2 || !partials) return MSGAT_ERR_NULL;
+  int st = check_small(G, R, T);
+  if (st) return st;
+  if (N <= 0 || K <= 0 || dilation < 0) return MSGAT_ERR_SHAPE;
+  return launch_tempatt_bwd(dtaps, att, lr, pooled, Wt1, Wt2, dpooled, dWt1, dWt2, partials, G, R, N, K, T, dilation,
+                            (hipStream_t)stream);
+}

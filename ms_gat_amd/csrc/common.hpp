@@ -260,6 +260,19 @@ int launch_layernorm_fwd(const float* x, const float* w, const float* b, float* 
 int launch_layernorm_bwd(const float* x, const float* w, const float* dy, const float* add, float* dx, float* dw,
                          float* db, float* part, long long rows, int T, float eps, int R, hipStream_t s);
 
+// the tiny attention matrices of a MEAM block (smallatt.hip)
+size_t chanatt_partial_floats(int G, int C, int cb, int T);
+int launch_chanatt_fwd(const float* pooled, const float* Wc, const float* conv, float* att, float* Mc, int G, int R,
+                       int C, int cb, int T, hipStream_t s);
+int launch_chanatt_bwd(const float* dMc, const float* att, const float* pooled, const float* Wc, const float* conv,
+                       float* dpooled, float* dWc, float* dconv, float* part, int G, int R, int C, int cb, int T,
+                       hipStream_t s);
+size_t tempatt_partial_floats(int G, int K, int N);
+int launch_tempatt_fwd(const float* pooled, const float* Wt1, const float* Wt2, float* lr, float* att, float* taps,
+                       int G, int R, int N, int K, int T, int dil, hipStream_t s);
+int launch_tempatt_bwd(const float* dtaps, const float* att, const float* lr, const float* pooled, const float* Wt1,
+                       const float* Wt2, float* dpooled, float* dWt1, float* dWt2, float* part, int G, int R, int N,
+                       int K, int T, int dil, hipStream_t s);
 // step tail (tail.hip)
 size_t huber_partial_doubles(long long n);
 int launch_huber_metrics(const float* pred, const float* truth, long long n, float delta, float mask_value,

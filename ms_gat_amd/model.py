@@ -142,20 +142,28 @@ class TACN(nn.Module):
         if not self.dilations:
             return self.seq[0](signals)
         mixed = ops.mix(signals, self.stacked_taps(0).unsqueeze(0))
-        return self.finish(mixed, self.seq[0].attention(signals))
+        return self.finish(mixed, ops.channel_pool(signals, self.seq[0].alpha))
 
-    def finish(self, mixed: torch.Tensor, att: torch.Tensor) -> torch.Tensor:
+    def first_taps(self, pooled: torch.Tensor) -> torch.Tensor:
+        """[B,2,T,T] taps of the first convolution -- (temporal attention shifted down by its dilation, temporal
+        attention) -- from the alpha-weighted channel sums `pooled` [B,N,T]: one launch in the library."""
+        ta = self.seq[0]
+        if 2 * pooled.shape[-1] * ta.rank > 256:          # beyond the fused kernel's lane budget (T = 16): eager ops
+            att = ta.attention(None, pooled=pooled)
+            return torch.stack([_shift_down(att, self.dilations[0]), att], dim=1)
+        return ops.temporal_attention_taps(pooled, ta.Wt1, ta.Wt2, self.dilations[0])
+
+    def finish(self, mixed: torch.Tensor, pooled: torch.Tensor) -> torch.Tensor:
         """The stack from the channel-mixed input of its first convolution (`mixed` = stacked_taps(0) applied to
-        the signals, [B,2Co,N,T]) and the temporal attention matrix `att` [B,T,T]."""
-        T = att.size(-1)
+        the signals, [B,2Co,N,T]) and the pooled signals of the temporal attention (`pooled` [B,N,T])."""
+        T = mixed.size(-1)
         h = None
         for i, d in enumerate(self.dilations):
             conv = self.seq[1 + 2 * i]
             if i == 0:
-                taps = torch.stack([_shift_down(att, d), att], dim=1)                         # [B,2,T,T]
+                taps = self.first_taps(pooled)                                                # [B,2,T,T]
             else:
-                eye = torch.eye(T, device=att.device, dtype=att.dtype)
-                taps = torch.stack([_shift_down(eye, d), eye], dim=0).unsqueeze(0)            # [1,2,T,T]
+                taps = ops.causal_shift_taps(T, d, mixed.device)                              # [1,2,T,T], cached constant
                 mixed = ops.mix(h, self.stacked_taps(i).unsqueeze(0))
             h = ops.time_mix(mixed, taps, conv.bias)
         return h
@@ -171,9 +179,13 @@ class CACN(nn.Module):
             in_channels, out_channels, n_nodes, n_timesteps)
         self.seq = nn.Sequential(ChannelAttention(n_nodes, n_timesteps), nn.Conv2d(in_channels, out_channels, 1))
 
+    def channel_matrix(self, signals: torch.Tensor) -> torch.Tensor:
+        """[B,Co,C] = conv.weight @ channel attention: node pooling in one pass, the rest in one launch."""
+        ca, conv = self.seq[0], self.seq[1]
+        return ops.channel_attention_mix(ops.node_pool(signals, ca.alpha), ca.Wc, conv.weight[:, :, 0, 0])
+
     def forward(self, signals: torch.Tensor) -> torch.Tensor:
-        conv = self.seq[1]
-        return ops.mix(signals, conv.weight[:, :, 0, 0] @ self.seq[0].attention(signals), conv.bias)
+        return ops.mix(signals, self.channel_matrix(signals), self.seq[1].bias)
 
 
 class MEAM(nn.Module):
@@ -221,14 +233,14 @@ class MEAM(nn.Module):
         ca, ta, gatt = self.cacn.seq[0], self.tacn.seq[0], self.gacn.gatt
         conv_c = self.cacn.seq[1]
         rows = torch.cat([
-            conv_c.weight[:, :, 0, 0] @ ca.attention(normed),                    # [B,cb,C]   needs the node pooling first
+            self.cacn.channel_matrix(normed),                                    # [B,cb,C]   needs the node pooling first
             self.tacn.stacked_taps(0).unsqueeze(0).expand(B, -1, -1),            # [B,2cb,C]
             self.gacn.W.unsqueeze(0).expand(B, -1, -1),                          # [B,cb,C]
             gatt.alpha.view(1, 1, C).expand(B, -1, -1),                          # [B,1,C]    q of the graph attention
             ta.alpha.view(1, 1, C).expand(B, -1, -1)], dim=1)                    # [B,1,C]    pooled signal of the temporal attention
         bias = torch.cat([conv_c.bias, conv_c.bias.new_zeros(3 * cb + 2)])
         cacn, mixed, u, q, pooled_t = ops.mix_multi([normed], rows, bias, out_channels=[cb, 2 * cb, cb, 1, 1])
-        tacn = self.tacn.finish(mixed, ta.attention(normed, pooled=pooled_t[:, 0]))
+        tacn = self.tacn.finish(mixed, pooled_t[:, 0])
         gacn = ops.attention_core(u, q[:, 0], gatt.Wg.unsqueeze(0), adjacency)
         return [cacn, tacn, gacn]
 

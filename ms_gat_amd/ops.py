@@ -751,6 +751,120 @@ def attention_core(u: torch.Tensor, q: torch.Tensor, Wg: torch.Tensor, adjacency
     return _AttentionCoreFunction.apply(u, q, Wg, graph)
 
 
+# ---- the tiny attention matrices of a MEAM block, one launch each way ----------------------------------------------
+
+class _ChannelAttentionMixFunction(torch.autograd.Function):
+    """pooled[G,C,T], Wc[R,T,T], conv[R,cb,C] -> Mc[G,cb,C] = conv_r softmax((p Wc_r) p^T): attention.py:88-94 folded
+    with CACN's 1x1 convolution weight (msgat.py:93-94)."""
+
+    @staticmethod
+    def forward(ctx, pooled, Wc, conv):
+        L = _lib.lib()
+        pooled, Wc, conv = pooled.contiguous(), Wc.contiguous(), conv.contiguous()
+        G, Cc, T = pooled.shape
+        R, cb = Wc.shape[0], conv.shape[1]
+        att, Mc = _new(pooled, G, Cc, Cc), _new(pooled, G, cb, Cc)
+        st = L.msgat_channel_attention_forward(_ptr(pooled), _ptr(Wc), _ptr(conv), _ptr(att), _ptr(Mc), G, R, Cc, cb, T,
+                                               _stream_handle(pooled.device))
+        _lib.check(st, "msgat_channel_attention_forward")
+        ctx.save_for_backward(pooled, Wc, conv, att)
+        return Mc
+
+    @staticmethod
+    def backward(ctx, dMc):
+        L = _lib.lib()
+        pooled, Wc, conv, att = ctx.saved_tensors
+        G, Cc, T = pooled.shape
+        R, cb = Wc.shape[0], conv.shape[1]
+        dMc = dMc.contiguous()
+        dp, dWc, dconv = torch.empty_like(pooled), torch.empty_like(Wc), torch.empty_like(conv)
+        part = _new(pooled, max(int(L.msgat_channel_attention_partial_floats(G, Cc, cb, T)), 1))
+        st = L.msgat_channel_attention_backward(_ptr(dMc), _ptr(att), _ptr(pooled), _ptr(Wc), _ptr(conv), _ptr(dp),
+                                                _ptr(dWc), _ptr(dconv), _ptr(part), G, R, Cc, cb, T,
+                                                _stream_handle(pooled.device))
+        _lib.check(st, "msgat_channel_attention_backward")
+        return dp, dWc, dconv
+
+
+def channel_attention_mix(pooled: torch.Tensor, Wc: torch.Tensor, conv: torch.Tensor) -> torch.Tensor:
+    """The per-sample channel matrix of CACN: conv @ softmax(pooled Wc pooled^T)  ([G,cb,C]).  pooled [G,C,T] (node-weighted
+    sums, `node_pool`), Wc [T,T] or [R,T,T], conv [cb,C] or [R,cb,C] with R dividing G."""
+    _require_device_tensor("pooled signals", pooled)
+    _require_device_tensor("Wc", Wc, pooled.device)
+    _require_device_tensor("conv weight", conv, pooled.device)
+    if Wc.dim() == 2:
+        Wc, conv = Wc.unsqueeze(0), conv.unsqueeze(0)
+    G, Cc, T = pooled.shape
+    if tuple(Wc.shape[1:]) != (T, T) or conv.dim() != 3 or conv.shape[0] != Wc.shape[0] or conv.shape[2] != Cc or G % Wc.shape[0]:
+        raise ValueError(f"channel_attention_mix: pooled {tuple(pooled.shape)}, Wc {tuple(Wc.shape)}, conv {tuple(conv.shape)}")
+    return _ChannelAttentionMixFunction.apply(pooled, Wc, conv)
+
+
+class _TemporalAttentionTapsFunction(torch.autograd.Function):
+    """pooled[G,N,T], Wt1/Wt2[R,K,N] -> taps[G,2,T,T]: (att shifted down by the dilation, att) with
+    att = softmax((q^T Wt1^T)(q^T Wt2^T)^T), attention.py:58-66 as the taps of TACN's first convolution (msgat.py:66-74)."""
+
+    @staticmethod
+    def forward(ctx, pooled, Wt1, Wt2, dilation: int):
+        L = _lib.lib()
+        pooled, Wt1, Wt2 = pooled.contiguous(), Wt1.contiguous(), Wt2.contiguous()
+        G, N, T = pooled.shape
+        R, K = Wt1.shape[0], Wt1.shape[1]
+        lr, att, taps = _new(pooled, G, 2, T, K), _new(pooled, G, T, T), _new(pooled, G, 2, T, T)
+        st = L.msgat_temporal_attention_forward(_ptr(pooled), _ptr(Wt1), _ptr(Wt2), _ptr(lr), _ptr(att), _ptr(taps), G, R, N,
+                                                K, T, int(dilation), _stream_handle(pooled.device))
+        _lib.check(st, "msgat_temporal_attention_forward")
+        ctx.dilation = int(dilation)
+        ctx.save_for_backward(pooled, Wt1, Wt2, lr, att)
+        return taps
+
+    @staticmethod
+    def backward(ctx, dtaps):
+        L = _lib.lib()
+        pooled, Wt1, Wt2, lr, att = ctx.saved_tensors
+        G, N, T = pooled.shape
+        R, K = Wt1.shape[0], Wt1.shape[1]
+        dtaps = dtaps.contiguous()
+        dp, dW1, dW2 = torch.empty_like(pooled), torch.empty_like(Wt1), torch.empty_like(Wt2)
+        part = _new(pooled, max(int(L.msgat_temporal_attention_partial_floats(G, K, N)), 1))
+        st = L.msgat_temporal_attention_backward(_ptr(dtaps), _ptr(att), _ptr(lr), _ptr(pooled), _ptr(Wt1), _ptr(Wt2), _ptr(dp),
+                                                 _ptr(dW1), _ptr(dW2), _ptr(part), G, R, N, K, T, ctx.dilation,
+                                                 _stream_handle(pooled.device))
+        _lib.check(st, "msgat_temporal_attention_backward")
+        return dp, dW1, dW2, None
+
+
+def temporal_attention_taps(pooled: torch.Tensor, Wt1: torch.Tensor, Wt2: torch.Tensor, dilation: int) -> torch.Tensor:
+    """[G,2,T,T] taps of TACN's first causal convolution: (temporal attention shifted down by `dilation`, temporal
+    attention).  pooled [G,N,T] (alpha-weighted channel sums, `channel_pool`), Wt1 / Wt2 [K,N] or [R,K,N]."""
+    _require_device_tensor("pooled signals", pooled)
+    _require_device_tensor("Wt1", Wt1, pooled.device)
+    _require_device_tensor("Wt2", Wt2, pooled.device)
+    if Wt1.dim() == 2:
+        Wt1, Wt2 = Wt1.unsqueeze(0), Wt2.unsqueeze(0)
+    G, N, T = pooled.shape
+    if Wt1.shape != Wt2.shape or Wt1.dim() != 3 or Wt1.shape[2] != N or G % Wt1.shape[0] or 2 * T * Wt1.shape[1] > 256:
+        raise ValueError(f"temporal_attention_taps: pooled {tuple(pooled.shape)}, Wt1 {tuple(Wt1.shape)}, Wt2 {tuple(Wt2.shape)}")
+    return _TemporalAttentionTapsFunction.apply(pooled, Wt1, Wt2, int(dilation))
+
+
+_shift_taps_cache = {}
+
+
+def causal_shift_taps(T: int, dilation: int, device) -> torch.Tensor:
+    """[1,2,T,T] constant taps of a plain causal dilated [1,2] convolution (identity shifted down by `dilation`, identity):
+    built once per (T, dilation, device)."""
+    key = (T, int(dilation), str(device))
+    taps = _shift_taps_cache.get(key)
+    if taps is None:
+        eye = torch.eye(T, device=device, dtype=torch.float32)
+        shifted = torch.zeros_like(eye)
+        if dilation < T:
+            shifted[dilation:] = eye[: T - dilation]
+        taps = _shift_taps_cache[key] = torch.stack([shifted, eye], dim=0).unsqueeze(0).contiguous()
+    return taps
+
+
 # ---- step tail: fused Huber loss + metric sums (SURVEY section 8 row f-4) ---------------------------------------
 
 class _HuberMetricsFunction(torch.autograd.Function):

@@ -80,13 +80,6 @@ def _per_group(p: torch.Tensor, B: int) -> torch.Tensor:
     return p.unsqueeze(1).expand(p.shape[0], B, *p.shape[1:]).reshape(p.shape[0] * B, *p.shape[1:])
 
 
-def _shift_down(att: torch.Tensor, d: int) -> torch.Tensor:
-    T = att.size(-2)
-    if d >= T:
-        return torch.zeros_like(att)
-    return torch.nn.functional.pad(att[..., : T - d, :], (0, 0, d, 0))
-
-
 def can_stack(model) -> bool:
     """Stacking needs R components of identical architecture (the reference builds them that way, msgat.py:220-229)."""
     first = model.tpcs[0]
@@ -101,32 +94,22 @@ def _taps(P, prefix: str, layer: int) -> torch.Tensor:
     return w[:, :, :, 0, :].permute(0, 3, 1, 2).reshape(R, 2 * Co, Ci)
 
 
-def _channel_attention(P, prefix: str, pooled: torch.Tensor, R: int, B: int) -> torch.Tensor:
-    """pooled [G,C,T] -> att [R,B,C,C]  (attention.py:90-92)."""
-    p = pooled.view(R, B, *pooled.shape[1:])
-    return torch.softmax(p @ P(prefix + "cacn.seq.0.Wc").unsqueeze(1) @ p.transpose(2, 3), dim=-1)
+def _first_taps(P, prefix: str, pooled: torch.Tensor, T: int, dilation: int) -> torch.Tensor:
+    """[G,2,T,T] taps of TACN's first convolution from the alpha-weighted channel sums [G,N,T] (attention.py:60-64,
+    msgat.py:66-74): one launch (`ops.temporal_attention_taps`)."""
+    return ops.temporal_attention_taps(pooled, P(prefix + "tacn.seq.0.Wt1"), P(prefix + "tacn.seq.0.Wt2"), dilation)
 
 
-def _temporal_attention(P, prefix: str, pooled: torch.Tensor, R: int, B: int) -> torch.Tensor:
-    """pooled [G,N,T] (alpha-weighted channel sum) -> att [G,T,T]  (attention.py:60-64)."""
-    per_t = pooled.view(R, B, *pooled.shape[1:]).transpose(2, 3)                      # [R,B,T,N]
-    left = per_t @ P(prefix + "tacn.seq.0.Wt1").transpose(1, 2).unsqueeze(1)          # [R,B,T,10]
-    right = per_t @ P(prefix + "tacn.seq.0.Wt2").transpose(1, 2).unsqueeze(1)
-    att = torch.softmax(left @ right.transpose(2, 3), dim=-1)
-    return att.reshape(R * B, att.shape[-2], att.shape[-1])
-
-
-def _tacn_finish(P, prefix: str, dilations, mixed: torch.Tensor, att: torch.Tensor) -> torch.Tensor:
+def _tacn_finish(P, prefix: str, dilations, mixed: torch.Tensor, taps0: torch.Tensor) -> torch.Tensor:
     """TACN from the channel-mixed input of its first convolution (see model.TACN.finish), R stacks at once."""
-    T = att.size(-1)
+    T = taps0.size(-1)
     h = None
     for i, d in enumerate(dilations):
         bias = P(f"{prefix}tacn.seq.{1 + 2 * i}.bias")                                 # [R,Co]
         if i == 0:
-            taps = torch.stack([_shift_down(att, d), att], dim=1)                      # [G,2,T,T]
+            taps = taps0                                                               # [G,2,T,T]
         else:
-            eye = torch.eye(T, device=att.device, dtype=att.dtype)
-            taps = torch.stack([_shift_down(eye, d), eye], dim=0).unsqueeze(0)         # [1,2,T,T]
+            taps = ops.causal_shift_taps(T, d, mixed.device)                           # [1,2,T,T], cached constant
             (mixed,) = ops.mix_multi([h], _taps(P, prefix, i))
         h = ops.time_mix(mixed, taps, bias)
     return h
@@ -134,24 +117,26 @@ def _tacn_finish(P, prefix: str, dilations, mixed: torch.Tensor, att: torch.Tens
 
 def _meam(P, prefix: str, m0, x: torch.Tensor, adjacency, R: int, B: int) -> torch.Tensor:
     C, cb = m0.in_channels, m0.out_channels // 3
+    T = x.shape[-1]
     # (normed, x): the residual tail below reads x again; its gradient joins the LayerNorm's in one kernel
     normed, x = ops.layer_norm_t_tee(x, P(prefix + "ln.weight"), P(prefix + "ln.bias"), m0.ln.eps)
 
-    att_c = _channel_attention(P, prefix, ops.node_pool(normed, P(prefix + "cacn.seq.0.alpha")), R, B)
+    # CACN's per-sample channel matrix conv @ softmax(p Wc p^T) (attention.py:90-92, msgat.py:93-94): one launch
     conv_w = P(prefix + "cacn.seq.1.weight")[:, :, :, 0, 0]                            # [R,cb,C]
     conv_b = P(prefix + "cacn.seq.1.bias")                                             # [R,cb]
-    Mc = (conv_w.unsqueeze(1) @ att_c).reshape(R * B, cb, C)                           # per-sample matrices
+    Mc = ops.channel_attention_mix(ops.node_pool(normed, P(prefix + "cacn.seq.0.alpha")), P(prefix + "cacn.seq.0.Wc"), conv_w)
     Wg, alpha_g, W_g = P(prefix + "gacn.gatt.Wg"), P(prefix + "gacn.gatt.alpha"), P(prefix + "gacn.W")
     alpha_t = P(prefix + "tacn.seq.0.alpha")
+    d0 = m0.dilations[0] if m0.dilations else 0
 
     if C <= cb or not m0.dilations:
         (cacn,) = ops.mix_multi([normed], Mc, _per_group(conv_b, B))
-        att_t = _temporal_attention(P, prefix, ops.channel_pool(normed, alpha_t), R, B)
+        pooled_t = ops.channel_pool(normed, alpha_t)
         if m0.dilations:
             (mixed,) = ops.mix_multi([normed], _taps(P, prefix, 0))
-            tacn = _tacn_finish(P, prefix, m0.dilations, mixed, att_t)
-        else:
-            tacn = ops.time_mix(normed, att_t.unsqueeze(1))
+            tacn = _tacn_finish(P, prefix, m0.dilations, mixed, _first_taps(P, prefix, pooled_t, T, d0))
+        else:   # bare temporal attention: K = 1 with the attention matrix itself (tap 1 of a dilation-0 pair)
+            tacn = ops.time_mix(normed, _first_taps(P, prefix, pooled_t, T, 0)[:, 1:2])
         gacn = ops.gacn(normed, alpha_g, Wg, W_g, adjacency)
     else:
         # every channel mixing of the normalised input as row blocks of one per-sample matrix (model.MEAM._merged_branches)
@@ -159,7 +144,7 @@ def _meam(P, prefix: str, m0, x: torch.Tensor, adjacency, R: int, B: int) -> tor
                           _per_group(alpha_g.unsqueeze(1), B), _per_group(alpha_t.unsqueeze(1), B)], dim=1)
         bias = _per_group(torch.cat([conv_b, conv_b.new_zeros(R, 3 * cb + 2)], dim=1), B)
         cacn, mixed, u, q, pooled_t = ops.mix_multi([normed], rows, bias, out_channels=[cb, 2 * cb, cb, 1, 1])
-        tacn = _tacn_finish(P, prefix, m0.dilations, mixed, _temporal_attention(P, prefix, pooled_t[:, 0], R, B))
+        tacn = _tacn_finish(P, prefix, m0.dilations, mixed, _first_taps(P, prefix, pooled_t[:, 0], T, d0))
         gacn = ops.attention_core(u, q[:, 0], Wg, adjacency)
     return ops.mix_multi([x], P(prefix + "res.weight")[:, :, :, 0, 0], P(prefix + "res.bias"),
                          adds=[cacn, tacn, gacn], relu=True)[0]

@@ -297,3 +297,43 @@ def test_parameter_sets_per_relation_in_one_launch():
         assert rel_err(a, b) < 1e-5
     for name, a, b in zip(["dx", "dlnw", "dlnb", "dnw", "dca", "dhw", "dhb", "dA", "dtb"], g1, g2):
         assert rel_err(a, b) < 2e-5, name
+
+
+@pytest.mark.parametrize("R,Bg,C,cb,T", [(1, 3, 7, 4, 12), (3, 2, 72, 24, 12), (2, 2, 1, 24, 12), (1, 2, 96, 32, 8), (1, 1, 5, 3, 16)])
+def test_channel_attention_mix_is_one_launch_each_way(R, Bg, C, cb, T):
+    """conv @ softmax((p Wc) p^T) -- attention.py:90-92 folded with CACN's convolution weight (msgat.py:93-94) -- and
+    every gradient, against the same chain of dense ops in float64."""
+    from ms_gat_amd import ops
+    gen = torch.Generator().manual_seed(C * 7 + T)
+    p, Wc, conv, dM = (_rand(gen, R * Bg, C, T, scale=0.7), _rand(gen, R, T, T, scale=0.4), _rand(gen, R, cb, C, scale=0.5),
+                       _rand(gen, R * Bg, cb, C))
+    a = _leaf(p, Wc, conv)
+    ours = _grads(ops.channel_attention_mix(*a), a, dM)
+    p64, W64, c64 = _leaf64(p, Wc, conv)
+    pv = p64.view(R, Bg, C, T)
+    att = torch.softmax(pv @ W64.unsqueeze(1) @ pv.transpose(2, 3), dim=-1)
+    ref = (c64.unsqueeze(1) @ att).reshape(R * Bg, cb, C)
+    _check(ours, _grads(ref, (p64, W64, c64), dM.double()), ["Mc", "dpooled", "dWc", "dconv"])
+
+
+@pytest.mark.parametrize("R,Bg,N,K,T,dil", [(1, 3, 23, 10, 12, 1), (3, 2, 883, 10, 12, 2), (2, 1, 64, 10, 8, 4), (1, 2, 40, 10, 12, 0),
+                                            (1, 1, 17, 10, 12, 12)])
+def test_temporal_attention_taps_are_one_launch_each_way(R, Bg, N, K, T, dil):
+    """(att shifted down by the dilation, att) with att = softmax((q^T Wt1^T)(q^T Wt2^T)^T) -- attention.py:60-64 as the
+    taps of TACN's first convolution (msgat.py:66-74) -- and every gradient, against dense float64 ops."""
+    from ms_gat_amd import ops
+    gen = torch.Generator().manual_seed(N + T + dil)
+    q, W1, W2, dtaps = (_rand(gen, R * Bg, N, T, scale=0.5), _rand(gen, R, K, N, scale=N ** -0.5), _rand(gen, R, K, N, scale=N ** -0.5),
+                        _rand(gen, R * Bg, 2, T, T))
+    a = _leaf(q, W1, W2)
+    ours = _grads(ops.temporal_attention_taps(*a, dil), a, dtaps)
+    q64, A64, B64 = _leaf64(q, W1, W2)
+    per_t = q64.view(R, Bg, N, T).transpose(2, 3)
+    att = torch.softmax((per_t @ A64.transpose(1, 2).unsqueeze(1)) @ (per_t @ B64.transpose(1, 2).unsqueeze(1)).transpose(2, 3), dim=-1)
+    att = att.reshape(R * Bg, T, T)
+    shifted = torch.zeros_like(att) if dil >= T else torch.nn.functional.pad(att[:, : T - dil], (0, 0, dil, 0))
+    ref = torch.stack([shifted, att], dim=1)
+    _check(ours, _grads(ref, (q64, A64, B64), dtaps.double()), ["taps", "dpooled", "dWt1", "dWt2"])
+    assert ops.causal_shift_taps(T, 2, _dev()) is ops.causal_shift_taps(T, 2, _dev())
+    eye = torch.eye(T)
+    assert torch.equal(ops.causal_shift_taps(T, 2, _dev()).cpu()[0, 0], torch.nn.functional.pad(eye[: T - 2], (0, 0, 2, 0)))
