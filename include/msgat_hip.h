@@ -242,6 +242,8 @@ int msgat_stage_contract(const msgat_shape_t* shape, int32_t Ca, int32_t Cb, con
  * (msgat_layernorm_partial_floats() floats).  dx_add (may be NULL) is added to dx in the same pass: the
  * gradient that reached x along its other path -- MEAM's residual convolution reads the block input too
  * (msgat.py:130) -- so autograd's separate accumulation pass over the activation disappears.
+ * relu_mask != 0: x is the output of a ReLU (MEAM's tail, msgat.py:131) whose backward is applied here,
+ * dx = 0 where x <= 0, instead of in a pass of its own (the caller then skips that ReLU's own mask).
  * T in {4, 8, 12, 16}.
  *
  * R ("relations") in this and the following entry points: the number of parameter sets evaluated in one
@@ -254,7 +256,7 @@ int msgat_layernorm_forward(const float* x, const float* weight, const float* bi
 size_t msgat_layernorm_partial_floats(int64_t rows, int32_t T, int32_t R);
 int msgat_layernorm_backward(const float* x, const float* weight, const float* dy, const float* dx_add,
                              float* dx, float* dweight, float* dbias, float* partials, int64_t rows,
-                             int32_t T, float eps, int32_t R, void* stream);
+                             int32_t T, float eps, int32_t R, int32_t relu_mask, void* stream);
 
 /* ---- device: the temporal and channel branches of MEAM ----
  * Building blocks for TACN (src/models/msgat.py:57-80, TemporalAttention attention.py:58-66) and CACN

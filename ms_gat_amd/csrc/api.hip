@@ -468,11 +468,12 @@ extern "C" size_t msgat_layernorm_partial_floats(int64_t rows, int32_t T, int32_
 
 extern "C" int msgat_layernorm_backward(const float* x, const float* weight, const float* dy, const float* dx_add,
                                         float* dx, float* dweight, float* dbias, float* partials, int64_t rows,
-                                        int32_t T, float eps, int32_t R, void* stream) {
+                                        int32_t T, float eps, int32_t R, int32_t relu_mask, void* stream) {
   if (!x || !dy || !dx || !partials) return MSGAT_ERR_NULL;
   if (rows <= 0 || !(eps >= 0.f) || R <= 0 || R > 65535 || rows % R) return MSGAT_ERR_SHAPE;
   if (!t_supported(T)) return MSGAT_ERR_UNSUPPORTED;
-  return launch_layernorm_bwd(x, weight, dy, dx_add, dx, dweight, dbias, partials, rows, T, eps, R, (hipStream_t)stream);
+  return launch_layernorm_bwd(x, weight, dy, dx_add, dx, dweight, dbias, partials, rows, T, eps, R, relu_mask != 0,
+                              (hipStream_t)stream);
 }
 
 // ---- fused forward ---------------------------------------------------------------------------------

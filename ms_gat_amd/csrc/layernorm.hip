@@ -68,7 +68,7 @@ template <int T>
 __global__ __launch_bounds__(kBlock) void k_ln_bwd(const float* __restrict__ x, const float* __restrict__ w,
                                                    const float* __restrict__ dy, const float* __restrict__ add,
                                                    float* __restrict__ dx, float* __restrict__ part, long long rows,
-                                                   float eps) {
+                                                   float eps, int relu_mask) {
   __shared__ float red[kBlock / kWave][2 * T];
   x += (size_t)blockIdx.y * rows * T;
   dy += (size_t)blockIdx.y * rows * T;
@@ -81,6 +81,9 @@ __global__ __launch_bounds__(kBlock) void k_ln_bwd(const float* __restrict__ x, 
     float xv[T], gv[T];
     load_row<T>(x + r * T, xv);
     load_row<T>(dy + r * T, gv);
+    unsigned positive = 0;  // x > 0, per element: x is a ReLU output when relu_mask is set
+#pragma unroll
+    for (int t = 0; t < T; ++t) positive |= (xv[t] > 0.f ? 1u : 0u) << t;
     const float rstd = centre_row<T>(xv, eps);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -101,6 +104,10 @@ __global__ __launch_bounds__(kBlock) void k_ln_bwd(const float* __restrict__ x, 
       load_row<T>(add + r * T, av);
 #pragma unroll
       for (int t = 0; t < T; ++t) gv[t] += av[t];
+    }
+    if (relu_mask) {  // the ReLU that produced x (MEAM's tail, msgat.py:131): its backward, applied where x is at hand
+#pragma unroll
+      for (int t = 0; t < T; ++t) gv[t] = ((positive >> t) & 1u) ? gv[t] : 0.f;
     }
     store_row<T>(dx + r * T, gv);
   }
@@ -142,14 +149,14 @@ int launch_layernorm_fwd(const float* x, const float* w, const float* b, float* 
 }
 
 int launch_layernorm_bwd(const float* x, const float* w, const float* dy, const float* add, float* dx, float* dw,
-                         float* db, float* part, long long rows, int T, float eps, int R, hipStream_t s) {
+                         float* db, float* part, long long rows, int T, float eps, int R, int relu_mask, hipStream_t s) {
   rows /= R;  // per relation
   const int nb = ln_blocks(rows);
   switch (T) {
-    case 4: hipLaunchKernelGGL(k_ln_bwd<4>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps); break;
-    case 8: hipLaunchKernelGGL(k_ln_bwd<8>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps); break;
-    case 12: hipLaunchKernelGGL(k_ln_bwd<12>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps); break;
-    case 16: hipLaunchKernelGGL(k_ln_bwd<16>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps); break;
+    case 4: hipLaunchKernelGGL(k_ln_bwd<4>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps, relu_mask); break;
+    case 8: hipLaunchKernelGGL(k_ln_bwd<8>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps, relu_mask); break;
+    case 12: hipLaunchKernelGGL(k_ln_bwd<12>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps, relu_mask); break;
+    case 16: hipLaunchKernelGGL(k_ln_bwd<16>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps, relu_mask); break;
     default: return MSGAT_ERR_UNSUPPORTED;
   }
   MSGAT_CHECK_LAUNCH();

@@ -207,10 +207,13 @@ class MEAM(nn.Module):
         self.tacn = TACN(in_channels, branch, n_nodes=n_nodes, dilations=dilations)
         self.gacn = GACN(in_channels, branch, n_timesteps=n_timesteps)
 
-    def forward(self, signals: torch.Tensor, adjacency) -> torch.Tensor:
+    def forward(self, signals: torch.Tensor, adjacency, relu_input: bool = False, premasked: bool = False) -> torch.Tensor:
+        """`relu_input` / `premasked` are for a caller that chains blocks itself (TPC): `relu_input` says `signals` is a
+        ReLU output whose backward mask this block's LayerNorm applies; `premasked` says the consumer of THIS block's
+        output will do the same for it, so the block skips its own mask pass.  Defaults: plain autograd semantics."""
         # (normed, signals): the residual convolution below reads the block input again (msgat.py:130); routed
         # through the LayerNorm op, its gradient is added inside the LayerNorm-backward kernel
-        normed, signals = ops.layer_norm_t_tee(signals, self.ln.weight, self.ln.bias, self.ln.eps)
+        normed, signals = ops.layer_norm_t_tee(signals, self.ln.weight, self.ln.bias, self.ln.eps, relu_input)
         res_w = self.res.weight[:, :, 0, 0].unsqueeze(0)
         if self.in_channels <= self.out_channels // 3 or not self.dilations:
             # few input channels (the first block of a component): the graph branch aggregates before it
@@ -220,7 +223,7 @@ class MEAM(nn.Module):
             branches = self._merged_branches(normed, adjacency)
         # relu(cat(branches) + res(signals)): the 1x1 residual convolution reads the three branch tensors as
         # its add operand (no concatenation) and applies the ReLU in its store epilogue
-        return ops.mix_multi([signals], res_w, self.res.bias, adds=branches, relu=True)[0]
+        return ops.mix_multi([signals], res_w, self.res.bias, adds=branches, relu=True, relu_grad_premasked=premasked)[0]
 
     def _merged_branches(self, normed: torch.Tensor, adjacency):
         """All channel mixings of the normalised input in ONE pass: CACN's per-sample
@@ -260,10 +263,18 @@ class TPC(nn.Module):
         self.fc = nn.Conv2d(in_timesteps, out_timesteps, kernel_size=(1, channels[-1]))
 
     def forward(self, signals: torch.Tensor, adjacency) -> torch.Tensor:
-        for block in self.tgacns:
-            signals = block(signals, adjacency)
+        # every block's output is a ReLU output consumed by exactly one LayerNorm (the next block's, or self.ln): that
+        # LayerNorm's backward kernel applies the ReLU mask, the blocks skip their own mask pass
+        # (only among this package's own modules: a swapped-in block or LayerNorm gets plain autograd semantics)
+        own = isinstance(self.ln, LayerNormT) and all(isinstance(b, MEAM) for b in self.tgacns)
+        for i, block in enumerate(self.tgacns):
+            signals = block(signals, adjacency, relu_input=i > 0, premasked=True) if own else block(signals, adjacency)
+        if own:
+            normed = ops.layer_norm_t(signals, self.ln.weight, self.ln.bias, self.ln.eps, relu_input=len(self.tgacns) > 0)
+        else:
+            normed = self.ln(signals)
         # fc over the transposed activation, squeezed and transposed back (msgat.py:159-160): one pass
-        return ops.head(self.ln(signals), self.fc.weight, self.fc.bias)            # [B,N,T_out]
+        return ops.head(normed, self.fc.weight, self.fc.bias)                      # [B,N,T_out]
 
 
 class TimeEmbedding(nn.Module):

@@ -152,11 +152,12 @@ class _LayerNormTFunction(torch.autograd.Function):
     """x[..., T], weight[T] | None, bias[T] | None -> LayerNorm over the last axis."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps: float):
+    def forward(ctx, x, weight, bias, eps: float, relu_input: bool = False):
         L = _lib.lib()
         x = x.contiguous()
         T = x.shape[-1]
         rows = x.numel() // T if T else 0
+        ctx.relu_input = bool(relu_input)
         y = torch.empty_like(x)
         w = None if weight is None else weight.contiguous()
         b = None if bias is None else bias.contiguous()
@@ -183,9 +184,9 @@ class _LayerNormTFunction(torch.autograd.Function):
         part = torch.empty(max(int(L.msgat_layernorm_partial_floats(rows, T, R)), 1), device=x.device,
                            dtype=torch.float32)
         st = L.msgat_layernorm_backward(_ptr(x), _ptr(w), _ptr(dy), None, _ptr(dx), _ptr(dw), _ptr(db), _ptr(part),
-                                        rows, T, ctx.eps, R, _stream_handle(x.device))
+                                        rows, T, ctx.eps, R, int(ctx.relu_input), _stream_handle(x.device))
         _lib.check(st, "msgat_layernorm_backward")
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class _LayerNormTeeFunction(torch.autograd.Function):
@@ -194,11 +195,12 @@ class _LayerNormTeeFunction(torch.autograd.Function):
     backward add its gradient inside the LayerNorm-backward kernel instead of in a separate accumulation pass."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps: float):
+    def forward(ctx, x, weight, bias, eps: float, relu_input: bool = False):
         L = _lib.lib()
         x = x.contiguous()
         T = x.shape[-1]
         rows = x.numel() // T
+        ctx.relu_input = bool(relu_input)
         y = torch.empty_like(x)
         w = None if weight is None else weight.contiguous()
         b = None if bias is None else bias.contiguous()
@@ -218,7 +220,9 @@ class _LayerNormTeeFunction(torch.autograd.Function):
         T = x.shape[-1]
         rows = x.numel() // T
         if dy is None:
-            return dx_other, None, None, None
+            if dx_other is not None and ctx.relu_input:
+                dx_other = torch.ops.aten.threshold_backward(dx_other.contiguous(), x, 0.0)
+            return dx_other, None, None, None, None
         dy = dy.contiguous()
         other = None if dx_other is None else dx_other.contiguous()
         dx = torch.empty_like(x)
@@ -227,30 +231,34 @@ class _LayerNormTeeFunction(torch.autograd.Function):
         db = torch.empty(w.shape if ctx.has_w else (T,), device=x.device, dtype=torch.float32) if ctx.has_b else None
         part = torch.empty(max(int(L.msgat_layernorm_partial_floats(rows, T, R)), 1), device=x.device, dtype=torch.float32)
         st = L.msgat_layernorm_backward(_ptr(x), _ptr(w), _ptr(dy), _ptr(other), _ptr(dx), _ptr(dw), _ptr(db), _ptr(part),
-                                        rows, T, ctx.eps, R, _stream_handle(x.device))
+                                        rows, T, ctx.eps, R, int(ctx.relu_input), _stream_handle(x.device))
         _lib.check(st, "msgat_layernorm_backward")
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 def layer_norm_t_tee(x: torch.Tensor, weight: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
-                     eps: float = 1e-5):
-    """(layer_norm_t(x), x): use the second value wherever the block reads its un-normalised input again."""
+                     eps: float = 1e-5, relu_input: bool = False):
+    """(layer_norm_t(x), x): use the second value wherever the block reads its un-normalised input again.
+    `relu_input`: see `layer_norm_t` (the mask then covers the gradients of both uses)."""
     _require_device_tensor("signals", x)
     if x.numel() == 0 or not x.requires_grad:
-        return layer_norm_t(x, weight, bias, eps), x
+        return layer_norm_t(x, weight, bias, eps, relu_input), x
     T = x.shape[-1]
     for name, t in (("weight", weight), ("bias", bias)):
         if t is not None:
             _require_device_tensor(name, t, x.device)
             if t.shape[-1] != T or t.dim() > 2 or (t.dim() == 2 and x.shape[0] % t.shape[0]):
                 raise ValueError(f"{name} must be [{T}] or [R,{T}] with R dividing the leading axis, got {tuple(t.shape)}")
-    return _LayerNormTeeFunction.apply(x, weight, bias, float(eps))
+    return _LayerNormTeeFunction.apply(x, weight, bias, float(eps), bool(relu_input))
 
 
 def layer_norm_t(x: torch.Tensor, weight: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
-                 eps: float = 1e-5) -> torch.Tensor:
+                 eps: float = 1e-5, relu_input: bool = False) -> torch.Tensor:
     """`F.layer_norm(x, [T], weight, bias, eps)` over the timestep axis, the op the reference applies
-    to every GACN input (msgat.py:122, :158), as one HBM-speed pass in libmsgat_hip.so."""
+    to every GACN input (msgat.py:122, :158), as one HBM-speed pass in libmsgat_hip.so.
+
+    `relu_input=True`: x is the output of a ReLU whose backward mask (gradient 0 where x <= 0) this op's backward
+    applies -- for a producer that was told to skip it (`mix_multi(..., relu=True, relu_grad_premasked=True)`)."""
     _require_device_tensor("signals", x)
     T = x.shape[-1]
     for name, t in (("weight", weight), ("bias", bias)):
@@ -262,7 +270,7 @@ def layer_norm_t(x: torch.Tensor, weight: Optional[torch.Tensor] = None, bias: O
         raise ValueError("weight and bias must have the same shape")
     if x.numel() == 0:
         return torch.empty_like(x)
-    return _LayerNormTFunction.apply(x, weight, bias, float(eps))
+    return _LayerNormTFunction.apply(x, weight, bias, float(eps), bool(relu_input))
 
 
 # ---- the temporal / channel branches of MEAM and its residual tail -----------
@@ -590,7 +598,7 @@ class _MixMultiFunction(torch.autograd.Function):
     """outs = split(relu?(M cat(ins) + bias + cat(adds))): see include/msgat_hip.h, msgat_mix_segments."""
 
     @staticmethod
-    def forward(ctx, M, bias, relu, n_in, n_add, out_channels, *tensors):
+    def forward(ctx, M, bias, relu, n_in, n_add, out_channels, premasked, *tensors):
         L = _lib.lib()
         ins, adds = tensors[:n_in], tensors[n_in:n_in + n_add]
         G, _, N, T = ins[0].shape
@@ -605,9 +613,10 @@ class _MixMultiFunction(torch.autograd.Function):
         st = L.msgat_mix_segments(R, G // R, N, T, ain, n_in, _ptr(M), 0, _ptr(b), per_rel, aad, n_add, int(relu), aout,
                                   len(outs), _stream_handle(M.device))
         _lib.check(st, "msgat_mix_segments")
-        ctx.meta = (relu, n_in, tuple(out_channels), (0 if bias is None else (R if per_rel else -1)),
+        relu_bwd = bool(relu and not premasked)   # premasked: the consumer of the output applies the ReLU's backward mask
+        ctx.meta = (relu_bwd, n_in, tuple(out_channels), (0 if bias is None else (R if per_rel else -1)),
                     [t.shape[1] for t in ins], [t.shape[1] for t in adds])
-        ctx.save_for_backward(M, *kin, *(outs if relu else []))
+        ctx.save_for_backward(M, *kin, *(outs if relu_bwd else []))
         return tuple(outs)
 
     @staticmethod
@@ -631,7 +640,7 @@ class _MixMultiFunction(torch.autograd.Function):
         need = ctx.needs_input_grad
         dM = dbias = None
         d_ins = [None] * n_in
-        if any(need[6:6 + n_in]):   # one pass: d cat(ins) = M^T cat(dpre), each input's range to its own tensor
+        if any(need[7:7 + n_in]):   # one pass: d cat(ins) = M^T cat(dpre), each input's range to its own tensor
             d_ins = [_new(like, G, c, N, T) for c in in_channels]
             _, ai, _ = _seg_array(d_ins)
             st = L.msgat_mix_segments(R, G // R, N, T, ad, nd, _ptr(M), 1, None, 0, None, 0, 0, ai, n_in, stream)
@@ -662,13 +671,17 @@ class _MixMultiFunction(torch.autograd.Function):
             for c in add_channels:
                 d_adds.append(whole[:, a:a + c])
                 a += c
-        return (dM, dbias, None, None, None, None, *d_ins, *d_adds)
+        return (dM, dbias, None, None, None, None, None, *d_ins, *d_adds)
 
 
-def mix_multi(ins, M, bias=None, adds=(), relu=False, out_channels=None):
+def mix_multi(ins, M, bias=None, adds=(), relu=False, out_channels=None, relu_grad_premasked=False):
     """One channel-mixing pass over cat(ins) with the [R, Co, Ci] matrix M (R | batch): relu?(M cat(ins) + bias +
     cat(adds)), the output channel ranges `out_channels` written to separate tensors (default: one).  Returns a
-    tuple.  Replaces torch.cat + several 1x1 convolutions by a single read of the inputs."""
+    tuple.  Replaces torch.cat + several 1x1 convolutions by a single read of the inputs.
+
+    `relu_grad_premasked=True` (with relu): EVERY consumer of the output promises to hand back a gradient that is
+    already zero where the output is <= 0 (`layer_norm_t(..., relu_input=True)` does, inside its backward kernel), so
+    this op's backward skips its own mask pass over the activation."""
     ins, adds = list(ins), list(adds)
     for t in ins + adds:
         _require_device_tensor("signals", t)
@@ -685,7 +698,8 @@ def mix_multi(ins, M, bias=None, adds=(), relu=False, out_channels=None):
         raise ValueError(f"bias must be [{Co}] or [{M.shape[0]},{Co}]")
     if max(len(ins), len(adds), len(out_channels)) > 6:
         raise ValueError("mix_multi: at most 6 tensors per channel axis")
-    return _MixMultiFunction.apply(M, bias, bool(relu), len(ins), len(adds), tuple(out_channels), *ins, *adds)
+    return _MixMultiFunction.apply(M, bias, bool(relu), len(ins), len(adds), tuple(out_channels),
+                                   bool(relu and relu_grad_premasked), *ins, *adds)
 
 
 class _AttentionCoreFunction(torch.autograd.Function):
@@ -846,6 +860,36 @@ def temporal_attention_taps(pooled: torch.Tensor, Wt1: torch.Tensor, Wt2: torch.
     if Wt1.shape != Wt2.shape or Wt1.dim() != 3 or Wt1.shape[2] != N or G % Wt1.shape[0] or 2 * T * Wt1.shape[1] > 256:
         raise ValueError(f"temporal_attention_taps: pooled {tuple(pooled.shape)}, Wt1 {tuple(Wt1.shape)}, Wt2 {tuple(Wt2.shape)}")
     return _TemporalAttentionTapsFunction.apply(pooled, Wt1, Wt2, int(dilation))
+
+
+class _AssembleRowsFunction(torch.autograd.Function):
+    """per_group [G,A,C], per_relation [R,Kr,C] -> rows [G,A+Kr,C]: each group's own rows followed by its relation's.
+    Two copies forward; backward = a view of the first block and ONE sum over each relation's groups for the second
+    (torch.cat of expanded tensors costs a copy per operand forward and a reduction per operand backward)."""
+
+    @staticmethod
+    def forward(ctx, per_group, per_relation):
+        G, A, Cc = per_group.shape
+        R, Kr, _ = per_relation.shape
+        rows = torch.empty(G, A + Kr, Cc, device=per_group.device, dtype=torch.float32)
+        rows[:, :A].copy_(per_group)
+        rows.view(R, G // R, A + Kr, Cc)[:, :, A:].copy_(per_relation.unsqueeze(1))
+        ctx.dims = (G, A, Cc, R, Kr)
+        return rows
+
+    @staticmethod
+    def backward(ctx, drows):
+        G, A, Cc, R, Kr = ctx.dims
+        d_rel = drows.view(R, G // R, A + Kr, Cc)[:, :, A:].sum(dim=1) if ctx.needs_input_grad[1] else None
+        return (drows[:, :A] if ctx.needs_input_grad[0] else None), d_rel
+
+
+def assemble_rows(per_group: torch.Tensor, per_relation: torch.Tensor) -> torch.Tensor:
+    """[G,A,C] rows of every group followed by the [Kr,C] rows of its relation (per_relation [R,Kr,C], R | G)."""
+    if per_group.dim() != 3 or per_relation.dim() != 3 or per_group.shape[2] != per_relation.shape[2] or \
+            per_group.shape[0] % per_relation.shape[0]:
+        raise ValueError(f"assemble_rows: {tuple(per_group.shape)} and {tuple(per_relation.shape)}")
+    return _AssembleRowsFunction.apply(per_group, per_relation)
 
 
 _shift_taps_cache = {}

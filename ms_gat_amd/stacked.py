@@ -115,11 +115,13 @@ def _tacn_finish(P, prefix: str, dilations, mixed: torch.Tensor, taps0: torch.Te
     return h
 
 
-def _meam(P, prefix: str, m0, x: torch.Tensor, adjacency, R: int, B: int) -> torch.Tensor:
+def _meam(P, prefix: str, m0, x: torch.Tensor, adjacency, R: int, B: int, relu_input: bool) -> torch.Tensor:
+    """One MEAM level of all R components.  Its output is a ReLU output whose backward mask the NEXT LayerNorm applies
+    (`relu_input` there; here for the level below): the caller chains levels and must end with such a LayerNorm."""
     C, cb = m0.in_channels, m0.out_channels // 3
     T = x.shape[-1]
     # (normed, x): the residual tail below reads x again; its gradient joins the LayerNorm's in one kernel
-    normed, x = ops.layer_norm_t_tee(x, P(prefix + "ln.weight"), P(prefix + "ln.bias"), m0.ln.eps)
+    normed, x = ops.layer_norm_t_tee(x, P(prefix + "ln.weight"), P(prefix + "ln.bias"), m0.ln.eps, relu_input)
 
     # CACN's per-sample channel matrix conv @ softmax(p Wc p^T) (attention.py:90-92, msgat.py:93-94): one launch
     conv_w = P(prefix + "cacn.seq.1.weight")[:, :, :, 0, 0]                            # [R,cb,C]
@@ -139,15 +141,20 @@ def _meam(P, prefix: str, m0, x: torch.Tensor, adjacency, R: int, B: int) -> tor
             tacn = ops.time_mix(normed, _first_taps(P, prefix, pooled_t, T, 0)[:, 1:2])
         gacn = ops.gacn(normed, alpha_g, Wg, W_g, adjacency)
     else:
-        # every channel mixing of the normalised input as row blocks of one per-sample matrix (model.MEAM._merged_branches)
-        rows = torch.cat([Mc, _per_group(_taps(P, prefix, 0), B), _per_group(W_g, B),
-                          _per_group(alpha_g.unsqueeze(1), B), _per_group(alpha_t.unsqueeze(1), B)], dim=1)
-        bias = _per_group(torch.cat([conv_b, conv_b.new_zeros(R, 3 * cb + 2)], dim=1), B)
-        cacn, mixed, u, q, pooled_t = ops.mix_multi([normed], rows, bias, out_channels=[cb, 2 * cb, cb, 1, 1])
+        # every channel mixing of the normalised input as row blocks of one per-sample matrix (model.MEAM._merged_branches):
+        # the group's own CACN matrix, then its relation's taps / projection / pooling vectors.  CACN's bias joins the
+        # residual bias below (both are per-channel constants added before the same ReLU).
+        shared = torch.cat([_taps(P, prefix, 0), W_g, alpha_g.unsqueeze(1), alpha_t.unsqueeze(1)], dim=1)   # [R,3cb+2,C]
+        rows = ops.assemble_rows(Mc, shared)
+        cacn, mixed, u, q, pooled_t = ops.mix_multi([normed], rows, None, out_channels=[cb, 2 * cb, cb, 1, 1])
         tacn = _tacn_finish(P, prefix, m0.dilations, mixed, _first_taps(P, prefix, pooled_t[:, 0], T, d0))
         gacn = ops.attention_core(u, q[:, 0], Wg, adjacency)
+        res_b = P(prefix + "res.bias")
+        tail_bias = res_b + torch.nn.functional.pad(conv_b, (0, res_b.shape[1] - cb))
+        return ops.mix_multi([x], P(prefix + "res.weight")[:, :, :, 0, 0], tail_bias, adds=[cacn, tacn, gacn], relu=True,
+                             relu_grad_premasked=True)[0]
     return ops.mix_multi([x], P(prefix + "res.weight")[:, :, :, 0, 0], P(prefix + "res.bias"),
-                         adds=[cacn, tacn, gacn], relu=True)[0]
+                         adds=[cacn, tacn, gacn], relu=True, relu_grad_premasked=True)[0]
 
 
 def forward(model, X: torch.Tensor, H: torch.Tensor, D: torch.Tensor) -> torch.Tensor:
@@ -157,8 +164,8 @@ def forward(model, X: torch.Tensor, H: torch.Tensor, D: torch.Tensor) -> torch.T
     P = _bank(model).get
     x = X.transpose(0, 1).reshape(R * B, *X.shape[2:])                                 # relation-major groups
     for level, m0 in enumerate(tpcs[0].tgacns):
-        x = _meam(P, f"tgacns.{level}.", m0, x, model.adj, R, B)
-    xn = ops.layer_norm_t(x, P("ln.weight"), P("ln.bias"), tpcs[0].ln.eps)
+        x = _meam(P, f"tgacns.{level}.", m0, x, model.adj, R, B, relu_input=level > 0)
+    xn = ops.layer_norm_t(x, P("ln.weight"), P("ln.bias"), tpcs[0].ln.eps, relu_input=len(tpcs[0].tgacns) > 0)
     pred = ops.head(xn, P("fc.weight"), P("fc.bias"))                                  # [R*B,N,T_out]
     pred = pred.view(R, B, *pred.shape[1:])
     gate = model.te(H, D).transpose(0, 1) if model.te is not None else model.W.unsqueeze(1)          # [R,B|1,N,T_out]
