@@ -275,8 +275,12 @@ int msgat_layernorm_backward(const float* x, const float* weight, const float* d
  *     channel mixing src = [W_0; W_1] x; with constant shift matrices it is a plain causal convolution.
  * msgat_time_mix_grad_matrix: dA[g,k,t,i] = sum_{o,n} dout[g,o,n,t] y[g,k*Co+o,n,i];
  *     `partials` needs msgat_time_mix_partial_floats() floats.
+ * Gradients arriving as channel slices [:, a:b] of a wider contiguous [G, group_stride, N, T] tensor (the block's
+ * concatenated gradient) are read in place: src_group_stride / dout_group_stride / (channels, group_stride) name the
+ * wider tensor's channel count (0 = the operand is contiguous by itself).
  * msgat_node_pool: pooled[s,t] = sum_n w[n] x[s,n,t] over `slabs` (sample, channel) slabs (attention.py:89);
- *     msgat_node_pool_grad_signal: dx[s,n,t] = w[n] dpooled[s,t];
+ *     msgat_node_pool_grad_signal: dx[s,n,t] = w[n] dpooled[s,t] (+ dx_add[s,n,t] when given: the gradient that
+ *     reached x along its other path, so autograd's separate accumulation pass over the activation disappears);
  *     msgat_node_pool_grad_weight: dw[n] = sum_{g,c,t} x[g,c,n,t] dpooled[g,c,t] (partials:
  *     msgat_node_pool_partial_floats()).
  * The channel pooling sum_c alpha_c x[b,c] (attention.py:59) is msgat_stage_project with W = u = NULL. */
@@ -285,14 +289,14 @@ int msgat_stage_mix_epilogue(const msgat_shape_t* shape, int32_t Ci, int32_t Co,
                              int32_t relu, float* out, void* stream);
 int msgat_time_mix(const float* src, const float* A, int32_t a_per_group, const float* bias, float* dst,
                    int32_t G, int32_t Co, int32_t K, int32_t N, int32_t T, int32_t backward, int32_t R,
-                   void* stream);
+                   int32_t src_group_stride, void* stream);
 size_t msgat_time_mix_partial_floats(int32_t G, int32_t K, int32_t T);
 int msgat_time_mix_grad_matrix(const float* dout, const float* y, float* dA, float* partials, int32_t G,
-                               int32_t Co, int32_t K, int32_t N, int32_t T, void* stream);
+                               int32_t Co, int32_t K, int32_t N, int32_t T, int32_t dout_group_stride, void* stream);
 int msgat_node_pool(const float* x, const float* w, float* pooled, int64_t slabs, int32_t N, int32_t T,
-                    int32_t R, void* stream);
-int msgat_node_pool_grad_signal(const float* w, const float* dpooled, float* dx, int64_t slabs, int32_t N,
-                                int32_t T, int32_t R, void* stream);
+                    int32_t R, int32_t channels, int32_t group_stride, void* stream);
+int msgat_node_pool_grad_signal(const float* w, const float* dpooled, const float* dx_add, float* dx,
+                                int64_t slabs, int32_t N, int32_t T, int32_t R, void* stream);
 size_t msgat_node_pool_partial_floats(int32_t G, int32_t C, int32_t N);
 int msgat_node_pool_grad_weight(const float* x, const float* dpooled, float* dw, float* partials, int32_t G,
                                 int32_t C, int32_t N, int32_t T, int32_t R, void* stream);

@@ -84,12 +84,12 @@ _PROTOTYPES = {
                                        C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "msgat_stage_mix_epilogue": (C.c_int, [C.POINTER(Shape), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                            C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
-    "msgat_time_mix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 7
+    "msgat_time_mix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 8
                        + [C.c_void_p]),
     "msgat_time_mix_partial_floats": (C.c_size_t, [C.c_int32] * 3),
-    "msgat_time_mix_grad_matrix": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 5 + [C.c_void_p]),
-    "msgat_node_pool": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
-    "msgat_node_pool_grad_signal": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "msgat_time_mix_grad_matrix": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 6 + [C.c_void_p]),
+    "msgat_node_pool": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "msgat_node_pool_grad_signal": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "msgat_node_pool_partial_floats": (C.c_size_t, [C.c_int32] * 3),
     "msgat_node_pool_grad_weight": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 5 + [C.c_void_p]),
     "msgat_mix_segments": (C.c_int, [C.c_int32] * 4 + [C.POINTER(Seg), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,

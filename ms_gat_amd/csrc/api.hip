@@ -242,13 +242,14 @@ static int check_rows(int32_t G, int32_t Co, int32_t K, int32_t N, int32_t T) {
 
 extern "C" int msgat_time_mix(const float* src, const float* A, int32_t a_per_group, const float* bias,
                               float* dst, int32_t G, int32_t Co, int32_t K, int32_t N, int32_t T,
-                              int32_t backward, int32_t R, void* stream) {
+                              int32_t backward, int32_t R, int32_t src_group_stride, void* stream) {
   if (!src || !A || !dst) return MSGAT_ERR_NULL;
   int st = check_rows(G, Co, K, N, T);
   if (st) return st;
   if (R <= 0 || G % R) return MSGAT_ERR_SHAPE;
+  if (src_group_stride != 0 && (!backward || src_group_stride < Co || src_group_stride > 4 * kMaxC)) return MSGAT_ERR_SHAPE;
   return launch_tmix(src, A, a_per_group, backward ? nullptr : bias, dst, G, Co, K, N, T, backward, R,
-                     (hipStream_t)stream);
+                     (hipStream_t)stream, src_group_stride);
 }
 
 extern "C" size_t msgat_time_mix_partial_floats(int32_t G, int32_t K, int32_t T) {
@@ -257,27 +258,30 @@ extern "C" size_t msgat_time_mix_partial_floats(int32_t G, int32_t K, int32_t T)
 }
 
 extern "C" int msgat_time_mix_grad_matrix(const float* dout, const float* y, float* dA, float* partials,
-                                          int32_t G, int32_t Co, int32_t K, int32_t N, int32_t T, void* stream) {
+                                          int32_t G, int32_t Co, int32_t K, int32_t N, int32_t T,
+                                          int32_t dout_group_stride, void* stream) {
   if (!dout || !y || !dA || !partials) return MSGAT_ERR_NULL;
   int st = check_rows(G, Co, K, N, T);
   if (st) return st;
-  return launch_tmix_dA(dout, y, dA, partials, G, Co, K, N, T, (hipStream_t)stream);
+  if (dout_group_stride != 0 && (dout_group_stride < Co || dout_group_stride > 4 * kMaxC)) return MSGAT_ERR_SHAPE;
+  return launch_tmix_dA(dout, y, dA, partials, G, Co, K, N, T, (hipStream_t)stream, dout_group_stride);
 }
 
 extern "C" int msgat_node_pool(const float* x, const float* w, float* pooled, int64_t slabs, int32_t N, int32_t T,
-                               int32_t R, void* stream) {
+                               int32_t R, int32_t channels, int32_t group_stride, void* stream) {
   if (!x || !w || !pooled) return MSGAT_ERR_NULL;
   if (slabs <= 0 || slabs > 0x7fffffff || N <= 0 || R <= 0 || slabs % R) return MSGAT_ERR_SHAPE;
   if (!t_supported(T)) return MSGAT_ERR_UNSUPPORTED;
-  return launch_node_pool(x, w, pooled, slabs, N, T, R, (hipStream_t)stream);
+  if (channels < 0 || (channels > 0 && (slabs % channels || group_stride < channels))) return MSGAT_ERR_SHAPE;
+  return launch_node_pool(x, w, pooled, slabs, N, T, R, (hipStream_t)stream, channels, group_stride);
 }
 
-extern "C" int msgat_node_pool_grad_signal(const float* w, const float* dpooled, float* dx, int64_t slabs,
-                                           int32_t N, int32_t T, int32_t R, void* stream) {
+extern "C" int msgat_node_pool_grad_signal(const float* w, const float* dpooled, const float* dx_add, float* dx,
+                                           int64_t slabs, int32_t N, int32_t T, int32_t R, void* stream) {
   if (!w || !dpooled || !dx) return MSGAT_ERR_NULL;
   if (slabs <= 0 || slabs > 0x7fffffff || N <= 0 || R <= 0 || slabs % R) return MSGAT_ERR_SHAPE;
   if (!t_supported(T)) return MSGAT_ERR_UNSUPPORTED;
-  return launch_node_pool_dx(w, dpooled, dx, slabs, N, T, R, (hipStream_t)stream);
+  return launch_node_pool_dx(w, dpooled, dx_add, dx, slabs, N, T, R, (hipStream_t)stream);
 }
 
 extern "C" size_t msgat_node_pool_partial_floats(int32_t G, int32_t C, int32_t N) {

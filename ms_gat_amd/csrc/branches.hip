@@ -44,7 +44,9 @@ __device__ __forceinline__ void st_row(float* __restrict__ p, const float (&v)[T
 template <int T, int K, bool BWD>
 __global__ __launch_bounds__(kBlock) void k_tmix(const float* __restrict__ src, const float* __restrict__ A,
                                                  int a_gstride, const float* __restrict__ bias, int Bg,
-                                                 float* __restrict__ dst, int Co, int N) {
+                                                 float* __restrict__ dst, int Co, int N, int src_gs) {
+  // src_gs: channels per group of the tensor src is a channel slice of (backward form: the incoming gradient is a
+  // slice [:, a:b] of the block's concatenated gradient, read in place)
   __shared__ float Al[K][T][T];
   const int g = blockIdx.y;
   for (int i = threadIdx.x; i < K * T * T; i += kBlock) {
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(kBlock) void k_tmix(const float* __restrict__ src, 
     st_row<T>(dst + ((size_t)g * Co * N + rr) * T, acc);
   } else {
     float v[T];
-    ld_row<T>(src + ((size_t)g * Co * N + rr) * T, v);
+    ld_row<T>(src + ((size_t)g * src_gs * N + rr) * T, v);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       float acc[T];
@@ -90,31 +92,32 @@ __global__ __launch_bounds__(kBlock) void k_tmix(const float* __restrict__ src, 
 
 template <int T, int K>
 static int launch_tmix_tk(const float* src, const float* A, int per_group, const float* bias, float* dst, int G,
-                          int Co, int N, int backward, int Bg, hipStream_t s) {
+                          int Co, int N, int backward, int Bg, int src_gs, hipStream_t s) {
   dim3 grid(cdiv(Co * N, kBlock), G);
   const int gs = per_group ? K * T * T : 0;
-  if (backward) hipLaunchKernelGGL((k_tmix<T, K, true>), grid, dim3(kBlock), 0, s, src, A, gs, bias, Bg, dst, Co, N);
-  else hipLaunchKernelGGL((k_tmix<T, K, false>), grid, dim3(kBlock), 0, s, src, A, gs, bias, Bg, dst, Co, N);
+  if (backward) hipLaunchKernelGGL((k_tmix<T, K, true>), grid, dim3(kBlock), 0, s, src, A, gs, bias, Bg, dst, Co, N, src_gs);
+  else hipLaunchKernelGGL((k_tmix<T, K, false>), grid, dim3(kBlock), 0, s, src, A, gs, bias, Bg, dst, Co, N, src_gs);
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
 
 template <int T>
 static int launch_tmix_t(const float* src, const float* A, int per_group, const float* bias, float* dst, int G,
-                         int Co, int K, int N, int backward, int Bg, hipStream_t s) {
-  if (K == 1) return launch_tmix_tk<T, 1>(src, A, per_group, bias, dst, G, Co, N, backward, Bg, s);
-  if (K == 2) return launch_tmix_tk<T, 2>(src, A, per_group, bias, dst, G, Co, N, backward, Bg, s);
+                         int Co, int K, int N, int backward, int Bg, int src_gs, hipStream_t s) {
+  if (K == 1) return launch_tmix_tk<T, 1>(src, A, per_group, bias, dst, G, Co, N, backward, Bg, src_gs, s);
+  if (K == 2) return launch_tmix_tk<T, 2>(src, A, per_group, bias, dst, G, Co, N, backward, Bg, src_gs, s);
   return MSGAT_ERR_UNSUPPORTED;
 }
 
 int launch_tmix(const float* src, const float* A, int per_group, const float* bias, float* dst, int G, int Co,
-                int K, int N, int T, int backward, int R, hipStream_t s) {
+                int K, int N, int T, int backward, int R, hipStream_t s, int src_gs) {
   const int Bg = G / R;
+  if (src_gs <= 0 || !backward) src_gs = Co;
   switch (T) {
-    case 4: return launch_tmix_t<4>(src, A, per_group, bias, dst, G, Co, K, N, backward, Bg, s);
-    case 8: return launch_tmix_t<8>(src, A, per_group, bias, dst, G, Co, K, N, backward, Bg, s);
-    case 12: return launch_tmix_t<12>(src, A, per_group, bias, dst, G, Co, K, N, backward, Bg, s);
-    case 16: return launch_tmix_t<16>(src, A, per_group, bias, dst, G, Co, K, N, backward, Bg, s);
+    case 4: return launch_tmix_t<4>(src, A, per_group, bias, dst, G, Co, K, N, backward, Bg, src_gs, s);
+    case 8: return launch_tmix_t<8>(src, A, per_group, bias, dst, G, Co, K, N, backward, Bg, src_gs, s);
+    case 12: return launch_tmix_t<12>(src, A, per_group, bias, dst, G, Co, K, N, backward, Bg, src_gs, s);
+    case 16: return launch_tmix_t<16>(src, A, per_group, bias, dst, G, Co, K, N, backward, Bg, src_gs, s);
   }
   return MSGAT_ERR_UNSUPPORTED;
 }
@@ -127,7 +130,7 @@ constexpr int kTmixChunks = 4;
 
 template <int T>
 __global__ __launch_bounds__(kBlock) void k_tmix_dA(const float* __restrict__ dout, const float* __restrict__ y,
-                                                    float* __restrict__ part, int Co, int K, int N) {
+                                                    float* __restrict__ part, int Co, int K, int N, int dout_gs) {
   __shared__ float red[kBlock / kWave][T * T];
   const int g = blockIdx.z, k = blockIdx.y;
   const int rows = Co * N;
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(kBlock) void k_tmix_dA(const float* __restrict__ do
   for (int t = 0; t < T; ++t)
 #pragma unroll
     for (int i = 0; i < T; ++i) acc[t][i] = 0.f;
-  const float* dbase = dout + (size_t)g * rows * T;
+  const float* dbase = dout + (size_t)g * dout_gs * N * T;  // dout may be a channel slice of a wider tensor
   const float* ybase = y + ((size_t)g * K + k) * rows * T;
   for (int rr = r0 + threadIdx.x; rr < r1; rr += kBlock) {
     float dv[T], yv[T];
@@ -168,13 +171,14 @@ __global__ __launch_bounds__(kBlock) void k_tmix_dA(const float* __restrict__ do
 size_t tmix_partial_floats(int G, int K, int T) { return (size_t)G * K * kTmixChunks * T * T; }
 
 int launch_tmix_dA(const float* dout, const float* y, float* dA, float* part, int G, int Co, int K, int N, int T,
-                   hipStream_t s) {
+                   hipStream_t s, int dout_gs) {
+  if (dout_gs <= 0) dout_gs = Co;
   dim3 grid(kTmixChunks, K, G);
   switch (T) {
-    case 4: hipLaunchKernelGGL(k_tmix_dA<4>, grid, dim3(kBlock), 0, s, dout, y, part, Co, K, N); break;
-    case 8: hipLaunchKernelGGL(k_tmix_dA<8>, grid, dim3(kBlock), 0, s, dout, y, part, Co, K, N); break;
-    case 12: hipLaunchKernelGGL(k_tmix_dA<12>, grid, dim3(kBlock), 0, s, dout, y, part, Co, K, N); break;
-    case 16: hipLaunchKernelGGL(k_tmix_dA<16>, grid, dim3(kBlock), 0, s, dout, y, part, Co, K, N); break;
+    case 4: hipLaunchKernelGGL(k_tmix_dA<4>, grid, dim3(kBlock), 0, s, dout, y, part, Co, K, N, dout_gs); break;
+    case 8: hipLaunchKernelGGL(k_tmix_dA<8>, grid, dim3(kBlock), 0, s, dout, y, part, Co, K, N, dout_gs); break;
+    case 12: hipLaunchKernelGGL(k_tmix_dA<12>, grid, dim3(kBlock), 0, s, dout, y, part, Co, K, N, dout_gs); break;
+    case 16: hipLaunchKernelGGL(k_tmix_dA<16>, grid, dim3(kBlock), 0, s, dout, y, part, Co, K, N, dout_gs); break;
     default: return MSGAT_ERR_UNSUPPORTED;
   }
   MSGAT_CHECK_LAUNCH();
@@ -185,16 +189,18 @@ int launch_tmix_dA(const float* dout, const float* y, float* dA, float* part, in
 // pooled[s,t] = sum_n w[n] x[s,n,t] for every (sample, channel) slab s (attention.py:89).
 template <int T>
 __global__ __launch_bounds__(kBlock) void k_node_pool(const float* __restrict__ x, const float* __restrict__ w,
-                                                      float* __restrict__ pooled, int N, int spr) {
+                                                      float* __restrict__ pooled, int N, int spr, int C, int gs) {
   __shared__ float red[kBlock / kWave][T];
   const size_t sl = blockIdx.x;
   w += (size_t)(blockIdx.x / spr) * N;  // weights [R,N]: spr slabs per relation
+  // C > 0: slab (g, c) of a channel slice of a [G, gs, N, T] tensor, read in place
+  const size_t xs = (C > 0) ? (size_t)(blockIdx.x / C) * gs + (blockIdx.x % C) : sl;
   float acc[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) acc[t] = 0.f;
   for (int n = threadIdx.x; n < N; n += kBlock) {
     float v[T];
-    ld_row<T>(x + (sl * N + n) * T, v);
+    ld_row<T>(x + (xs * N + n) * T, v);
     const float wn = w[n];
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = fmaf(wn, v[t], acc[t]);
@@ -213,18 +219,25 @@ __global__ __launch_bounds__(kBlock) void k_node_pool(const float* __restrict__ 
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-// dx[s,n,t] = w[n] dpooled[s,t]
+// dx[s,n,t] = w[n] dpooled[s,t] (+ add[s,n,t]: the gradient that reached x along its other path)
 template <int T>
 __global__ __launch_bounds__(kBlock) void k_node_pool_dx(const float* __restrict__ w, const float* __restrict__ dp,
-                                                         float* __restrict__ dx, int N, int spr) {
+                                                         const float* __restrict__ add, float* __restrict__ dx, int N,
+                                                         int spr) {
   const size_t sl = blockIdx.x;
   w += (size_t)(blockIdx.x / spr) * N;
   const int n = blockIdx.y * kBlock + threadIdx.x;
   if (n >= N) return;
   float v[T];
   const float wn = w[n];
+  if (add != nullptr) {
+    ld_row<T>(add + (sl * N + n) * T, v);
 #pragma unroll
-  for (int t = 0; t < T; ++t) v[t] = wn * dp[sl * T + t];
+    for (int t = 0; t < T; ++t) v[t] = fmaf(wn, dp[sl * T + t], v[t]);
+  } else {
+#pragma unroll
+    for (int t = 0; t < T; ++t) v[t] = wn * dp[sl * T + t];
+  }
   st_row<T>(dx + (sl * N + n) * T, v);
 }
 
@@ -252,29 +265,29 @@ __global__ __launch_bounds__(kBlock) void k_node_pool_dw(const float* __restrict
 }
 
 int launch_node_pool(const float* x, const float* w, float* pooled, long long slabs, int N, int T, int R,
-                     hipStream_t s) {
+                     hipStream_t s, int C, int gs) {
   dim3 grid((unsigned)slabs);
   const int spr = (int)(slabs / R);
   switch (T) {
-    case 4: hipLaunchKernelGGL(k_node_pool<4>, grid, dim3(kBlock), 0, s, x, w, pooled, N, spr); break;
-    case 8: hipLaunchKernelGGL(k_node_pool<8>, grid, dim3(kBlock), 0, s, x, w, pooled, N, spr); break;
-    case 12: hipLaunchKernelGGL(k_node_pool<12>, grid, dim3(kBlock), 0, s, x, w, pooled, N, spr); break;
-    case 16: hipLaunchKernelGGL(k_node_pool<16>, grid, dim3(kBlock), 0, s, x, w, pooled, N, spr); break;
+    case 4: hipLaunchKernelGGL(k_node_pool<4>, grid, dim3(kBlock), 0, s, x, w, pooled, N, spr, C, gs); break;
+    case 8: hipLaunchKernelGGL(k_node_pool<8>, grid, dim3(kBlock), 0, s, x, w, pooled, N, spr, C, gs); break;
+    case 12: hipLaunchKernelGGL(k_node_pool<12>, grid, dim3(kBlock), 0, s, x, w, pooled, N, spr, C, gs); break;
+    case 16: hipLaunchKernelGGL(k_node_pool<16>, grid, dim3(kBlock), 0, s, x, w, pooled, N, spr, C, gs); break;
     default: return MSGAT_ERR_UNSUPPORTED;
   }
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
 
-int launch_node_pool_dx(const float* w, const float* dp, float* dx, long long slabs, int N, int T, int R,
-                        hipStream_t s) {
+int launch_node_pool_dx(const float* w, const float* dp, const float* add, float* dx, long long slabs, int N, int T,
+                        int R, hipStream_t s) {
   dim3 grid((unsigned)slabs, cdiv(N, kBlock));
   const int spr = (int)(slabs / R);
   switch (T) {
-    case 4: hipLaunchKernelGGL(k_node_pool_dx<4>, grid, dim3(kBlock), 0, s, w, dp, dx, N, spr); break;
-    case 8: hipLaunchKernelGGL(k_node_pool_dx<8>, grid, dim3(kBlock), 0, s, w, dp, dx, N, spr); break;
-    case 12: hipLaunchKernelGGL(k_node_pool_dx<12>, grid, dim3(kBlock), 0, s, w, dp, dx, N, spr); break;
-    case 16: hipLaunchKernelGGL(k_node_pool_dx<16>, grid, dim3(kBlock), 0, s, w, dp, dx, N, spr); break;
+    case 4: hipLaunchKernelGGL(k_node_pool_dx<4>, grid, dim3(kBlock), 0, s, w, dp, add, dx, N, spr); break;
+    case 8: hipLaunchKernelGGL(k_node_pool_dx<8>, grid, dim3(kBlock), 0, s, w, dp, add, dx, N, spr); break;
+    case 12: hipLaunchKernelGGL(k_node_pool_dx<12>, grid, dim3(kBlock), 0, s, w, dp, add, dx, N, spr); break;
+    case 16: hipLaunchKernelGGL(k_node_pool_dx<16>, grid, dim3(kBlock), 0, s, w, dp, add, dx, N, spr); break;
     default: return MSGAT_ERR_UNSUPPORTED;
   }
   MSGAT_CHECK_LAUNCH();

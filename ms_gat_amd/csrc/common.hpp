@@ -232,14 +232,14 @@ int launch_reduce_rows(const float* part, int J, int Wd, float* dst0, int n0, fl
 int launch_reduce_groups(const float* part, int R, int J, int Wd, float* dst, hipStream_t s);
 // temporal / channel branch kernels (branches.hip)
 int launch_tmix(const float* src, const float* A, int per_group, const float* bias, float* dst, int G, int Co,
-                int K, int N, int T, int backward, int R, hipStream_t s);
+                int K, int N, int T, int backward, int R, hipStream_t s, int src_gs = 0);
 size_t tmix_partial_floats(int G, int K, int T);
 int launch_tmix_dA(const float* dout, const float* y, float* dA, float* part, int G, int Co, int K, int N, int T,
-                   hipStream_t s);
+                   hipStream_t s, int dout_gs = 0);
 int launch_node_pool(const float* x, const float* w, float* pooled, long long slabs, int N, int T, int R,
-                     hipStream_t s);
-int launch_node_pool_dx(const float* w, const float* dp, float* dx, long long slabs, int N, int T, int R,
-                        hipStream_t s);
+                     hipStream_t s, int C = 0, int gs = 0);
+int launch_node_pool_dx(const float* w, const float* dp, const float* add, float* dx, long long slabs, int N, int T,
+                        int R, hipStream_t s);
 size_t node_pool_partial_floats(int G, int C, int N);
 int launch_node_pool_dw(const float* x, const float* dp, float* dw, float* part, int G, int C, int N, int T, int R,
                         hipStream_t s);

@@ -292,7 +292,9 @@ def _channel_sums(t: torch.Tensor, R: int = 0) -> torch.Tensor:
     if ones is None:
         ones = _ones_cache[key] = torch.ones(N, device=t.device, dtype=torch.float32)
     pooled = _new(t, G, Cc, T)
-    st = _lib.lib().msgat_node_pool(_ptr(t), _ptr(ones), _ptr(pooled), G * Cc, N, T, 1, _stream_handle(t.device))
+    keep, seg = _as_segment(t)                    # a channel slice of a wider gradient tensor is read in place
+    st = _lib.lib().msgat_node_pool(seg.ptr, _ptr(ones), _ptr(pooled), G * Cc, N, T, 1, Cc if seg.group_stride else 0,
+                                    seg.group_stride, _stream_handle(t.device))
     _lib.check(st, "msgat_node_pool")
     if R > 0:
         return pooled.view(R, G // R, Cc, T).sum(dim=(1, 3))
@@ -376,7 +378,7 @@ class _TimeMixFunction(torch.autograd.Function):
         out = _new(y, G, Co, N, T)
         b = None if bias is None else bias.contiguous()
         Rb = 1 if b is None or b.dim() == 1 else b.shape[0]     # bias [Co] or [R,Co]
-        st = L.msgat_time_mix(_ptr(y), _ptr(A), per_group, _ptr(b), _ptr(out), G, Co, K, N, T, 0, Rb,
+        st = L.msgat_time_mix(_ptr(y), _ptr(A), per_group, _ptr(b), _ptr(out), G, Co, K, N, T, 0, Rb, 0,
                               _stream_handle(y.device))
         _lib.check(st, "msgat_time_mix")
         ctx.dims, ctx.per_group, ctx.has_bias = (G, Co, K, N, T), per_group, bias is not None
@@ -389,18 +391,20 @@ class _TimeMixFunction(torch.autograd.Function):
         L = _lib.lib()
         y, A = ctx.saved_tensors
         G, Co, K, N, T = ctx.dims
-        dout = dout.contiguous()
+        dout, seg = _as_segment(dout)              # a channel slice of the block's concatenated gradient is read in place
         stream = _stream_handle(y.device)
         need = ctx.needs_input_grad
         dy = dA = dbias = None
         if need[0]:
             dy = torch.empty_like(y)
-            st = L.msgat_time_mix(_ptr(dout), _ptr(A), ctx.per_group, None, _ptr(dy), G, Co, K, N, T, 1, 1, stream)
+            st = L.msgat_time_mix(seg.ptr, _ptr(A), ctx.per_group, None, _ptr(dy), G, Co, K, N, T, 1, 1, seg.group_stride,
+                                  stream)
             _lib.check(st, "msgat_time_mix (backward)")
         if need[1]:
             dAg = _new(y, G, K, T, T)
             part = _new(y, max(int(L.msgat_time_mix_partial_floats(G, K, T)), 1))
-            st = L.msgat_time_mix_grad_matrix(_ptr(dout), _ptr(y), _ptr(dAg), _ptr(part), G, Co, K, N, T, stream)
+            st = L.msgat_time_mix_grad_matrix(seg.ptr, _ptr(y), _ptr(dAg), _ptr(part), G, Co, K, N, T, seg.group_stride,
+                                              stream)
             _lib.check(st, "msgat_time_mix_grad_matrix")
             dA = dAg if A.shape[0] == G else dAg.sum(dim=0, keepdim=True)
         if ctx.has_bias and need[2]:
@@ -431,7 +435,7 @@ class _NodePoolFunction(torch.autograd.Function):
         B, Cc, N, T = x.shape
         pooled = _new(x, B, Cc, T)
         R = w.numel() // N                                   # weights [N] or [R,N]
-        st = L.msgat_node_pool(_ptr(x), _ptr(w), _ptr(pooled), B * Cc, N, T, R, _stream_handle(x.device))
+        st = L.msgat_node_pool(_ptr(x), _ptr(w), _ptr(pooled), B * Cc, N, T, R, 0, 0, _stream_handle(x.device))
         _lib.check(st, "msgat_node_pool")
         ctx.save_for_backward(x, w)
         return pooled
@@ -447,7 +451,7 @@ class _NodePoolFunction(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _lib.check(L.msgat_node_pool_grad_signal(_ptr(w), _ptr(dp), _ptr(dx), B * Cc, N, T, R, stream),
+            _lib.check(L.msgat_node_pool_grad_signal(_ptr(w), _ptr(dp), None, _ptr(dx), B * Cc, N, T, R, stream),
                        "msgat_node_pool_grad_signal")
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
@@ -455,6 +459,59 @@ class _NodePoolFunction(torch.autograd.Function):
             _lib.check(L.msgat_node_pool_grad_weight(_ptr(x), _ptr(dp), _ptr(dw), _ptr(part), B, Cc, N, T, R, stream),
                        "msgat_node_pool_grad_weight")
         return dx, dw
+
+
+class _NodePoolTeeFunction(torch.autograd.Function):
+    """x, w -> (node_pool(x, w), x): like `_LayerNormTeeFunction`, for the activation that is pooled AND read by another
+    consumer (MEAM's normalised input feeds the channel attention's pooling and the channel-mixing pass): the other
+    consumer's gradient comes back through the second output and joins inside the pooling's backward kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        L = _lib.lib()
+        x, w = x.contiguous(), w.contiguous()
+        B, Cc, N, T = x.shape
+        pooled = _new(x, B, Cc, T)
+        R = w.numel() // N
+        st = L.msgat_node_pool(_ptr(x), _ptr(w), _ptr(pooled), B * Cc, N, T, R, 0, 0, _stream_handle(x.device))
+        _lib.check(st, "msgat_node_pool")
+        ctx.save_for_backward(x, w)
+        return pooled, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dp, dx_other):
+        L = _lib.lib()
+        x, w = ctx.saved_tensors
+        B, Cc, N, T = x.shape
+        stream = _stream_handle(x.device)
+        R = w.numel() // N
+        if dp is None:
+            return dx_other, None
+        dp = dp.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            other = None if dx_other is None else dx_other.contiguous()
+            dx = torch.empty_like(x)
+            _lib.check(L.msgat_node_pool_grad_signal(_ptr(w), _ptr(dp), _ptr(other), _ptr(dx), B * Cc, N, T, R, stream),
+                       "msgat_node_pool_grad_signal")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            part = _new(x, max(int(L.msgat_node_pool_partial_floats(B, Cc, N)), 1))
+            _lib.check(L.msgat_node_pool_grad_weight(_ptr(x), _ptr(dp), _ptr(dw), _ptr(part), B, Cc, N, T, R, stream),
+                       "msgat_node_pool_grad_weight")
+        return dx, dw
+
+
+def node_pool_tee(x: torch.Tensor, w: torch.Tensor):
+    """(node_pool(x, w), x): use the second value for the other consumer of x."""
+    pooled_only = not x.requires_grad
+    if pooled_only:
+        return node_pool(x, w), x
+    _require_device_tensor("signals", x)
+    _require_device_tensor("weights", w, x.device)
+    if x.dim() != 4 or w.shape[-1] != x.shape[2] or w.dim() > 2 or (w.dim() == 2 and x.shape[0] % w.shape[0]):
+        raise ValueError(f"node_pool: signals {tuple(x.shape)}, weights {tuple(w.shape)}")
+    return _NodePoolTeeFunction.apply(x, w)
 
 
 def node_pool(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
@@ -556,7 +613,16 @@ class _HeadFunction(torch.autograd.Function):
             if W.dim() == 4:
                 dW = dW[0]
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dout.view(R, B // R, N, To).sum(dim=(1, 2)) if W.dim() == 5 else dout.sum(dim=(0, 1))
+            if To in (4, 8, 12, 16):   # one streaming pass over dout (node pooling with unit weights), then a tiny sum
+                key = (dout.device, N)
+                ones = _ones_cache.get(key)
+                if ones is None:
+                    ones = _ones_cache[key] = torch.ones(N, device=dout.device, dtype=torch.float32)
+                pooled = _new(dout, B, To)
+                _lib.check(L.msgat_node_pool(_ptr(dout), _ptr(ones), _ptr(pooled), B, N, To, 1, 0, 0, stream), "msgat_node_pool")
+                db = pooled.view(R, B // R, To).sum(dim=1) if W.dim() == 5 else pooled.sum(dim=0)
+            else:
+                db = dout.view(R, B // R, N, To).sum(dim=(1, 2)) if W.dim() == 5 else dout.sum(dim=(0, 1))
         return dx, dW, db
 
 

@@ -126,7 +126,9 @@ def _meam(P, prefix: str, m0, x: torch.Tensor, adjacency, R: int, B: int, relu_i
     # CACN's per-sample channel matrix conv @ softmax(p Wc p^T) (attention.py:90-92, msgat.py:93-94): one launch
     conv_w = P(prefix + "cacn.seq.1.weight")[:, :, :, 0, 0]                            # [R,cb,C]
     conv_b = P(prefix + "cacn.seq.1.bias")                                             # [R,cb]
-    Mc = ops.channel_attention_mix(ops.node_pool(normed, P(prefix + "cacn.seq.0.alpha")), P(prefix + "cacn.seq.0.Wc"), conv_w)
+    # (pooled, normed): the mixing passes below read `normed` too; their gradient joins inside the pooling's backward
+    pooled_c, normed = ops.node_pool_tee(normed, P(prefix + "cacn.seq.0.alpha"))
+    Mc = ops.channel_attention_mix(pooled_c, P(prefix + "cacn.seq.0.Wc"), conv_w)
     Wg, alpha_g, W_g = P(prefix + "gacn.gatt.Wg"), P(prefix + "gacn.gatt.alpha"), P(prefix + "gacn.W")
     alpha_t = P(prefix + "tacn.seq.0.alpha")
     d0 = m0.dilations[0] if m0.dilations else 0
