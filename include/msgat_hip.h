@@ -71,7 +71,10 @@ enum {
  *     entry (slice s, k-th edge, lane l)  at position  slice_off[s] + 256 (k / 4) + 4 l + k % 4
  * so lane l reads its edges 4t .. 4t+3 with ONE coalesced 16-B-per-lane load per array (1 KiB per
  * wave instruction): no dependent address, no mask (padding entries carry coefficient 0).
- * Sorting makes the degrees inside a slice nearly equal, so the padding is a few percent.
+ * Sorting makes the degrees inside a slice nearly equal, so the padding is a few percent.  WHICH of a row's
+ * edges is its k-th is the builder's choice: it fills every column so that the 16 lanes a ds_read_b128
+ * serves together gather from different LDS bank quads where the graph allows (a bipartite matching per
+ * column; 11.5 -> 6.5 LDS cycles per gather instruction at the stress graph).
  * Built on the host by msgat_graph_sell_build().  n_slices == 0: absent (the CSR kernels run). */
 #define MSGAT_SELL_SLACK 512 /* idx (and every per-position buffer) carries this many readable trailing entries */
 typedef struct msgat_sell {
