@@ -508,6 +508,142 @@ __global__ __launch_bounds__(kBlock) void k_sddmm(
   }
 }
 
+// ---- backward aggregate + SDDMM in one pass over dv (PROJ_FIRST) ------------------------------------------------
+//   du[g,c,m,:] = sum_{k into m} Ec[g,k] dv[g,c,crow[k],:]      dEp[g,chunk,k] = sum_{c,t} dv[g,c,crow[k],t] u[g,c,m,t]
+// Both walk the same pairs (column m, CSC edge k) and both want the dv slab in LDS for the random side, so one block
+// stages the slab once, and lane (m, j) -- which already holds dv[crow[k]][4j..4j+3] for the gather -- dots it with
+// its own u[m][4j..4j+3] (one coalesced float4, the mirror image of the du store).  Against k_agg_lds + k_sddmm
+// this reads dv once instead of twice: 3 slab units of HBM traffic instead of 4.  The T/4 lanes of a column leave
+// their shares of an edge's dot in LDS (lane-private entries, no atomics); after a barrier lane k adds them in a
+// fixed order and stores the chunk's partial in CSC order (k_edge_grad_csc maps it back through cperm).
+template <int T4, bool FIRST>
+__device__ __forceinline__ float4 gather_row_dot(const int* __restrict__ idx, const float* __restrict__ Eg, int e0,
+                                                 int e1, int nnz, const float4* rows, int j, const float4& own,
+                                                 float* __restrict__ pd, int dummy) {
+  float4 acc = f4zero();
+  // branch-free: an edge slot outside the column's range multiplies by 0 and parks its dot in the lane's dummy
+  // entry -- a branch per edge would put every LDS row read in its own basic block, one LDS round trip after another
+  auto edge = [&](int k, bool valid, float w, const float4& r) {
+    f4fma(valid ? w : 0.f, r, acc);
+    const float d = f4dot(r, own, 0.f);
+    const int a = valid ? k * T4 + j : dummy;
+    pd[a] = FIRST ? d : pd[a] + d;
+  };
+  const int b0 = min(e0, nnz - 8);  // nnz >= 8 (launch condition)
+  const int4u m0 = *reinterpret_cast<const int4u*>(idx + b0);
+  const int4u m1 = *reinterpret_cast<const int4u*>(idx + b0 + 4);
+  const float4u w0 = *reinterpret_cast<const float4u*>(Eg + b0);
+  const float4u w1 = *reinterpret_cast<const float4u*>(Eg + b0 + 4);
+  {  // four LDS rows in flight at a time: eight cost the second resident block its registers
+    float4 ra[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ra[k] = rows[m0.v[k] * T4 + j];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) edge(b0 + k, b0 + k >= e0 && b0 + k < e1, w0.v[k], ra[k]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    float4 rb[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rb[k] = rows[m1.v[k] * T4 + j];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) edge(b0 + 4 + k, b0 + 4 + k >= e0 && b0 + 4 + k < e1, w1.v[k], rb[k]);
+  }
+  for (int e = b0 + 8; e < e1; e += 4) {  // columns with more than 8 edges
+    const int b = min(e, nnz - 4);
+    const int4u m = *reinterpret_cast<const int4u*>(idx + b);
+    const float4u w = *reinterpret_cast<const float4u*>(Eg + b);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) edge(b + k, b + k >= e && b + k < e1, w.v[k], rows[m.v[k] * T4 + j]);
+  }
+  return acc;
+}
+
+// 768 lanes: the branch-free gather needs 72 registers, and 12 waves per block keep TWO blocks resident per CU
+// (one streams its slab while the other gathers): 67.8 us against 77.4 us with 1024 lanes (one resident block)
+constexpr int kAgsBlock = 768;
+
+template <int T4>
+__global__ __launch_bounds__(kAgsBlock) void k_agg_sddmm(
+    const int* __restrict__ ptr, const int* __restrict__ idx, const float4* __restrict__ dv4,
+    const float* __restrict__ Ec, const float4* __restrict__ u4, float4* __restrict__ du4,
+    float* __restrict__ dEp, int Cu, int N, int nnz, int CH, int nchunks) {
+  extern __shared__ float4 slab[];  // [CH][N][T4] of dv, then nnz * T4 floats of per-edge shares + a dummy per lane
+  const int g = blockIdx.y;
+  const int kc = blockIdx.x;
+  const int c0 = kc * CH;
+  const int ch = min(CH, Cu - c0);
+  const int NT4 = N * T4;
+  const size_t base = ((size_t)g * Cu + c0) * NT4;
+  const int total = ch * NT4;
+  float* pd = reinterpret_cast<float*>(slab + CH * NT4);
+  const int dummy = nnz * T4 + threadIdx.x;
+
+  for (int i = threadIdx.x; i < total; i += kAgsBlock) slab[i] = dv4[base + i];
+  __syncthreads();
+
+  const float* Eg = Ec + (size_t)g * nnz;
+  for (int s = threadIdx.x; s < NT4; s += kAgsBlock) {
+    const int n = s / T4;
+    const int j = s - n * T4;
+    const int e0 = ptr[n], e1 = ptr[n + 1];
+    du4[base + s] = gather_row_dot<T4, true>(idx, Eg, e0, e1, nnz, slab, j, u4[base + s], pd, dummy);
+    for (int c = 1; c < ch; ++c) {
+      const float4 own = u4[base + (size_t)c * NT4 + s];
+      du4[base + (size_t)c * NT4 + s] = gather_row_dot<T4, false>(idx, Eg, e0, e1, nnz, slab + c * NT4, j, own, pd, dummy);
+    }
+  }
+  __syncthreads();
+  float* out = dEp + ((size_t)g * nchunks + kc) * nnz;
+  for (int k = threadIdx.x; k < nnz; k += kAgsBlock) {
+    float a = pd[k * T4];
+#pragma unroll
+    for (int j = 1; j < T4; ++j) a += pd[k * T4 + j];
+    out[k] = a;
+  }
+}
+
+static size_t agg_sddmm_lds(int N, int T, int Cu, int nnz) {
+  const int CH = slab_channels(N, T, Cu, kLdsBudget);
+  return (size_t)CH * N * T * sizeof(float) + ((size_t)nnz * (T / 4) + kAgsBlock) * sizeof(float);
+}
+
+// the fused pass needs a CSC graph whose slab + per-edge shares leave room for two blocks per CU
+bool agg_sddmm_fusable(const msgat_graph_t& gr, int N, int T, int Cu) {
+  if (gr.nnz < 8 || sell_usable(gr.sell_rows, gr.nnz, N, T) || sell_usable(gr.sell_cols, gr.nnz, N, T)) return false;
+  if (slab_channels(N, T, Cu, kLdsBudget) < 1) return false;
+  return agg_sddmm_lds(N, T, Cu, gr.nnz) <= (size_t)(kLdsMax / 2);
+}
+
+template <int T4>
+static int launch_agg_sddmm_t(const msgat_graph_t& gr, const float* dv, const float* Ec, const float* u, float* du,
+                              float* dEp, int G, int Cu, int N, hipStream_t s) {
+  const int T = 4 * T4;
+  const int CH = slab_channels(N, T, Cu, kLdsBudget);
+  const size_t lds = agg_sddmm_lds(N, T, Cu, gr.nnz);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_sddmm<T4>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
+  }
+  const int nchunks = cdiv(Cu, CH);
+  hipLaunchKernelGGL(k_agg_sddmm<T4>, dim3(nchunks, G), dim3(kAgsBlock), lds, s, gr.colptr, gr.crow, (const float4*)dv,
+                     Ec, (const float4*)u, (float4*)du, dEp, Cu, N, gr.nnz, CH, nchunks);
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
+}
+
+int launch_agg_sddmm(const msgat_graph_t& gr, const float* dv, const float* Ec, const float* u, float* du, float* dEp,
+                     int G, int Cu, int N, int T, hipStream_t s) {
+  switch (T) {
+    case 4: return launch_agg_sddmm_t<1>(gr, dv, Ec, u, du, dEp, G, Cu, N, s);
+    case 8: return launch_agg_sddmm_t<2>(gr, dv, Ec, u, du, dEp, G, Cu, N, s);
+    case 12: return launch_agg_sddmm_t<3>(gr, dv, Ec, u, du, dEp, G, Cu, N, s);
+    case 16: return launch_agg_sddmm_t<4>(gr, dv, Ec, u, du, dEp, G, Cu, N, s);
+  }
+  return MSGAT_ERR_UNSUPPORTED;
+}
+
 // ---- SDDMM on the SELL layout: one 4-timestep column of u in LDS per pass -------------------------------------
 // Block (chunk kc, group g) walks its channels x T/4 columns; per pass it stages column j of u[c] and every
 // lane (= row, through lane_row) dots its dv[c,row,4j..4j+3] against the staged entries of its row's

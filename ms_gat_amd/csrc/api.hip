@@ -567,9 +567,19 @@ extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t*
     dv = dvb;
   }
 
-  st = launch_sddmm(*gr, u, dv, dEp, G, p.Cu, N, T, s);
+  // PROJ_FIRST: du = E^T dz does not wait for dq, and it walks the same (column, edge) pairs over the same dz slabs
+  // as the SDDMM -- one pass does both when the graph allows (CSC, slab + edge shares within half the LDS)
+  const bool fused = p.mode == MSGAT_MODE_PROJ_FIRST && agg_sddmm_fusable(*gr, N, T, p.Cu);
+  if (fused) {
+    st = launch_permute_edges(io->E, gr->cperm, Ec, G, gr->nnz, gr->nnz, s);
+    if (st) return st;
+    st = launch_agg_sddmm(*gr, dv, Ec, u, dvb, dEp, G, p.Cu, N, T, s);
+  } else {
+    st = launch_sddmm(*gr, u, dv, dEp, G, p.Cu, N, T, s);
+  }
   if (st) return st;
-  st = launch_bwd_edge(*gr, dEp, p.nch, io->E, io->q, io->pq, io->Wg, gE, delta, dkW, dq, G, Bg, N, T, s);
+  st = launch_bwd_edge(*gr, dEp, p.nch, io->E, io->q, io->pq, io->Wg, gE, delta, dkW, dq, G, Bg, N, T, s,
+                       fused ? Ec : nullptr);
   if (st) return st;
   st = launch_bwd_dense_col(*gr, io->q, io->kW, io->lse, delta, gE, dq, G, N, T, s);
   if (st) return st;
@@ -578,8 +588,10 @@ extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t*
 
   if (p.mode == MSGAT_MODE_PROJ_FIRST) {
     // du = E^T dz;  dx = W^T du + alpha (x) dq;  dW = du x^T;  dalpha = dq . x
-    st = aggregate_cols(sh, gr, Co, dv, io->E, Ec, nullptr, nullptr, dvb, s);
-    if (st) return st;
+    if (!fused) {
+      st = aggregate_cols(sh, gr, Co, dv, io->E, Ec, nullptr, nullptr, dvb, s);
+      if (st) return st;
+    }
     st = launch_project(dvb, io->W, 1, nullptr, io->alpha, dq, io->dx, nullptr, G, Bg, Co, C, P, s);
     if (st) return st;
     return launch_chanpair(dvb, dq, io->x, cpp, io->dW, Co * C, io->dalpha, C, G, Bg, Co + 1, C, P, s);

@@ -208,9 +208,15 @@ int launch_aggregate_project(const msgat_graph_t& gr, const float* x, const floa
 int sddmm_chunks(int G, int Cu, int N, int T, const msgat_sell_t* sell);
 int launch_sddmm(const msgat_graph_t& gr, const float* u, const float* dv, float* dEp, int G,
                  int Cu, int N, int T, hipStream_t s);
+// PROJ_FIRST backward, one pass over dv: du = E^T dv on the CSC (Ec = E in CSC order) AND the SDDMM partials, which
+// come out in CSC order (launch_bwd_edge: csc_order).  Usable when agg_sddmm_fusable(); chunks = sddmm_chunks().
+bool agg_sddmm_fusable(const msgat_graph_t& gr, int N, int T, int Cu);
+int launch_agg_sddmm(const msgat_graph_t& gr, const float* dv, const float* Ec, const float* u, float* du, float* dEp,
+                     int G, int Cu, int N, int T, hipStream_t s);
+// Ecsc != nullptr: the partials are in CSC order and Ecsc holds E in that order
 int launch_bwd_edge(const msgat_graph_t& gr, const float* dEp, int nchunks, const float* E,
                     const float* q, const float* pq, const float* Wg, float* gE, float* delta,
-                    float* dkW, float* dq, int G, int Bg, int N, int T, hipStream_t s);
+                    float* dkW, float* dq, int G, int Bg, int N, int T, hipStream_t s, const float* Ecsc = nullptr);
 int launch_bwd_dense_col(const msgat_graph_t& gr, const float* q, const float* kW,
                          const float* lse, const float* delta, const float* gE, float* dq, int G,
                          int N, int T, hipStream_t s);

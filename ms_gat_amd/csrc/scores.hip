@@ -29,6 +29,27 @@ __global__ __launch_bounds__(kBlock) void k_edge_grad(const float* __restrict__ 
   gE[(size_t)g * nnz + e] = E[(size_t)g * nnz + e] * ((a0 + a1) + (a2 + a3));
 }
 
+// the same for partials in CSC order (k_agg_sddmm): lane k reads Ec[k] and its partials coalesced and scatters
+// g to the CSR edge cperm[k]
+__global__ __launch_bounds__(kBlock) void k_edge_grad_csc(const float* __restrict__ dEp, int nchunks,
+                                                          const float* __restrict__ Ec, const int* __restrict__ cperm,
+                                                          float* __restrict__ gE, int nnz) {
+  const int g = blockIdx.y;
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= nnz) return;
+  const float* p = dEp + (size_t)g * nchunks * nnz + k;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int c = 0;
+  for (; c + 4 <= nchunks; c += 4) {
+    a0 += p[(size_t)(c + 0) * nnz];
+    a1 += p[(size_t)(c + 1) * nnz];
+    a2 += p[(size_t)(c + 2) * nnz];
+    a3 += p[(size_t)(c + 3) * nnz];
+  }
+  for (; c < nchunks; ++c) a0 += p[(size_t)c * nnz];
+  gE[(size_t)g * nnz + cperm[k]] = Ec[(size_t)g * nnz + k] * ((a0 + a1) + (a2 + a3));
+}
+
 template <int T>
 __global__ __launch_bounds__(kBlock) void k_bwd_row(
     const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ gE,
@@ -95,8 +116,12 @@ __global__ __launch_bounds__(kBlock) void k_bwd_row(
 
 int launch_bwd_edge(const msgat_graph_t& gr, const float* dEp, int nchunks, const float* E,
                     const float* q, const float* pq, const float* Wg, float* gE, float* delta,
-                    float* dkW, float* dq, int G, int Bg, int N, int T, hipStream_t s) {
-  if (gr.nnz > 0) {
+                    float* dkW, float* dq, int G, int Bg, int N, int T, hipStream_t s, const float* Ecsc) {
+  if (gr.nnz > 0 && Ecsc != nullptr) {
+    hipLaunchKernelGGL(k_edge_grad_csc, dim3(cdiv(gr.nnz, kBlock), G), dim3(kBlock), 0, s, dEp, nchunks, Ecsc, gr.cperm, gE,
+                       gr.nnz);
+    MSGAT_CHECK_LAUNCH();
+  } else if (gr.nnz > 0) {
     dim3 ge(cdiv(gr.nnz, kBlock), G);
     const bool sell = sell_usable(gr.sell_rows, gr.nnz, N, T);
     hipLaunchKernelGGL(k_edge_grad, ge, dim3(kBlock), 0, s, dEp, nchunks, E, sell ? gr.sell_rows.pos : nullptr,
