@@ -66,13 +66,17 @@ __device__ __forceinline__ float4 gather_row(const int* __restrict__ idx, const 
   return acc;
 }
 
-template <int T4>
+// DOT: the block also leaves dap[g,c] = sum_s <extra[g,s], xdot[g,c,s]> for its channels (ch <= kAggDotMaxC) --
+// dalpha = dq . x of the AGG_FIRST / PLAIN backward, whose dq is this kernel's `extra` anyway: one more coalesced
+// float4 per lane instead of a contraction launch over dq and x.  Fixed order: lane trips, shuffles, waves.
+template <int T4, bool DOT>
 __global__ __launch_bounds__(kAggBlock) void k_agg_lds(
     const int* __restrict__ ptr, const int* __restrict__ idx, const float4* __restrict__ u4,
     const float* __restrict__ E, const float* __restrict__ addvec,
     const float4* __restrict__ extra4, float4* __restrict__ v4, int Bg, int Cu, int N, int nnz,
-    int CH) {
+    int CH, const float4* __restrict__ xdot4, float* __restrict__ dap) {
   extern __shared__ float4 slab[];  // [ch][N][T4]
+  __shared__ float dred[kAggBlock / 64][kAggDotMaxC];
   const int g = blockIdx.y;
   const int r = g / Bg;
   const int c0 = blockIdx.x * CH;
@@ -84,6 +88,7 @@ __global__ __launch_bounds__(kAggBlock) void k_agg_lds(
   for (int i = threadIdx.x; i < total; i += kAggBlock) slab[i] = u4[base + i];
   __syncthreads();
 
+  float da[kAggDotMaxC] = {0.f, 0.f, 0.f, 0.f};
   const float* Eg = E + (size_t)g * nnz;
   for (int s = threadIdx.x; s < NT4; s += kAggBlock) {
     const int n = s / T4;
@@ -91,10 +96,32 @@ __global__ __launch_bounds__(kAggBlock) void k_agg_lds(
     const int e0 = ptr[n], e1 = ptr[n + 1];
     float4 ex = f4zero();
     if (addvec != nullptr) ex = extra4[(size_t)g * NT4 + s];
+    if (DOT) {
+#pragma unroll
+      for (int c = 0; c < kAggDotMaxC; ++c)
+        if (c < ch) da[c] = f4dot(ex, xdot4[base + (size_t)c * NT4 + s], da[c]);
+    }
     for (int c = 0; c < ch; ++c) {
       float4 acc = gather_row<T4>(idx, Eg, e0, e1, nnz, slab + c * NT4, j);
       if (addvec != nullptr) f4fma(addvec[r * Cu + c0 + c], ex, acc);
       v4[base + (size_t)c * NT4 + s] = acc;
+    }
+  }
+  if (DOT) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int c = 0; c < kAggDotMaxC; ++c) {
+      float w = da[c];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off);
+      if (lane == 0) dred[wave][c] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < ch) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < kAggBlock / 64; ++w) t += dred[w][threadIdx.x];
+      dap[(size_t)g * Cu + c0 + threadIdx.x] = t;
     }
   }
 }
@@ -303,7 +330,7 @@ __global__ __launch_bounds__(kBlock) void k_agg_glb(
 template <int T4>
 static int launch_aggregate_t(const int* ptr, const int* idx, int nnz, const msgat_sell_t* sell, const float* u,
                               const float* E, const float* addvec, const float* extra, float* v, int G, int Bg,
-                              int Cu, int N, hipStream_t s) {
+                              int Cu, int N, hipStream_t s, const float* xdot, float* dap, int* dot_done) {
   const int T = 4 * T4;
   const int CH = slab_channels(N, T, Cu, kLdsBudget);
   if (sell != nullptr) {  // E is in the position order of this layout (the caller permuted it by sell->src)
@@ -331,13 +358,22 @@ static int launch_aggregate_t(const int* ptr, const int* idx, int nnz, const msg
   } else if (CH >= 1) {
     const size_t lds = (size_t)CH * N * T * sizeof(float);
     if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_lds<T4>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_lds<T4, false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_lds<T4, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
     }
     dim3 grid(cdiv(Cu, CH), G);
-    hipLaunchKernelGGL(k_agg_lds<T4>, grid, dim3(kAggBlock), lds, s, ptr, idx, (const float4*)u, E, addvec,
-                       (const float4*)extra, (float4*)v, Bg, Cu, N, nnz, CH);
+    if (xdot != nullptr && dap != nullptr && addvec != nullptr && Cu <= kAggDotMaxC) {
+      hipLaunchKernelGGL((k_agg_lds<T4, true>), grid, dim3(kAggBlock), lds, s, ptr, idx, (const float4*)u, E, addvec,
+                         (const float4*)extra, (float4*)v, Bg, Cu, N, nnz, CH, (const float4*)xdot, dap);
+      if (dot_done != nullptr) *dot_done = 1;
+    } else {
+      hipLaunchKernelGGL((k_agg_lds<T4, false>), grid, dim3(kAggBlock), lds, s, ptr, idx, (const float4*)u, E, addvec,
+                         (const float4*)extra, (float4*)v, Bg, Cu, N, nnz, CH, nullptr, nullptr);
+    }
   } else if ((size_t)N * sizeof(float4) <= (size_t)kLdsMax - 1024 && nnz >= 8) {
     const size_t lds = (size_t)N * sizeof(float4);
     if (lds > 64 * 1024) {
@@ -358,12 +394,13 @@ static int launch_aggregate_t(const int* ptr, const int* idx, int nnz, const msg
 
 int launch_aggregate(const int* ptr, const int* idx, int nnz, const msgat_sell_t* sell, const float* u,
                      const float* E, const float* addvec, const float* extra, float* v, int G, int Bg, int Cu,
-                     int N, int T, hipStream_t s) {
+                     int N, int T, hipStream_t s, const float* xdot, float* dap, int* dot_done) {
+  if (dot_done != nullptr) *dot_done = 0;
   switch (T) {
-    case 4: return launch_aggregate_t<1>(ptr, idx, nnz, sell, u, E, addvec, extra, v, G, Bg, Cu, N, s);
-    case 8: return launch_aggregate_t<2>(ptr, idx, nnz, sell, u, E, addvec, extra, v, G, Bg, Cu, N, s);
-    case 12: return launch_aggregate_t<3>(ptr, idx, nnz, sell, u, E, addvec, extra, v, G, Bg, Cu, N, s);
-    case 16: return launch_aggregate_t<4>(ptr, idx, nnz, sell, u, E, addvec, extra, v, G, Bg, Cu, N, s);
+    case 4: return launch_aggregate_t<1>(ptr, idx, nnz, sell, u, E, addvec, extra, v, G, Bg, Cu, N, s, xdot, dap, dot_done);
+    case 8: return launch_aggregate_t<2>(ptr, idx, nnz, sell, u, E, addvec, extra, v, G, Bg, Cu, N, s, xdot, dap, dot_done);
+    case 12: return launch_aggregate_t<3>(ptr, idx, nnz, sell, u, E, addvec, extra, v, G, Bg, Cu, N, s, xdot, dap, dot_done);
+    case 16: return launch_aggregate_t<4>(ptr, idx, nnz, sell, u, E, addvec, extra, v, G, Bg, Cu, N, s, xdot, dap, dot_done);
   }
   return MSGAT_ERR_UNSUPPORTED;
 }

@@ -39,7 +39,7 @@ inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 // backward workspace layout, shared by the size query and the run
 struct BwdPlan {
   int mode, G, Cu, nch;
-  size_t off_dEp, off_gE, off_Ec, off_delta, off_dkW, off_dq, off_dv, off_dwg, off_cp, total;
+  size_t off_dEp, off_gE, off_Ec, off_delta, off_dkW, off_dq, off_dv, off_dwg, off_cp, off_cp2, total;
 };
 
 // the graph decides the edge layout (CSR, or SELL for large N) and with it the size of the per-edge buffers
@@ -67,17 +67,23 @@ BwdPlan plan_bwd(const msgat_shape_t& sh, const msgat_graph_t& gr) {
   // AGG_FIRST: dy = W^T dz [G,C,P];  PROJ_FIRST: du = E^T dz [G,Co,P];  PLAIN: none
   p.off_dv = take(p.mode == MSGAT_MODE_PLAIN ? 0 : G * (size_t)p.Cu * P);
   p.off_dwg = take(dwg_partial_floats(p.G, sh.N, sh.T));
-  size_t cp = 0;
+  // partials of the parameter gradients; cp2: dalpha of AGG_FIRST, whose dW partials (cp) wait for the same
+  // end-of-pass reduction
+  size_t cp = 0, cp2 = 0;
   if (p.mode == MSGAT_MODE_PLAIN) {
     cp = chanpair_partial_floats(p.G, sh.Bg, 1, sh.C);
+    if (G * (size_t)sh.C > cp) cp = G * (size_t)sh.C;
   } else if (p.mode == MSGAT_MODE_AGG_FIRST) {
     cp = chanpair_partial_floats(p.G, sh.Bg, sh.Co, sh.C);
-    const size_t cp2 = chanpair_partial_floats(p.G, sh.Bg, 1, sh.C);
-    if (cp2 > cp) cp = cp2;
+    const size_t fused = G * (size_t)aggfirst_blocks((int)P) * sh.Co * sh.C;
+    if (sh.C <= kAggFirstMaxC && fused > cp) cp = fused;
+    cp2 = chanpair_partial_floats(p.G, sh.Bg, 1, sh.C);
+    if (G * (size_t)sh.C > cp2) cp2 = G * (size_t)sh.C;
   } else {
     cp = chanpair_partial_floats(p.G, sh.Bg, sh.Co + 1, sh.C);
   }
   p.off_cp = take(cp);
+  p.off_cp2 = take(cp2);
   p.total = off;
   return p;
 }
@@ -147,14 +153,15 @@ static int aggregate_rows(const msgat_shape_t* sh, const msgat_graph_t* gr, int 
 
 // transposed aggregate over the CSC (backward): E goes to CSC order -- or to the SELL order of the CSC -- in Ec
 static int aggregate_cols(const msgat_shape_t* sh, const msgat_graph_t* gr, int Cu, const float* dv, const float* E,
-                          float* Ec, const float* addvec, const float* extra, float* out, hipStream_t s) {
+                          float* Ec, const float* addvec, const float* extra, float* out, hipStream_t s,
+                          const float* xdot = nullptr, float* dap = nullptr, int* dot_done = nullptr) {
   const int G = sh->R * sh->Bg;
   const bool sell = sell_usable(gr->sell_cols, gr->nnz, sh->N, sh->T);
   int st = launch_permute_edges(E, sell ? gr->sell_cols.src : gr->cperm, Ec, G, gr->nnz,
                                 sell ? gr->sell_cols.n_pos : gr->nnz, s);
   if (st) return st;
   return launch_aggregate(gr->colptr, gr->crow, gr->nnz, sell ? &gr->sell_cols : nullptr, dv, Ec, addvec, extra, out,
-                          G, sh->Bg, Cu, sh->N, sh->T, s);
+                          G, sh->Bg, Cu, sh->N, sh->T, s, xdot, dap, dot_done);
 }
 
 extern "C" size_t msgat_edge_scratch_floats(const msgat_shape_t* sh, const msgat_graph_t* gr) {
@@ -555,14 +562,23 @@ extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t*
   float* cpp = (float*)(ws + p.off_cp);
   const int G = p.G, Bg = sh->Bg, C = sh->C, Co = sh->Co, N = sh->N, T = sh->T, P = N * T;
 
+  // the fixed-order sums of the parameter-gradient partials (dW, dalpha, dWg) are queued and run as ONE launch at the
+  // end of the pass
+  ReduceJobs jobs{};
+  float* cpp2 = (float*)(ws + p.off_cp2);
+
   // features the attention acted on (u) and the gradient arriving at its output (dv)
   const float* u = (p.mode == MSGAT_MODE_PROJ_FIRST) ? io->u : io->x;
   const float* dv = io->dz;
   if (p.mode == MSGAT_MODE_AGG_FIRST) {
-    // z = W y:  dy = W^T dz,  dW = dz y^T
-    st = launch_project(io->dz, io->W, 1, nullptr, nullptr, nullptr, dvb, nullptr, G, Bg, Co, C, P, s);
-    if (st) return st;
-    st = launch_chanpair(io->dz, nullptr, io->u, cpp, io->dW, Co * C, nullptr, 0, G, Bg, Co, C, P, s);
+    // z = W y:  dy = W^T dz,  dW = dz y^T -- one pass over dz when the input has few channels
+    if (C <= kAggFirstMaxC) {
+      st = launch_aggfirst_bwd(io->dz, io->W, io->u, dvb, cpp, io->dW, G, Bg, C, Co, P, s, &jobs);
+    } else {
+      st = launch_project(io->dz, io->W, 1, nullptr, nullptr, nullptr, dvb, nullptr, G, Bg, Co, C, P, s);
+      if (st) return st;
+      st = launch_chanpair(io->dz, nullptr, io->u, cpp, io->dW, Co * C, nullptr, 0, G, Bg, Co, C, P, s, &jobs);
+    }
     if (st) return st;
     dv = dvb;
   }
@@ -583,7 +599,7 @@ extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t*
   if (st) return st;
   st = launch_bwd_dense_col(*gr, io->q, io->kW, io->lse, delta, gE, dq, G, N, T, s);
   if (st) return st;
-  st = launch_dwg(io->q, dkW, dwgp, io->dWg, G, Bg, N, T, s);
+  st = launch_dwg(io->q, dkW, dwgp, io->dWg, G, Bg, N, T, s, &jobs);
   if (st) return st;
 
   if (p.mode == MSGAT_MODE_PROJ_FIRST) {
@@ -594,12 +610,23 @@ extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t*
     }
     st = launch_project(dvb, io->W, 1, nullptr, io->alpha, dq, io->dx, nullptr, G, Bg, Co, C, P, s);
     if (st) return st;
-    return launch_chanpair(dvb, dq, io->x, cpp, io->dW, Co * C, io->dalpha, C, G, Bg, Co + 1, C, P, s);
+    st = launch_chanpair(dvb, dq, io->x, cpp, io->dW, Co * C, io->dalpha, C, G, Bg, Co + 1, C, P, s, &jobs);
+    if (st) return st;
+    return launch_reduce_jobs(jobs, s);
   }
-  // PLAIN / AGG_FIRST:  dx = E^T dv + alpha (x) dq;  dalpha = dq . x
-  st = aggregate_cols(sh, gr, C, dv, io->E, Ec, io->alpha, dq, io->dx, s);
+  // PLAIN / AGG_FIRST:  dx = E^T dv + alpha (x) dq;  dalpha = dq . x -- from the same kernel (it holds dq) when the
+  // slab form runs and the input has few channels, from a contraction otherwise
+  float* dap = (p.mode == MSGAT_MODE_AGG_FIRST) ? cpp2 : cpp;
+  int dot_done = 0;
+  st = aggregate_cols(sh, gr, C, dv, io->E, Ec, io->alpha, dq, io->dx, s, C <= kAggDotMaxC ? io->x : nullptr, dap,
+                      &dot_done);
   if (st) return st;
-  return launch_chanpair(nullptr, dq, io->x, cpp, nullptr, 0, io->dalpha, C, G, Bg, 1, C, P, s);
+  if (dot_done)
+    st = launch_reduce_groups_defer(dap, sh->R, Bg, C, io->dalpha, s, &jobs);
+  else
+    st = launch_chanpair(nullptr, dq, io->x, dap, nullptr, 0, io->dalpha, C, G, Bg, 1, C, P, s, &jobs);
+  if (st) return st;
+  return launch_reduce_jobs(jobs, s);
 }
 
 // ---- step tail: fused Huber loss + metric sums, flat Adam ------------------------------------------------------

@@ -194,9 +194,14 @@ int launch_scores(const msgat_graph_t& gr, const float* q, const float* Wg, floa
 // v[g,c,n,:] = sum_{e in ptr[n]..ptr[n+1]} E[g,e] u[g,c,idx[e],:] (+ addvec[r,c]*extra[g,n,:])
 // sell != nullptr: E is in that layout's position order (permuted by sell->src, row stride sell->n_pos, with
 // MSGAT_SELL_SLACK readable floats behind the last row) and the SELL kernel runs
+// xdot/dap (both or neither; Cu <= kAggDotMaxC, addvec given): the slab kernel also leaves dap[g,c] =
+// sum_p extra[g,p] xdot[g,c,p] -- dalpha = dq . x of the AGG_FIRST / PLAIN backward -- when it runs (returns
+// MSGAT_OK and sets *dot_done); other kernel forms leave *dot_done = 0 and the caller contracts separately
+constexpr int kAggDotMaxC = 4;
 int launch_aggregate(const int* ptr, const int* idx, int nnz, const msgat_sell_t* sell, const float* u,
                      const float* E, const float* addvec, const float* extra, float* v, int G, int Bg, int Cu,
-                     int N, int T, hipStream_t s);
+                     int N, int T, hipStream_t s, const float* xdot = nullptr, float* dap = nullptr,
+                     int* dot_done = nullptr);
 // Eo[g,k] = E[g, perm[k]] for k < n (0 where perm[k] < 0): edge coefficients in CSC or SELL position order
 int launch_permute_edges(const float* E, const int* perm, float* Eo, int G, int nnz, int n, hipStream_t s);
 int launch_aggregate_project(const msgat_graph_t& gr, const float* x, const float* E,
@@ -220,22 +225,46 @@ int launch_bwd_edge(const msgat_graph_t& gr, const float* dEp, int nchunks, cons
 int launch_bwd_dense_col(const msgat_graph_t& gr, const float* q, const float* kW,
                          const float* lse, const float* delta, const float* gE, float* dq, int G,
                          int N, int T, hipStream_t s);
+// A fixed-order sum of partials, out[r,i] = sum_j part[r,j,i] split over dst0 (first n0 columns) and dst1 (next n1),
+// that may wait for the end of a backward pass: the launchers below queue their reduction in `defer` when given one,
+// and launch_reduce_jobs runs the queue as ONE launch (each reduction alone is a 4-5 us launch of a few blocks).
+struct ReduceJob {
+  const float* part;
+  int R, J, Wd;
+  float* dst0;
+  int n0;
+  float* dst1;
+  int n1;
+};
+constexpr int kMaxReduceJobs = 4;
+struct ReduceJobs {
+  ReduceJob job[kMaxReduceJobs];
+  int n;
+};
+int launch_reduce_jobs(const ReduceJobs& jobs, hipStream_t s);
 // dWg[r,t,s] = sum_{g in r, n} q[g,n,t] dkW[g,n,s]
 size_t dwg_partial_floats(int G, int N, int T);
 int launch_dwg(const float* q, const float* dkW, float* part, float* dWg, int G, int Bg, int N,
-               int T, hipStream_t s);
+               int T, hipStream_t s, ReduceJobs* defer = nullptr);
 // out[r,a,c] = sum_{g in r, p} A(g,a,p) B[g,c,p];  channel a == Ca-1 comes from Aextra[g,p] when given
 size_t chanpair_partial_floats(int G, int Bg, int Ca, int Cb);
 int launch_chanpair(const float* A, const float* Aextra, const float* B, float* part, float* dst0,
                     int n0, float* dst1, int n1, int G, int Bg, int Ca, int Cb, int P,
-                    hipStream_t s);
+                    hipStream_t s, ReduceJobs* defer = nullptr);
 int launch_chanpair_seg(const SegList& A, const float* B, float* part, float* dst0, int n0, float* dst1, int n1,
-                        int G, int Bg, int Cb, int P, hipStream_t s, int b_ones = 0);
+                        int G, int Bg, int Cb, int P, hipStream_t s, int b_ones = 0, ReduceJobs* defer = nullptr);
+// AGG_FIRST backward with few input channels (C <= kAggFirstMaxC): dy = W^T dz and the partials of dW = dz y^T in ONE
+// pass over dz (project.hip); partials [G * aggfirst_blocks(P)][Co*C], summed per relation by the queued job
+constexpr int kAggFirstMaxC = 4;
+int aggfirst_blocks(int P);
+int launch_aggfirst_bwd(const float* dz, const float* W, const float* y, float* dy, float* part, float* dW, int G,
+                        int Bg, int C, int Co, int P, hipStream_t s, ReduceJobs* defer);
 // out[i] = sum_j part[j,i], i < Wd, split over dst0 (first n0) and dst1 (next n1); fixed order
 int launch_reduce_rows(const float* part, int J, int Wd, float* dst0, int n0, float* dst1, int n1,
                        hipStream_t s);
 // out[r,i] = sum_j part[r,j,i]
 int launch_reduce_groups(const float* part, int R, int J, int Wd, float* dst, hipStream_t s);
+int launch_reduce_groups_defer(const float* part, int R, int J, int Wd, float* dst, hipStream_t s, ReduceJobs* defer);
 // temporal / channel branch kernels (branches.hip)
 int launch_tmix(const float* src, const float* A, int per_group, const float* bias, float* dst, int G, int Co,
                 int K, int N, int T, int backward, int R, hipStream_t s, int src_gs = 0);

@@ -35,6 +35,88 @@ int launch_qonly(const float* x, const float* alpha, float* q, int G, int Bg, in
   return MSGAT_OK;
 }
 
+// ---- AGG_FIRST backward with few input channels: dy = W^T dz and dW = dz y^T in one pass over dz ---------------
+// z = W y with y = E x the aggregated input (C channels, msgat.py:27 after the aggregation when C <= Co).  The first
+// MEAM of every component has C = 1 (PEMSD7/8) or 3 (PEMSD3/4), so dz -- Co channels -- is the only large operand:
+//   dy[g,c,p] = sum_o W[r,o,c] dz[g,o,p]            dW[r,o,c] = sum_{g in r, p} dz[g,o,p] y[g,c,p]
+// As two launches (k_project 24 -> 1 and the channel-pair contraction) dz was read twice: 25 + 25 us at PEMSD7
+// size against one pass here.  Lane = 4 positions; the Co loop runs in chunks of 8 channels whose 8*C products are
+// wave-reduced by shuffles right away and parked in LDS, so the register footprint does not grow with Co; one
+// partial per block, fixed order everywhere.
+constexpr int kAfChunk = 8;
+
+template <int C>
+__global__ __launch_bounds__(kBlock) void k_aggfirst_bwd(const float4* __restrict__ dz4, const float* __restrict__ W,
+                                                         const float4* __restrict__ y4, float4* __restrict__ dy4,
+                                                         float* __restrict__ part, int Bg, int Co, int P4) {
+  extern __shared__ float lds[];
+  float* Wl = lds;                        // [Co][C]
+  float* red = lds + Co * C;              // [4 waves][Co*C]
+  const int g = blockIdx.y;
+  const int r = g / Bg;
+  for (int i = threadIdx.x; i < Co * C; i += kBlock) Wl[i] = W[(size_t)r * Co * C + i];
+  const int p4 = blockIdx.x * kBlock + threadIdx.x;
+  const float keep = p4 < P4 ? 1.f : 0.f;
+  const int p4c = min(p4, P4 - 1);  // clamped, unconditional loads; lanes past the end contribute keep = 0
+  float4 yv[C], acc[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float4 v = y4[((size_t)g * C + c) * P4 + p4c];
+    yv[c] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
+    acc[c] = f4zero();
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float4* src = dz4 + (size_t)g * Co * P4 + p4c;
+  for (int o0 = 0; o0 < Co; o0 += kAfChunk) {
+    float4 d[kAfChunk];
+#pragma unroll
+    for (int k = 0; k < kAfChunk; ++k) d[k] = src[(size_t)min(o0 + k, Co - 1) * P4];
+#pragma unroll
+    for (int k = 0; k < kAfChunk; ++k) {
+      const int o = min(o0 + k, Co - 1);  // a chunk past Co repeats the last channel; its results are not stored
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        if (o0 + k < Co) f4fma(Wl[o * C + c], d[k], acc[c]);  // wave-uniform, no load inside
+        float w = f4dot(d[k], yv[c], 0.f);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off);
+        if (lane == 0 && o0 + k < Co) red[wave * Co * C + o * C + c] = w;
+      }
+    }
+  }
+  if (p4 < P4) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) dy4[((size_t)g * C + c) * P4 + p4] = acc[c];
+  }
+  __syncthreads();
+  float* out = part + ((size_t)g * gridDim.x + blockIdx.x) * (Co * C);
+  for (int i = threadIdx.x; i < Co * C; i += kBlock)
+    out[i] = (red[i] + red[Co * C + i]) + (red[2 * Co * C + i] + red[3 * Co * C + i]);
+}
+
+int aggfirst_blocks(int P) { return cdiv(P / 4, kBlock); }
+
+int launch_aggfirst_bwd(const float* dz, const float* W, const float* y, float* dy, float* part, float* dW, int G,
+                        int Bg, int C, int Co, int P, hipStream_t s, ReduceJobs* defer) {
+  const int P4 = P / 4, nb = aggfirst_blocks(P);
+  const size_t lds = (size_t)5 * Co * C * sizeof(float);
+  dim3 grid(nb, G);
+#define MSGAT_AF(CC)                                                                                              \
+  hipLaunchKernelGGL(k_aggfirst_bwd<CC>, grid, dim3(kBlock), lds, s, (const float4*)dz, W, (const float4*)y, \
+                     (float4*)dy, part, Bg, Co, P4)
+  switch (C) {
+    case 1: MSGAT_AF(1); break;
+    case 2: MSGAT_AF(2); break;
+    case 3: MSGAT_AF(3); break;
+    case 4: MSGAT_AF(4); break;
+    default: return MSGAT_ERR_UNSUPPORTED;
+  }
+#undef MSGAT_AF
+  MSGAT_CHECK_LAUNCH();
+  return launch_reduce_groups_defer(part, G / Bg, Bg * nb, Co * C, dW, s, defer);
+}
+
 // ---- general channel projection --------------------------------------------------------
 // One block = 256 lanes x 4 positions of one group, OT output channels (blockIdx.z picks
 // the tile).  The [Ci x OT] slice of the matrix sits in LDS and is read as wave-uniform

@@ -15,19 +15,20 @@ namespace msgat {
 constexpr int kNS4 = 4;
 
 // ---- sum of partials: out[r,i] = sum_j part[r,j,i], split over two destinations -----------------
-__global__ __launch_bounds__(kBlock) void k_reduce_partials(const float* __restrict__ part, int J,
-                                                            int Wd, float* __restrict__ dst0, int n0,
-                                                            float* __restrict__ dst1, int n1) {
-  // block = 64 columns x 4 waves; wave w sums partials j = w, w+4, ... (8 loads in flight),
-  // the 4 wave sums are combined in a fixed order through LDS
+// blockIdx.z picks the job; block = 64 columns x 4 waves; wave w sums partials j = w, w+4, ... (8 loads in
+// flight), the 4 wave sums are combined in a fixed order through LDS
+__global__ __launch_bounds__(kBlock) void k_reduce_partials(ReduceJobs jobs) {
   __shared__ float red[kNS4][kWave];
+  const ReduceJob& jb = jobs.job[blockIdx.z];
   const int r = blockIdx.y;
   const int lane = threadIdx.x & (kWave - 1);
   const int w = threadIdx.x >> 6;
   const int i = blockIdx.x * kWave + lane;
+  const int Wd = jb.Wd, J = jb.J;
+  if (r >= jb.R || blockIdx.x * kWave >= Wd) return;  // the grid covers the largest job
   float acc = 0.f;
   if (i < Wd) {
-    const float* p = part + (size_t)r * J * Wd + i;
+    const float* p = jb.part + (size_t)r * J * Wd + i;
     float a[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) a[k] = 0.f;
@@ -43,19 +44,44 @@ __global__ __launch_bounds__(kBlock) void k_reduce_partials(const float* __restr
   __syncthreads();
   if (w != 0 || i >= Wd) return;
   const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-  if (i < n0) {
-    if (dst0 != nullptr) dst0[(size_t)r * n0 + i] = v;
-  } else if (dst1 != nullptr && i - n0 < n1) {
-    dst1[(size_t)r * n1 + (i - n0)] = v;
+  if (i < jb.n0) {
+    if (jb.dst0 != nullptr) jb.dst0[(size_t)r * jb.n0 + i] = v;
+  } else if (jb.dst1 != nullptr && i - jb.n0 < jb.n1) {
+    jb.dst1[(size_t)r * jb.n1 + (i - jb.n0)] = v;
   }
 }
 
-static int launch_reduce_partials(const float* part, int R, int J, int Wd, float* dst0, int n0,
-                                  float* dst1, int n1, hipStream_t s) {
-  dim3 grid(cdiv(Wd, kWave), R);
-  hipLaunchKernelGGL(k_reduce_partials, grid, dim3(kBlock), 0, s, part, J, Wd, dst0, n0, dst1, n1);
+int launch_reduce_jobs(const ReduceJobs& jobs, hipStream_t s) {
+  if (jobs.n <= 0) return MSGAT_OK;
+  int bx = 1, by = 1;
+  for (int k = 0; k < jobs.n; ++k) {
+    bx = max(bx, cdiv(jobs.job[k].Wd, kWave));
+    by = max(by, jobs.job[k].R);
+  }
+  hipLaunchKernelGGL(k_reduce_partials, dim3(bx, by, jobs.n), dim3(kBlock), 0, s, jobs);
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
+}
+
+// queue the reduction when the caller collects them, run it now otherwise
+static int reduce_or_defer(const ReduceJob& jb, ReduceJobs* defer, hipStream_t s) {
+  if (defer != nullptr && defer->n < kMaxReduceJobs) {
+    defer->job[defer->n++] = jb;
+    return MSGAT_OK;
+  }
+  ReduceJobs one{};
+  one.job[0] = jb;
+  one.n = 1;
+  return launch_reduce_jobs(one, s);
+}
+
+static int launch_reduce_partials(const float* part, int R, int J, int Wd, float* dst0, int n0,
+                                  float* dst1, int n1, hipStream_t s, ReduceJobs* defer = nullptr) {
+  return reduce_or_defer(ReduceJob{part, R, J, Wd, dst0, n0, dst1, n1}, defer, s);
+}
+
+int launch_reduce_groups_defer(const float* part, int R, int J, int Wd, float* dst, hipStream_t s, ReduceJobs* defer) {
+  return launch_reduce_partials(part, R, J, Wd, dst, Wd, nullptr, 0, s, defer);
 }
 
 int launch_reduce_rows(const float* part, int J, int Wd, float* dst0, int n0, float* dst1, int n1,
@@ -102,7 +128,7 @@ __global__ __launch_bounds__(kBlock) void k_dwg(const float* __restrict__ q,
 size_t dwg_partial_floats(int G, int N, int T) { return (size_t)G * cdiv(N, kRB) * T * T; }
 
 int launch_dwg(const float* q, const float* dkW, float* part, float* dWg, int G, int Bg, int N,
-               int T, hipStream_t s) {
+               int T, hipStream_t s, ReduceJobs* defer) {
   const int nblk = cdiv(N, kRB);
   dim3 grid(nblk, G);
   switch (T) {
@@ -113,7 +139,7 @@ int launch_dwg(const float* q, const float* dkW, float* part, float* dWg, int G,
     default: return MSGAT_ERR_UNSUPPORTED;
   }
   MSGAT_CHECK_LAUNCH();
-  return launch_reduce_partials(part, G / Bg, Bg * nblk, T * T, dWg, T * T, nullptr, 0, s);
+  return launch_reduce_partials(part, G / Bg, Bg * nblk, T * T, dWg, T * T, nullptr, 0, s, defer);
 }
 
 // ---- channel-pair contraction over positions --------------------------------------------------------
@@ -125,21 +151,21 @@ size_t chanpair_partial_floats(int G, int Bg, int Ca, int Cb) {
 }
 
 int launch_chanpair_seg(const SegList& A, const float* B, float* part, float* dst0, int n0, float* dst1, int n1,
-                        int G, int Bg, int Cb, int P, hipStream_t s, int b_ones) {
+                        int G, int Bg, int Cb, int P, hipStream_t s, int b_ones, ReduceJobs* defer) {
   const int R = G / Bg;
   const int nblk = chanpair_mfma_blocks(R);
   const int st = launch_chanpair_mfma(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
   if (st) return st;
-  return launch_reduce_partials(part, R, nblk, A.total() * Cb, dst0, n0, dst1, n1, s);
+  return launch_reduce_partials(part, R, nblk, A.total() * Cb, dst0, n0, dst1, n1, s, defer);
 }
 
 int launch_chanpair(const float* A, const float* Aextra, const float* B, float* part, float* dst0,
                     int n0, float* dst1, int n1, int G, int Bg, int Ca, int Cb, int P,
-                    hipStream_t s) {
+                    hipStream_t s, ReduceJobs* defer) {
   // channel axis [A | Aextra]: Aextra, when given, supplies the last row
   const SegList seg = (Aextra == nullptr) ? seg_single(A, Ca)
                       : (Ca == 1 ? seg_single(Aextra, 1) : seg_pair(A, Ca - 1, Aextra, 1));
-  return launch_chanpair_seg(seg, B, part, dst0, n0, dst1, n1, G, Bg, Cb, P, s);
+  return launch_chanpair_seg(seg, B, part, dst0, n0, dst1, n1, G, Bg, Cb, P, s, 0, defer);
 }
 
 }  // namespace msgat
