@@ -608,9 +608,11 @@ extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t*
       st = aggregate_cols(sh, gr, Co, dv, io->E, Ec, nullptr, nullptr, dvb, s);
       if (st) return st;
     }
-    st = launch_project(dvb, io->W, 1, nullptr, io->alpha, dq, io->dx, nullptr, G, Bg, Co, C, P, s);
-    if (st) return st;
+    // the contraction (reads only) goes first: behind the projection it would stream x while the 72-channel dx the
+    // projection has just written is still draining to HBM
     st = launch_chanpair(dvb, dq, io->x, cpp, io->dW, Co * C, io->dalpha, C, G, Bg, Co + 1, C, P, s, &jobs);
+    if (st) return st;
+    st = launch_project(dvb, io->W, 1, nullptr, io->alpha, dq, io->dx, nullptr, G, Bg, Co, C, P, s);
     if (st) return st;
     return launch_reduce_jobs(jobs, s);
   }

@@ -16,7 +16,7 @@ def main():
     ap.add_argument("--per-step", type=int, required=True, help="launches per step")
     ap.add_argument("--skip", type=int, default=0, help="launches after the last whole step (baselines etc.)")
     a = ap.parse_args()
-    f = sorted(glob.glob(os.path.join(a.dir, "**", "*kernel_trace.csv"), recursive=True))[0]
+    f = max(glob.glob(os.path.join(a.dir, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
     rows = list(csv.DictReader(open(f)))
     rows = [r for r in rows if "msgat::" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
