@@ -18,6 +18,7 @@
 //     loads, so 256-position tiles of all rows are staged through LDS in 1-KiB row pieces by a
 //     persistent split-K kernel (see k_chanpair_mfma).
 #include "common.hpp"
+#include <cstdlib>
 
 namespace msgat {
 
@@ -272,7 +273,10 @@ constexpr int kLPR = kTile / 4;        // lanes per row piece (64: one row per w
 constexpr int kRPI = 64 / kLPR;        // rows per wave-instruction
 constexpr int kRowF4 = kTile / 4 + 1;  // float4s per LDS row (piece + 16 B pad)
 
-template <int MA, int NB>
+// TWO = false: one register set in flight instead of two -- what the [64 x 80] block (MA = 4) has registers for.  It
+// exists for operands with 49..64 A channels per z-block: a 98-channel gradient against 73 channels (the merged
+// channel mixing of a MEAM block) takes 2 z-blocks instead of 3, i.e. reads B twice instead of three times.
+template <int MA, int NB, bool TWO = true>
 __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
     SegList A, const float* __restrict__ B, float* __restrict__ part, int Cb, int P, int Bg, int nzb, int b_ones) {
   // b_ones: B's last channel (index Cb-1) is a virtual row of ones, so part[a, Cb-1] = sum_p A[a,p] -- the bias
@@ -394,24 +398,36 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
   // two tiles in flight per wave (two register sets): while tile t is multiplied the loads of
   // t+1 and t+2 are outstanding.  All fetches are unconditional (clamped tile index) to keep
   // hipcc's vmcnt waits counted.
-  if (ntile > 0) {
-    float4 ra[RPW], rb[RPW];
+  if (TWO) {
+    if (ntile > 0) {
+      float4 ra[RPW], rb[RPW];
+      fetch(0, ra);
+      fetch(1, rb);
+      MSGAT_STAMP(1);
+      for (int t = 0; t < ntile; t += 2) {
+        lds_barrier();  // every wave is done reading the previous tile
+        stash(ra);
+        lds_barrier();
+        if (t == 0) MSGAT_STAMP(2);
+        fetch(t + 2, ra);
+        multiply();
+        if (t == 0) MSGAT_STAMP(3);
+        lds_barrier();
+        stash(rb);
+        lds_barrier();
+        fetch(t + 3, rb);
+        if (t + 1 < ntile) multiply();  // wave-uniform; LDS reads and MFMAs only
+      }
+    }
+  } else if (ntile > 0) {
+    float4 ra[RPW];
     fetch(0, ra);
-    fetch(1, rb);
-    MSGAT_STAMP(1);
-    for (int t = 0; t < ntile; t += 2) {
-      lds_barrier();  // every wave is done reading the previous tile
+    for (int t = 0; t < ntile; ++t) {
+      lds_barrier();
       stash(ra);
       lds_barrier();
-      if (t == 0) MSGAT_STAMP(2);
-      fetch(t + 2, ra);
+      fetch(t + 1, ra);  // clamped to the run: the last trip re-reads its own tile
       multiply();
-      if (t == 0) MSGAT_STAMP(3);
-      lds_barrier();
-      stash(rb);
-      lds_barrier();
-      fetch(t + 3, rb);
-      if (t + 1 < ntile) multiply();  // wave-uniform; LDS reads and MFMAs only
     }
   }
 
@@ -449,7 +465,7 @@ int chanpair_mfma_blocks(int R) {
   return max(1, ncu / R);
 }
 
-template <int MA, int NB>
+template <int MA, int NB, bool TWO = true>
 static int launch_chanpair_t(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
                              int b_ones, hipStream_t s) {
   const int Ca = A.total();
@@ -457,12 +473,12 @@ static int launch_chanpair_t(const SegList& A, const float* B, float* part, int 
   // tile rows + the zero row + the ones row, reused for the 8 x MA*NB*256-float reduction
   const size_t lds = sizeof(float4) * (size_t)max(((MA + NB) * 16 + 2) * kRowF4, kCpWaves * MA * NB * 64);
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chanpair_mfma<MA, NB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chanpair_mfma<MA, NB, TWO>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
   }
   dim3 grid(nblk, R, nza * nzb);
-  hipLaunchKernelGGL((k_chanpair_mfma<MA, NB>), grid, dim3(kCpBlock), lds, s, A, B, part, Cb, P, Bg, nzb, b_ones);
+  hipLaunchKernelGGL((k_chanpair_mfma<MA, NB, TWO>), grid, dim3(kCpBlock), lds, s, A, B, part, Cb, P, Bg, nzb, b_ones);
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
@@ -471,6 +487,17 @@ int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, i
                          int b_ones, hipStream_t s) {
   const int Ca = A.total();
   const int MA = min(cdiv(Ca, 16), 3), NB = min(cdiv(Cb, 16), 6);
+  // 64 A channels per z-block where that saves a pass over B (and the [64 + 16 NB] rows fit LDS: NB <= 5)
+  static const bool ma4 = !(getenv("MSGAT_CP_MA4") && getenv("MSGAT_CP_MA4")[0] == '0');  // diagnostic switch
+  if (ma4 && NB <= 5 && cdiv(Ca, 64) < cdiv(Ca, 48)) {
+    switch (NB) {
+      case 1: return launch_chanpair_t<4, 1, false>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
+      case 2: return launch_chanpair_t<4, 2, false>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
+      case 3: return launch_chanpair_t<4, 3, false>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
+      case 4: return launch_chanpair_t<4, 4, false>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
+      default: return launch_chanpair_t<4, 5, false>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
+    }
+  }
 #define MSGAT_CP(ma, nb) \
   if (MA == ma && NB == nb) return launch_chanpair_t<ma, nb>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
   MSGAT_CP(1, 1) MSGAT_CP(1, 2) MSGAT_CP(1, 3) MSGAT_CP(1, 4) MSGAT_CP(1, 5) MSGAT_CP(1, 6)

@@ -18,6 +18,7 @@ import ms_gat_amd  # noqa: E402
 from ms_gat_amd import _lib  # noqa: E402
 
 WL = {"pemsd7": dict(N=883, E=866, B=32, R=3, C=72, Co=24, T=12),
+      "aligned": dict(N=880, E=866, B=32, R=3, C=72, Co=24, T=12),   # N*T*4 a multiple of 128: rows start on cache lines
       "pemsd4": dict(N=307, E=340, B=64, R=1, C=72, Co=24, T=12),
       "stress": dict(N=8192, E=65536, B=8, R=4, C=72, Co=24, T=12)}
 
@@ -116,12 +117,25 @@ def main():
         lambda: _lib.check(L.msgat_stage_aggregate(sp, gp, Co, ptr(rot(us)), ptr(E), ptr(rot(ous)), ptr(escr), st()), "a"))
     reg("mix_bwd      du,dq->dx", 4 * G * P * (Co + 1 + Cc),
         lambda: _lib.check(L.msgat_stage_mix(sp, Co, Cc, ptr(rot(us)), ptr(W), 1, ptr(alpha), ptr(dq), ptr(rot(oxs)), st()), "m"))
+    # the merged channel mixing of a MEAM block (stacked.py): 72 -> 98 channels forward, 98 -> 72 backward
+    Cm = 98
+    ys = [rnd(G, Cm, N, T) for _ in range(min(a.sets, 2))]
+    Wm = rnd(R, Cm, Cc) * 0.1
+    reg("mix_fwd98    x(72)->98", 4 * G * P * (Cc + Cm),
+        lambda: _lib.check(L.msgat_stage_mix(sp, Cc, Cm, ptr(rot(xs)), ptr(Wm), 0, None, None, ptr(rot(ys)), st()), "m"))
+    reg("mix_bwd98    d98->dx(72)", 4 * G * P * (Cc + Cm),
+        lambda: _lib.check(L.msgat_stage_mix(sp, Cm, Cc, ptr(rot(ys)), ptr(Wm), 1, None, None, ptr(rot(oxs)), st()), "m"))
     nfl = L.msgat_contract_partial_floats(sp, Co + 1, Cc)
     part = torch.empty(nfl, device=dev)
     dW, da = torch.empty(R, Co, Cc, device=dev), torch.empty(R, Cc, device=dev)
     reg("contract     du,dq,x->dW,dalpha", 4 * G * P * (Co + 1 + Cc),
         lambda: _lib.check(L.msgat_stage_contract(sp, Co + 1, Cc, ptr(rot(us)), ptr(dq), ptr(rot(xs)), ptr(part), ptr(dW),
                                                   Co * Cc, ptr(da), Cc, st()), "c"))
+    nfl98 = L.msgat_contract_partial_floats(sp, Cm, Cc)
+    part98, dW98 = torch.empty(nfl98, device=dev), torch.empty(R, Cm, Cc, device=dev)
+    reg("contract98   d98,x->dW[98,72]", 4 * G * P * (Cm + Cc),
+        lambda: _lib.check(L.msgat_stage_contract(sp, Cm, Cc, ptr(rot(ys)), None, ptr(rot(xs)), ptr(part98), ptr(dW98),
+                                                  Cm * Cc, None, 0, st()), "c"))
     only = [s for s in a.only.split(",") if s]
     for name, (nbytes, fn) in stages.items():
         if only and not any(o in name for o in only):
