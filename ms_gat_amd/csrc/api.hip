@@ -407,15 +407,23 @@ extern "C" int msgat_attention_backward(const msgat_shape_t* shp, const msgat_gr
   float* dkW = (float*)(ws + p.off_dkW);
   float* dwgp = (float*)(ws + p.off_dwg);
   const int G = p.G, Bg = sh->Bg, N = sh->N, T = sh->T;
-  st = launch_sddmm(*gr, u, dv, dEp, G, sh->C, N, T, s);
+  // du = E^T dv and the SDDMM walk the same (column, edge) pairs over the same dv slabs: one pass when the graph allows
+  const bool fused = agg_sddmm_fusable(*gr, N, T, sh->C);
+  if (fused) {
+    st = launch_permute_edges(E, gr->cperm, Ec, G, gr->nnz, gr->nnz, s);
+    if (st) return st;
+    st = launch_agg_sddmm(*gr, dv, Ec, u, du, dEp, G, sh->C, N, T, s);
+  } else {
+    st = launch_sddmm(*gr, u, dv, dEp, G, sh->C, N, T, s);
+  }
   if (st) return st;
-  st = launch_bwd_edge(*gr, dEp, p.nch, E, q, pq, Wg, gE, delta, dkW, dq, G, Bg, N, T, s);
+  st = launch_bwd_edge(*gr, dEp, p.nch, E, q, pq, Wg, gE, delta, dkW, dq, G, Bg, N, T, s, fused ? Ec : nullptr);
   if (st) return st;
   st = launch_bwd_dense_col(*gr, q, kW, lse, delta, gE, dq, G, N, T, s);
   if (st) return st;
   st = launch_dwg(q, dkW, dwgp, dWg, G, Bg, N, T, s);
   if (st) return st;
-  return aggregate_cols(sh, gr, sh->C, dv, E, Ec, nullptr, nullptr, du, s);
+  return fused ? MSGAT_OK : aggregate_cols(sh, gr, sh->C, dv, E, Ec, nullptr, nullptr, du, s);
 }
 
 // ---- prediction head ----------------------------------------------------------------------------------
