@@ -334,7 +334,8 @@ int msgat_contract_segments(int32_t R, int32_t Bg, int32_t N, int32_t T, const m
  * Forward = msgat_stage_scores(q) + msgat_stage_aggregate(u) (above).  Backward of exactly that pair, for
  * callers that produced u and q themselves (e.g. in a merged channel-mixing pass):
  *   du = E^T dv  [G,Cu,N,T],   dq = total gradient at q  [G,N,T],   dWg [R,T,T].
- * shape->C is Cu (the channels of u), shape->Co is ignored. */
+ * shape->C is Cu (the channels of u), shape->Co is ignored.  du must not overlap u or dv (du and the edge gradients
+ * come out of one pass that reads both). */
 size_t msgat_attention_bwd_workspace_bytes(const msgat_shape_t* shape, const msgat_graph_t* graph);
 int msgat_attention_backward(const msgat_shape_t* shape, const msgat_graph_t* graph, const float* u,
                              const float* dv, const float* q, const float* kW, const float* lse,
