@@ -36,6 +36,7 @@ __device__ __forceinline__ f32x4 zero4() {
 // projection
 // ---------------------------------------------------------------------------------------------
 constexpr int kKC = 8;  // k-steps (groups of 4 input channels) per register buffer
+constexpr int kProjMaxMG = 7;
 
 __host__ __device__ static inline int proj_kpad(int Kx) {
   const int K4 = (Kx + 3) & ~3;
@@ -48,7 +49,7 @@ __host__ __device__ static inline int proj_kpad(int Kx) {
 // padding is neutralised by zero matrix entries): a load inside a branch makes hipcc fall back
 // to s_waitcnt vmcnt(0), which serialises the prefetch against the MFMAs.
 template <int MG, bool DO_Q, bool ONEPASS, bool SEGS>
-__global__ __launch_bounds__(kBlock) void k_project_mfma(
+__global__ __launch_bounds__(kBlock, MG > 5 ? 2 : 1) void k_project_mfma(
     SegList in, const float* __restrict__ M, int m_in_major,
     const float* __restrict__ qvec, const float* __restrict__ addvec,
     const float4* __restrict__ extra4, SegList out, float4* __restrict__ q4, int Bg,
@@ -191,7 +192,10 @@ __global__ __launch_bounds__(kBlock) void k_project_mfma(
 
 static int proj_passes_mg(int Co, int* mg_out) {
   const int Mt = cdiv(Co, 16);
-  const int passes = cdiv(Mt, 5);  // all output tiles in one pass when they fit 5 x 16 accumulator registers
+  // all output tiles in one pass when they fit the accumulator registers: up to 7 x 16 channels (188 registers, two
+  // waves per SIMD -- forced by the kernel's launch bounds, left alone the allocator took more than 256 and one wave).
+  // A 72 -> 98 channel mixing in ONE pass over its input: 288 -> 252 us against two passes of 4 and 3 tiles.
+  const int passes = cdiv(Mt, kProjMaxMG);
   *mg_out = cdiv(Mt, passes);
   return passes;
 }
@@ -237,7 +241,10 @@ int launch_project_mfma(const SegList& in, const float* M, int m_in_major, const
     case 2: return launch_project_mg<2>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, P4, epi, s);
     case 3: return launch_project_mg<3>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, P4, epi, s);
     case 4: return launch_project_mg<4>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, P4, epi, s);
-    default: return launch_project_mg<5>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, P4, epi, s);
+    case 5: return launch_project_mg<5>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, P4, epi, s);
+    case 6: return launch_project_mg<6>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, P4, epi, s);
+    default: return launch_project_mg<7>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, P4, epi, s);
+
   }
 }
 
