@@ -148,7 +148,7 @@ typedef struct msgat_bwd {
   const float* pq;
   const float* E;
   const float* u;
-  /* incoming gradient, contiguous, same shape as z */
+  /* incoming gradient, same shape as z; contiguous unless dz_group_channels says otherwise (below) */
   const float* dz;
   /* gradients out (overwritten, not accumulated) */
   float* dx;     /* [G,C,N,T]                       */
@@ -158,6 +158,10 @@ typedef struct msgat_bwd {
   /* scratch, >= msgat_bwd_workspace_bytes() bytes, 256-byte aligned */
   void* workspace;
   size_t workspace_bytes;
+  /* 0, or the channel count of the tensor dz is a channel slice of: group g of dz then starts at
+   * dz + g * dz_group_channels * N * T (a gradient that arrives as dout[:, a:b] of a wider [G,C',N,T] tensor is read in
+   * place instead of being copied).  Only where msgat_bwd_accepts_strided_dz() says so; 0 everywhere else. */
+  int32_t dz_group_channels;
 } msgat_bwd_t;
 
 /* ---- library ------------------------------------------------------------------- */
@@ -195,6 +199,9 @@ size_t msgat_edge_scratch_floats(const msgat_shape_t* shape, const msgat_graph_t
 int msgat_gacn_forward(const msgat_shape_t* shape, const msgat_graph_t* graph,
                        const msgat_fwd_t* io, void* stream);
 size_t msgat_bwd_workspace_bytes(const msgat_shape_t* shape, const msgat_graph_t* graph);
+/* 1 when msgat_gacn_backward reads a channel-sliced dz in place for this shape and graph (dz_group_channels), 0 when
+ * the caller must pass a contiguous copy. */
+int msgat_bwd_accepts_strided_dz(const msgat_shape_t* shape, const msgat_graph_t* graph);
 int msgat_gacn_backward(const msgat_shape_t* shape, const msgat_graph_t* graph,
                         const msgat_bwd_t* io, void* stream);
 
@@ -337,10 +344,13 @@ int msgat_contract_segments(int32_t R, int32_t Bg, int32_t N, int32_t T, const m
  * shape->C is Cu (the channels of u), shape->Co is ignored.  du must not overlap u or dv (du and the edge gradients
  * come out of one pass that reads both). */
 size_t msgat_attention_bwd_workspace_bytes(const msgat_shape_t* shape, const msgat_graph_t* graph);
+/* dv_group_channels: as msgat_bwd_t.dz_group_channels, for dv (0 = contiguous); non-zero only where
+ * msgat_attention_bwd_accepts_strided_dv() returns 1. */
+int msgat_attention_bwd_accepts_strided_dv(const msgat_shape_t* shape, const msgat_graph_t* graph);
 int msgat_attention_backward(const msgat_shape_t* shape, const msgat_graph_t* graph, const float* u,
-                             const float* dv, const float* q, const float* kW, const float* lse,
-                             const float* pq, const float* E, const float* Wg, float* du, float* dq,
-                             float* dWg, void* workspace, size_t workspace_bytes, void* stream);
+                             const float* dv, int32_t dv_group_channels, const float* q, const float* kW,
+                             const float* lse, const float* pq, const float* E, const float* Wg, float* du,
+                             float* dq, float* dWg, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- device: the prediction head of a component ----
  * TPC's Conv2d(T_in -> T_out, kernel [1, C]) over the transposed activation (src/models/msgat.py:153,

@@ -53,7 +53,7 @@ class Fwd(C.Structure):
 class Bwd(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "x", "alpha", "Wg", "W", "q", "kW", "lse", "pq", "E", "u", "dz", "dx", "dalpha", "dWg", "dW",
-        "workspace")] + [("workspace_bytes", C.c_size_t)]
+        "workspace")] + [("workspace_bytes", C.c_size_t), ("dz_group_channels", C.c_int32)]
 
 
 class Seg(C.Structure):
@@ -98,7 +98,10 @@ _PROTOTYPES = {
     "msgat_contract_segments": (C.c_int, [C.c_int32] * 4 + [C.POINTER(Seg), C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "msgat_attention_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Shape), C.POINTER(Graph)]),
-    "msgat_attention_backward": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)] + [C.c_void_p] * 12 + [C.c_size_t, C.c_void_p]),
+    "msgat_attention_backward": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_int32] +
+                                 [C.c_void_p] * 10 + [C.c_size_t, C.c_void_p]),
+    "msgat_attention_bwd_accepts_strided_dv": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)]),
+    "msgat_bwd_accepts_strided_dz": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)]),
     "msgat_head_forward_partial_floats": (C.c_size_t, [C.c_int32] * 4),
     "msgat_head_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p]),
     "msgat_head_grad_signal": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 6 + [C.c_void_p]),

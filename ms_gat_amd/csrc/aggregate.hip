@@ -604,7 +604,7 @@ template <int T4>
 __global__ __launch_bounds__(kAgsBlock) void k_agg_sddmm(
     const int* __restrict__ ptr, const int* __restrict__ idx, const float4* __restrict__ dv4,
     const float* __restrict__ Ec, const float4* __restrict__ u4, float4* __restrict__ du4,
-    float* __restrict__ dEp, int Cu, int N, int nnz, int CH, int nchunks) {
+    float* __restrict__ dEp, int Cu, int N, int nnz, int CH, int nchunks, int dvgs) {
   extern __shared__ float4 slab[];  // [CH][N][T4] of dv, then nnz * T4 floats of per-edge shares + a dummy per lane
   const int g = blockIdx.y;
   const int kc = blockIdx.x;
@@ -616,7 +616,8 @@ __global__ __launch_bounds__(kAgsBlock) void k_agg_sddmm(
   float* pd = reinterpret_cast<float*>(slab + CH * NT4);
   const int dummy = nnz * T4 + threadIdx.x;
 
-  for (int i = threadIdx.x; i < total; i += kAgsBlock) slab[i] = dv4[base + i];
+  const size_t vbase = ((size_t)g * dvgs + c0) * NT4;  // dv may be a channel slice of a wider tensor (dvgs channels per group)
+  for (int i = threadIdx.x; i < total; i += kAgsBlock) slab[i] = dv4[vbase + i];
   __syncthreads();
 
   const float* Eg = Ec + (size_t)g * nnz;
@@ -654,7 +655,7 @@ bool agg_sddmm_fusable(const msgat_graph_t& gr, int N, int T, int Cu) {
 
 template <int T4>
 static int launch_agg_sddmm_t(const msgat_graph_t& gr, const float* dv, const float* Ec, const float* u, float* du,
-                              float* dEp, int G, int Cu, int N, hipStream_t s) {
+                              float* dEp, int G, int Cu, int N, hipStream_t s, int dvgs) {
   const int T = 4 * T4;
   const int CH = slab_channels(N, T, Cu, kLdsBudget);
   const size_t lds = agg_sddmm_lds(N, T, Cu, gr.nnz);
@@ -665,18 +666,18 @@ static int launch_agg_sddmm_t(const msgat_graph_t& gr, const float* dv, const fl
   }
   const int nchunks = cdiv(Cu, CH);
   hipLaunchKernelGGL(k_agg_sddmm<T4>, dim3(nchunks, G), dim3(kAgsBlock), lds, s, gr.colptr, gr.crow, (const float4*)dv,
-                     Ec, (const float4*)u, (float4*)du, dEp, Cu, N, gr.nnz, CH, nchunks);
+                     Ec, (const float4*)u, (float4*)du, dEp, Cu, N, gr.nnz, CH, nchunks, dvgs > 0 ? dvgs : Cu);
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
 
 int launch_agg_sddmm(const msgat_graph_t& gr, const float* dv, const float* Ec, const float* u, float* du, float* dEp,
-                     int G, int Cu, int N, int T, hipStream_t s) {
+                     int G, int Cu, int N, int T, hipStream_t s, int dvgs) {
   switch (T) {
-    case 4: return launch_agg_sddmm_t<1>(gr, dv, Ec, u, du, dEp, G, Cu, N, s);
-    case 8: return launch_agg_sddmm_t<2>(gr, dv, Ec, u, du, dEp, G, Cu, N, s);
-    case 12: return launch_agg_sddmm_t<3>(gr, dv, Ec, u, du, dEp, G, Cu, N, s);
-    case 16: return launch_agg_sddmm_t<4>(gr, dv, Ec, u, du, dEp, G, Cu, N, s);
+    case 4: return launch_agg_sddmm_t<1>(gr, dv, Ec, u, du, dEp, G, Cu, N, s, dvgs);
+    case 8: return launch_agg_sddmm_t<2>(gr, dv, Ec, u, du, dEp, G, Cu, N, s, dvgs);
+    case 12: return launch_agg_sddmm_t<3>(gr, dv, Ec, u, du, dEp, G, Cu, N, s, dvgs);
+    case 16: return launch_agg_sddmm_t<4>(gr, dv, Ec, u, du, dEp, G, Cu, N, s, dvgs);
   }
   return MSGAT_ERR_UNSUPPORTED;
 }

@@ -384,10 +384,15 @@ extern "C" size_t msgat_attention_bwd_workspace_bytes(const msgat_shape_t* sh, c
   return plan_bwd(plain_shape(sh), *gr).total;
 }
 
+extern "C" int msgat_attention_bwd_accepts_strided_dv(const msgat_shape_t* sh, const msgat_graph_t* gr) {
+  if (check_shape(sh) != MSGAT_OK || check_graph(sh, gr) != MSGAT_OK) return 0;
+  return agg_sddmm_fusable(*gr, sh->N, sh->T, sh->C) ? 1 : 0;
+}
+
 extern "C" int msgat_attention_backward(const msgat_shape_t* shp, const msgat_graph_t* gr, const float* u,
-                                        const float* dv, const float* q, const float* kW, const float* lse,
-                                        const float* pq, const float* E, const float* Wg, float* du, float* dq,
-                                        float* dWg, void* workspace, size_t workspace_bytes, void* stream) {
+                                        const float* dv, int32_t dv_group_channels, const float* q, const float* kW,
+                                        const float* lse, const float* pq, const float* E, const float* Wg, float* du,
+                                        float* dq, float* dWg, void* workspace, size_t workspace_bytes, void* stream) {
   int st = check_shape(shp);
   if (st) return st;
   const msgat_shape_t shv = plain_shape(shp);
@@ -409,10 +414,11 @@ extern "C" int msgat_attention_backward(const msgat_shape_t* shp, const msgat_gr
   const int G = p.G, Bg = sh->Bg, N = sh->N, T = sh->T;
   // du = E^T dv and the SDDMM walk the same (column, edge) pairs over the same dv slabs: one pass when the graph allows
   const bool fused = agg_sddmm_fusable(*gr, N, T, sh->C);
+  if (dv_group_channels != 0 && (dv_group_channels < sh->C || !fused)) return MSGAT_ERR_SHAPE;  // see ..._accepts_strided_dv
   if (fused) {
     st = launch_permute_edges(E, gr->cperm, Ec, G, gr->nnz, gr->nnz, s);
     if (st) return st;
-    st = launch_agg_sddmm(*gr, dv, Ec, u, du, dEp, G, sh->C, N, T, s);
+    st = launch_agg_sddmm(*gr, dv, Ec, u, du, dEp, G, sh->C, N, T, s, dv_group_channels);
   } else {
     st = launch_sddmm(*gr, u, dv, dEp, G, sh->C, N, T, s);
   }
@@ -541,6 +547,14 @@ extern "C" size_t msgat_bwd_workspace_bytes(const msgat_shape_t* sh, const msgat
   return plan_bwd(*sh, *gr).total;
 }
 
+extern "C" int msgat_bwd_accepts_strided_dz(const msgat_shape_t* sh, const msgat_graph_t* gr) {
+  if (check_shape(sh) != MSGAT_OK || check_graph(sh, gr) != MSGAT_OK) return 0;
+  const int mode = msgat_gacn_mode(sh->C, sh->Co);
+  if (mode == MSGAT_MODE_AGG_FIRST) return 1;  // dz feeds channel-mixing passes only, which take a group stride
+  if (mode == MSGAT_MODE_PROJ_FIRST) return agg_sddmm_fusable(*gr, sh->N, sh->T, sh->Co) ? 1 : 0;
+  return 0;
+}
+
 extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t* gr,
                                    const msgat_bwd_t* io, void* stream) {
   int st = check_shape(sh);
@@ -575,17 +589,26 @@ extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t*
   ReduceJobs jobs{};
   float* cpp2 = (float*)(ws + p.off_cp2);
 
+  // dz as a channel slice of a wider tensor: group stride in channels (its own width when contiguous)
+  const int zc = (p.mode == MSGAT_MODE_PLAIN) ? C : Co;
+  const bool strided = io->dz_group_channels != 0 && io->dz_group_channels != zc;
+  if (io->dz_group_channels != 0 && io->dz_group_channels < zc) return MSGAT_ERR_SHAPE;
+  const int dzgs = strided ? io->dz_group_channels : zc;
+
   // features the attention acted on (u) and the gradient arriving at its output (dv)
   const float* u = (p.mode == MSGAT_MODE_PROJ_FIRST) ? io->u : io->x;
   const float* dv = io->dz;
   if (p.mode == MSGAT_MODE_AGG_FIRST) {
     // z = W y:  dy = W^T dz,  dW = dz y^T -- one pass over dz when the input has few channels
     if (C <= kAggFirstMaxC) {
-      st = launch_aggfirst_bwd(io->dz, io->W, io->u, dvb, cpp, io->dW, G, Bg, C, Co, P, s, &jobs);
+      st = launch_aggfirst_bwd(io->dz, io->W, io->u, dvb, cpp, io->dW, G, Bg, C, Co, P, s, &jobs, dzgs);
     } else {
-      st = launch_project(io->dz, io->W, 1, nullptr, nullptr, nullptr, dvb, nullptr, G, Bg, Co, C, P, s);
+      SegList dzs = seg_single(io->dz, Co);
+      dzs.gstride[0] = dzgs;
+      st = launch_project_seg(dzs, io->W, 1, nullptr, nullptr, nullptr, seg_single(dvb, C), nullptr, G, Bg, P,
+                              MixEpilogue{}, s);
       if (st) return st;
-      st = launch_chanpair(io->dz, nullptr, io->u, cpp, io->dW, Co * C, nullptr, 0, G, Bg, Co, C, P, s, &jobs);
+      st = launch_chanpair_seg(dzs, io->u, cpp, io->dW, Co * C, nullptr, 0, G, Bg, C, P, s, 0, &jobs);
     }
     if (st) return st;
     dv = dvb;
@@ -594,10 +617,11 @@ extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t*
   // PROJ_FIRST: du = E^T dz does not wait for dq, and it walks the same (column, edge) pairs over the same dz slabs
   // as the SDDMM -- one pass does both when the graph allows (CSC, slab + edge shares within half the LDS)
   const bool fused = p.mode == MSGAT_MODE_PROJ_FIRST && agg_sddmm_fusable(*gr, N, T, p.Cu);
+  if (strided && p.mode != MSGAT_MODE_AGG_FIRST && !fused) return MSGAT_ERR_SHAPE;  // see msgat_bwd_accepts_strided_dz
   if (fused) {
     st = launch_permute_edges(io->E, gr->cperm, Ec, G, gr->nnz, gr->nnz, s);
     if (st) return st;
-    st = launch_agg_sddmm(*gr, dv, Ec, u, dvb, dEp, G, p.Cu, N, T, s);
+    st = launch_agg_sddmm(*gr, dv, Ec, u, dvb, dEp, G, p.Cu, N, T, s, dzgs);
   } else {
     st = launch_sddmm(*gr, u, dv, dEp, G, p.Cu, N, T, s);
   }

@@ -217,7 +217,7 @@ int launch_sddmm(const msgat_graph_t& gr, const float* u, const float* dv, float
 // come out in CSC order (launch_bwd_edge: csc_order).  Usable when agg_sddmm_fusable(); chunks = sddmm_chunks().
 bool agg_sddmm_fusable(const msgat_graph_t& gr, int N, int T, int Cu);
 int launch_agg_sddmm(const msgat_graph_t& gr, const float* dv, const float* Ec, const float* u, float* du, float* dEp,
-                     int G, int Cu, int N, int T, hipStream_t s);
+                     int G, int Cu, int N, int T, hipStream_t s, int dv_group_channels = 0);
 // Ecsc != nullptr: the partials are in CSC order and Ecsc holds E in that order
 int launch_bwd_edge(const msgat_graph_t& gr, const float* dEp, int nchunks, const float* E,
                     const float* q, const float* pq, const float* Wg, float* gE, float* delta,
@@ -258,7 +258,7 @@ int launch_chanpair_seg(const SegList& A, const float* B, float* part, float* ds
 constexpr int kAggFirstMaxC = 4;
 int aggfirst_blocks(int P);
 int launch_aggfirst_bwd(const float* dz, const float* W, const float* y, float* dy, float* part, float* dW, int G,
-                        int Bg, int C, int Co, int P, hipStream_t s, ReduceJobs* defer);
+                        int Bg, int C, int Co, int P, hipStream_t s, ReduceJobs* defer, int dz_group_channels = 0);
 // out[i] = sum_j part[j,i], i < Wd, split over dst0 (first n0) and dst1 (next n1); fixed order
 int launch_reduce_rows(const float* part, int J, int Wd, float* dst0, int n0, float* dst1, int n1,
                        hipStream_t s);

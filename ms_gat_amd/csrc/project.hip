@@ -48,7 +48,7 @@ constexpr int kAfChunk = 8;
 template <int C>
 __global__ __launch_bounds__(kBlock) void k_aggfirst_bwd(const float4* __restrict__ dz4, const float* __restrict__ W,
                                                          const float4* __restrict__ y4, float4* __restrict__ dy4,
-                                                         float* __restrict__ part, int Bg, int Co, int P4) {
+                                                         float* __restrict__ part, int Bg, int Co, int P4, int dzgs) {
   extern __shared__ float lds[];
   float* Wl = lds;                        // [Co][C]
   float* red = lds + Co * C;              // [4 waves][Co*C]
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kBlock) void k_aggfirst_bwd(const float4* __restric
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const float4* src = dz4 + (size_t)g * Co * P4 + p4c;
+  const float4* src = dz4 + (size_t)g * dzgs * P4 + p4c;  // dz may be a channel slice of a wider tensor
   for (int o0 = 0; o0 < Co; o0 += kAfChunk) {
     float4 d[kAfChunk];
 #pragma unroll
@@ -98,13 +98,13 @@ __global__ __launch_bounds__(kBlock) void k_aggfirst_bwd(const float4* __restric
 int aggfirst_blocks(int P) { return cdiv(P / 4, kBlock); }
 
 int launch_aggfirst_bwd(const float* dz, const float* W, const float* y, float* dy, float* part, float* dW, int G,
-                        int Bg, int C, int Co, int P, hipStream_t s, ReduceJobs* defer) {
+                        int Bg, int C, int Co, int P, hipStream_t s, ReduceJobs* defer, int dzgs) {
   const int P4 = P / 4, nb = aggfirst_blocks(P);
   const size_t lds = (size_t)5 * Co * C * sizeof(float);
   dim3 grid(nb, G);
 #define MSGAT_AF(CC)                                                                                              \
   hipLaunchKernelGGL(k_aggfirst_bwd<CC>, grid, dim3(kBlock), lds, s, (const float4*)dz, W, (const float4*)y, \
-                     (float4*)dy, part, Bg, Co, P4)
+                     (float4*)dy, part, Bg, Co, P4, dzgs > 0 ? dzgs : Co)
   switch (C) {
     case 1: MSGAT_AF(1); break;
     case 2: MSGAT_AF(2); break;

@@ -261,6 +261,55 @@ def test_attention_core_equals_the_graph_attention_on_projected_features():
     _check(g_mine, [g.double() for g in g_ref], ["dx", "dW", "dalpha", "dWg"])
 
 
+class _GradArrivesAsSlice(torch.autograd.Function):
+    """Identity whose gradient reaches the producer as the channel slice [:, a:b] of a wider tensor -- what the residual
+    tail of a MEAM block hands to its three branches (msgat.py:130, one dout for cat(cacn, tacn, gacn))."""
+
+    @staticmethod
+    def forward(ctx, z):
+        return z.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        G, Ck, N, T = g.shape
+        wide = torch.full((G, 3 * Ck + 5, N, T), float("nan"), device=g.device)   # neighbours must never be read
+        wide[:, Ck + 2:2 * Ck + 2] = g
+        return wide[:, Ck + 2:2 * Ck + 2]
+
+
+@pytest.mark.parametrize("B,C,Co,N,edges", [(3, 1, 24, 61, 80), (2, 3, 24, 50, 60), (2, 6, 24, 40, 50),
+                                           (3, 72, 24, 61, 80), (2, 72, 24, 883, 866), (2, 40, 8, 2000, 2500)])
+def test_gradient_channel_slices_are_read_in_place(B, C, Co, N, edges):
+    """GACN and the attention core give bit-identical gradients whether dz arrives contiguous or as a channel slice of a
+    wider tensor (read in place where the library accepts it -- AGG_FIRST, fused PROJ_FIRST -- copied otherwise: N = 2000)."""
+    import ms_gat_amd
+    from ms_gat_amd import ops
+    gen = torch.Generator().manual_seed(29)
+    T = 12
+    adj = ms_gat_amd.synthetic_adjacency(N, edges, seed=4).to(_dev())
+    x, W, alpha, Wg = _rand(gen, B, C, N, T), _rand(gen, Co, C, scale=0.2), _rand(gen, C, scale=0.2), _rand(gen, T, T, scale=0.3)
+    dz = _rand(gen, B, Co, N, T)
+
+    def grads(sliced):
+        xa, Wa, aa, ga = _leaf(x, W, alpha, Wg)
+        z = ops.gacn(xa, aa.unsqueeze(0), ga.unsqueeze(0), Wa.unsqueeze(0), adj)
+        z = _GradArrivesAsSlice.apply(z) if sliced else z
+        return torch.autograd.grad(z, [xa, Wa, aa, ga], dz)
+
+    for a, b in zip(grads(True), grads(False)):
+        assert torch.equal(a, b)
+    if C > Co:
+        def core(sliced):
+            xa, Wa, aa, ga = _leaf(x, W, alpha, Wg)
+            u = torch.einsum("oc,bcnt->bont", Wa, xa)
+            q = torch.einsum("c,bcnt->bnt", aa, xa)
+            z = ops.attention_core(u, q, ga.unsqueeze(0), adj)
+            z = _GradArrivesAsSlice.apply(z) if sliced else z
+            return torch.autograd.grad(z, [xa, Wa, aa, ga], dz)
+        for a, b in zip(core(True), core(False)):
+            assert torch.equal(a, b)
+
+
 def test_parameter_sets_per_relation_in_one_launch():
     """R parameter sets evaluated in one launch (the relation count of include/msgat_hip.h) equal R separate calls:
     LayerNorm, node pooling, channel pooling, time mixing bias and the prediction head, forward and gradients."""
