@@ -127,45 +127,55 @@ int launch_tmix(const float* src, const float* A, int per_group, const float* bi
 // a group.  A lane keeps the T*T accumulators in registers over its rows; waves reduce by shuffles, the
 // block through LDS, and kTmixChunks blocks per (g, k) leave partials for the fixed-order final sum.
 constexpr int kTmixChunks = 4;
+constexpr int kTdaUnroll = 8;  // k-steps (of 4 rows) whose loads are in flight together
 
+// The outer-product sum on the matrix cores: D[t][i] += sum_rows A[t][row] B[row][i] with A = dout^T, B = y, 4 rows per
+// v_mfma_f32_16x16x4_f32 (exact fp32).  Lane (m = lane & 15, kq = lane >> 4) supplies dout[row 4s + kq][m] and
+// y[row 4s + kq][m]: the 16 lanes of a row read its T contiguous floats, the four rows of a k-step are adjacent, so a
+// wave-instruction reads 4 T contiguous floats.  The VALU form kept T*T accumulators per lane (144 registers at
+// T = 12, two waves per SIMD) and ran at 108 us for 294 MB; this one needs 4 + the loads in flight.
+// Columns m >= T and rows past the chunk's end are clamped addresses times a 0/1 mask (no load in a branch).
 template <int T>
 __global__ __launch_bounds__(kBlock) void k_tmix_dA(const float* __restrict__ dout, const float* __restrict__ y,
                                                     float* __restrict__ part, int Co, int K, int N, int dout_gs) {
-  __shared__ float red[kBlock / kWave][T * T];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  __shared__ float red[kBlock / kWave][256];
   const int g = blockIdx.z, k = blockIdx.y;
   const int rows = Co * N;
   const int per = cdiv(rows, (int)gridDim.x);
   const int r0 = blockIdx.x * per, r1 = min(r0 + per, rows);
-  float acc[T][T];
-#pragma unroll
-  for (int t = 0; t < T; ++t)
-#pragma unroll
-    for (int i = 0; i < T; ++i) acc[t][i] = 0.f;
-  const float* dbase = dout + (size_t)g * dout_gs * N * T;  // dout may be a channel slice of a wider tensor
-  const float* ybase = y + ((size_t)g * K + k) * rows * T;
-  for (int rr = r0 + threadIdx.x; rr < r1; rr += kBlock) {
-    float dv[T], yv[T];
-    ld_row<T>(dbase + (size_t)rr * T, dv);
-    ld_row<T>(ybase + (size_t)rr * T, yv);
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-      for (int i = 0; i < T; ++i) acc[t][i] = fmaf(dv[t], yv[i], acc[t][i]);
-  }
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const int m = lane & 15, kq = lane >> 4;
+  const int mc = min(m, T - 1);
+  const float colmask = m < T ? 1.f : 0.f;
+  const float* dbase = dout + (size_t)g * dout_gs * N * T + mc;  // dout may be a channel slice of a wider tensor
+  const float* ybase = y + ((size_t)g * K + k) * rows * T + mc;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // wave w takes k-steps w, w + 4, ... of the chunk, kTdaUnroll at a time
+  constexpr int kWaves = kBlock / kWave;
+  for (int s0 = r0 + 4 * wave * kTdaUnroll; s0 < r1; s0 += 4 * kWaves * kTdaUnroll) {
+    float a[kTdaUnroll], b[kTdaUnroll];
 #pragma unroll
-  for (int t = 0; t < T; ++t)
-#pragma unroll
-    for (int i = 0; i < T; ++i) {
-      float a = acc[t][i];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-      if (lane == 0) red[wave][t * T + i] = a;
+    for (int u = 0; u < kTdaUnroll; ++u) {
+      const int rr = s0 + 4 * u + kq;
+      const int rc = min(rr, r1 - 1);
+      const float keep = rr < r1 ? colmask : 0.f;
+      a[u] = dbase[(size_t)rc * T] * keep;
+      b[u] = ybase[(size_t)rc * T] * keep;
     }
+#pragma unroll
+    for (int u = 0; u < kTdaUnroll; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+  }
+  // D[t = 4 * (lane >> 4) + reg][i = lane & 15]; the four waves' tiles are added in a fixed order
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) red[wave][(4 * kq + reg) * 16 + m] = acc[reg];
   __syncthreads();
-  if (threadIdx.x < T * T)
+  if (threadIdx.x < T * T) {
+    const int t = threadIdx.x / T, i = threadIdx.x - t * T;
+    const int e = t * 16 + i;
     part[(((size_t)g * K + k) * gridDim.x + blockIdx.x) * (T * T) + threadIdx.x] =
-        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+  }
 }
 
 size_t tmix_partial_floats(int G, int K, int T) { return (size_t)G * K * kTmixChunks * T * T; }
