@@ -330,35 +330,63 @@ int launch_node_pool_dw(const float* x, const float* dp, float* dw, float* part,
 constexpr int kHeadCC = 8;
 constexpr int kHeadTo = 16;  // T_out <= 16
 
+// out[b,n,o] = bias[o] + sum_{c,t} x[b,c,n,t] W[o,t,c] on the matrix cores: a wave owns 16 nodes of one sample, the K axis
+// runs over (channel, timestep).  Lane (i, kq) loads ONE float4 per channel -- x[b,c,n0+i,4kq..4kq+3], the row's kq-th
+// quarter (kq < T/4; a wave-instruction reads 16 rows x T contiguous floats) -- and its component sigma is the lane's K
+// element of the channel's sigma-th MFMA (K slot kq <-> timestep 4 kq + sigma; slots kq >= T/4 carry zero weights: 4
+// MFMAs per channel at T = 12 where 3 dword loads per lane and MFMA would do, but those read 16 B of every 48-B row
+// per instruction: 149 us).  Weights come from LDS laid out [c][t][o].  The whole channel sum stays in one accumulator
+// tile: no channel-chunk partials (36 MB written and re-read by a reduction launch in the VALU form: 122 + 7 us).
+constexpr int kHeadFwdCC = 32;   // channels of W staged in LDS at a time (24 KB at T = 12: six blocks per CU)
+constexpr int kHeadFwdUn = 8;    // channels whose loads are in flight together
+
 template <int T>
 __global__ __launch_bounds__(kBlock) void k_head_fwd(const float* __restrict__ x, const float* __restrict__ W,
-                                                     const float* __restrict__ bias, float* __restrict__ part,
+                                                     const float* __restrict__ bias, float* __restrict__ out,
                                                      int C, int N, int To, int Bg) {
-  __shared__ float Wl[kHeadCC][kHeadTo][T];
-  const int b = blockIdx.z, ck = blockIdx.y;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  constexpr int T4 = T / 4;
+  __shared__ float Wl[kHeadFwdCC * T * kHeadTo];
+  const int b = blockIdx.y;
   W += (size_t)(b / Bg) * To * T * C;   // weights [R,To,T,1,C], bias [R,To]: Bg samples per relation
-  if (bias != nullptr) bias += (size_t)(b / Bg) * To;
-  const int c0 = ck * kHeadCC, cn = min(kHeadCC, C - c0);
-  for (int i = threadIdx.x; i < kHeadCC * kHeadTo * T; i += kBlock) {
-    const int c = i / (kHeadTo * T), o = (i / T) % kHeadTo, t = i % T;
-    Wl[c][o][t] = (c < cn && o < To) ? W[((size_t)o * T + t) * C + c0 + c] : 0.f;  // W is [To][T][1][C]
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const int m = lane & 15, kq = lane >> 4;
+  const int n0 = (blockIdx.x * (kBlock / kWave) + wave) * 16;
+  const int nrow = min(n0 + m, N - 1);  // clamped: rows past N are computed from row N-1 and never stored
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < C; c0 += kHeadFwdCC) {
+    const int cn = min(kHeadFwdCC, C - c0);
+    __syncthreads();  // the previous chunk's weights are no longer read
+    for (int i = threadIdx.x; i < kHeadFwdCC * T * kHeadTo; i += kBlock) {
+      const int c = i / (T * kHeadTo), t = (i / kHeadTo) % T, o = i % kHeadTo;
+      Wl[i] = (c < cn && o < To) ? W[((size_t)o * T + t) * C + c0 + c] : 0.f;  // W is [To][T][1][C]
+    }
+    __syncthreads();
+    const int kqc = min(kq, T4 - 1);
+    const float kmask = kq < T4 ? 1.f : 0.f;
+    const float4* src = reinterpret_cast<const float4*>(x + (((size_t)b * C + c0) * N + nrow) * T) + kqc;
+    for (int cc = 0; cc < cn; cc += kHeadFwdUn) {
+      float4 av[kHeadFwdUn];
+#pragma unroll
+      for (int u = 0; u < kHeadFwdUn; ++u) av[u] = src[(size_t)min(cc + u, cn - 1) * N * T4];
+#pragma unroll
+      for (int u = 0; u < kHeadFwdUn; ++u)
+        if (cc + u < cn) {  // wave-uniform; no loads inside
+          const float* wl = Wl + ((cc + u) * T + 4 * kqc) * kHeadTo + m;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, wl[0 * kHeadTo] * kmask, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, wl[1 * kHeadTo] * kmask, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, wl[2 * kHeadTo] * kmask, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, wl[3 * kHeadTo] * kmask, acc, 0, 0, 0);
+        }
+    }
   }
-  __syncthreads();
-  const int n = blockIdx.x * kBlock + threadIdx.x;
-  if (n >= N) return;
-  float acc[kHeadTo];
+  // D[node = 4 * (lane >> 4) + reg][o = lane & 15]
+  const float bo = (bias != nullptr && m < To) ? bias[(size_t)(b / Bg) * To + m] : 0.f;
 #pragma unroll
-  for (int o = 0; o < kHeadTo; ++o) acc[o] = (ck == 0 && bias != nullptr && o < To) ? bias[o] : 0.f;
-  for (int c = 0; c < cn; ++c) {
-    float v[T];
-    ld_row<T>(x + (((size_t)b * C + c0 + c) * N + n) * T, v);
-#pragma unroll
-    for (int o = 0; o < kHeadTo; ++o)
-#pragma unroll
-      for (int t = 0; t < T; ++t) acc[o] = fmaf(Wl[c][o][t], v[t], acc[o]);
+  for (int reg = 0; reg < 4; ++reg) {
+    const int n = n0 + 4 * kq + reg;
+    if (n < N && m < To) out[((size_t)b * N + n) * To + m] = acc[reg] + bo;
   }
-  float* dst = part + (((size_t)b * gridDim.y + ck) * N + n) * To;
-  for (int o = 0; o < To; ++o) dst[o] = acc[o];
 }
 
 // dx[b,c,n,t] = sum_o W[o,t,c] dout[b,n,o]
@@ -393,45 +421,50 @@ __global__ __launch_bounds__(kBlock) void k_head_dx(const float* __restrict__ do
   }
 }
 
-// dW partial[c, j, o, t] = sum over the j-th share of samples, all nodes: dout[b,n,o] x[b,c,n,t]
+// dW partial[c, j, o, t] = sum over the j-th share of samples, all nodes: dout[b,n,o] x[b,c,n,t] -- like k_tmix_dA a
+// [To x T] outer-product sum over rows (b, n), on the matrix cores: lane (m, kq) supplies dout[b][n = 4s + kq][o = m]
+// and x[b][c][n = 4s + kq][t = m] (the VALU form held To*T = 192 accumulators per lane: 193 us for 293 MB).
 constexpr int kHeadChunks = 4;
 
 template <int T>
 __global__ __launch_bounds__(kBlock) void k_head_dW(const float* __restrict__ dout, const float* __restrict__ x,
                                                     float* __restrict__ part, int B, int C, int N, int To) {
-  __shared__ float red[kBlock / kWave][kHeadTo * T];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  __shared__ float red[kBlock / kWave][256];
   const int c = blockIdx.y, j = blockIdx.x, rel = blockIdx.z;   // B = samples per relation
   const int b0 = rel * B + (int)((long long)B * j / gridDim.x), b1 = rel * B + (int)((long long)B * (j + 1) / gridDim.x);
-  float acc[kHeadTo][T];
-#pragma unroll
-  for (int o = 0; o < kHeadTo; ++o)
-#pragma unroll
-    for (int t = 0; t < T; ++t) acc[o][t] = 0.f;
-  for (int b = b0; b < b1; ++b)
-    for (int n = threadIdx.x; n < N; n += kBlock) {
-      float v[T], d[kHeadTo];
-      ld_row<T>(x + (((size_t)b * C + c) * N + n) * T, v);
-      const float* src = dout + ((size_t)b * N + n) * To;
-#pragma unroll
-      for (int o = 0; o < kHeadTo; ++o) d[o] = (o < To) ? src[min(o, To - 1)] : 0.f;
-#pragma unroll
-      for (int o = 0; o < kHeadTo; ++o)
-#pragma unroll
-        for (int t = 0; t < T; ++t) acc[o][t] = fmaf(d[o], v[t], acc[o][t]);
-    }
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const int m = lane & 15, kq = lane >> 4;
+  const int mo = min(m, To - 1), mt = min(m, T - 1);
+  const float omask = m < To ? 1.f : 0.f, tmask = m < T ? 1.f : 0.f;
+  constexpr int kWaves = kBlock / kWave;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int b = b0; b < b1; ++b) {
+    const float* dsrc = dout + (size_t)b * N * To + mo;
+    const float* xsrc = x + ((size_t)b * C + c) * N * T + mt;
+    for (int s0 = 4 * wave * kTdaUnroll; s0 < N; s0 += 4 * kWaves * kTdaUnroll) {
+      float av[kTdaUnroll], bv[kTdaUnroll];
 #pragma unroll
-  for (int o = 0; o < kHeadTo; ++o)
+      for (int u = 0; u < kTdaUnroll; ++u) {
+        const int n = s0 + 4 * u + kq;
+        const int nc = min(n, N - 1);
+        const float keep = n < N ? 1.f : 0.f;
+        av[u] = dsrc[(size_t)nc * To] * (keep * omask);
+        bv[u] = xsrc[(size_t)nc * T] * (keep * tmask);
+      }
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      float a = acc[o][t];
-#pragma unroll
-      for (int s = 32; s > 0; s >>= 1) a += __shfl_xor(a, s);
-      if (lane == 0) red[wave][o * T + t] = a;
+      for (int u = 0; u < kTdaUnroll; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
     }
+  }
+  // D[o = 4 * (lane >> 4) + reg][t = lane & 15]; the four waves' tiles are added in a fixed order
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) red[wave][(4 * kq + reg) * 16 + m] = acc[reg];
   __syncthreads();
-  for (int i = threadIdx.x; i < To * T; i += kBlock)
-    part[((((size_t)rel * gridDim.y + c) * gridDim.x + j) * To * T) + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+  for (int i = threadIdx.x; i < To * T; i += kBlock) {
+    const int o = i / T, t = i - o * T;
+    const int e = o * 16 + t;
+    part[((((size_t)rel * gridDim.y + c) * gridDim.x + j) * To * T) + i] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+  }
 }
 
 size_t head_fwd_partial_floats(int B, int C, int N, int To) { return (size_t)B * cdiv(C, kHeadCC) * N * To; }
@@ -448,12 +481,12 @@ size_t head_dw_partial_floats(int C, int T, int To, int R) { return (size_t)R * 
 
 int launch_head_fwd(const float* x, const float* W, const float* bias, float* out, float* part, int B, int C, int N,
                     int T, int To, int R, hipStream_t s) {
+  (void)part;  // the matrix-core form needs no partials; the argument stays for the ABI
   const int Bg = B / R;
-  const int nck = cdiv(C, kHeadCC);
-  dim3 grid(cdiv(N, kBlock), nck, B);
-  MSGAT_T_SWITCH(T, hipLaunchKernelGGL(k_head_fwd<TT>, grid, dim3(kBlock), 0, s, x, W, bias, part, C, N, To, Bg));
+  dim3 grid(cdiv(N, 16 * (kBlock / kWave)), B);
+  MSGAT_T_SWITCH(T, hipLaunchKernelGGL(k_head_fwd<TT>, grid, dim3(kBlock), 0, s, x, W, bias, out, C, N, To, Bg));
   MSGAT_CHECK_LAUNCH();
-  return launch_reduce_groups(part, B, nck, N * To, out, s);
+  return MSGAT_OK;
 }
 
 int launch_head_dx(const float* dout, const float* W, float* dx, int B, int C, int N, int T, int To, int R,
