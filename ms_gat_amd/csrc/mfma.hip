@@ -275,15 +275,15 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 constexpr int kCpWaves = 8;
 constexpr int kCpBlock = 64 * kCpWaves;
-constexpr int kTile = 32 * kCpWaves;   // positions per staged tile: 32 (8 k-steps) per wave
-constexpr int kLPR = kTile / 4;        // lanes per row piece (64: one row per wave-instruction)
-constexpr int kRPI = 64 / kLPR;        // rows per wave-instruction
-constexpr int kRowF4 = kTile / 4 + 1;  // float4s per LDS row (piece + 16 B pad)
+constexpr int kTile = 32 * kCpWaves;   // positions per staged tile (default): 32 (8 k-steps) per wave
 
 // TWO = false: one register set in flight instead of two -- what the [64 x 80] block (MA = 4) has registers for.  It
 // exists for operands with 49..64 A channels per z-block: a 98-channel gradient against 73 channels (the merged
 // channel mixing of a MEAM block) takes 2 z-blocks instead of 3, i.e. reads B twice instead of three times.
-template <int MA, int NB, bool TWO = true>
+// TILE = 128: half-length tiles (512-B row pieces, two rows per wave-instruction, 4 k-steps per wave).  Half the LDS
+// per row, so [80 x 80] and [112 x 80] channel blocks fit: a 72- or 98-channel gradient against 73 channels is ONE
+// pass over both operands instead of two z-blocks that each re-read B.
+template <int MA, int NB, bool TWO = true, int TILE = kTile>
 __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
     SegList A, const float* __restrict__ B, float* __restrict__ part, int Cb, int P, int Bg, int nzb, int b_ones) {
   // b_ones: B's last channel (index Cb-1) is a virtual row of ones, so part[a, Cb-1] = sum_p A[a,p] -- the bias
@@ -291,6 +291,10 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
   const int Cbr = Cb - b_ones;  // channels B really has
   const int Ca = A.total();
   extern __shared__ float4 lds4[];
+  constexpr int kLPR = TILE / 4;        // lanes per row piece (64: one row per wave-instruction)
+  constexpr int kRPI = 64 / kLPR;        // rows per wave-instruction
+  constexpr int kRowF4 = TILE / 4 + 1;  // float4s per LDS row (piece + 16 B pad)
+  constexpr int kPPW = TILE / kCpWaves;  // positions per wave and tile: 4 per k-step
   constexpr int RPW = ((MA + NB) * 16 + kCpWaves * kRPI - 1) / (kCpWaves * kRPI);  // load instructions per wave per tile
   const int r = blockIdx.y;
   const int nblk = gridDim.x;
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
   constexpr int kZeroRow = (MA + NB) * 16;  // an all-zero row for absent channels
   constexpr int kOnesRow = kZeroRow + 1;    // an all-ones row for the virtual channel
   // this block's run of the relation's tile stream
-  const int tpg = cdiv(P, kTile);  // tiles per group (the last one is partial)
+  const int tpg = cdiv(P, TILE);  // tiles per group (the last one is partial)
   const long long ntot = (long long)Bg * tpg;
   const int t0 = (int)(ntot * blockIdx.x / nblk), t1 = (int)(ntot * (blockIdx.x + 1) / nblk);
   const int ntile = t1 - t0;
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
   auto fetch = [&](int t, float4 (&regs)[RPW]) {  // t relative to t0, clamped to the run
     const int tau = t0 + min(t, ntile - 1);
     const int b = tau / tpg;
-    const int p0 = (tau - b * tpg) * kTile;
+    const int p0 = (tau - b * tpg) * TILE;
     const float keep = (p0 + 4 * lcol < P) ? 1.f : 0.f;
     const int poff = min(p0, plast);
 #pragma unroll
@@ -373,13 +377,13 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
 #pragma unroll
   for (int ma = 0; ma < MA; ++ma) {
     const int row = (ma * 16 + j < ca) ? ma * 16 + j : kZeroRow;
-    aw[ma] = row * (kRowF4 * 4) + 32 * wave + kq;
+    aw[ma] = row * (kRowF4 * 4) + kPPW * wave + kq;
   }
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int cl = nb * 16 + j;
     const int row = (cl < cb) ? ((b_ones && c0 + cl == Cbr) ? kOnesRow : ca + cl) : kZeroRow;
-    bw[nb] = row * (kRowF4 * 4) + 32 * wave + kq;
+    bw[nb] = row * (kRowF4 * 4) + kPPW * wave + kq;
   }
 
   f32x4 acc[MA][NB];
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
 
   auto multiply = [&]() {
 #pragma unroll
-    for (int qq = 0; qq < 8; ++qq) {
+    for (int qq = 0; qq < kPPW / 4; ++qq) {
       float av[MA], bv[NB];
 #pragma unroll
       for (int ma = 0; ma < MA; ++ma) av[ma] = ldsw[aw[ma] + 4 * qq];
@@ -438,28 +442,41 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
     }
   }
 
-  // sum the 8 waves' accumulators in a fixed order: element e = ((ma*NB + nb)*4 + reg)*64 + lane
+  // sum the 8 waves' accumulators in a fixed order, kRedTiles 16x16 tiles at a time (what the tile buffer holds:
+  // 8 waves x 1 KiB per tile): element e = (tile * 4 + reg) * 64 + lane
   MSGAT_STAMP(4);
-  __syncthreads();
-  float* red = reinterpret_cast<float*>(lds4) + (size_t)wave * (MA * NB * 256);
-#pragma unroll
-  for (int ma = 0; ma < MA; ++ma)
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) red[((ma * NB + nb) * 4 + reg) * 64 + lane] = acc[ma][nb][reg];
-  __syncthreads();
+  constexpr int kTiles = MA * NB;
+  constexpr int kBufTiles = (((MA + NB) * 16 + 2) * kRowF4 * 16) / (kCpWaves * 1024);  // tiles the staging buffer holds
+  constexpr int kRedTiles = kBufTiles >= kTiles ? kTiles : kBufTiles;
+  static_assert(kRedTiles >= 1, "tile buffer too small for the reduction");
+  float* red = reinterpret_cast<float*>(lds4) + (size_t)wave * (kRedTiles * 256);
   const float* all = reinterpret_cast<const float*>(lds4);
   float* out = part + ((size_t)r * nblk + blockIdx.x) * ((size_t)Ca * Cb);
-  for (int e = threadIdx.x; e < MA * NB * 256; e += kCpBlock) {
-    float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < kCpWaves; ++w) v += all[w * (MA * NB * 256) + e];
-    const int el = e & 63, reg = (e >> 6) & 3, tile = e >> 8;
-    const int ma = tile / NB, nb = tile - ma * NB;
-    const int a = a0 + ma * 16 + 4 * (el >> 4) + reg;  // D row = 4*(lane >> 4) + reg
-    const int c = c0 + nb * 16 + (el & 15);            // D column = lane & 15
-    if (a < Ca && c < Cb) out[(size_t)a * Cb + c] = v;
+  for (int t0r = 0; t0r < kTiles; t0r += kRedTiles) {
+    __syncthreads();  // the tile buffer (or the previous pass) is no longer read
+#pragma unroll
+    for (int ma = 0; ma < MA; ++ma)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int tile = ma * NB + nb;
+        if (tile >= t0r && tile < t0r + kRedTiles) {
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) red[((tile - t0r) * 4 + reg) * 64 + lane] = acc[ma][nb][reg];
+        }
+      }
+    __syncthreads();
+    const int ntl = (kTiles - t0r < kRedTiles) ? kTiles - t0r : kRedTiles;
+    for (int e = threadIdx.x; e < ntl * 256; e += kCpBlock) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < kCpWaves; ++w) v += all[w * (kRedTiles * 256) + e];
+      const int el = e & 63, reg = (e >> 6) & 3, tile = t0r + (e >> 8);
+      const int ma = tile / NB, nb = tile - ma * NB;
+      const int a = a0 + ma * 16 + 4 * (el >> 4) + reg;  // D row = 4*(lane >> 4) + reg
+      const int c = c0 + nb * 16 + (el & 15);            // D column = lane & 15
+      if (a < Ca && c < Cb) out[(size_t)a * Cb + c] = v;
+    }
   }
   MSGAT_STAMP(5);
 }
@@ -472,20 +489,20 @@ int chanpair_mfma_blocks(int R) {
   return max(1, ncu / R);
 }
 
-template <int MA, int NB, bool TWO = true>
+template <int MA, int NB, bool TWO = true, int TILE = kTile>
 static int launch_chanpair_t(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
                              int b_ones, hipStream_t s) {
   const int Ca = A.total();
   const int nza = cdiv(Ca, MA * 16), nzb = cdiv(Cb, NB * 16);
-  // tile rows + the zero row + the ones row, reused for the 8 x MA*NB*256-float reduction
-  const size_t lds = sizeof(float4) * (size_t)max(((MA + NB) * 16 + 2) * kRowF4, kCpWaves * MA * NB * 64);
+  // tile rows + the zero row + the ones row; the reduction re-uses the buffer a few tiles at a time
+  const size_t lds = sizeof(float4) * (size_t)(((MA + NB) * 16 + 2) * (TILE / 4 + 1));
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chanpair_mfma<MA, NB, TWO>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chanpair_mfma<MA, NB, TWO, TILE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
   }
   dim3 grid(nblk, R, nza * nzb);
-  hipLaunchKernelGGL((k_chanpair_mfma<MA, NB, TWO>), grid, dim3(kCpBlock), lds, s, A, B, part, Cb, P, Bg, nzb, b_ones);
+  hipLaunchKernelGGL((k_chanpair_mfma<MA, NB, TWO, TILE>), grid, dim3(kCpBlock), lds, s, A, B, part, Cb, P, Bg, nzb, b_ones);
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
@@ -494,9 +511,20 @@ int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, i
                          int b_ones, hipStream_t s) {
   const int Ca = A.total();
   const int MA = min(cdiv(Ca, 16), 3), NB = min(cdiv(Cb, 16), 6);
+  // 49..80 A channels against 17..80 B channels: half-length tiles hold all of A and B in LDS at once -- ONE pass over
+  // both operands where the [48 x 96] blocks take two z-blocks that each re-read B (72 x 73, the residual tail's weight
+  // gradient: 286 -> 174 us).  Not for wider A (a [112 x 80] block spills and ran at 372 us against 344 for the two
+  // [64 x 80] blocks below) nor for a B of one tile (re-reading it is cheap: 64 -> 84 us).
+  if (NB >= 2 && NB <= 5 && Ca > 48 && Ca <= 80) {
+    switch (NB) {
+      case 2: return launch_chanpair_t<5, 2, false, 128>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
+      case 3: return launch_chanpair_t<5, 3, false, 128>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
+      case 4: return launch_chanpair_t<5, 4, false, 128>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
+      default: return launch_chanpair_t<5, 5, false, 128>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
+    }
+  }
   // 64 A channels per z-block where that saves a pass over B (and the [64 + 16 NB] rows fit LDS: NB <= 5)
-  static const bool ma4 = !(getenv("MSGAT_CP_MA4") && getenv("MSGAT_CP_MA4")[0] == '0');  // diagnostic switch
-  if (ma4 && NB <= 5 && cdiv(Ca, 64) < cdiv(Ca, 48)) {
+  if (NB <= 5 && cdiv(Ca, 64) < cdiv(Ca, 48)) {
     switch (NB) {
       case 1: return launch_chanpair_t<4, 1, false>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
       case 2: return launch_chanpair_t<4, 2, false>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
