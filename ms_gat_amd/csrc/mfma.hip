@@ -18,7 +18,6 @@
 //     loads, so 256-position tiles of all rows are staged through LDS in 1-KiB row pieces by a
 //     persistent split-K kernel (see k_chanpair_mfma).
 #include "common.hpp"
-#include <cstdlib>
 
 namespace msgat {
 
