@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MSGAT_ABI_VERSION 3
+#define MSGAT_ABI_VERSION 4
 
 enum {
   MSGAT_OK = 0,
@@ -228,6 +228,14 @@ int msgat_stage_aggregate_project(const msgat_shape_t* shape, const msgat_graph_
                                   const float* x, const float* E, const float* W, float* y,
                                   float* z, void* stream);
 
+/* The dense column pass of the backward (autograd of the softmax of attention.py:34): given the row sums
+ * delta[G,N] of the edge gradients and the edge gradients gE[G,nnz] (CSR order),
+ *     dq[g,m,:] += sum_{e -> m} gE_e kW[row_e,:] - sum_n P[n,m] delta[n] kW[n,:],   P = 2^(S log2e - lse)
+ * re-creating P with the forward's operands and k order (bit-identical to the forward's).  dq is updated in place. */
+int msgat_stage_dense_column_pass(const msgat_shape_t* shape, const msgat_graph_t* graph, const float* q,
+                                  const float* kW, const float* lse, const float* delta, const float* gE,
+                                  float* dq, void* stream);
+
 /* Backward building blocks (also what msgat_gacn_backward enqueues).
  * msgat_stage_mix:      out[g,co,p] = sum_ci M[r,..] in[g,ci,p] (+ addvec[r,co] extra[g,p]);
  *                       M is [R,Co,Ci] (m_in_major = 0) or [R,Ci,Co] (m_in_major = 1, i.e. W^T applied).
@@ -400,9 +408,11 @@ int msgat_temporal_attention_backward(const float* dtaps, const float* att, cons
  *     metric sums of engine.py:70 / metrics.py:20-35, with nothing read back to the host:
  *       loss[0]  = mean over n of (|e| <= delta ? e^2 / 2 : delta |e| - delta^2 / 2),  e = pred - truth   (fp32)
  *       sums[0] += sum |e|;  sums[1] += 100 sum_{truth > mask_value} |e / truth|;  sums[2] += sum e^2;
- *       sums[3] += loss[0]                                                         (fp64 [4], running totals
- *     the caller zeroes per epoch; may be NULL).  `partials`: msgat_huber_partial_doubles(n)
- *     doubles.  Fixed summation order: bitwise reproducible.
+ *       sums[3] += loss_weight * loss[0]                                           (fp64 [4], running totals
+ *     the caller zeroes per epoch; may be NULL).  loss_weight = 1 for a whole batch; a rank holding n_r of a global
+ *     batch's n_b samples passes n_r / n_b, so the sum over ranks is the reference's per-batch mean loss
+ *     (engine.py:66-67).  `partials`: msgat_huber_partial_doubles(n) doubles.  Fixed summation order: bitwise
+ *     reproducible.
  * msgat_huber_grad: dpred = dloss[0] * clamp(e, -delta, delta) / n  -- the backward of the loss above.
  * msgat_adam_step: torch.optim.Adam's update (engine.py:106: lr 1e-3, weight_decay 5e-4 as L2 on the gradient,
  *     betas, eps outside the square root, bias correction) for ALL parameter tensors in one launch.  The
@@ -413,17 +423,26 @@ int msgat_temporal_attention_backward(const float* dtaps, const float* att, cons
  *     tensors listed in active_tensors (torch keeps one step count per parameter and skips parameters without a
  *     gradient); lr[0] = learning rate.  Both are device memory, so a captured launch follows the scheduler.
  *     The hyper-parameters are doubles, like the Python floats the reference's optimizer holds: 1 - beta2 must
- *     be rounded to fp32 once, not computed from an fp32 beta2. */
+ *     be rounded to fp32 once, not computed from an fp32 beta2.
+ *     grad_divisor (device, may be NULL): when given, every gradient is divided by grad_divisor[0] on the way in.
+ * msgat_gather_scaled: the front half of a data-parallel step (replaces nn.DataParallel's gradient reduce-add,
+ *     main.py:52-55): flat[chunk_off[c] + i] = scale * chunk_src[c][i] for chunk_len[c] elements per chunk (device
+ *     table, as above, but of GRADIENT pointers) and flat[weight_index] = scale (weight_index < 0: not written).
+ *     With scale = the rank's sample count and weight_index = the buffer's last element, ONE all-reduce of `flat`
+ *     yields sum_r(w_r g_r) and sum_r(w_r); msgat_adam_step(grad_divisor = flat + weight_index) finishes the mean. */
 size_t msgat_huber_partial_doubles(int64_t n);
 int msgat_huber_metrics(const float* pred, const float* truth, int64_t n, float delta, float mask_value,
-                        double* partials, float* loss, double* sums, void* stream);
+                        double* partials, float* loss, double* sums, float loss_weight, void* stream);
 int msgat_huber_grad(const float* pred, const float* truth, const float* dloss, int64_t n, float delta,
                      float* dpred, void* stream);
 int msgat_adam_chunk_elems(void);
 int msgat_adam_step(float* const* chunk_param, const int64_t* chunk_off, const int32_t* chunk_len,
                     const int32_t* chunk_tensor, int32_t n_chunks, const int32_t* active_tensors, int32_t n_active,
                     const float* grad, float* exp_avg, float* exp_avg_sq, float* steps, const float* lr,
-                    double beta1, double beta2, double eps, double weight_decay, void* stream);
+                    double beta1, double beta2, double eps, double weight_decay, const float* grad_divisor,
+                    void* stream);
+int msgat_gather_scaled(const float* const* chunk_src, const int64_t* chunk_off, const int32_t* chunk_len,
+                        int32_t n_chunks, float scale, float* flat, int64_t weight_index, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libmsgat_hip.so")
 
 MSGAT_OK = 0
+ABI_VERSION = 4  # MSGAT_ABI_VERSION of include/msgat_hip.h
 MODE_PLAIN, MODE_AGG_FIRST, MODE_PROJ_FIRST = 0, 1, 2
 
 c_float_p = C.POINTER(C.c_float)
@@ -75,6 +76,7 @@ _PROTOTYPES = {
     "msgat_gacn_backward": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph), C.POINTER(Bwd), C.c_void_p]),
     "msgat_stage_project": (C.c_int, [C.POINTER(Shape)] + [C.c_void_p] * 6),
     "msgat_stage_scores": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)] + [C.c_void_p] * 7),
+    "msgat_stage_dense_column_pass": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)] + [C.c_void_p] * 7),
     "msgat_stage_aggregate": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph), C.c_int32] + [C.c_void_p] * 5),
     "msgat_stage_aggregate_project": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)] + [C.c_void_p] * 6),
     "msgat_stage_mix": (C.c_int, [C.POINTER(Shape), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
@@ -117,10 +119,12 @@ _PROTOTYPES = {
     "msgat_temporal_attention_partial_floats": (C.c_size_t, [C.c_int32] * 3),
     "msgat_temporal_attention_backward": (C.c_int, [C.c_void_p] * 10 + [C.c_int32] * 6 + [C.c_void_p]),
     "msgat_huber_partial_doubles": (C.c_size_t, [C.c_int64]),
-    "msgat_huber_metrics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float] + [C.c_void_p] * 4),
+    "msgat_huber_metrics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float] + [C.c_void_p] * 3
+                            + [C.c_float, C.c_void_p]),
     "msgat_huber_grad": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
     "msgat_adam_chunk_elems": (C.c_int, []),
-    "msgat_adam_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int32, C.c_void_p, C.c_int32] + [C.c_void_p] * 5 + [C.c_double] * 4 + [C.c_void_p]),
+    "msgat_adam_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int32, C.c_void_p, C.c_int32] + [C.c_void_p] * 5 + [C.c_double] * 4 + [C.c_void_p, C.c_void_p]),
+    "msgat_gather_scaled": (C.c_int, [C.c_void_p] * 3 + [C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
 }
 
 _lock = threading.Lock()
@@ -146,7 +150,7 @@ def lib() -> C.CDLL:
             for name, (res, args) in _PROTOTYPES.items():
                 fn = getattr(h, name)  # AttributeError here = header/library mismatch
                 fn.restype, fn.argtypes = res, args
-            if h.msgat_abi_version() != 3:
+            if h.msgat_abi_version() != ABI_VERSION:
                 raise MsgatError("libmsgat_hip.so ABI version mismatch; rebuild")
             _handle = h
     return _handle

@@ -432,6 +432,19 @@ extern "C" int msgat_attention_backward(const msgat_shape_t* shp, const msgat_gr
   return fused ? MSGAT_OK : aggregate_cols(sh, gr, sh->C, dv, E, Ec, nullptr, nullptr, du, s);
 }
 
+// The dense column pass of the backward alone (what msgat_attention_backward / msgat_gacn_backward enqueue after the
+// edge gradients): dq[g,m] -= sum_n P[n,m] delta[n] kW[n] (+ the CSC edge term from gE).  For profiling and bench.py.
+extern "C" int msgat_stage_dense_column_pass(const msgat_shape_t* sh, const msgat_graph_t* gr, const float* q,
+                                             const float* kW, const float* lse, const float* delta, const float* gE,
+                                             float* dq, void* stream) {
+  int st = check_shape(sh);
+  if (st) return st;
+  st = check_graph(sh, gr);
+  if (st) return st;
+  if (!q || !kW || !lse || !delta || !dq || (gr->nnz > 0 && !gE)) return MSGAT_ERR_NULL;
+  return launch_bwd_dense_col(*gr, q, kW, lse, delta, gE, dq, sh->R * sh->Bg, sh->N, sh->T, (hipStream_t)stream);
+}
+
 // ---- prediction head ----------------------------------------------------------------------------------
 static int check_head(int32_t B, int32_t C, int32_t N, int32_t T, int32_t To) {
   if (B <= 0 || B > 65535 || C <= 0 || C > 65535 || N <= 0 || To <= 0) return MSGAT_ERR_SHAPE;
@@ -667,10 +680,10 @@ extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t*
 extern "C" size_t msgat_huber_partial_doubles(int64_t n) { return n > 0 ? huber_partial_doubles(n) : 0; }
 
 extern "C" int msgat_huber_metrics(const float* pred, const float* truth, int64_t n, float delta, float mask_value,
-                                   double* partials, float* loss, double* sums, void* stream) {
+                                   double* partials, float* loss, double* sums, float loss_weight, void* stream) {
   if (!pred || !truth || !partials || !loss) return MSGAT_ERR_NULL;
-  if (n <= 0 || !(delta > 0.f)) return MSGAT_ERR_SHAPE;
-  return launch_huber_metrics(pred, truth, n, delta, mask_value, partials, loss, sums, (hipStream_t)stream);
+  if (n <= 0 || !(delta > 0.f) || !(loss_weight >= 0.f)) return MSGAT_ERR_SHAPE;
+  return launch_huber_metrics(pred, truth, n, delta, mask_value, partials, loss, sums, loss_weight, (hipStream_t)stream);
 }
 
 extern "C" int msgat_huber_grad(const float* pred, const float* truth, const float* dloss, int64_t n, float delta,
@@ -686,14 +699,22 @@ extern "C" int msgat_adam_step(float* const* chunk_param, const int64_t* chunk_o
                                const int32_t* chunk_tensor, int32_t n_chunks, const int32_t* active_tensors,
                                int32_t n_active, const float* grad, float* exp_avg, float* exp_avg_sq, float* steps,
                                const float* lr, double beta1, double beta2, double eps, double weight_decay,
-                               void* stream) {
+                               const float* grad_divisor, void* stream) {
   if (n_chunks < 0 || n_active < 0) return MSGAT_ERR_SHAPE;
   if (!steps || !lr) return MSGAT_ERR_NULL;
   if (n_active > 0 && !active_tensors) return MSGAT_ERR_NULL;
   if (n_chunks > 0 && (!chunk_param || !chunk_off || !chunk_len || !chunk_tensor || !grad || !exp_avg || !exp_avg_sq)) return MSGAT_ERR_NULL;
   if (!(beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1. && eps >= 0. && weight_decay >= 0.)) return MSGAT_ERR_SHAPE;
   return launch_adam(chunk_param, (const long long*)chunk_off, chunk_len, chunk_tensor, n_chunks, active_tensors, n_active,
-                     grad, exp_avg, exp_avg_sq, steps, lr, beta1, beta2, eps, weight_decay, (hipStream_t)stream);
+                     grad, exp_avg, exp_avg_sq, steps, lr, beta1, beta2, eps, weight_decay, grad_divisor, (hipStream_t)stream);
+}
+
+extern "C" int msgat_gather_scaled(const float* const* chunk_src, const int64_t* chunk_off, const int32_t* chunk_len,
+                                   int32_t n_chunks, float scale, float* flat, int64_t weight_index, void* stream) {
+  if (n_chunks <= 0) return MSGAT_ERR_SHAPE;
+  if (!chunk_src || !chunk_off || !chunk_len || !flat) return MSGAT_ERR_NULL;
+  return launch_gather_scaled(chunk_src, (const long long*)chunk_off, chunk_len, n_chunks, scale, flat, weight_index,
+                              (hipStream_t)stream);
 }
 
 // ---- the tiny attention matrices of a MEAM block ----------------------------------------------------------------

@@ -311,12 +311,15 @@ int launch_tempatt_bwd(const float* dtaps, const float* att, const float* lr, co
 // step tail (tail.hip)
 size_t huber_partial_doubles(long long n);
 int launch_huber_metrics(const float* pred, const float* truth, long long n, float delta, float mask_value,
-                         double* part, float* loss, double* sums, hipStream_t s);
+                         double* part, float* loss, double* sums, float loss_weight, hipStream_t s);
 int launch_huber_grad(const float* pred, const float* truth, const float* dloss, long long n, float delta,
                       float* dpred, hipStream_t s);
 int adam_chunk_elems();
 int launch_adam(float* const* chunk_param, const long long* chunk_off, const int* chunk_len, const int* chunk_tensor,
                 int nchunks, const int* active, int n_active, const float* grad, float* m, float* v, float* steps,
-                const float* lr, double beta1, double beta2, double eps, double weight_decay, hipStream_t s);
+                const float* lr, double beta1, double beta2, double eps, double weight_decay, const float* grad_divisor,
+                hipStream_t s);
+int launch_gather_scaled(const float* const* chunk_src, const long long* chunk_off, const int* chunk_len, int nchunks,
+                         float scale, float* flat, long long weight_index, hipStream_t s);
 
 }  // namespace msgat

@@ -55,16 +55,17 @@ __global__ __launch_bounds__(kTailBlock) void k_huber_metrics(const float* __res
 }
 
 // loss[0] = mean Huber loss (fp32, what the reference's loss tensor holds); sums[0..2] += AE, APE, SE and
-// sums[3] += that mean (the epoch's running total of batch losses), all double
+// sums[3] += loss_weight * that mean (the epoch's running total of batch losses; a rank that holds n_r of a global
+// batch's n_b samples passes n_r / n_b, so the sum over ranks is the global batch's mean loss), all double
 __global__ void k_huber_finish(const double* __restrict__ part, int nblocks, long long n, float* __restrict__ loss,
-                               double* __restrict__ sums) {
+                               double* __restrict__ sums, float loss_weight) {
   const int k = threadIdx.x;
   if (k >= 4) return;
   double t = 0.0;
   for (int b = 0; b < nblocks; ++b) t += part[(size_t)b * 4 + k];
   if (k == 0) {
     loss[0] = (float)(t / (double)n);
-    if (sums != nullptr) sums[3] += t / (double)n;
+    if (sums != nullptr) sums[3] += (t / (double)n) * (double)loss_weight;
   } else if (sums != nullptr) {
     sums[k - 1] += t;
   }
@@ -89,11 +90,11 @@ static int huber_blocks(long long n) {
 size_t huber_partial_doubles(long long n) { return (size_t)huber_blocks(n) * 4; }
 
 int launch_huber_metrics(const float* pred, const float* truth, long long n, float delta, float mask_value,
-                         double* part, float* loss, double* sums, hipStream_t s) {
+                         double* part, float* loss, double* sums, float loss_weight, hipStream_t s) {
   const int nb = huber_blocks(n);
   hipLaunchKernelGGL(k_huber_metrics, dim3(nb), dim3(kTailBlock), 0, s, pred, truth, n, delta, mask_value, part);
   MSGAT_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_huber_finish, dim3(1), dim3(64), 0, s, part, nb, n, loss, sums);
+  hipLaunchKernelGGL(k_huber_finish, dim3(1), dim3(64), 0, s, part, nb, n, loss, sums, loss_weight);
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
@@ -125,12 +126,17 @@ __global__ __launch_bounds__(kTailBlock) void k_adam(float* const* __restrict__ 
                                                      const float* __restrict__ grad, float* __restrict__ m,
                                                      float* __restrict__ v, const float* __restrict__ steps,
                                                      const float* __restrict__ lrp, double beta1d, double beta2d,
-                                                     float eps, float weight_decay) {
+                                                     float eps, float weight_decay,
+                                                     const float* __restrict__ grad_divisor) {
   const int c = blockIdx.x;
   float* p = chunk_param[c];
   const long long off = chunk_off[c];
   const int len = chunk_len[c];
   const float t = steps[chunk_tensor[c]], lr = lrp[0];
+  // data-parallel step: the flat buffer holds sum_ranks(w_r g_r) and *grad_divisor = sum_ranks(w_r) (the last element
+  // of the same all-reduced buffer); the division that used to be a pass of its own happens on the way in
+  const bool scaled = grad_divisor != nullptr;
+  const float div = scaled ? grad_divisor[0] : 1.f;
   // torch.optim.Adam (_single_tensor_adam): bias_correction = 1 - beta^t; step_size = lr / bc1;
   // denom = sqrt(v) / sqrt(bc2) + eps; p -= step_size * m / denom
   // (in double, as the host-side Python floats of the reference optimizer are: 1 - 0.999^t cancels badly in fp32)
@@ -139,7 +145,8 @@ __global__ __launch_bounds__(kTailBlock) void k_adam(float* const* __restrict__ 
   const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
   for (int i = threadIdx.x; i < len; i += kTailBlock) {
     const float w = p[i];
-    const float g = fmaf(weight_decay, w, grad[off + i]);
+    const float gin = scaled ? grad[off + i] / div : grad[off + i];
+    const float g = fmaf(weight_decay, w, gin);
     float mi = m[off + i], vi = v[off + i];
     mi = fmaf(g - mi, omb1, mi);                      // exp_avg.lerp_(grad, 1 - beta1)
     vi = fmaf(g * g, omb2, vi * beta2);               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
@@ -152,19 +159,44 @@ __global__ __launch_bounds__(kTailBlock) void k_adam(float* const* __restrict__ 
 
 int launch_adam(float* const* chunk_param, const long long* chunk_off, const int* chunk_len, const int* chunk_tensor,
                 int nchunks, const int* active, int n_active, const float* grad, float* m, float* v, float* steps,
-                const float* lr, double beta1, double beta2, double eps, double weight_decay, hipStream_t s) {
+                const float* lr, double beta1, double beta2, double eps, double weight_decay, const float* grad_divisor,
+                hipStream_t s) {
   if (n_active > 0) {
     hipLaunchKernelGGL(k_adam_advance, dim3(cdiv(n_active, kTailBlock)), dim3(kTailBlock), 0, s, steps, active, n_active);
     MSGAT_CHECK_LAUNCH();
   }
   if (nchunks > 0) {
     hipLaunchKernelGGL(k_adam, dim3(nchunks), dim3(kTailBlock), 0, s, chunk_param, chunk_off, chunk_len, chunk_tensor,
-                       grad, m, v, steps, lr, beta1, beta2, (float)eps, (float)weight_decay);
+                       grad, m, v, steps, lr, beta1, beta2, (float)eps, (float)weight_decay, grad_divisor);
     MSGAT_CHECK_LAUNCH();
   }
   return MSGAT_OK;
 }
 
 int adam_chunk_elems() { return kAdamChunk; }
+
+// ---- gather of the gradients into the flat buffer a data-parallel step all-reduces -----------------------------------
+// flat[chunk_off[c] + i] = scale * chunk_src[c][i]; block 0 also writes flat[weight_index] = scale: the rank's weight
+// (its sample count) rides in the buffer's last element, so sum(w g) and sum(w) come out of ONE collective.  Replaces
+// a multi-tensor copy + mul_ + fill_ over the 7.8 MB buffer by one pass.
+__global__ __launch_bounds__(kTailBlock) void k_gather_scaled(const float* const* __restrict__ chunk_src,
+                                                              const long long* __restrict__ chunk_off,
+                                                              const int* __restrict__ chunk_len, float scale,
+                                                              float* __restrict__ flat, long long weight_index) {
+  const int c = blockIdx.x;
+  const float* __restrict__ src = chunk_src[c];
+  float* __restrict__ dst = flat + chunk_off[c];
+  const int len = chunk_len[c];
+  for (int i = threadIdx.x; i < len; i += kTailBlock) dst[i] = scale * src[i];
+  if (c == 0 && threadIdx.x == 0 && weight_index >= 0) flat[weight_index] = scale;
+}
+
+int launch_gather_scaled(const float* const* chunk_src, const long long* chunk_off, const int* chunk_len, int nchunks,
+                         float scale, float* flat, long long weight_index, hipStream_t s) {
+  hipLaunchKernelGGL(k_gather_scaled, dim3(nchunks), dim3(kTailBlock), 0, s, chunk_src, chunk_off, chunk_len, scale, flat,
+                     weight_index);
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
+}
 
 }  // namespace msgat

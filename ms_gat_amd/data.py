@@ -116,6 +116,11 @@ class ShardedBatchSampler(Sampler):
     def __len__(self) -> int:
         return len(self._starts())
 
+    def global_batch_sizes(self) -> List[int]:
+        """Sample count of every global batch this sampler yields a shard of, in order (the engine weights a shard's
+        loss by its share of the global batch)."""
+        return [min(self.batch_size, self.n - b) for b in self._starts()]
+
     def __iter__(self):
         from .parallel import shard_bounds
         if self.shuffle:

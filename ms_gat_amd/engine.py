@@ -24,6 +24,7 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 from time import localtime, strftime
+from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -56,13 +57,21 @@ class Metrics:
     """Running MAE / MAPE / RMSE with the reference's definitions (metrics.py:11-38): MAPE sums
     |err/y| over entries with y > mask_value but divides by ALL entries, like the reference.
     Totals [AE, APE, SE, sum of batch losses] accumulate on the device in float64; properties synchronise
-    when read."""
+    when read.  Under a process group a rank adds its share n_r / n_b of every global batch's loss
+    (`loss_weight`), so the all-reduced total is the sum of the reference's per-batch mean losses
+    (engine.py:66-67) -- also for uneven shards -- and `batches` counts GLOBAL batches (every rank sees them all)."""
 
     def __init__(self, mask_value: float = 0.0):
         self.mask_value = mask_value
         self.n = 0
         self.batches = 0
         self._sums: Optional[torch.Tensor] = None
+
+    def reset(self) -> None:
+        """Start a new epoch on the SAME totals buffer (captured loss kernels hold its address)."""
+        if self._sums is not None:
+            self._sums.zero_()
+        self.n = self.batches = 0
 
     def totals(self, device) -> torch.Tensor:
         if self._sums is None:
@@ -75,14 +84,14 @@ class Metrics:
         self.batches += 1
 
     def update(self, y_pred: torch.Tensor, y_true: torch.Tensor, loss: Optional[torch.Tensor] = None,
-               count: bool = True) -> None:
+               count: bool = True, loss_weight: float = 1.0) -> None:
         err = (y_pred.detach() - y_true).double()
         truth = y_true.double()
         mask = truth > self.mask_value
         ape = torch.where(mask, (err / torch.where(mask, truth, torch.ones_like(truth))).abs(), torch.zeros_like(err))
         zero = err.new_zeros(())
         s = torch.stack([err.abs().sum(), 100.0 * ape.sum(), (err * err).sum(),
-                         zero if loss is None else loss.detach().double()])
+                         zero if loss is None else loss.detach().double() * loss_weight])
         self.totals(y_pred.device).add_(s)
         if count:
             self.count(y_true)
@@ -92,10 +101,10 @@ class Metrics:
 
     def all_reduce(self) -> None:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and self._sums is not None:
-            buf = torch.cat([self._sums, self._sums.new_tensor([float(self.n), float(self.batches)])])
+            buf = torch.cat([self._sums, self._sums.new_tensor([float(self.n)])])
             dist.all_reduce(buf)
-            self._sums, self.n = buf[:4].clone(), int(buf[4].item())
-            self._loss_batches = float(buf[5].item())
+            self._sums.copy_(buf[:4])      # in place: the kernels of a captured step keep adding to THIS buffer
+            self.n = int(buf[4].item())
 
     @property
     def MAE(self) -> float:
@@ -111,8 +120,8 @@ class Metrics:
 
     @property
     def loss(self) -> float:
-        """Mean of the batch losses (over all ranks' batches after `all_reduce`)."""
-        return self._get(3) / max(getattr(self, "_loss_batches", self.batches), 1)
+        """Mean over the (global) batches of the batch-mean loss, the reference's `loss_ave` (engine.py:66-67)."""
+        return self._get(3) / max(self.batches, 1)
 
     def todict(self):
         return {"MAE": self.MAE, "MAPE": self.MAPE, "RMSE": self.RMSE}
@@ -138,7 +147,11 @@ class FlatAdam(optim.Optimizer):
         self._host_steps: List[int] = []             # host mirror of the per-parameter step counts
         self._captured_active: Optional[tuple] = None
         self._tables: Dict[tuple, tuple] = {}
+        self._gather_tables: "OrderedDict[tuple, tuple]" = OrderedDict()
         self._lr_on_device = None
+        self._last_active: Optional[tuple] = None
+        self.flat_grad = None
+        self.numel = -1
 
     # -- flat buffers ----------------------------------------------------------------------------------------
     def _build(self) -> None:
@@ -152,23 +165,44 @@ class FlatAdam(optim.Optimizer):
         for p in self._params:
             self._offsets.append(off)
             off += p.numel()
+        # A rebuild with the same layout (load_state_dict on a live optimizer) keeps every device buffer and writes
+        # into it: step graphs captured earlier hold these addresses (and those of the chunk tables).
+        reuse = (self.flat_grad is not None and self.numel == off and self.flat_grad.device == dev
+                 and len(self._host_steps) == len(self._params))
         self.numel = off
-        self.flat_grad = torch.zeros(off + 1, device=dev, dtype=torch.float32)   # + the rank's weight (all-reduce)
-        self.exp_avg = torch.zeros(off, device=dev, dtype=torch.float32)
-        self.exp_avg_sq = torch.zeros(off, device=dev, dtype=torch.float32)
-        self._grad_views = [self.flat_grad[o:o + p.numel()].view_as(p) for p, o in zip(self._params, self._offsets)]
         self._host_steps = [int(self._loaded_steps.get(id(p), 0)) for p in self._params]
-        self._dev_steps = torch.tensor([float(t) for t in self._host_steps], device=dev)
-        self._dev_lr = torch.tensor([float(self.param_groups[0]["lr"])], device=dev)
+        steps = torch.tensor([float(t) for t in self._host_steps])
+        if reuse:
+            self._dev_steps.copy_(steps)
+            self._dev_lr.fill_(float(self.param_groups[0]["lr"]))
+        else:
+            self.flat_grad = torch.zeros(off + 1, device=dev, dtype=torch.float32)   # + the rank's weight (all-reduce)
+            self.exp_avg = torch.zeros(off, device=dev, dtype=torch.float32)
+            self.exp_avg_sq = torch.zeros(off, device=dev, dtype=torch.float32)
+            self._dev_steps = steps.to(dev)
+            self._dev_lr = torch.tensor([float(self.param_groups[0]["lr"])], device=dev)
+            self._tables.clear()
+            self._gather_tables.clear()
+        self._grad_views = [self.flat_grad[o:o + p.numel()].view_as(p) for p, o in zip(self._params, self._offsets)]
         self._lr_on_device = float(self.param_groups[0]["lr"])
         for i, (p, o) in enumerate(zip(self._params, self._offsets)):
             old = self.state.get(p, {})
             m, v = self.exp_avg[o:o + p.numel()].view_as(p), self.exp_avg_sq[o:o + p.numel()].view_as(p)
             if "exp_avg" in old:      # state that arrived through load_state_dict: move it into the flat buffers
-                m.copy_(old["exp_avg"])
-                v.copy_(old["exp_avg_sq"])
+                if old["exp_avg"].data_ptr() != m.data_ptr():
+                    m.copy_(old["exp_avg"])
+                    v.copy_(old["exp_avg_sq"])
+            elif reuse:               # no state for this parameter in what was loaded: fresh moments
+                m.zero_()
+                v.zero_()
             self.state[p] = {"step": torch.tensor(float(self._host_steps[i])), "exp_avg": m, "exp_avg_sq": v}
-        self._tables.clear()
+
+    def buffer_token(self) -> tuple:
+        """Addresses a captured step graph depends on; a change means such graphs must be dropped."""
+        if self.flat_grad is None:
+            return ()
+        return (self.flat_grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                self._dev_steps.data_ptr(), self._dev_lr.data_ptr())
 
     def _table(self, active: tuple):
         """Device chunk table of the parameters that have a gradient (torch's Adam skips the others)."""
@@ -193,8 +227,13 @@ class FlatAdam(optim.Optimizer):
             hit = (torch.tensor(ptrs, dtype=torch.int64).to(dev), torch.tensor(offs, dtype=torch.int64).to(dev),
                    torch.tensor(lens, dtype=torch.int32).to(dev), torch.tensor(tens, dtype=torch.int32).to(dev),
                    torch.tensor(act, dtype=torch.int32).to(dev), len(ptrs), len(act))
-            self._tables = {key: hit}     # parameter storage moved or the gradient pattern changed: one table alive
+            self._tables[key] = hit       # never evicted: a captured step may hold the addresses of an older table
         return hit
+
+    def _gather(self, grads: List[torch.Tensor], active: tuple, weight: float) -> None:
+        """flat = weight * gradients, flat[-1] = weight, in ONE launch (`parallel.gather_scaled`)."""
+        offsets = [o for o, on in zip(self._offsets, active) if on]
+        parallel.gather_scaled(self.flat_grad, grads, offsets, weight, self.numel, self._gather_tables)
 
     def sync_lr(self) -> None:
         """Write the group's learning rate (a host float the scheduler edits) into device memory when it changed."""
@@ -218,24 +257,32 @@ class FlatAdam(optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        if not self._params or self._params[0].device != self.flat_grad.device:
+        if not self._params or self.flat_grad is None or self._params[0].device != self.flat_grad.device:
             self._build()
         active = tuple(p.grad is not None for p in self._params)
         grads = [p.grad for p in self._params if p.grad is not None]
-        if grads:
-            torch._foreach_copy_([v for v, on in zip(self._grad_views, active) if on], grads)
+        divisor = 0
         if rank_weight is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            self.flat_grad[: self.numel].mul_(float(rank_weight))
-            self.flat_grad[self.numel:].fill_(float(rank_weight))
+            # one launch before the collective (gather, scaled by the rank's weight, which also rides in the last
+            # element) and one after it (the update divides by the summed weight on the way in)
+            if active != self._last_active:
+                self.flat_grad.zero_()           # parameters without a gradient contribute zeros on every rank
+            if grads:
+                self._gather(grads, active, float(rank_weight))
+            else:
+                self.flat_grad[self.numel:].fill_(float(rank_weight))
             dist.all_reduce(self.flat_grad)
-            self.flat_grad[: self.numel].div_(self.flat_grad[self.numel])
+            divisor = self.flat_grad.data_ptr() + 4 * self.numel
+        elif grads:
+            torch._foreach_copy_([v for v, on in zip(self._grad_views, active) if on], grads)
+        self._last_active = active
         self.sync_lr()
         ptrs, offs, lens, tens, act, n, n_act = self._table(active)
         g = self.param_groups[0]
         st = _lib.lib().msgat_adam_step(ptrs.data_ptr(), offs.data_ptr(), lens.data_ptr(), tens.data_ptr(), n, act.data_ptr(),
                                         n_act, self.flat_grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                         self._dev_steps.data_ptr(), self._dev_lr.data_ptr(), float(g["betas"][0]),
-                                        float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+                                        float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), divisor,
                                         torch.cuda.current_stream(self.flat_grad.device).cuda_stream)
         _lib.check(st, "msgat_adam_step")
         if torch.cuda.is_current_stream_capturing():
@@ -287,7 +334,7 @@ class _GraphedStep:
     (they initialise the optimizer's lazy state), then capture -- with parameters and optimizer state put back
     afterwards, so the captured run starts from exactly the state an eager run would."""
 
-    def __init__(self, engine: "Engine", batch, training: bool, step_in_graph: bool):
+    def __init__(self, engine: "Engine", batch, training: bool, step_in_graph: bool, loss_weight: float = 1.0):
         model, opt = engine.model, engine.optimizer
         self.static = [t.clone() for t in batch]
         *inputs, truth = self.static
@@ -329,14 +376,14 @@ class _GraphedStep:
         with torch.cuda.graph(self.graph):
             if training:
                 self.pred = model(*inputs)
-                self.loss = engine._loss(self.pred, truth, engine._graph_metrics)
+                self.loss = engine._loss(self.pred, truth, engine._graph_metrics, loss_weight)
                 self.loss.backward()
                 if step_in_graph:
                     opt.step()
             else:
                 with torch.no_grad():
                     self.pred = model(*inputs)
-                    self.loss = engine._loss(self.pred, truth, engine._graph_metrics)
+                    self.loss = engine._loss(self.pred, truth, engine._graph_metrics, loss_weight)
         if training:
             # the gradients of THIS capture live in its private pool: whoever reads p.grad after a replay (the eager
             # all-reduce + optimizer of a multi-rank step) must see these tensors, not those of a later capture
@@ -378,15 +425,18 @@ class Engine:
             return dist.get_rank(), dist.get_world_size()
         return 0, 1
 
-    def _loss(self, pred: torch.Tensor, truth: torch.Tensor, metrics: Optional[Metrics]) -> torch.Tensor:
-        """Huber loss of a batch; feeds `metrics` (engine.py:56,66-70).  On the GPU one library pass does both."""
+    def _loss(self, pred: torch.Tensor, truth: torch.Tensor, metrics: Optional[Metrics],
+              loss_weight: float = 1.0) -> torch.Tensor:
+        """Huber loss of a batch; feeds `metrics` (engine.py:56,66-70).  On the GPU one library pass does both.
+        `loss_weight` = this rank's share of the global batch (1 without a process group)."""
         if pred.is_cuda:
             from . import ops
             sums = None if metrics is None else metrics.totals(pred.device)
-            return ops.huber_metrics(pred, truth, self.loss_fn.delta, 0.0 if metrics is None else metrics.mask_value, sums)
+            return ops.huber_metrics(pred, truth, self.loss_fn.delta, 0.0 if metrics is None else metrics.mask_value, sums,
+                                     loss_weight)
         loss = huber_loss(pred, truth, self.loss_fn.delta)
         if metrics is not None:
-            metrics.update(pred, truth, loss, count=False)   # counted by the caller, as for the fused path
+            metrics.update(pred, truth, loss, count=False, loss_weight=loss_weight)   # counted by the caller
         return loss
 
     def _optimizer_step(self, n_samples: int, world: int) -> None:
@@ -418,32 +468,39 @@ class Engine:
             metrics = Metrics()
         else:
             metrics = self._graph_metrics       # captured kernels hold its totals buffer: re-use it, zeroed
-            metrics.totals(device).zero_()
-            metrics.n = metrics.batches = 0
+            metrics.reset()
         if self.hip_graph and device.type == "cuda":
             self._graph_metrics = metrics
             metrics.totals(device)
+        # sizes of the GLOBAL batches behind pre-sharded ones (the sampler knows them); without a sampler the
+        # shards are taken to be even
+        global_sizes = iter(sampler.global_batch_sizes()) if presharded and hasattr(sampler, "global_batch_sizes") else None
         guard = torch.cuda.device(device) if device.type == "cuda" else _NullContext()
         with guard, torch.set_grad_enabled(training):
             for batch in data:
+                n_global = batch[0].shape[0]
                 if world > 1 and not presharded:
-                    if batch[0].shape[0] < world:
+                    if n_global < world:
                         continue
                     batch = parallel.shard_batch(batch, rank, world)
+                elif world > 1:
+                    n_global = next(global_sizes) if global_sizes is not None else n_global * world
+                loss_weight = batch[0].shape[0] / n_global
                 batch = [t.to(device, non_blocking=True) for t in batch]
                 *inputs, truth = batch
                 if self.hip_graph:
-                    key = (training, tuple(tuple(t.shape) for t in batch))
+                    key = (training, tuple(tuple(t.shape) for t in batch), n_global)
                     graphed = self._graphs.get(key)
                     if graphed is None:
                         with torch.enable_grad():
-                            graphed = self._graphs[key] = _GraphedStep(self, batch, training, step_in_graph=world == 1)
+                            graphed = self._graphs[key] = _GraphedStep(self, batch, training, step_in_graph=world == 1,
+                                                                       loss_weight=loss_weight)
                     pred, loss, truth = graphed.replay(batch)
                     if training and world == 1 and isinstance(self.optimizer, FlatAdam):
                         self.optimizer.note_replayed_step()
                 else:
                     pred = self.model(*inputs)
-                    loss = self._loss(pred, truth, metrics)
+                    loss = self._loss(pred, truth, metrics, loss_weight)
                     if training:
                         self.optimizer.zero_grad(set_to_none=True)
                         loss.backward()
@@ -531,10 +588,14 @@ class Trainer(Engine):
         states = torch.load(ckpt, map_location=next(self.model.parameters()).device, weights_only=False)
         self.best = states["best"]
         self.epoch = states["epoch"] + 1
+        token = self.optimizer.buffer_token() if isinstance(self.optimizer, FlatAdam) else ()
         self.model.load_state_dict(strip_data_parallel_prefix(states["model"]))
         self.optimizer.load_state_dict(states["optimizer"])
         self.scheduler.load_state_dict(states["scheduler"])
         self._sync_lr()
+        if isinstance(self.optimizer, FlatAdam) and token and token != self.optimizer.buffer_token():
+            self._graphs.clear()            # the optimizer's buffers moved: captured steps point at the old ones
+            self._graph_metrics = None
 
 
 def default_grad_scaler_state() -> dict:

@@ -997,14 +997,14 @@ class _HuberMetricsFunction(torch.autograd.Function):
     itself to the running fp64 totals `sums` [4] on the device (engine.py:56,66-70; loss.py:51-52; metrics.py:20-35)."""
 
     @staticmethod
-    def forward(ctx, pred, truth, delta: float, mask_value: float, sums):
+    def forward(ctx, pred, truth, delta: float, mask_value: float, sums, loss_weight: float = 1.0):
         L = _lib.lib()
         pred_c, truth_c = pred.contiguous(), truth.contiguous()
         n = pred_c.numel()
         part = torch.empty(max(int(L.msgat_huber_partial_doubles(n)), 1), device=pred.device, dtype=torch.float64)
         loss = torch.empty((), device=pred.device, dtype=torch.float32)
         st = L.msgat_huber_metrics(_ptr(pred_c), _ptr(truth_c), n, float(delta), float(mask_value), _ptr(part), _ptr(loss),
-                                   _ptr(sums), _stream_handle(pred.device))
+                                   _ptr(sums), float(loss_weight), _stream_handle(pred.device))
         _lib.check(st, "msgat_huber_metrics")
         ctx.delta = float(delta)
         ctx.save_for_backward(pred_c, truth_c)
@@ -1017,19 +1017,20 @@ class _HuberMetricsFunction(torch.autograd.Function):
         st = _lib.lib().msgat_huber_grad(_ptr(pred), _ptr(truth), _ptr(dloss.contiguous()), pred.numel(), ctx.delta,
                                          _ptr(dpred), _stream_handle(pred.device))
         _lib.check(st, "msgat_huber_grad")
-        return dpred, None, None, None, None
+        return dpred, None, None, None, None, None
 
 
 def huber_metrics(pred: torch.Tensor, truth: torch.Tensor, delta: float, mask_value: float = 0.0,
-                  sums: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Mean Huber loss of `pred` against `truth` in one pass that also feeds the epoch's metric totals."""
+                  sums: Optional[torch.Tensor] = None, loss_weight: float = 1.0) -> torch.Tensor:
+    """Mean Huber loss of `pred` against `truth` in one pass that also feeds the epoch's metric totals.
+    `loss_weight` scales what is added to the running loss total (a rank's share n_r / n_b of a global batch)."""
     _require_device_tensor("prediction", pred)
     _require_device_tensor("target", truth, pred.device)
     if pred.shape != truth.shape or pred.numel() == 0:
         raise ValueError(f"prediction {tuple(pred.shape)} and target {tuple(truth.shape)} must match and be non-empty")
     if sums is not None and (sums.dtype != torch.float64 or sums.numel() != 4 or sums.device != pred.device):
         raise ValueError("sums must be a float64 [4] tensor on the prediction's device")
-    return _HuberMetricsFunction.apply(pred, truth, delta, mask_value, sums)
+    return _HuberMetricsFunction.apply(pred, truth, delta, mask_value, sums, float(loss_weight))
 
 
 # ---- boundary hygiene for every autograd.Function above -----------------------------------------------------------

@@ -12,6 +12,7 @@ size, so per-tensor buckets or overlap would only add launches).
 from __future__ import annotations
 
 import os
+from collections import OrderedDict
 from typing import Iterable, List, Sequence
 
 import torch
@@ -50,6 +51,38 @@ def shard_batch(tensors: Sequence[torch.Tensor], rank: int, world: int) -> List[
     return [t[lo:hi] for t in tensors]
 
 
+def gather_scaled(flat: torch.Tensor, grads: Sequence[torch.Tensor], offsets: Sequence[int], weight: float,
+                  weight_index: int, cache: "OrderedDict") -> None:
+    """flat[offsets[i] : ...] = weight * grads[i] for every gradient and flat[weight_index] = weight, in ONE launch
+    (`msgat_gather_scaled`, csrc/tail.hip).  The device table of gradient pointers is cached in `cache` by those
+    pointers: a replayed HIP graph or a warm caching allocator hands out the same ones step after step."""
+    from . import _lib
+    keep = [g if g.is_contiguous() else g.contiguous() for g in grads]
+    key = (tuple(g.data_ptr() for g in keep), tuple(offsets))
+    hit = cache.get(key)
+    if hit is None:
+        chunk = int(_lib.lib().msgat_adam_chunk_elems())
+        ptrs, offs, lens = [], [], []
+        for g, o in zip(keep, offsets):
+            for s in range(0, g.numel(), chunk):
+                ptrs.append(g.data_ptr() + 4 * s)
+                offs.append(o + s)
+                lens.append(min(chunk, g.numel() - s))
+        dev = flat.device
+        hit = (torch.tensor(ptrs, dtype=torch.int64).to(dev), torch.tensor(offs, dtype=torch.int64).to(dev),
+               torch.tensor(lens, dtype=torch.int32).to(dev), len(ptrs))
+        cache[key] = hit
+        while len(cache) > 8:            # eager launches only (never captured): old tables may go
+            cache.popitem(last=False)
+    else:
+        cache.move_to_end(key)
+    src, offs, lens, n = hit
+    st = _lib.lib().msgat_gather_scaled(src.data_ptr(), offs.data_ptr(), lens.data_ptr(), n, float(weight),
+                                        flat.data_ptr(), int(weight_index),
+                                        torch.cuda.current_stream(flat.device).cuda_stream)
+    _lib.check(st, "msgat_gather_scaled")
+
+
 class FlatGradAllReduce:
     """Averages the gradients of `params` across ranks through one contiguous fp32 buffer.
 
@@ -64,10 +97,12 @@ class FlatGradAllReduce:
         dev = self.params[0].device
         self.numel = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(self.numel + 1, device=dev, dtype=torch.float32)
-        self.views, off = [], 0
+        self.views, self.offsets, off = [], [], 0
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            self.offsets.append(off)
             off += p.numel()
+        self._tables: "OrderedDict" = OrderedDict()
 
     @property
     def nbytes(self) -> int:
@@ -78,6 +113,15 @@ class FlatGradAllReduce:
         sample count the result is the gradient of the mean loss over the global batch,
         also when the shards are uneven."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        if self.flat.is_cuda and all(p.grad is not None for p in self.params):
+            # device tensors: one launch in front of the collective, one behind it; the averaged gradients are
+            # handed back as views of the flat buffer (no copy back)
+            gather_scaled(self.flat, [p.grad for p in self.params], self.offsets, weight, self.numel, self._tables)
+            dist.all_reduce(self.flat)
+            self.flat[: self.numel].div_(self.flat[self.numel])
+            for p, v in zip(self.params, self.views):
+                p.grad = v
             return
         for p, v in zip(self.params, self.views):
             if p.grad is None:

@@ -97,7 +97,19 @@ def _taps(P, prefix: str, layer: int) -> torch.Tensor:
 def _first_taps(P, prefix: str, pooled: torch.Tensor, T: int, dilation: int) -> torch.Tensor:
     """[G,2,T,T] taps of TACN's first convolution from the alpha-weighted channel sums [G,N,T] (attention.py:60-64,
     msgat.py:66-74): one launch (`ops.temporal_attention_taps`)."""
-    return ops.temporal_attention_taps(pooled, P(prefix + "tacn.seq.0.Wt1"), P(prefix + "tacn.seq.0.Wt2"), dilation)
+    Wt1, Wt2 = P(prefix + "tacn.seq.0.Wt1"), P(prefix + "tacn.seq.0.Wt2")               # [R,K,N]
+    if 2 * T * Wt1.shape[1] > 256:
+        # beyond the fused kernel's lane budget (T = 16 with the rank-10 projections): the same batched torch ops as
+        # model.TACN.first_taps, over all R relations at once
+        R = Wt1.shape[0]
+        per_t = pooled.transpose(1, 2).reshape(R, -1, T, pooled.shape[1])             # [R,B,T,N]
+        left = per_t @ Wt1.transpose(1, 2).unsqueeze(1)                                # [R,B,T,K]
+        right = per_t @ Wt2.transpose(1, 2).unsqueeze(1)
+        att = torch.softmax(left @ right.transpose(-1, -2), dim=-1).reshape(-1, T, T)  # [G,T,T]
+        shifted = (torch.zeros_like(att) if dilation >= T else
+                   torch.nn.functional.pad(att[:, : T - dilation], (0, 0, dilation, 0)))
+        return torch.stack([shifted, att], dim=1)
+    return ops.temporal_attention_taps(pooled, Wt1, Wt2, dilation)
 
 
 def _tacn_finish(P, prefix: str, dilations, mixed: torch.Tensor, taps0: torch.Tensor) -> torch.Tensor:

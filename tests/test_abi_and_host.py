@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(h, n), f"{n} declared in include/msgat_hip.h but not exported"
     assert sorted(_lib.exported_symbols()) == names, "ctypes prototypes and header disagree"
-    assert _lib.lib().msgat_abi_version() == 3
+    assert _lib.lib().msgat_abi_version() == _lib.ABI_VERSION
 
 
 def test_struct_layouts_match_the_header(tmp_path):

@@ -176,22 +176,25 @@ def test_cfg1_pemsd4_five_components_forward_matches_the_reference():
     assert rel_err(pred.cpu(), g["pred"]) < TOL
 
 
-@pytest.mark.parametrize("factory,cin,R,use_te", [("msgat72", 3, 3, True), ("msgat96", 1, 2, False), ("msgat48", 3, 4, True)])
-def test_stacked_components_equal_the_component_loop(factory, cin, R, use_te):
+@pytest.mark.parametrize("factory,cin,R,use_te,T", [("msgat72", 3, 3, True, 12), ("msgat96", 1, 2, False, 12),
+                                                    ("msgat48", 3, 4, True, 12), ("msgat48", 1, 2, True, 16)])
+def test_stacked_components_equal_the_component_loop(factory, cin, R, use_te, T):
     """stacked.forward (all R components in each launch) against the module-by-module loop of the same model:
-    prediction and every parameter gradient."""
+    prediction and every parameter gradient.  T = 16: the rank-10 temporal attention needs 2*T*10 = 320 lanes, beyond
+    the fused kernel's 256 -- both schedules fall back to batched torch ops for that one matrix (round-2 advisor
+    finding: the stacked schedule raised instead)."""
     import ms_gat_amd
     from ms_gat_amd import model
     torch.manual_seed(3)
-    N, T, B = 29, 12, 4
+    N, B = 29, 4
     adj = ms_gat_amd.synthetic_adjacency(N, 40, seed=9)
-    net = getattr(model, factory)(n_components=R, in_channels=cin, in_timesteps=T, out_timesteps=T, use_te=use_te,
+    net = getattr(model, factory)(n_components=R, in_channels=cin, in_timesteps=T, out_timesteps=12, use_te=use_te,
                                   adj=adj).to(_dev())
     gen = torch.Generator().manual_seed(5)
     X = torch.randn(B, R, cin, N, T, generator=gen).to(_dev())
     H = torch.randint(0, 24, (B,), generator=gen).to(_dev())
     D = torch.randint(0, 7, (B,), generator=gen).to(_dev())
-    dout = torch.randn(B, N, T, generator=gen).to(_dev())
+    dout = torch.randn(B, N, 12, generator=gen).to(_dev())
     params = [p for p in net.parameters() if p.requires_grad]
     names = [n for n, p in net.named_parameters() if p.requires_grad]
     results = []

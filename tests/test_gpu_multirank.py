@@ -1,0 +1,158 @@
+"""GPU: the data-parallel training step with SEVERAL ranks on one MI355X.
+
+The 8-GPU node runs `Trainer.run_epoch` with `FlatAdam.step(rank_weight=...)`: one launch gathers the gradients into
+the flat buffer scaled by the rank's sample count (`msgat_gather_scaled`), ONE all-reduce sums buffer and weights, and
+`msgat_adam_step` divides by the summed weight on the way in (replaces nn.DataParallel, reference main.py:52-55,
+engine.py:49-63).  A one-GPU box cannot form an RCCL group of two ranks on one device, so the ranks here are two
+fresh processes sharing cuda:0 that talk over `gloo` on device tensors: every line of the branch except the
+transport is the code the 8-GPU run executes.
+"""
+import copy
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _model_and_batches(sizes):
+    """A small msgat48 (two components) and global batches of the given sizes, identical in every process."""
+    from ms_gat_amd import data, model
+    torch.manual_seed(0)
+    ds = data.SyntheticPEMS(n_nodes=40, n_edges=50, n_channels=1, in_hours=[1, 2], batch_size=8, days=2)
+    net = model.msgat48(n_components=2, in_channels=1, in_timesteps=12, out_timesteps=12, use_te=True, adj=ds.adj)
+    full = [b for _, b in zip(range(len(sizes)), ds.training)]
+    return net.to("cuda:0"), [[t[:n] for t in b] for b, n in zip(full, sizes)]
+
+
+def _join(rank, world, port):
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK="0")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+
+
+def _leave(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _epochs_worker(rank, world, port, sizes, hip_graph, out_dir):
+    """Two training epochs and a validation pass through engine.Trainer; rank 0 stores what it ended with."""
+    from ms_gat_amd import engine
+    _join(rank, world, port)
+    net, batches = _model_and_batches(sizes)
+    if world == 1:
+        batches = [b for b in batches if b[0].shape[0] >= 2]     # a 2-rank run skips batches smaller than the world
+    tr = engine.Trainer(net, 50.0, os.path.join(out_dir, f"w{world}g{int(hip_graph)}"), hip_graph=hip_graph)
+    assert isinstance(tr.optimizer, engine.FlatAdam)
+    stats = []
+    for epoch in (1, 2):
+        tr.run_epoch(batches, gpu_id=0, epoch=epoch, mode="train")
+        stats.append(dict(tr.last_stats))
+    tr.run_epoch(batches, gpu_id=0, epoch=2, mode="validate")
+    stats.append(dict(tr.last_stats))
+    if rank == 0:
+        torch.save(dict(stats=stats, params={k: v.detach().cpu() for k, v in net.named_parameters()},
+                        steps=list(tr.optimizer._host_steps), n_graphs=len(tr._graphs)),
+                   os.path.join(out_dir, f"epochs_w{world}_g{int(hip_graph)}.pt"))
+    _leave(world)
+
+
+def _run_epochs(world, sizes, hip_graph, out_dir):
+    mp.spawn(_epochs_worker, args=(world, _free_port(), sizes, hip_graph, out_dir), nprocs=world, join=True)
+    return torch.load(os.path.join(out_dir, f"epochs_w{world}_g{int(hip_graph)}.pt"), weights_only=False)
+
+
+def _branch_worker(rank, world, port, sizes, out_dir):
+    """FlatAdam's collective branch against the same step spelled out with torch ops: per-tensor gradients scaled by
+    the shard size, all-reduced, divided by the summed size, torch.optim.Adam.  Both models see the same shards and
+    run the same kernels, so the parameters must agree to rounding after every step."""
+    from ms_gat_amd import engine, parallel
+    _join(rank, world, port)
+    net, batches = _model_and_batches(sizes)
+    twin = copy.deepcopy(net)
+    tr = engine.Trainer(net, 50.0, os.path.join(out_dir, "branch"))
+    ref = torch.optim.Adam(twin.parameters(), lr=1e-3, weight_decay=5e-4)
+    worst = 0.0
+    for batch in batches:
+        shard = [t.to("cuda:0") for t in parallel.shard_batch(batch, rank, world)]
+        tr.run_epoch([batch], gpu_id=0, epoch=1, mode="train")             # shards by itself, steps FlatAdam
+        *inputs, truth = shard
+        ref.zero_grad(set_to_none=True)
+        tr._loss(twin(*inputs), truth, None).backward()
+        w = torch.tensor([float(truth.shape[0])], device="cuda:0")
+        total = w.clone()
+        dist.all_reduce(total)
+        for p in twin.parameters():
+            if p.grad is not None:
+                p.grad.mul_(w)
+                dist.all_reduce(p.grad)
+                p.grad.div_(total)
+        ref.step()
+        for (name, p), q in zip(net.named_parameters(), twin.parameters()):
+            worst = max(worst, rel_err(p.detach(), q.detach()))
+    opt = tr.optimizer
+    ok_weight = float(opt.flat_grad[opt.numel]) == float(sizes[-1])      # sum over ranks of the shard sizes
+    if rank == 0:
+        torch.save(dict(worst=worst, ok_weight=ok_weight, steps=list(opt._host_steps)), os.path.join(out_dir, "branch.pt"))
+    _leave(world)
+
+
+def test_flat_adam_collective_branch_equals_the_step_spelled_out_in_torch(tmp_path):
+    """engine.FlatAdam.step(rank_weight): gather scaled by the rank's weight, one all-reduce, Adam dividing by the summed
+    weight -- on two ranks with even (8 = 4 + 4) and uneven (7 = 4 + 3, 3 = 2 + 1) shards."""
+    sizes = (8, 7, 8, 3)
+    mp.spawn(_branch_worker, args=(2, _free_port(), sizes, str(tmp_path)), nprocs=2, join=True)
+    got = torch.load(str(tmp_path / "branch.pt"), weights_only=False)
+    assert got["worst"] < 1e-6, got
+    assert got["ok_weight"]                     # the last element of the buffer carries sum_r(w_r) after the collective
+    assert set(got["steps"]) == {len(sizes)}
+
+
+@pytest.mark.parametrize("sizes", [(8, 8, 8), (8, 7, 3, 1)])   # even shards; ragged ones incl. a batch smaller than the world
+def test_two_ranks_on_the_device_track_the_single_process_run(tmp_path, sizes):
+    """Two ranks, each on its shard of every global batch, against one process on the whole batches: losses and metrics
+    (weighted by the shard's share of the batch) agree; parameters agree to what Adam's sign-like first steps allow
+    (an entry whose gradient is rounding noise may step the other way: the bar of the hip-graph test)."""
+    one = _run_epochs(1, sizes, False, str(tmp_path))
+    two = _run_epochs(2, sizes, False, str(tmp_path))
+    first1, first2 = one["stats"][0], two["stats"][0]
+    for a, b in zip(one["stats"], two["stats"]):
+        for k in ("loss", "MAE", "MAPE", "RMSE"):
+            assert abs(a[k] - b[k]) <= 2e-4 * abs(a[k]), (k, a, b)
+    assert first1.keys() == first2.keys()
+    assert one["steps"] == two["steps"]
+    for name, p in one["params"].items():
+        assert rel_err(two["params"][name], p) < 2e-2, name
+
+
+def test_two_ranks_with_hip_graph_replay_equal_the_two_rank_eager_run(tmp_path):
+    """hip_graph=True under a process group: the captured graph ends after backward, the gather / all-reduce / Adam run
+    eagerly on the gradients of THAT capture, and the loss kernels of every replay keep adding to the one totals
+    buffer the epoch reads (round-2 advisor finding: `Metrics.all_reduce` re-bound the buffer, so epoch 2 reported 0)."""
+    sizes = (8, 7, 8)
+    eager = _run_epochs(2, sizes, False, str(tmp_path))
+    graph = _run_epochs(2, sizes, True, str(tmp_path))
+    assert graph["n_graphs"] == 4      # (train, validate) x (a shard of 4 out of 8, a shard of 4 out of 7: other loss weight)
+    for a, b in zip(eager["stats"], graph["stats"]):
+        for k in ("loss", "MAE", "MAPE", "RMSE"):
+            assert b[k] > 0 and abs(a[k] - b[k]) <= 1e-5 * abs(a[k]), (k, a, b)
+    assert eager["steps"] == graph["steps"]
+    for name, p in eager["params"].items():
+        assert rel_err(graph["params"][name], p) < 1e-5, name

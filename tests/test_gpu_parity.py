@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, record_err, rel_err
+from conftest import elementwise_violations, load_golden, record_err, rel_err
 from oracle import dense_torch, gat_oracle
 
 pytestmark = pytest.mark.gpu
@@ -67,13 +67,20 @@ def oracle_f64(x, adj, Wg, alpha, W, dz):
 
 
 def assert_close(got, want, tol=TOL, what="", floor=0.0):
-    """`floor` is an absolute scale for tensors whose exact value is 0 (inputs are O(1))."""
+    """Max-norm bar `tol` AND, per entry, |a-b| <= 1e-4 |b| + 1e-5 max|b| (an entry far below the tensor's maximum
+    may not be wrong by more than ~its own 1e-4 plus a tenth of the bar); the violating fraction at the tighter
+    floor 1e-6 max|b| goes on record.  `floor` is an absolute scale for tensors whose exact value is 0 (inputs are
+    O(1)); they have no per-entry scale and are held to the max-norm bar only."""
     for k in want:
         e = rel_err(got[k], want[k])
+        viol = None
         if floor > 0.0:
             e = min(e, float(np.abs(np.asarray(got[k], dtype=np.float64) - want[k]).max()) / floor)
-        record_err(what, k, e, tol)
+        elif tol <= TOL:
+            viol = (elementwise_violations(got[k], want[k], 1e-4, 1e-6), elementwise_violations(got[k], want[k], 1e-4, 1e-5))
+        record_err(what, k, e, tol, viol)
         assert e < tol, f"{what} {k}: rel err {e:.3e} >= {tol}"
+        assert viol is None or viol[1] == 0.0, f"{what} {k}: {viol[1]:.2e} of the entries outside 1e-4|b| + 1e-5 max|b|"
 
 
 def random_problem(R, Bg, C, Co, N, T, n_edges, seed, x_scale=1.0):
