@@ -47,8 +47,30 @@ __host__ __device__ static inline int proj_kpad(int Kx) {
 // k + kKC right after k-step k consumed it.  Every load is unconditional (addresses are clamped,
 // padding is neutralised by zero matrix entries): a load inside a branch makes hipcc fall back
 // to s_waitcnt vmcnt(0), which serialises the prefetch against the MFMAs.
-template <int MG, bool DO_Q, bool ONEPASS, bool SEGS>
-__global__ __launch_bounds__(kBlock, MG > 5 ? 2 : 1) void k_project_mfma(
+// Global-address-space views of pointers that reach the kernel through LDS (the row-pointer table) or through a
+// select between kernel arguments: hipcc cannot prove such a pointer global and falls back to flat_load, which counts
+// on BOTH vmcnt and lgkmcnt -- every LDS operand read of the MFMAs then waits for the whole register ring
+// (s_waitcnt vmcnt(0) lgkmcnt(0) at the top of each chunk: load burst, drain, compute, instead of a ring).
+typedef const f32x4 __attribute__((address_space(1)))* gf4_in;   // (a builtin vector: float4 is a class, whose
+typedef f32x4 __attribute__((address_space(1)))* gf4_out;         //  copy constructor only binds generic references)
+__device__ __forceinline__ float4 load_global(const float* p) {
+  const f32x4 v = *(gf4_in)(const f32x4*)p;
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void store_global(const float* p, const float4& v) {
+  const f32x4 w = {v.x, v.y, v.z, v.w};
+#ifdef MSGAT_PROJ_NT
+  __builtin_nontemporal_store(w, (gf4_out)(f32x4*)const_cast<float*>(p));
+#else
+  *(gf4_out)(f32x4*)const_cast<float*>(p) = w;
+#endif
+}
+
+#ifndef MSGAT_PROJ_LB
+#define MSGAT_PROJ_LB 2   // waves per SIMD the register allocation must leave room for (= blocks per CU)
+#endif
+template <int MG, bool DO_Q, bool ONEPASS, bool SEGS, bool HAS_ADD>
+__global__ __launch_bounds__(kBlock, MSGAT_PROJ_LB) void k_project_mfma(
     SegList in, const float* __restrict__ M, int m_in_major,
     const float* __restrict__ qvec, const float* __restrict__ addvec,
     const float4* __restrict__ extra4, SegList out, float4* __restrict__ q4, int Bg,
@@ -63,6 +85,7 @@ __global__ __launch_bounds__(kBlock, MG > 5 ? 2 : 1) void k_project_mfma(
   const int Mrows = cdiv(Mt, MG) * MG * 16;  // rows padded to whole passes (zeros)
   float* Wl = lds;                           // [Mrows][Kpad]
   float* ql = lds + Mrows * Kpad;            // [4*K4]
+  float* bl = ql + 4 * K4;                   // [Mrows] bias of every output row (0 without one)
   const int g = blockIdx.y;
   const int r = g / Bg;
 
@@ -71,17 +94,17 @@ __global__ __launch_bounds__(kBlock, MG > 5 ? 2 : 1) void k_project_mfma(
   const int p4 = (blockIdx.x * 4 + wave) * 16 + j;
   const bool pvalid = p4 < P4;
   const int p4c = min(p4, P4 - 1);  // out-of-range lanes re-read the last position; their stores are masked
-  const float4* ex = has_extra ? extra4 + (size_t)g * P4 + p4c : nullptr;
+  const float4* ex = has_extra ? extra4 + (size_t)g * P4 + p4c : nullptr;   // already at this lane's position
 
   // SEGS: the segment lists (3 x 26 scalars) are resolved ONCE per block into a row-pointer table in LDS
   // -- entry c = address of channel c of this group.  Looked up per load from the kernel arguments they
   // spilled the scalar registers and halved the occupancy (203 us for a pass that takes 66 us unsegmented).
-  const float** rowtab = reinterpret_cast<const float**>(lds + ((Mrows * Kpad + 4 * K4 + 1) & ~1));  // [Ci | Co | Co]
+  const float** rowtab = reinterpret_cast<const float**>(lds + ((Mrows * Kpad + 4 * K4 + Mrows + 1) & ~1));  // [Ci | Co | Co]
   if (SEGS) {
     for (int c = threadIdx.x; c < Ci; c += kBlock) rowtab[c] = in.row(g, c, 4 * P4);
     for (int c = threadIdx.x; c < Co; c += kBlock) {
       rowtab[Ci + c] = out.row(g, c, 4 * P4);
-      rowtab[Ci + Co + c] = (epi.add.n > 0) ? epi.add.row(g, c, 4 * P4) : nullptr;
+      rowtab[Ci + Co + c] = HAS_ADD ? epi.add.row(g, c, 4 * P4) : nullptr;
     }
     __syncthreads();
   }
@@ -91,9 +114,8 @@ __global__ __launch_bounds__(kBlock, MG > 5 ? 2 : 1) void k_project_mfma(
   auto loadB = [&](int kk) -> float4 {
     const int ci = 4 * min(kk, K4 - 1) + kq;
     const float* base = SEGS ? rowtab[min(ci, Ci - 1)] : in.template row<false>(g, min(ci, Ci - 1), 4 * P4);
-    const float4* row = reinterpret_cast<const float4*>(base) + p4c;
-    const float4* p = (ci == Ci && has_extra) ? ex : row;
-    return *p;
+    const float* p = (ci == Ci && has_extra) ? reinterpret_cast<const float*>(ex) : base + 4 * (size_t)p4c;
+    return load_global(p);
   };
 
   // ONEPASS (all output tiles fit the accumulators, the usual case): the first chunk of the stream is
@@ -125,7 +147,10 @@ __global__ __launch_bounds__(kBlock, MG > 5 ? 2 : 1) void k_project_mfma(
   }
   if (DO_Q)
     for (int i = threadIdx.x; i < 4 * K4; i += kBlock) ql[i] = (i < Ci) ? qvec[r * Ci + i] : 0.f;
+  for (int i = threadIdx.x; i < Mrows; i += kBlock)
+    bl[i] = (epi.bias != nullptr && i < Co) ? epi.bias[(size_t)r * epi.bias_rstride + i] : 0.f;
   __syncthreads();
+  const float relu_floor = epi.relu ? 0.f : -3.4e38f;   // kernel-uniform: max(v, floor) is the ReLU or nothing
 
   float4 qa = f4zero();
   for (int m0 = 0; m0 < Mt; m0 += MG) {
@@ -163,24 +188,39 @@ __global__ __launch_bounds__(kBlock, MG > 5 ? 2 : 1) void k_project_mfma(
 #pragma unroll
     for (int i = 0; i < kKC; ++i)
       if (k0 + i < K4) step(k0 + i, ring[i]);
-    // D tile i: column = lane & 15 <-> position 4*p4 + i;  row = 4*(lane >> 4) + reg
+    // D tile i: column = lane & 15 <-> position 4*p4 + i;  row = 4*(lane >> 4) + reg.
+    // Epilogue = bias (LDS) + add operand + ReLU + store.  The add operand's 4 float4 of tile mg + 1 are requested
+    // before tile mg is finished and stored, every load unconditional (clamped row and position): a load inside the
+    // `co < Co` branch made hipcc emit load, s_waitcnt vmcnt(0), store -- 2 x 20 dependent round trips per wave.
+    float4 addv[2][4];
+    auto load_add = [&](int mg, float4 (&dst)[4]) {
 #pragma unroll
-    for (int mg = 0; mg < MG; ++mg)
+      for (int reg = 0; reg < 4; ++reg) {
+        const int coc = min((m0 + mg) * 16 + 4 * kq + reg, Co - 1);
+        const float* arow = SEGS ? rowtab[Ci + Co + coc] : epi.add.template row<false>(g, coc, 4 * P4);
+        dst[reg] = load_global(arow + 4 * (size_t)p4c);
+      }
+    };
+    if (HAS_ADD) load_add(0, addv[0]);
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) {
+      if (HAS_ADD && mg + 1 < MG) load_add(mg + 1, addv[(mg + 1) & 1]);
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int co = (m0 + mg) * 16 + 4 * kq + reg;
+        const float b = bl[co];
+        float4 v = make_float4(acc[mg][0][reg] + b, acc[mg][1][reg] + b, acc[mg][2][reg] + b, acc[mg][3][reg] + b);
+        if (HAS_ADD) {
+          const float4 a = addv[mg & 1][reg];
+          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
         if (co < Co && pvalid) {
-          float4 v = make_float4(acc[mg][0][reg], acc[mg][1][reg], acc[mg][2][reg], acc[mg][3][reg]);
-          if (SEGS) {
-            const float* arow = rowtab[Ci + Co + co];
-            v = epi.apply_rows(v, r, co, arow != nullptr ? reinterpret_cast<const float4*>(arow) + p4 : nullptr);
-            reinterpret_cast<float4*>(const_cast<float*>(rowtab[Ci + co]))[p4] = v;
-          } else {
-            float4* dst = reinterpret_cast<float4*>(const_cast<float*>(out.template row<false>(g, co, 4 * P4)));
-            dst[p4] = epi.template apply<false>(v, r, g, co, p4, P4);
-          }
+          const float* orow = SEGS ? rowtab[Ci + min(co, Co - 1)] : out.template row<false>(g, co, 4 * P4);
+          store_global(orow + 4 * (size_t)p4, v);
         }
       }
+    }
   }
   if (DO_Q) {  // the four lane quarters hold the 4k + kq channels' share of q
     qa.x += __shfl_xor(qa.x, 16); qa.y += __shfl_xor(qa.y, 16); qa.z += __shfl_xor(qa.z, 16); qa.w += __shfl_xor(qa.w, 16);
@@ -203,8 +243,8 @@ size_t project_mfma_lds_bytes(int Ci, int Co, bool has_extra) {  // Ci, Co: tota
   const int Kx = Ci + (has_extra ? 1 : 0);
   int MG;
   const int passes = proj_passes_mg(Co, &MG);
-  // matrix + q vector (+ 1 float of alignment) + the row-pointer table of the segmented form
-  return (size_t)(passes * MG * 16 * proj_kpad(Kx) + 4 * ((Kx + 3) / 4) + 1) * sizeof(float) +
+  // matrix + q vector + bias per output row (+ 1 float of alignment) + the row-pointer table of the segmented form
+  return (size_t)(passes * MG * 16 * proj_kpad(Kx) + 4 * ((Kx + 3) / 4) + passes * MG * 16 + 1) * sizeof(float) +
          (size_t)(Ci + 2 * Co) * sizeof(float*);
 }
 
@@ -217,10 +257,15 @@ static int launch_project_mg(const SegList& in, const float* M, int m_in_major, 
   dim3 grid(cdiv(P4, 64), G);
   const bool one = cdiv(Co, 16) <= MG;
   const bool segs = in.n > 1 || out.n > 1 || epi.add.n > 1;
-#define MSGAT_PROJ(Q, ONE, SG)                                                                                      \
-  hipLaunchKernelGGL((k_project_mfma<MG, Q, ONE, SG>), grid, dim3(kBlock), lds, s, in, M, m_in_major, qvec, addvec, \
+  const bool has_add = epi.add.n > 0;
+#define MSGAT_PROJ(Q, ONE, SG, AD)                                                                                      \
+  hipLaunchKernelGGL((k_project_mfma<MG, Q, ONE, SG, AD>), grid, dim3(kBlock), lds, s, in, M, m_in_major, qvec, addvec, \
                      (const float4*)extra, out, (float4*)q, Bg, P4, epi)
-#define MSGAT_PROJ2(Q, ONE) do { if (segs) MSGAT_PROJ(Q, ONE, true); else MSGAT_PROJ(Q, ONE, false); } while (0)
+#define MSGAT_PROJ2(Q, ONE)                                                          \
+  do {                                                                               \
+    if (segs) { if (has_add) MSGAT_PROJ(Q, ONE, true, true); else MSGAT_PROJ(Q, ONE, true, false); }   \
+    else { if (has_add) MSGAT_PROJ(Q, ONE, false, true); else MSGAT_PROJ(Q, ONE, false, false); }      \
+  } while (0)
   if (qvec != nullptr) { if (one) MSGAT_PROJ2(true, true); else MSGAT_PROJ2(true, false); }
   else { if (one) MSGAT_PROJ2(false, true); else MSGAT_PROJ2(false, false); }
 #undef MSGAT_PROJ2

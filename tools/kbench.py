@@ -67,7 +67,10 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--sets", type=int, default=1, help="copies of the big operands to rotate through (cold-cache timing)")
     ap.add_argument("--eager", action="store_true", help="plain launches instead of graph replay (counter collection)")
+    ap.add_argument("--lib", default="", help="another build of libmsgat_hip.so to time (A/B runs of one kernel)")
     a = ap.parse_args()
+    if a.lib:
+        _lib.LIB_PATH = os.path.abspath(a.lib)
     if a.eager:
         globals()["timeit"] = timeit_eager
     w = WL[a.workload]
@@ -125,6 +128,45 @@ def main():
         lambda: _lib.check(L.msgat_stage_mix(sp, Cc, Cm, ptr(rot(xs)), ptr(Wm), 0, None, None, ptr(rot(ys)), st()), "m"))
     reg("mix_bwd98    d98->dx(72)", 4 * G * P * (Cc + Cm),
         lambda: _lib.check(L.msgat_stage_mix(sp, Cm, Cc, ptr(rot(ys)), ptr(Wm), 1, None, None, ptr(rot(oxs)), st()), "m"))
+    # the same passes as the model issues them (stacked.py / model.MEAM): channel axes assembled from several tensors
+    def segs(*items):
+        arr = (_lib.Seg * len(items))()
+        for i, (t, ch, gstride) in enumerate(items):
+            arr[i] = _lib.Seg(t.data_ptr(), ch, gstride)
+        return arr, len(items)
+
+    br = [[rnd(G, Co, N, T) for _ in range(3)] for _ in range(a.sets)]      # the three branch outputs
+    Wres, bres = rnd(R, Cc, Cc) * 0.1, rnd(R, Cc) * 0.1
+
+    def seg_tail():   # relu(cat(branches) + res(x) + bias): in x[72], add = 3 x 24 channels, out [72]
+        xi, oi, bi = rot(xs), rot(oxs), rot(br)
+        i_, ni = segs((xi, Cc, 0))
+        a_, na = segs(*[(b, Co, 0) for b in bi])
+        o_, no = segs((oi, Cc, 0))
+        _lib.check(L.msgat_mix_segments(R, B, N, T, i_, ni, ptr(Wres), 0, ptr(bres), 1, a_, na, 1, o_, no, st()), "t")
+    reg("seg_tail     x(72)+3x24->72 relu", 4 * G * P * (Cc + 3 * Co + Cc), seg_tail)
+
+    o98 = [[rnd(G, Co, N, T), rnd(G, 2 * Co, N, T), rnd(G, Co, N, T), rnd(G, 1, N, T), rnd(G, 1, N, T)]
+           for _ in range(min(a.sets, 2))]
+
+    def seg_fwd98():  # all channel mixings of one LayerNorm output: 72 -> 24 | 48 | 24 | 1 | 1
+        xi, oi = rot(xs), rot(o98)
+        i_, ni = segs((xi, Cc, 0))
+        o_, no = segs(*[(t, t.shape[1], 0) for t in oi])
+        _lib.check(L.msgat_mix_segments(R, B, N, T, i_, ni, ptr(Wm), 0, None, 0, None, 0, 0, o_, no, st()), "f")
+    reg("seg_fwd98    x(72)->24|48|24|1|1", 4 * G * P * (Cc + Cm), seg_fwd98)
+
+    def seg_bwd98():  # its backward: the five gradients -> dx[72]
+        gi, oi = rot(o98), rot(oxs)
+        i_, ni = segs(*[(t, t.shape[1], 0) for t in gi])
+        o_, no = segs((oi, Cc, 0))
+        _lib.check(L.msgat_mix_segments(R, B, N, T, i_, ni, ptr(Wm), 1, None, 0, None, 0, 0, o_, no, st()), "b")
+    reg("seg_bwd98    24|48|24|1|1->dx(72)", 4 * G * P * (Cc + Cm), seg_bwd98)
+
+    def mix_bias72():  # a 72 -> 72 1x1 convolution with bias (unsegmented, epilogue only)
+        _lib.check(L.msgat_stage_mix_epilogue(sp, Cc, Cc, ptr(rot(xs)), ptr(Wres), 0, ptr(bres), 1, None, 0, ptr(rot(oxs)), st()), "e")
+    reg("mix_bias72   x(72)->72 +bias", 4 * G * P * 2 * Cc, mix_bias72)
+
     nfl = L.msgat_contract_partial_floats(sp, Co + 1, Cc)
     part = torch.empty(nfl, device=dev)
     dW, da = torch.empty(R, Co, Cc, device=dev), torch.empty(R, Cc, device=dev)

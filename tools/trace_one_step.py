@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Prints the launches of ONE step (the last complete one) of a rocprofv3 kernel trace in launch order.
 
-    python tools/trace_one_step.py <dir with *_kernel_trace.csv> --anchor k_project_mfma --per-step 30
+    python tools/trace_one_step.py <dir with *_kernel_trace.csv> --per-step 30 [--skip K]
+    python tools/trace_one_step.py <dir with *_kernel_trace.csv> --anchor k_qonly     # a kernel launched once per step
 """
 import argparse
 import csv
@@ -13,15 +14,20 @@ import re
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("dir")
-    ap.add_argument("--per-step", type=int, required=True, help="launches per step")
+    ap.add_argument("--per-step", type=int, default=0, help="launches per step")
+    ap.add_argument("--anchor", default="", help="name of a kernel launched once per step: the step between its last two launches")
     ap.add_argument("--skip", type=int, default=0, help="launches after the last whole step (baselines etc.)")
     a = ap.parse_args()
     f = max(glob.glob(os.path.join(a.dir, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
     rows = list(csv.DictReader(open(f)))
     rows = [r for r in rows if "msgat::" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    end = len(rows) - a.skip
-    step = rows[end - a.per_step:end]
+    if a.anchor:
+        marks = [i for i, r in enumerate(rows) if a.anchor in r["Kernel_Name"]]
+        step = rows[marks[-2]:marks[-1]]
+    else:
+        end = len(rows) - a.skip
+        step = rows[end - a.per_step:end]
     t0 = int(step[0]["Start_Timestamp"])
     prev_end = t0
     tot = 0
