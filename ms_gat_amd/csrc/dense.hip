@@ -42,7 +42,10 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(
 // 8 waves = 2 per SIMD.  Tried (round 2): 7 waves per block, which makes the PEMSD7 grid (N = 883, G = 96) exactly
 // 3.0 blocks per CU instead of 2.6 (3 rounds of 112 rows instead of 3 of 128): k_scores 60.7 -> 63.7 us,
 // k_bwd_dense_col 60.2 -> 61.0 us -- 7 waves spread 2,2,2,1 over the SIMDs, and the matrix pipe is per SIMD.
-constexpr int kDWaves = 8;             // the whole grid must be resident at once: leftover blocks run as a second round
+#ifndef MSGAT_DWAVES
+#define MSGAT_DWAVES 8
+#endif
+constexpr int kDWaves = MSGAT_DWAVES;  // the whole grid must be resident at once: leftover blocks run as a second round
 constexpr int kDBlock = 64 * kDWaves;
 constexpr int kDRows = 16 * kDWaves;   // own rows (forward) / columns (backward) per block
 constexpr int kDMC = 128;              // streamed columns (forward) / rows (backward) staged per step
@@ -59,7 +62,11 @@ static size_t balance_pad_bytes(int nblocks, size_t static_lds) {
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
     ncu = 256;  // MI355X
+#ifdef MSGAT_DCAP
+  const int per_cu = MSGAT_DCAP;        // lab: resident blocks per CU capped, the rest dispatched as slots free up
+#else
   const int per_cu = cdiv(nblocks, ncu);
+#endif
   const size_t share = (size_t)kLdsMax / per_cu;  // LDS a block may occupy so that exactly per_cu fit
   if (share <= static_lds + 1024) return 0;        // already limited by its own LDS
   size_t pad = share - static_lds - 512;
@@ -117,8 +124,12 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
   }
 
   MSGAT_STAMP(1);
+  // WITH_PQ and a spare row in the payload tile (T < 16): the row sum rides in the payload product -- staged
+  // column m carries a 1 behind its T values of q, so D2[s = T][row] accumulates sum_m p[row][m] on the matrix core
+  // and three v_add per tile leave the VALU stream (which the fp32 MFMAs share an issue port with)
+  constexpr bool ONES = WITH_PQ && T < 16;
   float m = -3.0e38f;  // running max of the row, identical in its 4 quads; finite floor, not -inf
-  float lsum = 0.f;    // this quad's share of sum_m 2^(S - m)
+  float lsum = 0.f;    // this quad's share of sum_m 2^(S - m) (unused with ONES)
   f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = da, dc = da, dd = da;  // payload accumulators (four independent chains)
 
   // Staging is double-buffered through registers: the loads of chunk c+1 are issued before chunk c
@@ -137,7 +148,8 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
       const bool live = (c < cols) && (f < T4);
       const float4 v = reinterpret_cast<const float4*>(qg + (size_t)(c0 + (live ? c : 0)) * T)[live ? f : 0];
       const float keep = live ? 1.f : 0.f;  // multiply, not select: keeps the load out of a branch
-      pre[k] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
+      const float one = (ONES && c < cols && f == T4) ? 1.f : 0.f;  // the ones column, at index T of the staged row
+      pre[k] = make_float4(fmaf(v.x, keep, one), v.y * keep, v.z * keep, v.w * keep);
     }
   };
   prefetch(0);
@@ -152,20 +164,27 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
     }
     __syncthreads();
     prefetch(min(c0 + kDMC, max(N - 1, 0) / kDMC * kDMC));  // next chunk (the last trip re-reads its own)
-    for (int m0 = 0; m0 < cols16; m0 += 16) {
-      f32x4 S = {0.f, 0.f, 0.f, 0.f};
+    // two score tiles per trip: one max / vote / re-base decision for 32 columns, and the second tile's score chain
+    // is independent of the first tile's exponentials.  An odd last tile is a tile of padding columns (masked).
+    for (int m0 = 0; m0 < cols16; m0 += 32) {
+      f32x4 S0 = {0.f, 0.f, 0.f, 0.f}, S1 = S0;
 #pragma unroll
-      for (int kk = 0; kk < T4; ++kk) S = mfma16(qsw[(m0 + j) * kPS + 4 * kk + quad], bfrag[kk], S);
-      const int mq = m0 + 4 * quad;  // this lane's 4 columns: mq .. mq+3
-      float sv[4];
-      if (m0 + 16 > cols) {  // wave-uniform: only the chunk's last tile can hold padding columns
+      for (int kk = 0; kk < T4; ++kk) S0 = mfma16(qsw[(m0 + j) * kPS + 4 * kk + quad], bfrag[kk], S0);
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) sv[rr] = (mq + rr < cols) ? S[rr] : -3.0e38f;
+      for (int kk = 0; kk < T4; ++kk) S1 = mfma16(qsw[(m0 + 16 + j) * kPS + 4 * kk + quad], bfrag[kk], S1);
+      const int mq = m0 + 4 * quad;  // this lane's columns: mq .. mq+3 and mq+16 .. mq+19
+      float sv[8];
+      if (m0 + 32 > cols) {  // wave-uniform: only the chunk's last trip can hold padding columns
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          sv[rr] = (mq + rr < cols) ? S0[rr] : -3.0e38f;
+          sv[4 + rr] = (mq + 16 + rr < cols) ? S1[rr] : -3.0e38f;
+        }
       } else {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) sv[rr] = S[rr];
+        for (int rr = 0; rr < 4; ++rr) { sv[rr] = S0[rr]; sv[4 + rr] = S1[rr]; }
       }
-      const float cm = max3(max3(sv[0], sv[1], sv[2]), sv[3], sv[3]);
+      const float cm = max3(max3(sv[0], sv[1], sv[2]), max3(sv[3], sv[4], sv[5]), fmaxf(sv[6], sv[7]));
       if (__any(cm > m + kDefer)) {  // rare (deferred re-base); the row's 4 quads must agree on m
         float cx = fmaxf(cm, __shfl_xor(cm, 16));
         cx = fmaxf(cx, __shfl_xor(cx, 32));
@@ -178,25 +197,33 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
           for (int rr = 0; rr < 4; ++rr) { da[rr] *= sc; db[rr] *= sc; dc[rr] *= sc; dd[rr] *= sc; }
         }
       }
-      float p[4];
+      float p[8];
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) p[rr] = fast_exp2(sv[rr] - m);
-      lsum += (p[0] + p[1]) + (p[2] + p[3]);
+      for (int rr = 0; rr < 8; ++rr) p[rr] = fast_exp2(sv[rr] - m);
+      if (!ONES) lsum += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
       if (WITH_PQ) {
         // A2[i = s][k = quad] = q[column mq + rr][s = j]; B2[k = quad][j = row] = p[rr]
         da = mfma16(qsw[(mq + 0) * kPS + j], p[0], da);
         db = mfma16(qsw[(mq + 1) * kPS + j], p[1], db);
         dc = mfma16(qsw[(mq + 2) * kPS + j], p[2], dc);
         dd = mfma16(qsw[(mq + 3) * kPS + j], p[3], dd);
+        da = mfma16(qsw[(mq + 16) * kPS + j], p[4], da);
+        db = mfma16(qsw[(mq + 17) * kPS + j], p[5], db);
+        dc = mfma16(qsw[(mq + 18) * kPS + j], p[6], dc);
+        dd = mfma16(qsw[(mq + 19) * kPS + j], p[7], dd);
       }
     }
     if (c0 == 0) MSGAT_STAMP(2);
   }
 
   MSGAT_STAMP(3);
-  // the row's 4 quads share m: their partial sums simply add
-  lsum += __shfl_xor(lsum, 16);
-  lsum += __shfl_xor(lsum, 32);
+  if (ONES) {  // D2[s = T][row] sits in register T % 4 of the lanes with quad == T / 4
+    const float mine = (da[T % 4] + db[T % 4]) + (dc[T % 4] + dd[T % 4]);
+    lsum = __shfl(mine, j + 16 * (T / 4));
+  } else {     // the row's 4 quads share m: their partial sums simply add
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
+  }
   const float lse2 = m + fast_log2(lsum);
   if (quad == 0) {
     lse2s[16 * wave + j] = lse2;
@@ -332,19 +359,28 @@ __global__ __launch_bounds__(kDBlock) void k_bwd_dense_col(
     // same products in the same k order as the forward's edge pass, accumulator starting at 0: the
     // score is re-created bit for bit, so 2^(s - lse2) equals the forward's softmax value (rows that
     // are one-hot on an edge cancel against the sparse term; a 1e-4 slip in the exponent would not).
-    for (int rb = 0; rb < rows16; rb += 16) {
-      f32x4 S = {0.f, 0.f, 0.f, 0.f};
+    // two row tiles per trip (rows past the end carry lse = +inf and zero payload, so an odd last tile is harmless)
+    for (int rb = 0; rb < rows16; rb += 32) {
+      f32x4 S0 = {0.f, 0.f, 0.f, 0.f}, S1 = S0;
 #pragma unroll
-      for (int kk = 0; kk < T4; ++kk) S = mfma16(kwr[(rb + j) * T + 4 * kk + quad], bfrag[kk], S);
-      const int rq = rb + 4 * quad;            // this lane's 4 rows: rq .. rq+3
-      const float4 l4 = lse4[rq >> 2];         // quad-uniform
-      const float p0 = fast_exp2(S[0] - l4.x), p1 = fast_exp2(S[1] - l4.y);
-      const float p2 = fast_exp2(S[2] - l4.z), p3 = fast_exp2(S[3] - l4.w);
+      for (int kk = 0; kk < T4; ++kk) S0 = mfma16(kwr[(rb + j) * T + 4 * kk + quad], bfrag[kk], S0);
+#pragma unroll
+      for (int kk = 0; kk < T4; ++kk) S1 = mfma16(kwr[(rb + 16 + j) * T + 4 * kk + quad], bfrag[kk], S1);
+      const int rq = rb + 4 * quad;            // this lane's rows: rq .. rq+3 and rq+16 .. rq+19
+      const float4 l4 = lse4[rq >> 2], l5 = lse4[(rq + 16) >> 2];         // quad-uniform
+      const float p0 = fast_exp2(S0[0] - l4.x), p1 = fast_exp2(S0[1] - l4.y);
+      const float p2 = fast_exp2(S0[2] - l4.z), p3 = fast_exp2(S0[3] - l4.w);
+      const float p4 = fast_exp2(S1[0] - l5.x), p5 = fast_exp2(S1[1] - l5.y);
+      const float p6 = fast_exp2(S1[2] - l5.z), p7 = fast_exp2(S1[3] - l5.w);
       // A2[i = s][k = quad] = (delta kW)[row rq + rr][s = j]; B2[k = quad][j = column] = p[rr]
       da = mfma16(dkr[(rq + 0) * kPS + j], p0, da);
       db = mfma16(dkr[(rq + 1) * kPS + j], p1, db);
       dc = mfma16(dkr[(rq + 2) * kPS + j], p2, dc);
       dd = mfma16(dkr[(rq + 3) * kPS + j], p3, dd);
+      da = mfma16(dkr[(rq + 16) * kPS + j], p4, da);
+      db = mfma16(dkr[(rq + 17) * kPS + j], p5, db);
+      dc = mfma16(dkr[(rq + 18) * kPS + j], p6, dc);
+      dd = mfma16(dkr[(rq + 19) * kPS + j], p7, dd);
     }
   }
   if (!valid || quad >= T4) return;
