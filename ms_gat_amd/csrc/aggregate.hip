@@ -782,8 +782,19 @@ __global__ __launch_bounds__(kAggBlock) void k_sddmm_sellreg(
     acc[t] = f4zero();
   }
 
+  // Pass order.  Every 128-B line of a [N,T] slab holds the T/4 columns of 2.67 nodes, so the T/4 passes over one
+  // slab touch the SAME lines T/4 times, microseconds apart, with 32 blocks streaming through the XCD's 4 MB L2 in
+  // between.  The Q blocks of a group (side by side on one XCD, in step with each other) therefore walk the columns
+  // of a slab in ROTATED order, block q starting at column q % T4: at any moment they cover all T4 columns of the
+  // slab together and share its lines (2.96 -> 2.73 ms).  What was tried beyond that, and what it showed
+  // (profiles/r03/stress_sddmm_lab.txt): one block per (group, slice quarter, COLUMN) with per-column partials cuts the
+  // fabric traffic from 2.8x to 1.4x the algorithmic bytes -- an XCD then holds 2.7 groups' lines instead of 8 -- and
+  // runs no faster (2.99 ms + 0.17 ms more in k_edge_grad): the kernel is not fabric-bound but serialised inside the
+  // CU (staging round trip, then ~770 conflicted ds_read_b128 per pass, one block per CU); reading a wave's dv rows
+  // whole, once per channel, needs 16 more registers than 4 waves per SIMD leave (scratch: 5.3 ms).
   for (int pass = 0; pass < Cu * T4; ++pass) {
-    const int c = pass / T4, j = pass - c * T4;
+    const int c = pass / T4, jr = pass - c * T4;
+    const int j = (jr + q) % T4;
     const size_t base = ((size_t)g * Cu + c) * N * T4;
     const float4 aA = dv4[base + (size_t)rowA * T4 + j];
     const float4 aB = dv4[base + (size_t)rowB * T4 + j];
