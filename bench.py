@@ -407,7 +407,7 @@ def time_dense_kernels(hp, reps=20):
 
     def scores():
         _lib.check(L.msgat_stage_scores(C.byref(shape), C.byref(gs), q.data_ptr(), Wg.data_ptr(), kW.data_ptr(),
-                                        lse.data_ptr(), pq.data_ptr(), E.data_ptr(), stream.cuda_stream), "msgat_stage_scores")
+                                        lse.data_ptr(), pq.data_ptr(), E.data_ptr(), None, stream.cuda_stream), "msgat_stage_scores")
 
     def column():
         _lib.check(L.msgat_stage_dense_column_pass(C.byref(shape), C.byref(gs), q.data_ptr(), kW.data_ptr(), lse.data_ptr(),

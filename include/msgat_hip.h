@@ -103,6 +103,8 @@ typedef struct msgat_graph {
   const int32_t* colptr; /* [N+1]  CSC column starts                                */
   const int32_t* crow;   /* [nnz]  row of each CSC entry                            */
   const int32_t* cperm;  /* [nnz]  CSC position -> CSR edge index                   */
+  const int32_t* cpos;   /* [nnz]  CSR edge index -> CSC position (inverse of cperm): lets the forward leave the
+                                   edge coefficients in CSC order too, so backward starts without a re-ordering pass */
   msgat_sell_t sell_rows; /* SELL of the CSR (forward aggregate, SDDMM); optional     */
   msgat_sell_t sell_cols; /* SELL of the CSC (transposed aggregate of backward); opt. */
 } msgat_graph_t;
@@ -134,6 +136,8 @@ typedef struct msgat_fwd {
   int32_t need_bwd;
   float* edge_scratch; /* tmp msgat_edge_scratch_floats() floats (0 unless the graph carries a SELL
                              layout the aggregate will use: E re-ordered for it); may be NULL then */
+  float* Ec;          /* out [G,nnz]      E in CSC order (Ec[g, cpos[e]] = E[g, e]), written by the score kernel
+                             itself; optional (NULL: not written).  Hand it to msgat_bwd_t.Ec */
 } msgat_fwd_t;
 
 typedef struct msgat_bwd {
@@ -162,6 +166,8 @@ typedef struct msgat_bwd {
    * dz + g * dz_group_channels * N * T (a gradient that arrives as dout[:, a:b] of a wider [G,C',N,T] tensor is read in
    * place instead of being copied).  Only where msgat_bwd_accepts_strided_dz() says so; 0 everywhere else. */
   int32_t dz_group_channels;
+  /* E in CSC order as the forward left it (msgat_fwd_t.Ec); NULL: backward re-orders E itself (one more launch) */
+  const float* Ec;
 } msgat_bwd_t;
 
 /* ---- library ------------------------------------------------------------------- */
@@ -177,7 +183,7 @@ int msgat_gacn_mode(int32_t C, int32_t Co);
 int msgat_graph_count(const float* adj, int32_t n, int64_t ld, int32_t* nnz_out);
 int msgat_graph_build(const float* adj, int32_t n, int64_t ld, int32_t nnz,
                       int32_t* rowptr, int32_t* col, float* val, int32_t* erow,
-                      int32_t* colptr, int32_t* crow, int32_t* cperm);
+                      int32_t* colptr, int32_t* crow, int32_t* cperm, int32_t* cpos);
 /* Host-side structural check of a (host-resident) graph (its SELL forms too, when present). */
 int msgat_graph_validate(const msgat_graph_t* host_graph);
 /* SELL form of a CSR (ptr = rowptr, idx = col, perm = NULL) or CSC (ptr = colptr, idx = crow,
@@ -213,10 +219,11 @@ int msgat_gacn_backward(const msgat_shape_t* shape, const msgat_graph_t* graph,
 int msgat_stage_project(const msgat_shape_t* shape, const float* x, const float* alpha,
                         const float* W, float* q, float* u, void* stream);
 /* attention.py:34 + the edge part of :36: kW = q Wg, lse = row log-sum-exp over ALL N
- * columns of kW q^T (log2 units), pq = softmax @ q (optional), E = softmax * adj at the edges. */
+ * columns of kW q^T (log2 units), pq = softmax @ q (optional), E = softmax * adj at the edges (Ec, optional: the
+ * same values in CSC order). */
 int msgat_stage_scores(const msgat_shape_t* shape, const msgat_graph_t* graph,
                        const float* q, const float* Wg, float* kW, float* lse, float* pq,
-                       float* E, void* stream);
+                       float* E, float* Ec, void* stream);
 /* attention.py:36: v[g,c,n,:] = sum_{e in row n} E[g,e] u[g,c,col_e,:] over Cu channels.
  * edge_scratch: msgat_edge_scratch_floats() floats (NULL when that is 0). */
 int msgat_stage_aggregate(const msgat_shape_t* shape, const msgat_graph_t* graph,
@@ -353,12 +360,12 @@ int msgat_contract_segments(int32_t R, int32_t Bg, int32_t N, int32_t T, const m
  * come out of one pass that reads both). */
 size_t msgat_attention_bwd_workspace_bytes(const msgat_shape_t* shape, const msgat_graph_t* graph);
 /* dv_group_channels: as msgat_bwd_t.dz_group_channels, for dv (0 = contiguous); non-zero only where
- * msgat_attention_bwd_accepts_strided_dv() returns 1. */
+ * msgat_attention_bwd_accepts_strided_dv() returns 1.  Ec: E in CSC order from msgat_stage_scores, or NULL. */
 int msgat_attention_bwd_accepts_strided_dv(const msgat_shape_t* shape, const msgat_graph_t* graph);
 int msgat_attention_backward(const msgat_shape_t* shape, const msgat_graph_t* graph, const float* u,
                              const float* dv, int32_t dv_group_channels, const float* q, const float* kW,
-                             const float* lse, const float* pq, const float* E, const float* Wg, float* du,
-                             float* dq, float* dWg, void* workspace, size_t workspace_bytes, void* stream);
+                             const float* lse, const float* pq, const float* E, const float* Ec, const float* Wg,
+                             float* du, float* dq, float* dWg, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- device: the prediction head of a component ----
  * TPC's Conv2d(T_in -> T_out, kernel [1, C]) over the transposed activation (src/models/msgat.py:153,

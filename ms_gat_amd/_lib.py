@@ -36,7 +36,7 @@ class Graph(C.Structure):
     _fields_ = [
         ("n_nodes", C.c_int32), ("nnz", C.c_int32),
         ("rowptr", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p), ("erow", C.c_void_p),
-        ("colptr", C.c_void_p), ("crow", C.c_void_p), ("cperm", C.c_void_p),
+        ("colptr", C.c_void_p), ("crow", C.c_void_p), ("cperm", C.c_void_p), ("cpos", C.c_void_p),
         ("sell_rows", Sell), ("sell_cols", Sell),
     ]
 
@@ -48,13 +48,13 @@ class Shape(C.Structure):
 
 class Fwd(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x", "alpha", "Wg", "W", "z", "q", "kW", "lse", "pq", "E", "u")] + [
-        ("need_bwd", C.c_int32), ("edge_scratch", C.c_void_p)]
+        ("need_bwd", C.c_int32), ("edge_scratch", C.c_void_p), ("Ec", C.c_void_p)]
 
 
 class Bwd(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "x", "alpha", "Wg", "W", "q", "kW", "lse", "pq", "E", "u", "dz", "dx", "dalpha", "dWg", "dW",
-        "workspace")] + [("workspace_bytes", C.c_size_t), ("dz_group_channels", C.c_int32)]
+        "workspace")] + [("workspace_bytes", C.c_size_t), ("dz_group_channels", C.c_int32), ("Ec", C.c_void_p)]
 
 
 class Seg(C.Structure):
@@ -66,7 +66,7 @@ _PROTOTYPES = {
     "msgat_status_string": (C.c_char_p, [C.c_int]),
     "msgat_gacn_mode": (C.c_int, [C.c_int32, C.c_int32]),
     "msgat_graph_count": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, c_int_p]),
-    "msgat_graph_build": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32] + [C.c_void_p] * 7),
+    "msgat_graph_build": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32] + [C.c_void_p] * 8),
     "msgat_graph_validate": (C.c_int, [C.POINTER(Graph)]),
     "msgat_graph_sell_count": (C.c_int, [C.c_void_p, C.c_int32, c_int_p, c_int_p, c_int_p]),
     "msgat_graph_sell_build": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p] * 5),
@@ -75,7 +75,7 @@ _PROTOTYPES = {
     "msgat_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Shape), C.POINTER(Graph)]),
     "msgat_gacn_backward": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph), C.POINTER(Bwd), C.c_void_p]),
     "msgat_stage_project": (C.c_int, [C.POINTER(Shape)] + [C.c_void_p] * 6),
-    "msgat_stage_scores": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)] + [C.c_void_p] * 7),
+    "msgat_stage_scores": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)] + [C.c_void_p] * 8),
     "msgat_stage_dense_column_pass": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)] + [C.c_void_p] * 7),
     "msgat_stage_aggregate": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph), C.c_int32] + [C.c_void_p] * 5),
     "msgat_stage_aggregate_project": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)] + [C.c_void_p] * 6),
@@ -101,7 +101,7 @@ _PROTOTYPES = {
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "msgat_attention_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Shape), C.POINTER(Graph)]),
     "msgat_attention_backward": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_int32] +
-                                 [C.c_void_p] * 10 + [C.c_size_t, C.c_void_p]),
+                                 [C.c_void_p] * 11 + [C.c_size_t, C.c_void_p]),
     "msgat_attention_bwd_accepts_strided_dv": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)]),
     "msgat_bwd_accepts_strided_dz": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)]),
     "msgat_head_forward_partial_floats": (C.c_size_t, [C.c_int32] * 4),

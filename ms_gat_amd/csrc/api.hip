@@ -23,7 +23,7 @@ int check_graph(const msgat_shape_t* sh, const msgat_graph_t* gr) {
   if (!gr) return MSGAT_ERR_NULL;
   if (gr->n_nodes != sh->N || gr->nnz < 0) return MSGAT_ERR_SHAPE;
   if (!gr->rowptr || !gr->colptr) return MSGAT_ERR_NULL;
-  if (gr->nnz > 0 && (!gr->col || !gr->val || !gr->erow || !gr->crow || !gr->cperm)) return MSGAT_ERR_NULL;
+  if (gr->nnz > 0 && (!gr->col || !gr->val || !gr->erow || !gr->crow || !gr->cperm || !gr->cpos)) return MSGAT_ERR_NULL;
   for (const msgat_sell_t* j : {&gr->sell_rows, &gr->sell_cols}) {
     if (j->n_slices == 0) continue;
     if (j->n_slices != cdiv(sh->N, 64) || j->n_pos < gr->nnz) return MSGAT_ERR_GRAPH;
@@ -124,7 +124,7 @@ extern "C" int msgat_stage_project(const msgat_shape_t* sh, const float* x, cons
 }
 
 extern "C" int msgat_stage_scores(const msgat_shape_t* sh, const msgat_graph_t* gr, const float* q,
-                                  const float* Wg, float* kW, float* lse, float* pq, float* E,
+                                  const float* Wg, float* kW, float* lse, float* pq, float* E, float* Ec,
                                   void* stream) {
   int st = check_shape(sh);
   if (st) return st;
@@ -132,7 +132,7 @@ extern "C" int msgat_stage_scores(const msgat_shape_t* sh, const msgat_graph_t* 
   if (st) return st;
   if (!q || !Wg || !kW || !lse) return MSGAT_ERR_NULL;
   if (gr->nnz > 0 && !E) return MSGAT_ERR_NULL;
-  return launch_scores(*gr, q, Wg, kW, lse, pq, E, sh->R * sh->Bg, sh->Bg, sh->N, sh->T, (hipStream_t)stream);
+  return launch_scores(*gr, q, Wg, kW, lse, pq, E, Ec, sh->R * sh->Bg, sh->Bg, sh->N, sh->T, (hipStream_t)stream);
 }
 
 // forward aggregate over the CSR: on the SELL layout when the graph carries a usable one (E re-ordered into
@@ -152,15 +152,22 @@ static int aggregate_rows(const msgat_shape_t* sh, const msgat_graph_t* gr, int 
 }
 
 // transposed aggregate over the CSC (backward): E goes to CSC order -- or to the SELL order of the CSC -- in Ec
+// (Ec_ready: E already in CSC order, as the forward's score kernel left it -- used when the CSC itself is walked)
 static int aggregate_cols(const msgat_shape_t* sh, const msgat_graph_t* gr, int Cu, const float* dv, const float* E,
                           float* Ec, const float* addvec, const float* extra, float* out, hipStream_t s,
-                          const float* xdot = nullptr, float* dap = nullptr, int* dot_done = nullptr) {
+                          const float* xdot = nullptr, float* dap = nullptr, int* dot_done = nullptr,
+                          const float* Ec_ready = nullptr) {
   const int G = sh->R * sh->Bg;
   const bool sell = sell_usable(gr->sell_cols, gr->nnz, sh->N, sh->T);
-  int st = launch_permute_edges(E, sell ? gr->sell_cols.src : gr->cperm, Ec, G, gr->nnz,
-                                sell ? gr->sell_cols.n_pos : gr->nnz, s);
-  if (st) return st;
-  return launch_aggregate(gr->colptr, gr->crow, gr->nnz, sell ? &gr->sell_cols : nullptr, dv, Ec, addvec, extra, out,
+  const float* Eo = Ec;
+  if (!sell && Ec_ready != nullptr) {
+    Eo = Ec_ready;
+  } else {
+    int st = launch_permute_edges(E, sell ? gr->sell_cols.src : gr->cperm, Ec, G, gr->nnz,
+                                  sell ? gr->sell_cols.n_pos : gr->nnz, s);
+    if (st) return st;
+  }
+  return launch_aggregate(gr->colptr, gr->crow, gr->nnz, sell ? &gr->sell_cols : nullptr, dv, Eo, addvec, extra, out,
                           G, sh->Bg, Cu, sh->N, sh->T, s, xdot, dap, dot_done);
 }
 
@@ -391,8 +398,9 @@ extern "C" int msgat_attention_bwd_accepts_strided_dv(const msgat_shape_t* sh, c
 
 extern "C" int msgat_attention_backward(const msgat_shape_t* shp, const msgat_graph_t* gr, const float* u,
                                         const float* dv, int32_t dv_group_channels, const float* q, const float* kW,
-                                        const float* lse, const float* pq, const float* E, const float* Wg, float* du,
-                                        float* dq, float* dWg, void* workspace, size_t workspace_bytes, void* stream) {
+                                        const float* lse, const float* pq, const float* E, const float* Ec_in,
+                                        const float* Wg, float* du, float* dq, float* dWg, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
   int st = check_shape(shp);
   if (st) return st;
   const msgat_shape_t shv = plain_shape(shp);
@@ -415,21 +423,26 @@ extern "C" int msgat_attention_backward(const msgat_shape_t* shp, const msgat_gr
   // du = E^T dv and the SDDMM walk the same (column, edge) pairs over the same dv slabs: one pass when the graph allows
   const bool fused = agg_sddmm_fusable(*gr, N, T, sh->C);
   if (dv_group_channels != 0 && (dv_group_channels < sh->C || !fused)) return MSGAT_ERR_SHAPE;  // see ..._accepts_strided_dv
+  const float* Ecsc = Ec;  // E in CSC order: the forward's, or re-ordered here
+  const int direct_c = (!fused && sh->C <= bwd_rows_direct_max_channels()) ? sh->C : 0;  // few channels: no SDDMM launch
   if (fused) {
-    st = launch_permute_edges(E, gr->cperm, Ec, G, gr->nnz, gr->nnz, s);
-    if (st) return st;
-    st = launch_agg_sddmm(*gr, dv, Ec, u, du, dEp, G, sh->C, N, T, s, dv_group_channels);
-  } else {
+    if (Ec_in != nullptr) {
+      Ecsc = Ec_in;
+    } else {
+      st = launch_permute_edges(E, gr->cperm, Ec, G, gr->nnz, gr->nnz, s);
+      if (st) return st;
+    }
+    st = launch_agg_sddmm(*gr, dv, Ecsc, u, du, dEp, G, sh->C, N, T, s, dv_group_channels);
+  } else if (direct_c == 0) {
     st = launch_sddmm(*gr, u, dv, dEp, G, sh->C, N, T, s);
   }
   if (st) return st;
-  st = launch_bwd_edge(*gr, dEp, p.nch, E, q, pq, Wg, gE, delta, dkW, dq, G, Bg, N, T, s, fused ? Ec : nullptr);
+  st = launch_bwd_rows(*gr, dEp, p.nch, fused, direct_c, u, dv, E, q, pq, Wg, gE, delta, dkW, dq, dwgp, dWg, G, Bg, N,
+                       T, s);
   if (st) return st;
   st = launch_bwd_dense_col(*gr, q, kW, lse, delta, gE, dq, G, N, T, s);
   if (st) return st;
-  st = launch_dwg(q, dkW, dwgp, dWg, G, Bg, N, T, s);
-  if (st) return st;
-  return fused ? MSGAT_OK : aggregate_cols(sh, gr, sh->C, dv, E, Ec, nullptr, nullptr, du, s);
+  return fused ? MSGAT_OK : aggregate_cols(sh, gr, sh->C, dv, E, Ec, nullptr, nullptr, du, s, nullptr, nullptr, nullptr, Ec_in);
 }
 
 // The dense column pass of the backward alone (what msgat_attention_backward / msgat_gacn_backward enqueue after the
@@ -540,7 +553,7 @@ extern "C" int msgat_gacn_forward(const msgat_shape_t* sh, const msgat_graph_t* 
     st = launch_qonly(io->x, io->alpha, io->q, G, sh->Bg, sh->C, P, s);
   if (st) return st;
 
-  st = launch_scores(*gr, io->q, io->Wg, io->kW, io->lse, pq, io->E, G, sh->Bg, sh->N, sh->T, s);
+  st = launch_scores(*gr, io->q, io->Wg, io->kW, io->lse, pq, io->E, io->Ec, G, sh->Bg, sh->N, sh->T, s);
   if (st) return st;
 
   switch (mode) {
@@ -631,26 +644,31 @@ extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t*
   // as the SDDMM -- one pass does both when the graph allows (CSC, slab + edge shares within half the LDS)
   const bool fused = p.mode == MSGAT_MODE_PROJ_FIRST && agg_sddmm_fusable(*gr, N, T, p.Cu);
   if (strided && p.mode != MSGAT_MODE_AGG_FIRST && !fused) return MSGAT_ERR_SHAPE;  // see msgat_bwd_accepts_strided_dz
+  const float* Ecsc = Ec;  // E in CSC order: the forward's (io->Ec), or re-ordered here
+  // attention over few channels (the first MEAM of every component): dE is computed inside the row pass, no SDDMM
+  const int direct_c = (!fused && p.Cu <= bwd_rows_direct_max_channels()) ? p.Cu : 0;
   if (fused) {
-    st = launch_permute_edges(io->E, gr->cperm, Ec, G, gr->nnz, gr->nnz, s);
-    if (st) return st;
-    st = launch_agg_sddmm(*gr, dv, Ec, u, dvb, dEp, G, p.Cu, N, T, s, dzgs);
-  } else {
+    if (io->Ec != nullptr) {
+      Ecsc = io->Ec;
+    } else {
+      st = launch_permute_edges(io->E, gr->cperm, Ec, G, gr->nnz, gr->nnz, s);
+      if (st) return st;
+    }
+    st = launch_agg_sddmm(*gr, dv, Ecsc, u, dvb, dEp, G, p.Cu, N, T, s, dzgs);
+  } else if (direct_c == 0) {
     st = launch_sddmm(*gr, u, dv, dEp, G, p.Cu, N, T, s);
   }
   if (st) return st;
-  st = launch_bwd_edge(*gr, dEp, p.nch, io->E, io->q, io->pq, io->Wg, gE, delta, dkW, dq, G, Bg, N, T, s,
-                       fused ? Ec : nullptr);
+  st = launch_bwd_rows(*gr, dEp, p.nch, fused, direct_c, u, dv, io->E, io->q, io->pq, io->Wg, gE, delta, dkW, dq, dwgp,
+                       io->dWg, G, Bg, N, T, s, &jobs);
   if (st) return st;
   st = launch_bwd_dense_col(*gr, io->q, io->kW, io->lse, delta, gE, dq, G, N, T, s);
-  if (st) return st;
-  st = launch_dwg(io->q, dkW, dwgp, io->dWg, G, Bg, N, T, s, &jobs);
   if (st) return st;
 
   if (p.mode == MSGAT_MODE_PROJ_FIRST) {
     // du = E^T dz;  dx = W^T du + alpha (x) dq;  dW = du x^T;  dalpha = dq . x
     if (!fused) {
-      st = aggregate_cols(sh, gr, Co, dv, io->E, Ec, nullptr, nullptr, dvb, s);
+      st = aggregate_cols(sh, gr, Co, dv, io->E, Ec, nullptr, nullptr, dvb, s, nullptr, nullptr, nullptr, io->Ec);
       if (st) return st;
     }
     // the contraction (reads only) goes first: behind the projection it would stream x while the 72-channel dx the
@@ -666,7 +684,7 @@ extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t*
   float* dap = (p.mode == MSGAT_MODE_AGG_FIRST) ? cpp2 : cpp;
   int dot_done = 0;
   st = aggregate_cols(sh, gr, C, dv, io->E, Ec, io->alpha, dq, io->dx, s, C <= kAggDotMaxC ? io->x : nullptr, dap,
-                      &dot_done);
+                      &dot_done, io->Ec);
   if (st) return st;
   if (dot_done)
     st = launch_reduce_groups_defer(dap, sh->R, Bg, C, io->dalpha, s, &jobs);

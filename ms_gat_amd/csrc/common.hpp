@@ -190,7 +190,7 @@ int chanpair_mfma_blocks(int R);  // blocks (= partials) per relation
 int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
                          int b_ones, hipStream_t s);
 int launch_scores(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW, float* lse,
-                  float* pq, float* E, int G, int Bg, int N, int T, hipStream_t s);
+                  float* pq, float* E, float* Ec, int G, int Bg, int N, int T, hipStream_t s);
 // v[g,c,n,:] = sum_{e in ptr[n]..ptr[n+1]} E[g,e] u[g,c,idx[e],:] (+ addvec[r,c]*extra[g,n,:])
 // sell != nullptr: E is in that layout's position order (permuted by sell->src, row stride sell->n_pos, with
 // MSGAT_SELL_SLACK readable floats behind the last row) and the SELL kernel runs
@@ -209,19 +209,15 @@ int launch_aggregate_project(const msgat_graph_t& gr, const float* x, const floa
                              int N, int T, hipStream_t s);
 // dEp[g,k,e] = sum over channel chunk k of <dv[g,c,erow[e],:], u[g,c,col[e],:]>
 // (with gr.sell_rows usable the partials are [G,chunks,n_pos] in SELL position order + MSGAT_SELL_SLACK floats
-// of slack, and launch_bwd_edge reads them through sell.pos)
+// of slack, and launch_bwd_rows reads them through sell.pos)
 int sddmm_chunks(int G, int Cu, int N, int T, const msgat_sell_t* sell);
 int launch_sddmm(const msgat_graph_t& gr, const float* u, const float* dv, float* dEp, int G,
                  int Cu, int N, int T, hipStream_t s);
 // PROJ_FIRST backward, one pass over dv: du = E^T dv on the CSC (Ec = E in CSC order) AND the SDDMM partials, which
-// come out in CSC order (launch_bwd_edge: csc_order).  Usable when agg_sddmm_fusable(); chunks = sddmm_chunks().
+// come out in CSC order (launch_bwd_rows: partials_in_csc).  Usable when agg_sddmm_fusable(); chunks = sddmm_chunks().
 bool agg_sddmm_fusable(const msgat_graph_t& gr, int N, int T, int Cu);
 int launch_agg_sddmm(const msgat_graph_t& gr, const float* dv, const float* Ec, const float* u, float* du, float* dEp,
                      int G, int Cu, int N, int T, hipStream_t s, int dv_group_channels = 0);
-// Ecsc != nullptr: the partials are in CSC order and Ecsc holds E in that order
-int launch_bwd_edge(const msgat_graph_t& gr, const float* dEp, int nchunks, const float* E,
-                    const float* q, const float* pq, const float* Wg, float* gE, float* delta,
-                    float* dkW, float* dq, int G, int Bg, int N, int T, hipStream_t s, const float* Ecsc = nullptr);
 int launch_bwd_dense_col(const msgat_graph_t& gr, const float* q, const float* kW,
                          const float* lse, const float* delta, const float* gE, float* dq, int G,
                          int N, int T, hipStream_t s);
@@ -242,10 +238,16 @@ struct ReduceJobs {
   int n;
 };
 int launch_reduce_jobs(const ReduceJobs& jobs, hipStream_t s);
-// dWg[r,t,s] = sum_{g in r, n} q[g,n,t] dkW[g,n,s]
+// The edge and row work of backward in one launch (scores.hip): g_e = E_e dE_e (dE from the SDDMM partials, or --
+// direct_c > 0 -- computed on the spot from u / dv with direct_c <= bwd_rows_direct_max_channels() channels, no SDDMM
+// launch at all), delta, dkW, the row-local part of dq, and the per-block partials of
+// dWg[r,t,s] = sum_{g in r, n} q[g,n,t] dkW[g,n,s] (dwg_part: dwg_partial_floats() floats; reduction queued in `defer`).
 size_t dwg_partial_floats(int G, int N, int T);
-int launch_dwg(const float* q, const float* dkW, float* part, float* dWg, int G, int Bg, int N,
-               int T, hipStream_t s, ReduceJobs* defer = nullptr);
+int bwd_rows_direct_max_channels();
+int launch_bwd_rows(const msgat_graph_t& gr, const float* dEp, int nchunks, bool partials_in_csc, int direct_c,
+                    const float* u, const float* dv, const float* E, const float* q, const float* pq, const float* Wg,
+                    float* gE, float* delta, float* dkW, float* dq, float* dwg_part, float* dWg, int G, int Bg, int N,
+                    int T, hipStream_t s, ReduceJobs* defer = nullptr);
 // out[r,a,c] = sum_{g in r, p} A(g,a,p) B[g,c,p];  channel a == Ca-1 comes from Aextra[g,p] when given
 size_t chanpair_partial_floats(int G, int Bg, int Ca, int Cb);
 int launch_chanpair(const float* A, const float* Aextra, const float* B, float* part, float* dst0,

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
     const float* __restrict__ q, const float* __restrict__ Wg, const int* __restrict__ rowptr,
     const int* __restrict__ col, const float* __restrict__ val, const int* __restrict__ erow,
     float* __restrict__ kW, float* __restrict__ lse, float* __restrict__ pq, float* __restrict__ E,
-    int Bg, int N, int nnz) {
+    const int* __restrict__ cpos, float* __restrict__ Ec, int Bg, int N, int nnz) {
   constexpr int T4 = T / 4;
   __shared__ float4 qs4[kDMC * kPS / 4];  // staged columns: [column][q(T) | zeros]
   __shared__ float kw2s[kDRows][T];       // the block's rows, log2-scaled, for the edge pass
@@ -254,34 +254,38 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
       a = fmaf(v.z, kw2s[nl][4 * t4 + 2], a);
       a = fmaf(v.w, kw2s[nl][4 * t4 + 3], a);
     }
-    E[(size_t)g * nnz + e] = fast_exp2(a - lse2s[nl]) * val[e];
+    const float ev = fast_exp2(a - lse2s[nl]) * val[e];
+    E[(size_t)g * nnz + e] = ev;
+    // the same coefficient at its CSC position: the transposed passes of backward (du = E^T dv on the CSC) then
+    // start without a re-ordering launch
+    if (Ec != nullptr) Ec[(size_t)g * nnz + cpos[e]] = ev;
   }
   MSGAT_STAMP(5);
 }
 
 template <int T>
 static int launch_scores_t(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW,
-                           float* lse, float* pq, float* E, int G, int Bg, int N, hipStream_t s) {
+                           float* lse, float* pq, float* E, float* Ec, int G, int Bg, int N, hipStream_t s) {
   dim3 grid(cdiv(N, kDRows), G);
   const size_t static_lds = sizeof(float) * (kDMC * kPS + kDRows * T + kDRows);
   const size_t pad = balance_pad_bytes((int)(grid.x * grid.y), static_lds);
   if (pq != nullptr)
     hipLaunchKernelGGL((k_scores<T, true>), grid, dim3(kDBlock), pad, s, q, Wg, gr.rowptr, gr.col, gr.val,
-                       gr.erow, kW, lse, pq, E, Bg, N, gr.nnz);
+                       gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz);
   else
     hipLaunchKernelGGL((k_scores<T, false>), grid, dim3(kDBlock), pad, s, q, Wg, gr.rowptr, gr.col, gr.val,
-                       gr.erow, kW, lse, pq, E, Bg, N, gr.nnz);
+                       gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz);
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
 
 int launch_scores(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW, float* lse,
-                  float* pq, float* E, int G, int Bg, int N, int T, hipStream_t s) {
+                  float* pq, float* E, float* Ec, int G, int Bg, int N, int T, hipStream_t s) {
   switch (T) {
-    case 4: return launch_scores_t<4>(gr, q, Wg, kW, lse, pq, E, G, Bg, N, s);
-    case 8: return launch_scores_t<8>(gr, q, Wg, kW, lse, pq, E, G, Bg, N, s);
-    case 12: return launch_scores_t<12>(gr, q, Wg, kW, lse, pq, E, G, Bg, N, s);
-    case 16: return launch_scores_t<16>(gr, q, Wg, kW, lse, pq, E, G, Bg, N, s);
+    case 4: return launch_scores_t<4>(gr, q, Wg, kW, lse, pq, E, Ec, G, Bg, N, s);
+    case 8: return launch_scores_t<8>(gr, q, Wg, kW, lse, pq, E, Ec, G, Bg, N, s);
+    case 12: return launch_scores_t<12>(gr, q, Wg, kW, lse, pq, E, Ec, G, Bg, N, s);
+    case 16: return launch_scores_t<16>(gr, q, Wg, kW, lse, pq, E, Ec, G, Bg, N, s);
   }
   return MSGAT_ERR_UNSUPPORTED;
 }

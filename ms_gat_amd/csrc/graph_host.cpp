@@ -30,9 +30,9 @@ extern "C" int msgat_graph_count(const float* adj, int32_t n, int64_t ld, int32_
 
 extern "C" int msgat_graph_build(const float* adj, int32_t n, int64_t ld, int32_t nnz,
                                  int32_t* rowptr, int32_t* col, float* val, int32_t* erow,
-                                 int32_t* colptr, int32_t* crow, int32_t* cperm) {
+                                 int32_t* colptr, int32_t* crow, int32_t* cperm, int32_t* cpos) {
   if (!adj || !rowptr || !colptr) return MSGAT_ERR_NULL;
-  if (nnz > 0 && (!col || !val || !erow || !crow || !cperm)) return MSGAT_ERR_NULL;
+  if (nnz > 0 && (!col || !val || !erow || !crow || !cperm || !cpos)) return MSGAT_ERR_NULL;
   if (n <= 0 || ld < n || nnz < 0) return MSGAT_ERR_SHAPE;
 
   // CSR, rows in order, columns ascending inside a row
@@ -62,6 +62,7 @@ extern "C" int msgat_graph_build(const float* adj, int32_t n, int64_t ld, int32_
     const int32_t pos = cursor[col[k]]++;
     crow[pos] = erow[k];
     cperm[pos] = k;
+    cpos[k] = pos;
   }
   return MSGAT_OK;
 }
@@ -70,7 +71,7 @@ extern "C" int msgat_graph_validate(const msgat_graph_t* g) {
   if (!g || !g->rowptr || !g->colptr) return MSGAT_ERR_NULL;
   const int32_t n = g->n_nodes, nnz = g->nnz;
   if (n <= 0 || nnz < 0) return MSGAT_ERR_SHAPE;
-  if (nnz > 0 && (!g->col || !g->val || !g->erow || !g->crow || !g->cperm)) return MSGAT_ERR_NULL;
+  if (nnz > 0 && (!g->col || !g->val || !g->erow || !g->crow || !g->cperm || !g->cpos)) return MSGAT_ERR_NULL;
   if (g->rowptr[0] != 0 || g->rowptr[n] != nnz || g->colptr[0] != 0 || g->colptr[n] != nnz)
     return MSGAT_ERR_GRAPH;
   for (int32_t i = 0; i < n; ++i) {
@@ -86,7 +87,7 @@ extern "C" int msgat_graph_validate(const msgat_graph_t* g) {
       const int32_t p = g->cperm[k];
       if (p < 0 || p >= nnz || seen[(size_t)p]) return MSGAT_ERR_GRAPH;
       seen[(size_t)p] = 1;
-      if (g->col[p] != j || g->erow[p] != g->crow[k]) return MSGAT_ERR_GRAPH;
+      if (g->col[p] != j || g->erow[p] != g->crow[k] || g->cpos[p] != k) return MSGAT_ERR_GRAPH;
     }
   }
   // SELL forms: every CSR edge sits at exactly one position, in the lane that owns the row the edge starts from
@@ -96,7 +97,7 @@ extern "C" int msgat_graph_validate(const msgat_graph_t* g) {
     const msgat_sell_t& j = form == 0 ? g->sell_rows : g->sell_cols;
     if (j.n_slices == 0) continue;
     if (j.n_slices != (n + 63) / 64 || j.n_pos < nnz || !j.slice_off || !j.lane_row) return MSGAT_ERR_GRAPH;
-    if (j.n_pos > 0 && (!j.idx || !j.src)) return MSGAT_ERR_GRAPH;
+    if (!j.idx || !j.src) return MSGAT_ERR_NULL;  // read below whatever n_pos is (padding entries, the slack)
     if (j.slice_off[0] != 0 || j.slice_off[j.n_slices] != j.n_pos) return MSGAT_ERR_GRAPH;
     const int32_t* ptr = form == 0 ? g->rowptr : g->colptr;
     std::vector<char> used((size_t)nnz, 0), seen_row((size_t)n, 0);

@@ -98,50 +98,6 @@ int launch_reduce_groups(const float* part, int R, int J, int Wd, float* dst, hi
   return launch_reduce_partials(part, R, J, Wd, dst, Wd, nullptr, 0, s);
 }
 
-// ---- dWg -------------------------------------------------------------------------------------------
-constexpr int kRB = 128;  // rows per block
-
-template <int T>
-__global__ __launch_bounds__(kBlock) void k_dwg(const float* __restrict__ q,
-                                                const float* __restrict__ dkW,
-                                                float* __restrict__ part, int N, int nblk) {
-  __shared__ float qs[kRB * T];
-  __shared__ float ds[kRB * T];
-  const int g = blockIdx.y;
-  const int n0 = blockIdx.x * kRB;
-  const int rows = min(kRB, N - n0);
-  const float* qsrc = q + ((size_t)g * N + n0) * T;
-  const float* dsrc = dkW + ((size_t)g * N + n0) * T;
-  for (int i = threadIdx.x; i < rows * T; i += kBlock) {
-    qs[i] = qsrc[i];
-    ds[i] = dsrc[i];
-  }
-  __syncthreads();
-  if (threadIdx.x < T * T) {
-    const int t = threadIdx.x / T, s = threadIdx.x - t * T;
-    float acc = 0.f;
-    for (int row = 0; row < rows; ++row) acc = fmaf(qs[row * T + t], ds[row * T + s], acc);
-    part[((size_t)g * nblk + blockIdx.x) * (T * T) + threadIdx.x] = acc;
-  }
-}
-
-size_t dwg_partial_floats(int G, int N, int T) { return (size_t)G * cdiv(N, kRB) * T * T; }
-
-int launch_dwg(const float* q, const float* dkW, float* part, float* dWg, int G, int Bg, int N,
-               int T, hipStream_t s, ReduceJobs* defer) {
-  const int nblk = cdiv(N, kRB);
-  dim3 grid(nblk, G);
-  switch (T) {
-    case 4: hipLaunchKernelGGL(k_dwg<4>, grid, dim3(kBlock), 0, s, q, dkW, part, N, nblk); break;
-    case 8: hipLaunchKernelGGL(k_dwg<8>, grid, dim3(kBlock), 0, s, q, dkW, part, N, nblk); break;
-    case 12: hipLaunchKernelGGL(k_dwg<12>, grid, dim3(kBlock), 0, s, q, dkW, part, N, nblk); break;
-    case 16: hipLaunchKernelGGL(k_dwg<16>, grid, dim3(kBlock), 0, s, q, dkW, part, N, nblk); break;
-    default: return MSGAT_ERR_UNSUPPORTED;
-  }
-  MSGAT_CHECK_LAUNCH();
-  return launch_reduce_partials(part, G / Bg, Bg * nblk, T * T, dWg, T * T, nullptr, 0, s, defer);
-}
-
 // ---- channel-pair contraction over positions --------------------------------------------------------
 // k_chanpair_mfma (mfma.hip) leaves one [Ca x Cb] partial per block of its persistent grid; the
 // fixed-order sum over a relation's blocks happens here.

@@ -4,83 +4,93 @@
 
 namespace msgat {
 
-// ---- backward: edge and row passes ---------------------------------------------------------
-// k_edge_grad (one lane per edge, coalesced over e):  dE_e = sum of the per-chunk SDDMM partials,
-//   g_e = E_e dE_e.
-// k_bwd_row (one lane per row): delta_n = sum_e g_e;  dkW[n] = sum_e g_e (q[col_e] - pq[n]);
-//   dq[n] = dkW[n] Wg^T  (the row-local part of dq).
-__global__ __launch_bounds__(kBlock) void k_edge_grad(const float* __restrict__ dEp, int nchunks,
-                                                      const float* __restrict__ E, const int* __restrict__ epos,
-                                                      int stride, float* __restrict__ gE, int nnz) {
-  const int g = blockIdx.y;
-  const int e = blockIdx.x * kBlock + threadIdx.x;
-  if (e >= nnz) return;
-  // epos: the SDDMM ran on the SELL layout and left its partials in position order (chunk stride = n_pos)
-  const float* p = dEp + (size_t)g * nchunks * stride + (epos != nullptr ? epos[e] : e);
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int k = 0;
-  for (; k + 4 <= nchunks; k += 4) {  // 4 independent loads in flight; fixed summation order
-    a0 += p[(size_t)(k + 0) * stride];
-    a1 += p[(size_t)(k + 1) * stride];
-    a2 += p[(size_t)(k + 2) * stride];
-    a3 += p[(size_t)(k + 3) * stride];
-  }
-  for (; k < nchunks; ++k) a0 += p[(size_t)k * stride];
-  gE[(size_t)g * nnz + e] = E[(size_t)g * nnz + e] * ((a0 + a1) + (a2 + a3));
-}
+// ---- backward: the edge and row work of a group in ONE launch -----------------------------------------------------
+// Per row n (one lane per row, a block of kRowBlock rows):
+//   g_e      = E_e dE_e for the row's edges, where dE_e is
+//                DC = 0: the sum of the SDDMM's per-chunk partials (CSR order, or through `eidx`: the SELL positions
+//                        of k_sddmm_sell*, or the CSC positions cpos[e] of k_agg_sddmm), or
+//                DC > 0: computed here -- dE_e = sum_{c < DC, t} dv[c,n,t] u[c,col_e,t] -- when the attention acted on
+//                        DC <= 4 channels (the first MEAM of every component): no SDDMM launch, no partial buffer;
+//   delta_n  = sum_e g_e;   dkW[n] = sum_e g_e (q[col_e] - pq[n]);   dq[n] = dkW[n] Wg^T  (the row-local part of dq);
+//   dWg partial of the block = sum_rows q[n]^T dkW[n]  (summed over blocks in a fixed order by the caller's reduction).
+// Round 2 ran this as k_edge_grad (lane per edge) + k_bwd_row + k_dwg, plus k_sddmm for the DC > 0 case: 4 launches
+// of 5-11 us each per GACN depth, none of which filled the chip.
+constexpr int kRowBlock = 256;
 
-// the same for partials in CSC order (k_agg_sddmm): lane k reads Ec[k] and its partials coalesced and scatters
-// g to the CSR edge cperm[k]
-__global__ __launch_bounds__(kBlock) void k_edge_grad_csc(const float* __restrict__ dEp, int nchunks,
-                                                          const float* __restrict__ Ec, const int* __restrict__ cperm,
-                                                          float* __restrict__ gE, int nnz) {
-  const int g = blockIdx.y;
-  const int k = blockIdx.x * kBlock + threadIdx.x;
-  if (k >= nnz) return;
-  const float* p = dEp + (size_t)g * nchunks * nnz + k;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int c = 0;
-  for (; c + 4 <= nchunks; c += 4) {
-    a0 += p[(size_t)(c + 0) * nnz];
-    a1 += p[(size_t)(c + 1) * nnz];
-    a2 += p[(size_t)(c + 2) * nnz];
-    a3 += p[(size_t)(c + 3) * nnz];
-  }
-  for (; c < nchunks; ++c) a0 += p[(size_t)c * nnz];
-  gE[(size_t)g * nnz + cperm[k]] = Ec[(size_t)g * nnz + k] * ((a0 + a1) + (a2 + a3));
-}
-
-template <int T>
-__global__ __launch_bounds__(kBlock) void k_bwd_row(
-    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ gE,
+template <int T, int DC>
+__global__ __launch_bounds__(kRowBlock) void k_bwd_rows(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ E,
+    const float* __restrict__ dEp, int nchunks, const int* __restrict__ eidx, int stride,
+    const float* __restrict__ u, const float* __restrict__ dv,
     const float* __restrict__ q, const float* __restrict__ pq, const float* __restrict__ Wg,
-    float* __restrict__ delta, float* __restrict__ dkW, float* __restrict__ dq, int Bg, int N,
-    int nnz) {
+    float* __restrict__ gE, float* __restrict__ delta, float* __restrict__ dkW, float* __restrict__ dq,
+    float* __restrict__ dwg_part, int Bg, int N, int nnz, int nblk) {
   constexpr int T4 = T / 4;
+  constexpr int DCn = DC > 0 ? DC : 1;
+  __shared__ float qs[kRowBlock * T];
+  __shared__ float ds[kRowBlock * T];
   const int g = blockIdx.y;
   const int r = g / Bg;
-  const int n = blockIdx.x * kBlock + threadIdx.x;
-  if (n >= N) return;
+  const int n = blockIdx.x * kRowBlock + threadIdx.x;
+  const bool valid = n < N;
+  const int nc = valid ? n : 0;
+  const float* qg = q + (size_t)g * N * T;
   float d = 0.f;
   float dk[T], pr[T];
 #pragma unroll
   for (int t4 = 0; t4 < T4; ++t4) {
-    const float4 v = reinterpret_cast<const float4*>(pq + ((size_t)g * N + n) * T)[t4];
+    const float4 v = reinterpret_cast<const float4*>(pq + ((size_t)g * N + nc) * T)[t4];
     pr[4 * t4 + 0] = v.x; pr[4 * t4 + 1] = v.y; pr[4 * t4 + 2] = v.z; pr[4 * t4 + 3] = v.w;
     dk[4 * t4 + 0] = 0.f; dk[4 * t4 + 1] = 0.f; dk[4 * t4 + 2] = 0.f; dk[4 * t4 + 3] = 0.f;
   }
+  float4 dvr[DCn][T4];  // DC > 0: this row of dv, all DC channels
+  if (DC > 0) {
+#pragma unroll
+    for (int c = 0; c < DCn; ++c)
+#pragma unroll
+      for (int t4 = 0; t4 < T4; ++t4)
+        dvr[c][t4] = reinterpret_cast<const float4*>(dv + (((size_t)g * DC + c) * N + nc) * T)[t4];
+  }
+  // the gradient of one edge coefficient
+  auto edge_grad = [&](int e, int ce) -> float {
+    float dE;
+    if (DC > 0) {
+      dE = 0.f;
+#pragma unroll
+      for (int c = 0; c < DCn; ++c) {
+        const float4* um = reinterpret_cast<const float4*>(u + (((size_t)g * DC + c) * N + ce) * T);
+#pragma unroll
+        for (int t4 = 0; t4 < T4; ++t4) dE = f4dot(dvr[c][t4], um[t4], dE);
+      }
+    } else {
+      const float* p = dEp + (size_t)g * nchunks * stride + (eidx != nullptr ? eidx[e] : e);
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int k = 0;
+      for (; k + 4 <= nchunks; k += 4) {  // 4 independent loads in flight; fixed summation order
+        a0 += p[(size_t)(k + 0) * stride];
+        a1 += p[(size_t)(k + 1) * stride];
+        a2 += p[(size_t)(k + 2) * stride];
+        a3 += p[(size_t)(k + 3) * stride];
+      }
+      for (; k < nchunks; ++k) a0 += p[(size_t)k * stride];
+      dE = (a0 + a1) + (a2 + a3);
+    }
+    return E[(size_t)g * nnz + e] * dE;
+  };
   // dkW[n] = sum_e g_e q[col_e] - delta_n pq[n] = sum_e g_e (q[col_e] - pq[n]): subtracting
   // first keeps a saturated (one-hot) row exact -- pq[n] then equals q[col_e] bit for bit.
   // Two edges per trip: their index / weight loads are independent and issue together.
-  const float* gEg = gE + (size_t)g * nnz;
-  const float* qg = q + (size_t)g * N * T;
-  const int e1 = rowptr[n + 1];
-  for (int e = rowptr[n]; e < e1; e += 2) {
-    const int eb = min(e + 1, e1 - 1);
-    const float ga = gEg[e];
-    const float gb = (e + 1 < e1) ? gEg[eb] : 0.f;
-    const float4* qa = reinterpret_cast<const float4*>(qg + (size_t)col[e] * T);
-    const float4* qb = reinterpret_cast<const float4*>(qg + (size_t)col[eb] * T);
+  const int e1 = valid ? rowptr[n + 1] : 0;
+  for (int e = valid ? rowptr[n] : 0; e < e1; e += 2) {
+    const bool two = e + 1 < e1;
+    const int eb = two ? e + 1 : e;
+    const int ca = col[e], cb = col[eb];
+    const float ga = edge_grad(e, ca);
+    const float gb = two ? edge_grad(eb, cb) : 0.f;
+    gE[(size_t)g * nnz + e] = ga;
+    if (two) gE[(size_t)g * nnz + eb] = gb;
+    const float4* qa = reinterpret_cast<const float4*>(qg + (size_t)ca * T);
+    const float4* qb = reinterpret_cast<const float4*>(qg + (size_t)cb * T);
     d += ga;
     d += gb;
 #pragma unroll
@@ -96,52 +106,87 @@ __global__ __launch_bounds__(kBlock) void k_bwd_row(
       dk[4 * t4 + 3] = fmaf(gb, vb.w - pr[4 * t4 + 3], dk[4 * t4 + 3]);
     }
   }
-  float4* dkdst = reinterpret_cast<float4*>(dkW + ((size_t)g * N + n) * T);
+  if (valid) {
+    float4* dkdst = reinterpret_cast<float4*>(dkW + ((size_t)g * N + n) * T);
 #pragma unroll
-  for (int t4 = 0; t4 < T4; ++t4) dkdst[t4] = make_float4(dk[4 * t4], dk[4 * t4 + 1], dk[4 * t4 + 2], dk[4 * t4 + 3]);
-  delta[(size_t)g * N + n] = d;
-  const float* wg = Wg + (size_t)r * T * T;
-  float out[T];
+    for (int t4 = 0; t4 < T4; ++t4) dkdst[t4] = make_float4(dk[4 * t4], dk[4 * t4 + 1], dk[4 * t4 + 2], dk[4 * t4 + 3]);
+    delta[(size_t)g * N + n] = d;
+    const float* wg = Wg + (size_t)r * T * T;
+    float out[T];
 #pragma unroll
-  for (int t = 0; t < T; ++t) {
-    float a = 0.f;
+    for (int t = 0; t < T; ++t) {
+      float a = 0.f;
 #pragma unroll
-    for (int s = 0; s < T; ++s) a = fmaf(dk[s], wg[t * T + s], a);
-    out[t] = a;
+      for (int s = 0; s < T; ++s) a = fmaf(dk[s], wg[t * T + s], a);
+      out[t] = a;
+    }
+    float4* dqdst = reinterpret_cast<float4*>(dq + ((size_t)g * N + n) * T);
+#pragma unroll
+    for (int t4 = 0; t4 < T4; ++t4) dqdst[t4] = make_float4(out[4 * t4], out[4 * t4 + 1], out[4 * t4 + 2], out[4 * t4 + 3]);
   }
-  float4* dqdst = reinterpret_cast<float4*>(dq + ((size_t)g * N + n) * T);
+  // dWg partial of this block: rows past N contribute zeros (their dk is zero)
 #pragma unroll
-  for (int t4 = 0; t4 < T4; ++t4) dqdst[t4] = make_float4(out[4 * t4], out[4 * t4 + 1], out[4 * t4 + 2], out[4 * t4 + 3]);
+  for (int t4 = 0; t4 < T4; ++t4) {
+    const float4 v = reinterpret_cast<const float4*>(qg + (size_t)nc * T)[t4];
+    reinterpret_cast<float4*>(qs + threadIdx.x * T)[t4] = v;
+    reinterpret_cast<float4*>(ds + threadIdx.x * T)[t4] = make_float4(dk[4 * t4], dk[4 * t4 + 1], dk[4 * t4 + 2], dk[4 * t4 + 3]);
+  }
+  __syncthreads();
+  if (threadIdx.x < T * T) {
+    const int t = threadIdx.x / T, s = threadIdx.x - t * T;
+    float a0 = 0.f, a1 = 0.f;
+    for (int row = 0; row < kRowBlock; row += 2) {
+      a0 = fmaf(qs[row * T + t], ds[row * T + s], a0);
+      a1 = fmaf(qs[(row + 1) * T + t], ds[(row + 1) * T + s], a1);
+    }
+    dwg_part[((size_t)g * nblk + blockIdx.x) * (T * T) + threadIdx.x] = a0 + a1;
+  }
 }
 
-int launch_bwd_edge(const msgat_graph_t& gr, const float* dEp, int nchunks, const float* E,
-                    const float* q, const float* pq, const float* Wg, float* gE, float* delta,
-                    float* dkW, float* dq, int G, int Bg, int N, int T, hipStream_t s, const float* Ecsc) {
-  if (gr.nnz > 0 && Ecsc != nullptr) {
-    hipLaunchKernelGGL(k_edge_grad_csc, dim3(cdiv(gr.nnz, kBlock), G), dim3(kBlock), 0, s, dEp, nchunks, Ecsc, gr.cperm, gE,
-                       gr.nnz);
-    MSGAT_CHECK_LAUNCH();
-  } else if (gr.nnz > 0) {
-    dim3 ge(cdiv(gr.nnz, kBlock), G);
-    const bool sell = sell_usable(gr.sell_rows, gr.nnz, N, T);
-    hipLaunchKernelGGL(k_edge_grad, ge, dim3(kBlock), 0, s, dEp, nchunks, E, sell ? gr.sell_rows.pos : nullptr,
-                       sell ? gr.sell_rows.n_pos : gr.nnz, gE, gr.nnz);
-    MSGAT_CHECK_LAUNCH();
+size_t dwg_partial_floats(int G, int N, int T) { return (size_t)G * cdiv(N, kRowBlock) * T * T; }
+int bwd_rows_direct_max_channels() { return 4; }
+
+// eidx / stride describe where the SDDMM left its partials: CSR order (nullptr, nnz), SELL positions (sell.pos,
+// n_pos) or CSC positions (cpos, nnz).  direct_c > 0: no partials at all, dE from u / dv with direct_c channels.
+int launch_bwd_rows(const msgat_graph_t& gr, const float* dEp, int nchunks, bool partials_in_csc, int direct_c,
+                    const float* u, const float* dv, const float* E, const float* q, const float* pq, const float* Wg,
+                    float* gE, float* delta, float* dkW, float* dq, float* dwg_part, float* dWg, int G, int Bg, int N,
+                    int T, hipStream_t s, ReduceJobs* defer) {
+  const int nblk = cdiv(N, kRowBlock);
+  dim3 grid(nblk, G);
+  const int* eidx = nullptr;
+  int stride = gr.nnz;
+  if (direct_c == 0) {
+    if (partials_in_csc) {
+      eidx = gr.cpos;
+    } else if (sell_usable(gr.sell_rows, gr.nnz, N, T)) {
+      eidx = gr.sell_rows.pos;
+      stride = gr.sell_rows.n_pos;
+    }
   }
-  dim3 grid(cdiv(N, kBlock), G);
-#define MSGAT_ROW(TT)                                                                               \
-  hipLaunchKernelGGL(k_bwd_row<TT>, grid, dim3(kBlock), 0, s, gr.rowptr, gr.col, gE, q, pq, Wg, delta, \
-                     dkW, dq, Bg, N, gr.nnz)
+#define MSGAT_ROWS(TT, DC)                                                                                          \
+  hipLaunchKernelGGL((k_bwd_rows<TT, DC>), grid, dim3(kRowBlock), 0, s, gr.rowptr, gr.col, E, dEp, nchunks, eidx,    \
+                     stride, u, dv, q, pq, Wg, gE, delta, dkW, dq, dwg_part, Bg, N, gr.nnz, nblk)
+#define MSGAT_ROWS_T(TT)                        \
+  switch (direct_c) {                           \
+    case 0: MSGAT_ROWS(TT, 0); break;           \
+    case 1: MSGAT_ROWS(TT, 1); break;           \
+    case 2: MSGAT_ROWS(TT, 2); break;           \
+    case 3: MSGAT_ROWS(TT, 3); break;           \
+    case 4: MSGAT_ROWS(TT, 4); break;           \
+    default: return MSGAT_ERR_UNSUPPORTED;      \
+  }
   switch (T) {
-    case 4: MSGAT_ROW(4); break;
-    case 8: MSGAT_ROW(8); break;
-    case 12: MSGAT_ROW(12); break;
-    case 16: MSGAT_ROW(16); break;
+    case 4: MSGAT_ROWS_T(4); break;
+    case 8: MSGAT_ROWS_T(8); break;
+    case 12: MSGAT_ROWS_T(12); break;
+    case 16: MSGAT_ROWS_T(16); break;
     default: return MSGAT_ERR_UNSUPPORTED;
   }
-#undef MSGAT_ROW
+#undef MSGAT_ROWS_T
+#undef MSGAT_ROWS
   MSGAT_CHECK_LAUNCH();
-  return MSGAT_OK;
+  return launch_reduce_groups_defer(dwg_part, G / Bg, Bg * nblk, T * T, dWg, s, defer);
 }
 
 }  // namespace msgat

@@ -89,9 +89,10 @@ class SparseGraph:
         self.erow = torch.zeros(m, dtype=torch.int32)
         self.crow = torch.zeros(m, dtype=torch.int32)
         self.cperm = torch.zeros(m, dtype=torch.int32)
+        self.cpos = torch.zeros(m, dtype=torch.int32)
         _lib.check(L.msgat_graph_build(a.data_ptr(), n, n, self.nnz, self.rowptr.data_ptr(), self.col.data_ptr(),
                                        self.val.data_ptr(), self.erow.data_ptr(), self.colptr.data_ptr(),
-                                       self.crow.data_ptr(), self.cperm.data_ptr()), "msgat_graph_build")
+                                       self.crow.data_ptr(), self.cperm.data_ptr(), self.cpos.data_ptr()), "msgat_graph_build")
         self._dev = {}
         if sell not in ("auto", "always", "never"):
             raise ValueError(f"sell must be 'auto', 'always' or 'never', got {sell!r}")
@@ -101,7 +102,7 @@ class SparseGraph:
             self._sell["sell_rows"] = self._build_sell(self.rowptr, self.col, None, with_pos=True)
             self._sell["sell_cols"] = self._build_sell(self.colptr, self.crow, self.cperm, with_pos=False)
 
-    _FIELDS = ("rowptr", "col", "val", "erow", "colptr", "crow", "cperm")
+    _FIELDS = ("rowptr", "col", "val", "erow", "colptr", "crow", "cperm", "cpos")
     _SELL_FIELDS = ("slice_off", "lane_row", "idx", "src", "pos")
 
     def _build_sell(self, ptr, idx, perm, with_pos: bool):

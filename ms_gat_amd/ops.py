@@ -66,6 +66,7 @@ class _GACNFunction(torch.autograd.Function):
         z = new(G, Co if Co else Cin, N, T)
         q, kW, lse, E = new(G, N, T), new(G, N, T), new(G, N), new(G, nnz)
         pq = new(G, N, T) if need_bwd else None
+        Ec = new(G, nnz) if need_bwd else None          # E in CSC order, for the transposed passes of backward
         if mode == _lib.MODE_PROJ_FIRST:
             u = new(G, Co, N, T)
         elif mode == _lib.MODE_AGG_FIRST and need_bwd:
@@ -75,13 +76,13 @@ class _GACNFunction(torch.autograd.Function):
         nscratch = int(L.msgat_edge_scratch_floats(C.byref(shape), C.byref(gstruct)))
         scratch = new(nscratch) if nscratch else None   # E in the order of the SELL layout (large graphs)
         io = _lib.Fwd(_ptr(x), _ptr(alpha), _ptr(Wg), _ptr(W), _ptr(z), _ptr(q), _ptr(kW), _ptr(lse), _ptr(pq),
-                      _ptr(E), _ptr(u), int(need_bwd), _ptr(scratch))
+                      _ptr(E), _ptr(u), int(need_bwd), _ptr(scratch), _ptr(Ec))
         st = L.msgat_gacn_forward(C.byref(shape), C.byref(gstruct), C.byref(io), _stream_handle(dev))
         _lib.check(st, "msgat_gacn_forward")
 
         if need_bwd:
             ctx.graph, ctx.dims, ctx.has_W = graph, (R, G // R, Cin, Co, N, T), W is not None
-            saved = [x, alpha, Wg, q, kW, lse, pq, E]
+            saved = [x, alpha, Wg, q, kW, lse, pq, E, Ec]
             if W is not None:
                 saved.append(W)
             if u is not None:
@@ -94,8 +95,8 @@ class _GACNFunction(torch.autograd.Function):
     def backward(ctx, dz):
         L = _lib.lib()
         saved = list(ctx.saved_tensors)
-        x, alpha, Wg, q, kW, lse, pq, E = saved[:8]
-        rest = saved[8:]
+        x, alpha, Wg, q, kW, lse, pq, E, Ec = saved[:9]
+        rest = saved[9:]
         W = rest.pop(0) if ctx.has_W else None
         u = rest.pop(0) if ctx.has_u else None
         dev = x.device
@@ -113,7 +114,8 @@ class _GACNFunction(torch.autograd.Function):
         nbytes = L.msgat_bwd_workspace_bytes(C.byref(shape), C.byref(gstruct))
         ws = torch.empty(max(int(nbytes), 256), device=dev, dtype=torch.uint8)
         io = _lib.Bwd(_ptr(x), _ptr(alpha), _ptr(Wg), _ptr(W), _ptr(q), _ptr(kW), _ptr(lse), _ptr(pq), _ptr(E),
-                      _ptr(u), _ptr(dz), _ptr(dx), _ptr(dalpha), _ptr(dWg), _ptr(dW), _ptr(ws), ws.numel(), dz_gs)
+                      _ptr(u), _ptr(dz), _ptr(dx), _ptr(dalpha), _ptr(dWg), _ptr(dW), _ptr(ws), ws.numel(), dz_gs,
+                      _ptr(Ec))
         st = L.msgat_gacn_backward(C.byref(shape), C.byref(gstruct), C.byref(io), _stream_handle(dev))
         _lib.check(st, "msgat_gacn_backward")
         return dx, dalpha, dWg, dW, None
@@ -800,23 +802,24 @@ class _AttentionCoreFunction(torch.autograd.Function):
         need_bwd = any(ctx.needs_input_grad)
         kW, lse, E = _new(u, G, N, T), _new(u, G, N), _new(u, G, max(graph.nnz, 1))
         pq = _new(u, G, N, T) if need_bwd else None
+        Ec = _new(u, G, max(graph.nnz, 1)) if need_bwd else None     # E in CSC order, for backward's transposed pass
         z = torch.empty_like(u)
         stream = _stream_handle(dev)
         _lib.check(L.msgat_stage_scores(C.byref(shape), C.byref(gstruct), _ptr(q), _ptr(Wg), _ptr(kW), _ptr(lse), _ptr(pq),
-                                        _ptr(E), stream), "msgat_stage_scores")
+                                        _ptr(E), _ptr(Ec), stream), "msgat_stage_scores")
         nscratch = int(L.msgat_edge_scratch_floats(C.byref(shape), C.byref(gstruct)))
         scratch = _new(u, nscratch) if nscratch else None
         _lib.check(L.msgat_stage_aggregate(C.byref(shape), C.byref(gstruct), Cu, _ptr(u), _ptr(E), _ptr(z), _ptr(scratch),
                                            stream), "msgat_stage_aggregate")
         if need_bwd:
             ctx.graph, ctx.R = graph, R
-            ctx.save_for_backward(u, q, Wg, kW, lse, pq, E)
+            ctx.save_for_backward(u, q, Wg, kW, lse, pq, E, Ec)
         return z
 
     @staticmethod
     def backward(ctx, dz):
         L = _lib.lib()
-        u, q, Wg, kW, lse, pq, E = ctx.saved_tensors
+        u, q, Wg, kW, lse, pq, E, Ec = ctx.saved_tensors
         G, Cu, N, T = u.shape
         dev = u.device
         shape = _lib.Shape(ctx.R, G // ctx.R, Cu, 0, N, T)
@@ -826,8 +829,8 @@ class _AttentionCoreFunction(torch.autograd.Function):
         nbytes = L.msgat_attention_bwd_workspace_bytes(C.byref(shape), C.byref(gstruct))
         ws = torch.empty(max(int(nbytes), 256), device=dev, dtype=torch.uint8)
         st = L.msgat_attention_backward(C.byref(shape), C.byref(gstruct), _ptr(u), _ptr(dz), dz_gs, _ptr(q), _ptr(kW), _ptr(lse),
-                                        _ptr(pq), _ptr(E), _ptr(Wg), _ptr(du), _ptr(dq), _ptr(dWg), _ptr(ws), ws.numel(),
-                                        _stream_handle(dev))
+                                        _ptr(pq), _ptr(E), _ptr(Ec), _ptr(Wg), _ptr(du), _ptr(dq), _ptr(dWg), _ptr(ws),
+                                        ws.numel(), _stream_handle(dev))
         _lib.check(st, "msgat_attention_backward")
         return du, dq, dWg, None
 

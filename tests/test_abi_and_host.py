@@ -114,6 +114,9 @@ def test_native_csr_csc_build_matches_numpy(n, e, seed):
     # CSC: entries sorted by column then row, cperm maps back into the CSR order
     order = np.lexsort((rows, cols))
     assert np.array_equal(g.cperm[: g.nnz].numpy(), order)
+    inverse = np.empty_like(order)
+    inverse[order] = np.arange(len(order))
+    assert np.array_equal(g.cpos[: g.nnz].numpy(), inverse)      # CSR edge -> CSC position
     assert np.array_equal(g.crow[: g.nnz].numpy(), rows[order])
     assert np.array_equal(g.colptr.numpy(), np.concatenate([[0], np.cumsum(np.bincount(cols, minlength=n))]))
     assert torch.equal(g.dense(), adj)

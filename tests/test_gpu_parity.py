@@ -262,12 +262,14 @@ def test_stage_outputs_lse_and_edge_coefficients():
     kW, pq = torch.empty_like(q), torch.empty_like(q)
     lse = torch.empty(G, N, device=_dev())
     E = torch.empty(G, g.nnz, device=_dev())
+    Ec = torch.empty(G, g.nnz, device=_dev())
     L = _lib.lib()
     s = torch.cuda.current_stream().cuda_stream
     _lib.check(L.msgat_stage_project(C.byref(shape), xt.data_ptr(), at.data_ptr(), None, q.data_ptr(), None, s), "project")
     _lib.check(L.msgat_stage_scores(C.byref(shape), C.byref(gs), q.data_ptr(), Wgt.data_ptr(), kW.data_ptr(),
-                                    lse.data_ptr(), pq.data_ptr(), E.data_ptr(), s), "scores")
+                                    lse.data_ptr(), pq.data_ptr(), E.data_ptr(), Ec.data_ptr(), s), "scores")
     torch.cuda.synchronize()
+    assert torch.equal(Ec.cpu(), E.cpu()[:, g.cperm[: g.nnz].long()])      # the same coefficients in CSC order, bit for bit
     rows, cols = g.erow[: g.nnz].long().numpy(), g.col[: g.nnz].long().numpy()
     for r in range(2):
         sl = slice(2 * r, 2 * r + 2)

@@ -69,7 +69,7 @@ def main():
     nb = int(L.msgat_attention_bwd_workspace_bytes(C.byref(shp), gp))
     ws = torch.empty(nb, device=dev, dtype=torch.uint8)
     ms = timed(lambda: _lib.check(L.msgat_attention_backward(C.byref(shp), gp, u.data_ptr(), dv.data_ptr(), 0, q.data_ptr(),
-                                                             kW.data_ptr(), lse.data_ptr(), pq.data_ptr(), E.data_ptr(),
+                                                             kW.data_ptr(), lse.data_ptr(), pq.data_ptr(), E.data_ptr(), None,
                                                              Wg.data_ptr(), du.data_ptr(), dq.data_ptr(), dWg.data_ptr(),
                                                              ws.data_ptr(), ws.numel(), st), "bwd"))
     print(f"attention backward (all stages) {ms:8.3f} ms", flush=True)
