@@ -437,7 +437,7 @@ extern "C" int msgat_attention_backward(const msgat_shape_t* shp, const msgat_gr
     st = launch_sddmm(*gr, u, dv, dEp, G, sh->C, N, T, s);
   }
   if (st) return st;
-  st = launch_bwd_rows(*gr, dEp, p.nch, fused, direct_c, u, dv, E, q, pq, Wg, gE, delta, dkW, dq, dwgp, dWg, G, Bg, N,
+  st = launch_bwd_rows(*gr, dEp, p.nch, fused ? Ecsc : nullptr, direct_c, u, dv, E, q, pq, Wg, gE, delta, dkW, dq, dwgp, dWg, G, Bg, N,
                        T, s);
   if (st) return st;
   st = launch_bwd_dense_col(*gr, q, kW, lse, delta, gE, dq, G, N, T, s);
@@ -659,7 +659,7 @@ extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t*
     st = launch_sddmm(*gr, u, dv, dEp, G, p.Cu, N, T, s);
   }
   if (st) return st;
-  st = launch_bwd_rows(*gr, dEp, p.nch, fused, direct_c, u, dv, io->E, io->q, io->pq, io->Wg, gE, delta, dkW, dq, dwgp,
+  st = launch_bwd_rows(*gr, dEp, p.nch, fused ? Ecsc : nullptr, direct_c, u, dv, io->E, io->q, io->pq, io->Wg, gE, delta, dkW, dq, dwgp,
                        io->dWg, G, Bg, N, T, s, &jobs);
   if (st) return st;
   st = launch_bwd_dense_col(*gr, io->q, io->kW, io->lse, delta, gE, dq, G, N, T, s);

@@ -238,13 +238,13 @@ struct ReduceJobs {
   int n;
 };
 int launch_reduce_jobs(const ReduceJobs& jobs, hipStream_t s);
-// The edge and row work of backward in one launch (scores.hip): g_e = E_e dE_e (dE from the SDDMM partials, or --
-// direct_c > 0 -- computed on the spot from u / dv with direct_c <= bwd_rows_direct_max_channels() channels, no SDDMM
-// launch at all), delta, dkW, the row-local part of dq, and the per-block partials of
+// The edge and row work of backward (scores.hip): g_e = E_e dE_e (an edge-parallel pass over the SDDMM partials --
+// in CSC order with E = Ecsc when Ecsc != nullptr -- or, direct_c > 0, computed inside the row pass from u / dv with
+// direct_c <= bwd_rows_direct_max_channels() channels: no SDDMM launch at all), then in ONE launch delta, dkW, the row-local part of dq, and the per-block partials of
 // dWg[r,t,s] = sum_{g in r, n} q[g,n,t] dkW[g,n,s] (dwg_part: dwg_partial_floats() floats; reduction queued in `defer`).
 size_t dwg_partial_floats(int G, int N, int T);
 int bwd_rows_direct_max_channels();
-int launch_bwd_rows(const msgat_graph_t& gr, const float* dEp, int nchunks, bool partials_in_csc, int direct_c,
+int launch_bwd_rows(const msgat_graph_t& gr, const float* dEp, int nchunks, const float* Ecsc, int direct_c,
                     const float* u, const float* dv, const float* E, const float* q, const float* pq, const float* Wg,
                     float* gE, float* delta, float* dkW, float* dq, float* dwg_part, float* dWg, int G, int Bg, int N,
                     int T, hipStream_t s, ReduceJobs* defer = nullptr);

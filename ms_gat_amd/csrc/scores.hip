@@ -6,24 +6,69 @@ namespace msgat {
 
 // ---- backward: the edge and row work of a group in ONE launch -----------------------------------------------------
 // Per row n (one lane per row, a block of kRowBlock rows):
-//   g_e      = E_e dE_e for the row's edges, where dE_e is
-//                DC = 0: the sum of the SDDMM's per-chunk partials (CSR order, or through `eidx`: the SELL positions
-//                        of k_sddmm_sell*, or the CSC positions cpos[e] of k_agg_sddmm), or
+//   g_e      = E_e dE_e for the row's edges:
+//                DC = 0: read from gE, where the edge-parallel pass below left it (sum of the SDDMM's chunk partials);
 //                DC > 0: computed here -- dE_e = sum_{c < DC, t} dv[c,n,t] u[c,col_e,t] -- when the attention acted on
-//                        DC <= 4 channels (the first MEAM of every component): no SDDMM launch, no partial buffer;
+//                        DC <= 4 channels (the first MEAM of every component): no SDDMM launch, no partial buffer,
+//                        no edge pass;
 //   delta_n  = sum_e g_e;   dkW[n] = sum_e g_e (q[col_e] - pq[n]);   dq[n] = dkW[n] Wg^T  (the row-local part of dq);
 //   dWg partial of the block = sum_rows q[n]^T dkW[n]  (summed over blocks in a fixed order by the caller's reduction).
-// Round 2 ran this as k_edge_grad (lane per edge) + k_bwd_row + k_dwg, plus k_sddmm for the DC > 0 case: 4 launches
-// of 5-11 us each per GACN depth, none of which filled the chip.
+// Round 2 ran this as k_edge_grad + k_bwd_row + k_dwg, plus k_sddmm for the DC > 0 case: 3-4 launches of 5-11 us each
+// per GACN depth, none of which filled the chip.
 constexpr int kRowBlock = 256;
+
+// g_e = E_e (sum of the SDDMM's per-chunk partials), one lane per edge, coalesced over the partials' own order:
+// CSR / SELL positions (k_edge_grad) or CSC (k_edge_grad_csc, which scatters g to the CSR edge cperm[k]).  Folding
+// this into the row pass (a lane walking its row's edges through cpos / sell.pos, 8 chunk partials each) turned 9 us
+// of coalesced reads into 40 us of dependent scattered ones.
+__global__ __launch_bounds__(kBlock) void k_edge_grad(const float* __restrict__ dEp, int nchunks,
+                                                      const float* __restrict__ E, const int* __restrict__ epos,
+                                                      int stride, float* __restrict__ gE, int nnz) {
+  const int g = blockIdx.y;
+  const int e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= nnz) return;
+  // epos: the SDDMM ran on the SELL layout and left its partials in position order (chunk stride = n_pos)
+  const float* p = dEp + (size_t)g * nchunks * stride + (epos != nullptr ? epos[e] : e);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int k = 0;
+  for (; k + 4 <= nchunks; k += 4) {  // 4 independent loads in flight; fixed summation order
+    a0 += p[(size_t)(k + 0) * stride];
+    a1 += p[(size_t)(k + 1) * stride];
+    a2 += p[(size_t)(k + 2) * stride];
+    a3 += p[(size_t)(k + 3) * stride];
+  }
+  for (; k < nchunks; ++k) a0 += p[(size_t)k * stride];
+  gE[(size_t)g * nnz + e] = E[(size_t)g * nnz + e] * ((a0 + a1) + (a2 + a3));
+}
+
+// the same for partials in CSC order (k_agg_sddmm): lane k reads Ec[k] and its partials coalesced and scatters
+// g to the CSR edge cperm[k]
+__global__ __launch_bounds__(kBlock) void k_edge_grad_csc(const float* __restrict__ dEp, int nchunks,
+                                                          const float* __restrict__ Ec, const int* __restrict__ cperm,
+                                                          float* __restrict__ gE, int nnz) {
+  const int g = blockIdx.y;
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= nnz) return;
+  const float* p = dEp + (size_t)g * nchunks * nnz + k;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int c = 0;
+  for (; c + 4 <= nchunks; c += 4) {
+    a0 += p[(size_t)(c + 0) * nnz];
+    a1 += p[(size_t)(c + 1) * nnz];
+    a2 += p[(size_t)(c + 2) * nnz];
+    a3 += p[(size_t)(c + 3) * nnz];
+  }
+  for (; c < nchunks; ++c) a0 += p[(size_t)c * nnz];
+  gE[(size_t)g * nnz + cperm[k]] = Ec[(size_t)g * nnz + k] * ((a0 + a1) + (a2 + a3));
+}
+
 
 template <int T, int DC>
 __global__ __launch_bounds__(kRowBlock) void k_bwd_rows(
     const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ E,
-    const float* __restrict__ dEp, int nchunks, const int* __restrict__ eidx, int stride,
     const float* __restrict__ u, const float* __restrict__ dv,
     const float* __restrict__ q, const float* __restrict__ pq, const float* __restrict__ Wg,
-    float* __restrict__ gE, float* __restrict__ delta, float* __restrict__ dkW, float* __restrict__ dq,
+    float* gE, float* __restrict__ delta, float* __restrict__ dkW, float* __restrict__ dq,
     float* __restrict__ dwg_part, int Bg, int N, int nnz, int nblk) {
   constexpr int T4 = T / 4;
   constexpr int DCn = DC > 0 ? DC : 1;
@@ -63,17 +108,7 @@ __global__ __launch_bounds__(kRowBlock) void k_bwd_rows(
         for (int t4 = 0; t4 < T4; ++t4) dE = f4dot(dvr[c][t4], um[t4], dE);
       }
     } else {
-      const float* p = dEp + (size_t)g * nchunks * stride + (eidx != nullptr ? eidx[e] : e);
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      int k = 0;
-      for (; k + 4 <= nchunks; k += 4) {  // 4 independent loads in flight; fixed summation order
-        a0 += p[(size_t)(k + 0) * stride];
-        a1 += p[(size_t)(k + 1) * stride];
-        a2 += p[(size_t)(k + 2) * stride];
-        a3 += p[(size_t)(k + 3) * stride];
-      }
-      for (; k < nchunks; ++k) a0 += p[(size_t)k * stride];
-      dE = (a0 + a1) + (a2 + a3);
+      return gE[(size_t)g * nnz + e];  // left by k_edge_grad / k_edge_grad_csc
     }
     return E[(size_t)g * nnz + e] * dE;
   };
@@ -87,8 +122,10 @@ __global__ __launch_bounds__(kRowBlock) void k_bwd_rows(
     const int ca = col[e], cb = col[eb];
     const float ga = edge_grad(e, ca);
     const float gb = two ? edge_grad(eb, cb) : 0.f;
-    gE[(size_t)g * nnz + e] = ga;
-    if (two) gE[(size_t)g * nnz + eb] = gb;
+    if (DC > 0) {
+      gE[(size_t)g * nnz + e] = ga;
+      if (two) gE[(size_t)g * nnz + eb] = gb;
+    }
     const float4* qa = reinterpret_cast<const float4*>(qg + (size_t)ca * T);
     const float4* qb = reinterpret_cast<const float4*>(qg + (size_t)cb * T);
     d += ga;
@@ -146,27 +183,30 @@ __global__ __launch_bounds__(kRowBlock) void k_bwd_rows(
 size_t dwg_partial_floats(int G, int N, int T) { return (size_t)G * cdiv(N, kRowBlock) * T * T; }
 int bwd_rows_direct_max_channels() { return 4; }
 
-// eidx / stride describe where the SDDMM left its partials: CSR order (nullptr, nnz), SELL positions (sell.pos,
-// n_pos) or CSC positions (cpos, nnz).  direct_c > 0: no partials at all, dE from u / dv with direct_c channels.
-int launch_bwd_rows(const msgat_graph_t& gr, const float* dEp, int nchunks, bool partials_in_csc, int direct_c,
+// Ecsc != nullptr: the SDDMM partials are in CSC order (k_agg_sddmm) and Ecsc holds E in that order; otherwise they
+// are in CSR order, or in the SELL position order when the graph carries a usable sell_rows.  direct_c > 0: no
+// partials at all, dE from u / dv with direct_c channels.
+int launch_bwd_rows(const msgat_graph_t& gr, const float* dEp, int nchunks, const float* Ecsc, int direct_c,
                     const float* u, const float* dv, const float* E, const float* q, const float* pq, const float* Wg,
                     float* gE, float* delta, float* dkW, float* dq, float* dwg_part, float* dWg, int G, int Bg, int N,
                     int T, hipStream_t s, ReduceJobs* defer) {
   const int nblk = cdiv(N, kRowBlock);
   dim3 grid(nblk, G);
-  const int* eidx = nullptr;
-  int stride = gr.nnz;
-  if (direct_c == 0) {
-    if (partials_in_csc) {
-      eidx = gr.cpos;
-    } else if (sell_usable(gr.sell_rows, gr.nnz, N, T)) {
-      eidx = gr.sell_rows.pos;
-      stride = gr.sell_rows.n_pos;
+  const bool partials_in_csc = Ecsc != nullptr;
+  if (direct_c == 0 && gr.nnz > 0) {
+    dim3 ge(cdiv(gr.nnz, kBlock), G);
+    if (partials_in_csc) {   // k_agg_sddmm: partials in CSC order; E itself is read at cperm[k] (== Ec[k])
+      hipLaunchKernelGGL(k_edge_grad_csc, ge, dim3(kBlock), 0, s, dEp, nchunks, Ecsc, gr.cperm, gE, gr.nnz);
+    } else {
+      const bool sell = sell_usable(gr.sell_rows, gr.nnz, N, T);
+      hipLaunchKernelGGL(k_edge_grad, ge, dim3(kBlock), 0, s, dEp, nchunks, E, sell ? gr.sell_rows.pos : nullptr,
+                         sell ? gr.sell_rows.n_pos : gr.nnz, gE, gr.nnz);
     }
+    MSGAT_CHECK_LAUNCH();
   }
 #define MSGAT_ROWS(TT, DC)                                                                                          \
-  hipLaunchKernelGGL((k_bwd_rows<TT, DC>), grid, dim3(kRowBlock), 0, s, gr.rowptr, gr.col, E, dEp, nchunks, eidx,    \
-                     stride, u, dv, q, pq, Wg, gE, delta, dkW, dq, dwg_part, Bg, N, gr.nnz, nblk)
+  hipLaunchKernelGGL((k_bwd_rows<TT, DC>), grid, dim3(kRowBlock), 0, s, gr.rowptr, gr.col, E, u, dv, q, pq, Wg, gE,  \
+                     delta, dkW, dq, dwg_part, Bg, N, gr.nnz, nblk)
 #define MSGAT_ROWS_T(TT)                        \
   switch (direct_c) {                           \
     case 0: MSGAT_ROWS(TT, 0); break;           \
