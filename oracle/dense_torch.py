@@ -71,8 +71,10 @@ def cacn_dense(x, Wc, alpha, weight, bias):
     return torch.nn.functional.conv2d(channel_attention_dense(x, Wc, alpha), weight, bias)
 
 
-def meam_dense(x, adj, p, dilations, eps=1e-5):
-    """msgat.py:117-131 with the parameters of one MEAM in `p` (reference state_dict keys)."""
+def meam_dense(x, adj, p, dilations, eps=1e-5, relu_mask=None):
+    """msgat.py:117-131 with the parameters of one MEAM in `p` (reference state_dict keys).
+    `relu_mask` (bool, output-shaped): apply THIS mask instead of the ReLU's own -- a test pins the set of active units
+    to the one another implementation chose, so that pre-activations within rounding of zero do not decide a comparison."""
     T = x.shape[-1]
     normed = torch.nn.functional.layer_norm(x, [T], p["ln.weight"], p["ln.bias"], eps)
     convs = [(p[f"tacn.seq.{2 * i + 1}.weight"], p[f"tacn.seq.{2 * i + 1}.bias"], d) for i, d in enumerate(dilations)]
@@ -80,4 +82,5 @@ def meam_dense(x, adj, p, dilations, eps=1e-5):
         cacn_dense(normed, p["cacn.seq.0.Wc"], p["cacn.seq.0.alpha"], p["cacn.seq.1.weight"], p["cacn.seq.1.bias"]),
         tacn_dense(normed, p["tacn.seq.0.Wt1"], p["tacn.seq.0.Wt2"], p["tacn.seq.0.alpha"], convs),
         gacn_dense(normed, adj, p["gacn.gatt.Wg"], p["gacn.gatt.alpha"], p["gacn.W"])], dim=1)
-    return torch.relu(branches + torch.nn.functional.conv2d(x, p["res.weight"], p["res.bias"]))
+    pre = branches + torch.nn.functional.conv2d(x, p["res.weight"], p["res.bias"])
+    return torch.relu(pre) if relu_mask is None else pre * relu_mask.to(pre.dtype)

@@ -20,6 +20,19 @@ def load_golden(name):
         return {k: z[k] for k in z.files}
 
 
+def load_headline_golden():
+    """gacn_headline_n883.npz as dense fp32 arrays: GACN(72 -> 24) fwd+bwd by the REFERENCE at the headline graph size
+    (N = 883).  Inputs are stored as int8 multiples of 1/32, the adjacency as its non-zeros."""
+    g = load_golden("gacn_headline_n883.npz")
+    n = int(g["n_nodes"])
+    adj = np.zeros((n, n), dtype=np.float32)
+    adj[g["adj_rows"], g["adj_cols"]] = g["adj_vals"]
+    g["x"] = g.pop("x_q32").astype(np.float32) / 32
+    g["dz"] = g.pop("dz_q32").astype(np.float32) / 32
+    g["adj"] = adj
+    return g
+
+
 def rel_err(a, b):
     """max|a-b| / max|b| -- the parity figure quoted everywhere (bar: 1e-4 in fp32)."""
     a, b = (t.detach().cpu().numpy() if hasattr(t, "detach") else t for t in (a, b))

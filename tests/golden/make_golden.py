@@ -18,6 +18,11 @@ Fixtures:
   slices_*.npz TimeSeriesSlice / normalize (data_loader.py:92-120)
   loader_tiny.npz  DataLoaderForMSGAT on csv + npz + meta.yaml files (data_loader.py:29-89)
   msgat72_cfg1_pemsd4.npz  BASELINE.json configs[0]: msgat72 forward, N=307, 3 features, B=4, five components
+  gacn_headline_n883.npz   GACN(72 -> 24) fwd+bwd at the HEADLINE graph size (PEMSD7-like N=883, 866 edges, T=12), one
+                           sample: the size bench.py reports on is pinned by the reference itself, not only by the oracle.
+                           Inputs are stored as int8 multiples of 1/32 (exact in fp32), the adjacency as its non-zeros.
+
+    python tests/golden/make_golden.py --only headline     # just that one
 """
 import os
 import sys
@@ -101,6 +106,36 @@ def gatt_case(tag, B, C, N, T, n_edges, seed):
     # x/adj/Wg/alpha are shared with gatt_{tag}.npz and not stored twice
     save(f"gacn_{tag}.npz", W=W, dz=dz, z=z, dx=xt.grad, dWg=g.gatt.Wg.grad,
          dalpha=g.gatt.alpha.grad, dW=g.W.grad)
+
+
+def headline_case(seed):
+    """GACN(72 -> 24) on one sample of the PEMSD7-sized graph (the second-MEAM width of msgat72, msgat.py:220-229)."""
+    B, C, O, N, T, E = 1, 72, 24, 883, 12, 866
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, C, N, T))
+    x = (x - x.mean(-1, keepdims=True)) / np.sqrt(x.var(-1, keepdims=True) + 1e-5)     # LayerNorm output, as msgat.py:122 feeds it
+    xq = np.clip(np.rint(x * 32), -127, 127).astype(np.int8)                           # multiples of 1/32: exact in fp32
+    dzq = np.clip(np.rint(rng.standard_normal((B, O, N, T)) * 32), -127, 127).astype(np.int8)
+    x32, dz32 = xq.astype(np.float32) / 32, dzq.astype(np.float32) / 32
+    adj = synthetic_adjacency(N, E, seed + 1)
+    Wg = (rng.standard_normal((T, T)) * (2.0 / (T + T)) ** 0.5).astype(np.float32)
+    alpha = rng.uniform(-C ** -0.5, C ** -0.5, size=C).astype(np.float32)
+    W = (rng.standard_normal((O, C)) * (2.0 / (O + C)) ** 0.5).astype(np.float32)
+    g = GACN(C, O, T)
+    with torch.no_grad():
+        g.gatt.Wg.copy_(t(Wg))
+        g.gatt.alpha.copy_(t(alpha))
+        g.W.copy_(t(W))
+    xt = t(x32).requires_grad_(True)
+    z = g(xt, t(adj))
+    z.backward(t(dz32))
+    rows, cols = np.nonzero(adj)
+    out = dict(x_q32=xq, dz_q32=dzq, adj_rows=rows.astype(np.int32), adj_cols=cols.astype(np.int32), adj_vals=adj[rows, cols],
+               n_nodes=np.int32(N), Wg=Wg, alpha=alpha, W=W, z=z.detach().numpy(), dx=xt.grad.numpy(),
+               dWg=g.gatt.Wg.grad.numpy(), dalpha=g.gatt.alpha.grad.numpy(), dW=g.W.grad.numpy())
+    path = os.path.join(HERE, "gacn_headline_n883.npz")
+    np.savez_compressed(path, **out)
+    print(f"gacn_headline_n883.npz: {os.path.getsize(path) / 1024:.0f} KiB")
 
 
 def meam_case(tag, cin, cout, N, B, seed):
@@ -256,6 +291,10 @@ def loader_case(seed):
 
 
 if __name__ == "__main__":
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "headline":
+        headline_case(1100)
+        sys.exit(0)
+    headline_case(1100)
     gatt_case("b2c3n16", 2, 3, 16, 12, 20, 100)
     gatt_case("b2c1n64", 2, 1, 64, 12, 70, 200)
     gatt_case("b2c72n64", 2, 72, 64, 12, 70, 300)

@@ -143,7 +143,8 @@ def test_whole_model_matches_the_dense_op_sequence(factory, cin, R):
         tpc = net.tpcs[r]
         for l, meam in enumerate(tpc.tgacns):
             sub = {k[len(f"tpcs.{r}.tgacns.{l}."):]: v for k, v in leaves.items() if k.startswith(f"tpcs.{r}.tgacns.{l}.")}
-            x = dense_torch.meam_dense(x, P["adj"], sub, meam.dilations)
+            x = dense_torch.meam_dense(x, P["adj"], sub, meam.dilations,
+                                       relu_mask=None if masks is None else masks[(r, l)])
         x = torch.nn.functional.layer_norm(x, [T], leaves[f"tpcs.{r}.ln.weight"], leaves[f"tpcs.{r}.ln.bias"], 1e-5)
         y = torch.nn.functional.conv2d(x.transpose(1, 3), leaves[f"tpcs.{r}.fc.weight"], leaves[f"tpcs.{r}.fc.bias"])
         out = out + y[..., 0].transpose(1, 2) * gate[:, r]
@@ -241,9 +242,10 @@ def test_training_with_the_parameter_bank_tracks_the_component_loop(tmp_path):
     assert rel_err(p1, p2) < 1e-5
 
 
-def _dense_restatement(net, X, H, D, Y, dtype):
+def _dense_restatement(net, X, H, D, Y, dtype, masks=None):
     """The whole model as the reference's dense op sequence (oracle/dense_torch.py) in `dtype`, with `net`'s parameters:
-    prediction, Huber(50) loss and the gradient of every trainable parameter."""
+    prediction, Huber(50) loss and the gradient of every trainable parameter.  `masks[(r, l)]`: the active units of MEAM
+    l of component r as another run chose them (applied instead of the ReLU's own decision)."""
     from ms_gat_amd import engine
     from oracle import dense_torch
     R, B = len(net.tpcs), X.shape[0]
@@ -256,7 +258,8 @@ def _dense_restatement(net, X, H, D, Y, dtype):
         x = X[:, r].to(dtype)
         for l, meam in enumerate(net.tpcs[r].tgacns):
             sub = {k[len(f"tpcs.{r}.tgacns.{l}."):]: v for k, v in leaves.items() if k.startswith(f"tpcs.{r}.tgacns.{l}.")}
-            x = dense_torch.meam_dense(x, P["adj"], sub, meam.dilations)
+            x = dense_torch.meam_dense(x, P["adj"], sub, meam.dilations,
+                                       relu_mask=None if masks is None else masks[(r, l)])
         x = torch.nn.functional.layer_norm(x, [T], leaves[f"tpcs.{r}.ln.weight"], leaves[f"tpcs.{r}.ln.bias"], 1e-5)
         y = torch.nn.functional.conv2d(x.transpose(1, 3), leaves[f"tpcs.{r}.fc.weight"], leaves[f"tpcs.{r}.fc.bias"])
         out = out + y[..., 0].transpose(1, 2) * gate[:, r]
@@ -298,7 +301,13 @@ def test_cfg4_per_rank_workload_full_training_step(tmp_path):
     loop = copy.deepcopy(net)
     loop.stack_components = False                                              # msgat.py:204: one component at a time
     p_s, l_s, g_s = fwd_bwd(net)
+    masks = {}                                                                 # which units each MEAM's ReLU left active
+    hooks = [m.register_forward_hook(lambda mod, inp, out, key=(r, l): masks.__setitem__(key, out.detach() > 0))
+             for r, tpc in enumerate(loop.tpcs) for l, m in enumerate(tpc.tgacns)]
     p_l, l_l, g_l = fwd_bwd(loop)
+    for h in hooks:
+        h.remove()
+    assert len(masks) == 10
     what = "cfg4 R=5 N=883 B=32: stacked vs component loop"
     e = rel_err(p_s, p_l)
     record_err(what, "pred", e, 1e-5)
@@ -330,6 +339,22 @@ def test_cfg4_per_rank_workload_full_training_step(tmp_path):
     record_err(what, "gradients, median tensor (dense fp32 eager ops)", float(np.median(list(ref.values()))), TOL)
     assert max(lib.values()) <= max(2e-3, max(ref.values()))
     assert float(np.median(list(lib.values()))) < TOL
+
+    # The mask-flip explanation as a test: the float64 op sequence again, but with every ReLU applying the set of active
+    # units the LIBRARY chose (the component-loop run above).  With the borderline pre-activations out of the comparison
+    # every gradient tensor must meet the 1e-4 bar of the hot path (tensors > 100x below the largest gradient are judged
+    # on that scale, as above).
+    del p32, g32
+    p64m, l64m, g64m = _dense_restatement(loop, X, H, D, Y, torch.float64, masks)
+    what = "cfg4 R=5 N=883 B=32 vs dense float64 ops with the library's ReLU masks"
+    gs64 = max(float(g.abs().max()) for g in g64m.values())
+    fixed = {k: float((g_l[k].double() - g64m[k]).abs().max()) / max(float(g64m[k].abs().max()), 1e-2 * gs64) for k in g64m}
+    worst = max(fixed, key=fixed.get)
+    record_err(what, "pred", rel_err(p_l.double(), p64m), TOL)
+    record_err(what, f"gradients, worst tensor ({worst})", fixed[worst], TOL)
+    record_err(what, "gradients, median tensor", float(np.median(list(fixed.values()))), TOL)
+    assert rel_err(p_l.double(), p64m) < TOL and abs(l_l - l64m) < TOL * abs(l64m)
+    assert fixed[worst] < TOL, (worst, fixed[worst])
 
     before = [p.detach().clone() for p in net.parameters() if p.requires_grad]
     loss = ts.run(1)

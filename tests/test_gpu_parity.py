@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import elementwise_violations, load_golden, record_err, rel_err
+from conftest import elementwise_violations, load_golden, load_headline_golden, record_err, rel_err
 from oracle import dense_torch, gat_oracle
 
 pytestmark = pytest.mark.gpu
@@ -110,6 +110,15 @@ def test_gacn_matches_reference_golden(gatt_case):
     got = run_ours(g["x"], g["adj"], g["Wg"][None], g["alpha"][None], c["W"][None], c["dz"])
     want = dict(z=c["z"], dx=c["dx"], dWg=c["dWg"][None], dalpha=c["dalpha"][None], dW=c["dW"][None])
     assert_close(got, want, what=f"GACN[{tag}]")
+
+
+def test_gacn_matches_the_reference_at_the_headline_size():
+    """The graph size bench.py reports on (PEMSD7-like N = 883, C = 72 -> 24: PROJ_FIRST, slab-in-LDS aggregate, fused
+    du / SDDMM pass, dense passes with 7 row blocks) against the REFERENCE's own forward and autograd, not the oracle."""
+    g = load_headline_golden()
+    got = run_ours(g["x"], g["adj"], g["Wg"][None], g["alpha"][None], g["W"][None], g["dz"])
+    want = dict(z=g["z"], dx=g["dx"], dWg=g["dWg"][None], dalpha=g["dalpha"][None], dW=g["dW"][None])
+    assert_close(got, want, what="GACN[reference golden, N=883 C=72->24]")
 
 
 def test_modules_are_drop_in_for_the_reference_golden():

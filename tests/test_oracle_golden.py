@@ -7,7 +7,7 @@ reference's fp32 results to 2e-5 relative (the reference's own rounding).
 import numpy as np
 import torch
 
-from conftest import load_golden, rel_err
+from conftest import load_golden, load_headline_golden, rel_err
 from oracle import dense_torch, gat_oracle
 
 
@@ -62,6 +62,25 @@ def test_dense_torch_matches_reference(gatt_case):
     assert rel_err(z.detach(), c["z"]) < 2e-6
     assert rel_err(x.grad, c["dx"]) < 2e-6
     assert rel_err(W.grad, c["dW"]) < 5e-6
+
+
+def test_oracles_match_the_reference_at_the_headline_size():
+    """N = 883 (PEMSD7-like), C = 72 -> 24, one sample: both oracles against what the reference itself computed there."""
+    g = load_headline_golden()
+    f64 = lambda k: g[k].astype(np.float64)  # noqa: E731
+    z = gat_oracle.gacn_forward(f64("x"), f64("adj"), f64("Wg"), f64("alpha"), f64("W"))
+    assert rel_err(z, g["z"]) < 2e-5
+    dx, dWg, dalpha, dW = gat_oracle.gacn_backward(f64("x"), f64("adj"), f64("Wg"), f64("alpha"), f64("W"), f64("dz"))
+    for name, got in (("dx", dx), ("dWg", dWg), ("dalpha", dalpha), ("dW", dW)):
+        assert rel_err(got, g[name]) < 2e-5, name
+    t = lambda a: torch.from_numpy(a)  # noqa: E731
+    x = t(g["x"]).requires_grad_(True)
+    W = t(g["W"]).requires_grad_(True)
+    zt = dense_torch.gacn_dense(x, t(g["adj"]), t(g["Wg"]), t(g["alpha"]), W)
+    zt.backward(t(g["dz"]))
+    assert rel_err(zt.detach(), g["z"]) < 2e-6
+    assert rel_err(x.grad, g["dx"]) < 2e-6
+    assert rel_err(W.grad, g["dW"]) < 5e-6
 
 
 def test_lse_matches_dense_softmax_denominator():
