@@ -22,7 +22,10 @@ OBJDIR = os.path.join(ROOT, "build", "obj")
 LIB = os.path.join(PKG, "libmsgat_hip.so")
 
 SOURCES = ["api.hip", "project.hip", "mfma.hip", "dense.hip", "scores.hip", "aggregate.hip", "reduce.hip", "layernorm.hip", "branches.hip", "smallatt.hip", "tail.hip", "graph_host.cpp"]
-HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(INCLUDE, "msgat_hip.h")]
+HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "sell.hpp"), os.path.join(INCLUDE, "msgat_hip.h")]
+# diagnostic translation units (never part of the product library): `build(lab=True)` / `--lab` adds them and their
+# extra, undeclared entry points for tools/stress_kernels.py --lab
+LAB_SOURCES = [os.path.join(ROOT, "tools", "agg_sell_lab.hip")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize",
          f"--offload-arch={ARCH}",
@@ -54,14 +57,15 @@ def _compile(hipcc: str, src: str, obj: str, extra) -> None:
         sys.stderr.write(r.stderr)
 
 
-def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
-    """Compile every HIP source for gfx950 and link libmsgat_hip.so; returns its path."""
+def build(force: bool = False, verbose: bool = True, extra_flags=(), lab: bool = False, out: str = LIB) -> str:
+    """Compile every HIP source for gfx950 and link libmsgat_hip.so; returns its path.
+    lab=True: a diagnostic build (give it another `out`) that also carries the tools/*_lab.hip units."""
     hipcc = _hipcc()
     os.makedirs(OBJDIR, exist_ok=True)
     jobs, objs = [], []
-    for name in SOURCES:
-        src = os.path.join(CSRC, name)
-        obj = os.path.join(OBJDIR, name.rsplit(".", 1)[0] + ".o")
+    for name in SOURCES + (LAB_SOURCES if lab else []):
+        src = name if os.path.isabs(name) else os.path.join(CSRC, name)
+        obj = os.path.join(OBJDIR, os.path.basename(name).rsplit(".", 1)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src, *HEADERS, os.path.abspath(__file__)]):
             jobs.append((src, obj))
@@ -72,15 +76,19 @@ def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
         with cf.ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             for f in [ex.submit(_compile, hipcc, s, o, list(extra_flags)) for s, o in jobs]:
                 f.result()
-    if jobs or force or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
+    if jobs or force or _stale(out, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", out]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
         if verbose:
-            print(f"[ms_gat_amd.build] linked {LIB}", flush=True)
-    return LIB
+            print(f"[ms_gat_amd.build] linked {out}", flush=True)
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--lab" in sys.argv:   # python -m ms_gat_amd.build --lab  ->  build/lab/libmsgat_lab.so
+        os.makedirs(os.path.join(ROOT, "build", "lab"), exist_ok=True)
+        build(force="--force" in sys.argv, lab=True, out=os.path.join(ROOT, "build", "lab", "libmsgat_lab.so"))
+    else:
+        build(force="--force" in sys.argv)

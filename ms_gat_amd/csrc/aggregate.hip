@@ -12,7 +12,7 @@
 // gather-from-L2 kernel.  Either way the kernel is HBM-bound: algorithmic bytes =
 // read u once + write v once.
 #include "common.hpp"
-#include <cstdlib>
+#include "sell.hpp"
 
 namespace msgat {
 
@@ -20,7 +20,7 @@ namespace msgat {
 // 1024 lanes per block: the gather phase is a chain of dependent loads (row extent -> edge
 // index/weight -> LDS row), so it is latency-, not bandwidth-limited; 16 waves per block and two
 // blocks per CU keep the CU's 32 wave slots full while one block streams its slab in or out.
-constexpr int kAggBlock = 1024;
+// kAggBlock (1024 lanes per block): sell.hpp
 
 // 4 edges per trip, fetched as ONE 16-byte load of indices and one of weights.  Edge ranges start
 // at arbitrary dword offsets; gfx950 global loads of 128 bits need only dword alignment, which the
@@ -166,65 +166,7 @@ __global__ __launch_bounds__(kAggBlock) void k_agg_cols(
 // coefficients) with no address arithmetic and no mask (padding carries coefficient 0), several trips in flight.
 // Per edge that leaves 4 FMAs, one shift and one LDS read.  The CSR form spent ~16 vector + ~9 scalar
 // instructions and ~4 dependent global round trips per row on the same work (profiles/r02/stress_*).
-constexpr int kSD = 4;  // trips (of 4 edges per row) in flight per wave
-constexpr int kSellMaxSlices = 10;  // slices per wave: ceil(ceil(10176 / 64) / 16), 10176 = the most nodes whose float4 column fits LDS
-
-struct SellTrip {
-  uint2 id;  // 4 neighbour indices, 16 bits each
-  float4 e;
-};
-
-// Requests trip min(t, ntrip-1) of a slice: unconditional, so hipcc keeps counted vmcnt waits; a trip index past
-// the slice re-reads its last trip (the lines are in L2) and is simply not consumed.  pi2 / pe4 point at this
-// lane's entry of trip 0.
-__device__ __forceinline__ void sell_issue(const uint2* __restrict__ pi2, const float4* pe4, int t, int ntrip,
-                                           SellTrip& x) {
-  const int tc = min(t, ntrip - 1);
-  x.id = pi2[64 * tc];
-  x.e = pe4[64 * tc];
-}
-// lab: the same trip without global loads
-__device__ __forceinline__ void sell_fake(int t, SellTrip& x) {
-  const unsigned l = threadIdx.x & 63;
-  x.id = make_uint2(((l * 37 + t * 101) & 8191) | (((l * 53 + t * 211) & 8191) << 16),
-                    ((l * 71 + t * 307) & 8191) | (((l * 89 + t * 401) & 8191) << 16));
-  x.e = make_float4(1.f, 0.5f, 0.25f, 0.125f);
-}
-__device__ __forceinline__ int4 sell_unpack(uint2 v) {
-  return make_int4((int)(v.x & 0xffffu), (int)(v.x >> 16), (int)(v.y & 0xffffu), (int)(v.y >> 16));
-}
-
-template <int LAB = 0>
-__device__ __forceinline__ void sell_gather(const SellTrip& x, const float4* slab, float4& acc) {
-  const int4 id = sell_unpack(x.id);
-  if (LAB == 1) {  // lab: conflict-free LDS reads that still depend on the loaded indices
-    const int l = threadIdx.x & 63;
-    f4fma(x.e.x, slab[(id.x & 0) + l], acc);
-    f4fma(x.e.y, slab[(id.y & 0) + l + 64], acc);
-    f4fma(x.e.z, slab[(id.z & 0) + l + 128], acc);
-    f4fma(x.e.w, slab[(id.w & 0) + l + 192], acc);
-    return;
-  }
-  f4fma(x.e.x, slab[id.x], acc);
-  f4fma(x.e.y, slab[id.y], acc);
-  f4fma(x.e.z, slab[id.z], acc);
-  f4fma(x.e.w, slab[id.w], acc);
-}
-
-// stage column j of the [N][T4] slab at `src`: NB loads in flight per lane; lanes past N re-write entry N-1 with
-// the value they re-read from it (no branch, so the loads stay in flight together)
-template <int T4, int NB = 8>
-__device__ __forceinline__ void stage_column(float4* slab, const float4* __restrict__ src, int j, int N) {
-  for (int n0 = 0; n0 < N; n0 += NB * kAggBlock) {
-    float4 t[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) t[i] = src[(size_t)min(n0 + i * kAggBlock + (int)threadIdx.x, N - 1) * T4 + j];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) slab[min(n0 + i * kAggBlock + (int)threadIdx.x, N - 1)] = t[i];
-  }
-}
-
-template <int T4, int LAB = 0>
+template <int T4>
 __global__ __launch_bounds__(kAggBlock) void k_agg_sell(
     const int* __restrict__ slice_off, const int* __restrict__ lane_row, const uint16_t* __restrict__ sidx,
     const float4* __restrict__ u4, const float* __restrict__ Es, const float* __restrict__ addvec,
@@ -250,7 +192,7 @@ __global__ __launch_bounds__(kAggBlock) void k_agg_sell(
   const size_t base = ((size_t)g * Cu + c) * N * T4;
   const float* Eg = Es + (size_t)g * n_pos;
   const float av = (addvec != nullptr) ? addvec[r * Cu + c] : 0.f;
-  if (LAB != 3) stage_column<T4>(slab, u4 + base, j, N);
+  stage_column<T4>(slab, u4 + base, j, N);
   __syncthreads();
   // The rows of a slice are scattered over N (the layout is sorted by degree), so results are not stored from
   // here: 64 lanes x 16 B to 64 different 128-B lines per instruction cost 1.07 of the kernel's 2.95 ms (lab
@@ -272,19 +214,19 @@ __global__ __launch_bounds__(kAggBlock) void k_agg_sell(
         // kSD trips in flight, rotating through four register sets; consumption is guarded by wave-uniform
         // branches that contain no load
         SellTrip a, b, c4, d;
-        if (LAB == 2) sell_fake(0, a); else sell_issue(pi4, pe4, 0, ntrip, a);
-        if (LAB == 2) sell_fake(1, b); else sell_issue(pi4, pe4, 1, ntrip, b);
-        if (LAB == 2) sell_fake(2, c4); else sell_issue(pi4, pe4, 2, ntrip, c4);
-        if (LAB == 2) sell_fake(3, d); else sell_issue(pi4, pe4, 3, ntrip, d);
+        sell_issue(pi4, pe4, 0, ntrip, a);
+        sell_issue(pi4, pe4, 1, ntrip, b);
+        sell_issue(pi4, pe4, 2, ntrip, c4);
+        sell_issue(pi4, pe4, 3, ntrip, d);
         for (int t = 0; t < ntrip; t += kSD) {
-          sell_gather<LAB>(a, slab, acc);
-          if (LAB == 2) sell_fake(t + 4, a); else sell_issue(pi4, pe4, t + 4, ntrip, a);
-          if (t + 1 < ntrip) sell_gather<LAB>(b, slab, acc);
-          if (LAB == 2) sell_fake(t + 5, b); else sell_issue(pi4, pe4, t + 5, ntrip, b);
-          if (t + 2 < ntrip) sell_gather<LAB>(c4, slab, acc);
-          if (LAB == 2) sell_fake(t + 6, c4); else sell_issue(pi4, pe4, t + 6, ntrip, c4);
-          if (t + 3 < ntrip) sell_gather<LAB>(d, slab, acc);
-          if (LAB == 2) sell_fake(t + 7, d); else sell_issue(pi4, pe4, t + 7, ntrip, d);
+          sell_gather(a, slab, acc);
+          sell_issue(pi4, pe4, t + 4, ntrip, a);
+          if (t + 1 < ntrip) sell_gather(b, slab, acc);
+          sell_issue(pi4, pe4, t + 5, ntrip, b);
+          if (t + 2 < ntrip) sell_gather(c4, slab, acc);
+          sell_issue(pi4, pe4, t + 6, ntrip, c4);
+          if (t + 3 < ntrip) sell_gather(d, slab, acc);
+          sell_issue(pi4, pe4, t + 7, ntrip, d);
         }
       }
       accs[i] = acc;
@@ -303,7 +245,7 @@ __global__ __launch_bounds__(kAggBlock) void k_agg_sell(
   for (int n = threadIdx.x; n < N; n += kAggBlock) {
     float4 acc = slab[n];
     if (addvec != nullptr) f4fma(av, extra4[((size_t)g * N + n) * T4 + j], acc);
-    if (LAB != 4 || acc.x == 12345.678f) v4[base + (size_t)n * T4 + j] = acc;
+    v4[base + (size_t)n * T4 + j] = acc;
   }
 }
 
@@ -340,21 +282,9 @@ static int launch_aggregate_t(const int* ptr, const int* idx, int nnz, const msg
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
     }
-#define MSGAT_AGG_SELL(LAB)                                                                                          \
-  hipLaunchKernelGGL((k_agg_sell<T4, LAB>), dim3((unsigned)cdiv(G, 8) * 8 * Cu * T4), dim3(kAggBlock), lds, s,       \
-                     sell->slice_off, sell->lane_row, sell->idx, (const float4*)u, E, addvec, (const float4*)extra, \
-                     (float4*)v, G, Bg, Cu, N, sell->n_pos, sell->n_slices)
-#ifdef MSGAT_LAB  // diagnostic builds only (tools/_lab.sh): time the kernel with one phase removed
-    const char* lab = getenv("MSGAT_AGG_LAB");
-    const int labv = (lab && T4 == 3) ? atoi(lab) : 0;
-    if (labv == 1) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_sell<T4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); MSGAT_AGG_SELL(1); }
-    else if (labv == 2) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_sell<T4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); MSGAT_AGG_SELL(2); }
-    else if (labv == 3) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_sell<T4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); MSGAT_AGG_SELL(3); }
-    else if (labv == 4) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_sell<T4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); MSGAT_AGG_SELL(4); }
-    else
-#endif
-    MSGAT_AGG_SELL(0);
-#undef MSGAT_AGG_SELL
+    hipLaunchKernelGGL((k_agg_sell<T4>), dim3((unsigned)cdiv(G, 8) * 8 * Cu * T4), dim3(kAggBlock), lds, s,
+                       sell->slice_off, sell->lane_row, sell->idx, (const float4*)u, E, addvec, (const float4*)extra,
+                       (float4*)v, G, Bg, Cu, N, sell->n_pos, sell->n_slices);
   } else if (CH >= 1) {
     const size_t lds = (size_t)CH * N * T * sizeof(float);
     if (lds > 64 * 1024) {

@@ -25,7 +25,11 @@ def main():
     ap.add_argument("--E", type=int, default=65536)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--sell", default="auto")
+    ap.add_argument("--lab", type=int, default=-1, help="time tools/agg_sell_lab.hip's k_agg_sell with one phase removed "
+                    "(0..4; needs `python -m ms_gat_amd.build --lab`)")
     a = ap.parse_args()
+    if a.lab >= 0:
+        _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "lab", "libmsgat_lab.so")
     N, T, R, B, Cc, Co = a.N, 12, a.R, a.B, 72, 24
     G = R * B
     dev = torch.device("cuda:0")
@@ -58,6 +62,14 @@ def main():
                                                           scr.data_ptr() if nscr else None, st), "agg"))
     print(f"aggregate (incl. edge permute)  {ms:8.3f} ms   {alg / ms / 1e6:8.1f} GB/s algorithmic  sell={graph.has_sell} nnz={nnz}",
           flush=True)
+
+    if a.lab >= 0:
+        fn = L.msgat_lab_aggregate_sell
+        fn.restype, fn.argtypes = C.c_int, [C.POINTER(_lib.Shape), C.POINTER(_lib.Graph), C.c_int32] + [C.c_void_p] * 3 + [C.c_int32, C.c_void_p]
+        Es = torch.rand(G, gs.sell_rows.n_pos + _lib.SELL_SLACK, device=dev)
+        ms = timed(lambda: _lib.check(fn(sp, gp, Co, u.data_ptr(), Es.data_ptr(), v.data_ptr(), a.lab, st), "lab"))
+        print(f"k_agg_sell lab variant {a.lab}       {ms:8.3f} ms", flush=True)
+        return
 
     # attention backward on the projected features: SDDMM + edge/row passes + dense column pass + transposed aggregate
     shp = _lib.Shape(R, B, Co, 0, N, T)
