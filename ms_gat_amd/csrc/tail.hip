@@ -59,10 +59,13 @@ __global__ __launch_bounds__(kTailBlock) void k_huber_metrics(const float* __res
 // batch's n_b samples passes n_r / n_b, so the sum over ranks is the global batch's mean loss), all double
 __global__ void k_huber_finish(const double* __restrict__ part, int nblocks, long long n, float* __restrict__ loss,
                                double* __restrict__ sums, float loss_weight) {
-  const int k = threadIdx.x;
-  if (k >= 4) return;
+  // wave k adds sum k: lane l takes blocks l, l + 64, ... in order, then the lanes are combined by the fixed butterfly
+  // of wave_sum (a serial loop over up to 1024 partials by one lane took 19 us)
+  const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double t = 0.0;
-  for (int b = 0; b < nblocks; ++b) t += part[(size_t)b * 4 + k];
+  for (int b = lane; b < nblocks; b += 64) t += part[(size_t)b * 4 + k];
+  t = wave_sum(t);
+  if (lane != 0) return;
   if (k == 0) {
     loss[0] = (float)(t / (double)n);
     if (sums != nullptr) sums[3] += (t / (double)n) * (double)loss_weight;
@@ -94,7 +97,7 @@ int launch_huber_metrics(const float* pred, const float* truth, long long n, flo
   const int nb = huber_blocks(n);
   hipLaunchKernelGGL(k_huber_metrics, dim3(nb), dim3(kTailBlock), 0, s, pred, truth, n, delta, mask_value, part);
   MSGAT_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_huber_finish, dim3(1), dim3(64), 0, s, part, nb, n, loss, sums, loss_weight);
+  hipLaunchKernelGGL(k_huber_finish, dim3(1), dim3(256), 0, s, part, nb, n, loss, sums, loss_weight);
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }

@@ -136,7 +136,7 @@ class TACN(nn.Module):
     def stacked_taps(self, layer: int) -> torch.Tensor:
         """[2*Co, Ci]: the two taps of convolution `layer` stacked on the output axis (tap 0 acts on in[t-d])."""
         w = self.seq[1 + 2 * layer].weight
-        return torch.cat([w[:, :, 0, 0], w[:, :, 0, 1]], dim=0)
+        return w.flatten(1, 2).permute(2, 0, 1).reshape(2 * w.shape[0], w.shape[1])   # [tap 0 rows; tap 1 rows], one copy
 
     def forward(self, signals: torch.Tensor) -> torch.Tensor:
         if not self.dilations:
@@ -182,7 +182,7 @@ class CACN(nn.Module):
     def channel_matrix(self, signals: torch.Tensor) -> torch.Tensor:
         """[B,Co,C] = conv.weight @ channel attention: node pooling in one pass, the rest in one launch."""
         ca, conv = self.seq[0], self.seq[1]
-        return ops.channel_attention_mix(ops.node_pool(signals, ca.alpha), ca.Wc, conv.weight[:, :, 0, 0])
+        return ops.channel_attention_mix(ops.node_pool(signals, ca.alpha), ca.Wc, conv.weight.flatten(1))
 
     def forward(self, signals: torch.Tensor) -> torch.Tensor:
         return ops.mix(signals, self.channel_matrix(signals), self.seq[1].bias)
@@ -214,7 +214,7 @@ class MEAM(nn.Module):
         # (normed, signals): the residual convolution below reads the block input again (msgat.py:130); routed
         # through the LayerNorm op, its gradient is added inside the LayerNorm-backward kernel
         normed, signals = ops.layer_norm_t_tee(signals, self.ln.weight, self.ln.bias, self.ln.eps, relu_input)
-        res_w = self.res.weight[:, :, 0, 0].unsqueeze(0)
+        res_w = self.res.weight.flatten(1).unsqueeze(0)
         if self.in_channels <= self.out_channels // 3 or not self.dilations:
             # few input channels (the first block of a component): the graph branch aggregates before it
             # projects, nothing to merge -- branch by branch
@@ -243,8 +243,8 @@ class MEAM(nn.Module):
             ta.alpha.view(1, 1, C).expand(B, -1, -1)], dim=1)                    # [B,1,C]    pooled signal of the temporal attention
         bias = torch.cat([conv_c.bias, conv_c.bias.new_zeros(3 * cb + 2)])
         cacn, mixed, u, q, pooled_t = ops.mix_multi([normed], rows, bias, out_channels=[cb, 2 * cb, cb, 1, 1])
-        tacn = self.tacn.finish(mixed, pooled_t[:, 0])
-        gacn = ops.attention_core(u, q[:, 0], gatt.Wg.unsqueeze(0), adjacency)
+        tacn = self.tacn.finish(mixed, pooled_t.flatten(1, 2))
+        gacn = ops.attention_core(u, q.flatten(1, 2), gatt.Wg.unsqueeze(0), adjacency)
         return [cacn, tacn, gacn]
 
 

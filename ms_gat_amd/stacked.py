@@ -91,7 +91,8 @@ def _taps(P, prefix: str, layer: int) -> torch.Tensor:
     """[R, 2*Co, Ci]: both taps of convolution `layer` of the TACN stacks (model.TACN.stacked_taps), one copy kernel."""
     w = P(f"{prefix}tacn.seq.{1 + 2 * layer}.weight")                                   # [R,Co,Ci,1,2]
     R, Co, Ci = w.shape[:3]
-    return w[:, :, :, 0, :].permute(0, 3, 1, 2).reshape(R, 2 * Co, Ci)
+    # (a view + one copy kernel; indexing the size-1 axis with `[..., 0, :]` would cost a zero-fill + copy in backward)
+    return w.reshape(R, Co, Ci, 2).permute(0, 3, 1, 2).reshape(R, 2 * Co, Ci)
 
 
 def _first_taps(P, prefix: str, pooled: torch.Tensor, T: int, dilation: int) -> torch.Tensor:
@@ -136,7 +137,7 @@ def _meam(P, prefix: str, m0, x: torch.Tensor, adjacency, R: int, B: int, relu_i
     normed, x = ops.layer_norm_t_tee(x, P(prefix + "ln.weight"), P(prefix + "ln.bias"), m0.ln.eps, relu_input)
 
     # CACN's per-sample channel matrix conv @ softmax(p Wc p^T) (attention.py:90-92, msgat.py:93-94): one launch
-    conv_w = P(prefix + "cacn.seq.1.weight")[:, :, :, 0, 0]                            # [R,cb,C]
+    conv_w = P(prefix + "cacn.seq.1.weight").flatten(2)                                # [R,cb,C,1,1] -> [R,cb,C]: a view
     conv_b = P(prefix + "cacn.seq.1.bias")                                             # [R,cb]
     # (pooled, normed): the mixing passes below read `normed` too; their gradient joins inside the pooling's backward
     pooled_c, normed = ops.node_pool_tee(normed, P(prefix + "cacn.seq.0.alpha"))
@@ -161,13 +162,14 @@ def _meam(P, prefix: str, m0, x: torch.Tensor, adjacency, R: int, B: int, relu_i
         shared = torch.cat([_taps(P, prefix, 0), W_g, alpha_g.unsqueeze(1), alpha_t.unsqueeze(1)], dim=1)   # [R,3cb+2,C]
         rows = ops.assemble_rows(Mc, shared)
         cacn, mixed, u, q, pooled_t = ops.mix_multi([normed], rows, None, out_channels=[cb, 2 * cb, cb, 1, 1])
-        tacn = _tacn_finish(P, prefix, m0.dilations, mixed, _first_taps(P, prefix, pooled_t[:, 0], T, d0))
-        gacn = ops.attention_core(u, q[:, 0], Wg, adjacency)
+        # pooled_t, q: [G,1,N,T] -> [G,N,T] as views (a `[:, 0]` select costs a zero-fill + copy in backward)
+        tacn = _tacn_finish(P, prefix, m0.dilations, mixed, _first_taps(P, prefix, pooled_t.flatten(1, 2), T, d0))
+        gacn = ops.attention_core(u, q.flatten(1, 2), Wg, adjacency)
         res_b = P(prefix + "res.bias")
         tail_bias = res_b + torch.nn.functional.pad(conv_b, (0, res_b.shape[1] - cb))
-        return ops.mix_multi([x], P(prefix + "res.weight")[:, :, :, 0, 0], tail_bias, adds=[cacn, tacn, gacn], relu=True,
+        return ops.mix_multi([x], P(prefix + "res.weight").flatten(2), tail_bias, adds=[cacn, tacn, gacn], relu=True,
                              relu_grad_premasked=True)[0]
-    return ops.mix_multi([x], P(prefix + "res.weight")[:, :, :, 0, 0], P(prefix + "res.bias"),
+    return ops.mix_multi([x], P(prefix + "res.weight").flatten(2), P(prefix + "res.bias"),
                          adds=[cacn, tacn, gacn], relu=True, relu_grad_premasked=True)[0]
 
 

@@ -143,8 +143,7 @@ def test_whole_model_matches_the_dense_op_sequence(factory, cin, R):
         tpc = net.tpcs[r]
         for l, meam in enumerate(tpc.tgacns):
             sub = {k[len(f"tpcs.{r}.tgacns.{l}."):]: v for k, v in leaves.items() if k.startswith(f"tpcs.{r}.tgacns.{l}.")}
-            x = dense_torch.meam_dense(x, P["adj"], sub, meam.dilations,
-                                       relu_mask=None if masks is None else masks[(r, l)])
+            x = dense_torch.meam_dense(x, P["adj"], sub, meam.dilations)
         x = torch.nn.functional.layer_norm(x, [T], leaves[f"tpcs.{r}.ln.weight"], leaves[f"tpcs.{r}.ln.bias"], 1e-5)
         y = torch.nn.functional.conv2d(x.transpose(1, 3), leaves[f"tpcs.{r}.fc.weight"], leaves[f"tpcs.{r}.fc.bias"])
         out = out + y[..., 0].transpose(1, 2) * gate[:, r]
