@@ -613,7 +613,9 @@ class _HeadFunction(torch.autograd.Function):
             part = _new(x, max(int(L.msgat_head_grad_weight_partial_floats(Cc, T, To, R)), 1))
             _lib.check(L.msgat_head_grad_weight(_ptr(dout), _ptr(x), _ptr(dWc), _ptr(part), B, Cc, N, T, To, R, stream),
                        "msgat_head_grad_weight")
-            dW = dWc.permute(0, 2, 3, 1).unsqueeze(3)       # [R,To,T,1,C]
+            # [R,To,T,1,C], made contiguous HERE, once for all R components: each component's parameter receives its row,
+            # and a non-contiguous row would be copied per component when it is accumulated into .grad
+            dW = dWc.permute(0, 2, 3, 1).contiguous().unsqueeze(3)
             if W.dim() == 4:
                 dW = dW[0]
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -740,9 +742,11 @@ class _MixMultiFunction(torch.autograd.Function):
                 st = L.msgat_contract_segments(R, G // R, N, T, ad, nd, _ptr(x), c, ones, _ptr(part), _ptr(dMi), stream)
                 _lib.check(st, "msgat_contract_segments")
                 if ones:
-                    colsum = dMi[:, :, c]                                  # [R,Co]: sum over the relation's groups and positions
+                    # contiguous once per stacked tensor (see the head's weight gradient): a column slice handed down to the
+                    # components' parameters costs one copy per component in AccumulateGrad
+                    colsum = dMi[:, :, c].contiguous()                     # [R,Co]: sum over the relation's groups and positions
                     dbias = colsum if has_bias > 0 else colsum.sum(dim=0)
-                    dMi = dMi[:, :, :c]
+                    dMi = dMi[:, :, :c].contiguous()
                 parts.append(dMi)
             dM = parts[0] if len(parts) == 1 else torch.cat(parts, dim=2)
         elif want_bias:
@@ -991,6 +995,27 @@ def causal_shift_taps(T: int, dilation: int, device) -> torch.Tensor:
             shifted[dilation:] = eye[: T - dilation]
         taps = _shift_taps_cache[key] = torch.stack([shifted, eye], dim=0).unsqueeze(0).contiguous()
     return taps
+
+
+class _Relayout(torch.autograd.Function):
+    """t.permute(perm).contiguous() whose backward is ALSO one contiguous copy (autograd's own backward of a permute is a
+    strided view: handed down to R per-component parameters it is copied R times by AccumulateGrad)."""
+
+    @staticmethod
+    def forward(ctx, t, perm):
+        ctx.perm = tuple(perm)
+        return t.permute(*perm).contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        inv = [0] * len(ctx.perm)
+        for i, p in enumerate(ctx.perm):
+            inv[p] = i
+        return g.permute(*inv).contiguous(), None
+
+
+def relayout(t: torch.Tensor, perm) -> torch.Tensor:
+    return _Relayout.apply(t, tuple(perm))
 
 
 # ---- step tail: fused Huber loss + metric sums (SURVEY section 8 row f-4) ---------------------------------------

@@ -91,8 +91,9 @@ def _taps(P, prefix: str, layer: int) -> torch.Tensor:
     """[R, 2*Co, Ci]: both taps of convolution `layer` of the TACN stacks (model.TACN.stacked_taps), one copy kernel."""
     w = P(f"{prefix}tacn.seq.{1 + 2 * layer}.weight")                                   # [R,Co,Ci,1,2]
     R, Co, Ci = w.shape[:3]
-    # (a view + one copy kernel; indexing the size-1 axis with `[..., 0, :]` would cost a zero-fill + copy in backward)
-    return w.reshape(R, Co, Ci, 2).permute(0, 3, 1, 2).reshape(R, 2 * Co, Ci)
+    # one copy kernel each way (ops.relayout); indexing the size-1 axis with `[..., 0, :]` would cost a zero-fill + copy
+    # in backward, a plain permute one strided copy per COMPONENT when the gradient reaches the parameters
+    return ops.relayout(w.reshape(R, Co, Ci, 2), (0, 3, 1, 2)).reshape(R, 2 * Co, Ci)
 
 
 def _first_taps(P, prefix: str, pooled: torch.Tensor, T: int, dilation: int) -> torch.Tensor:
