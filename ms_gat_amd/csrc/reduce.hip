@@ -12,38 +12,56 @@
 
 namespace msgat {
 
-constexpr int kNS4 = 4;
 
 // ---- sum of partials: out[r,i] = sum_j part[r,j,i], split over two destinations -----------------
-// blockIdx.z picks the job; block = 64 columns x 4 waves; wave w sums partials j = w, w+4, ... (8 loads in
-// flight), the 4 wave sums are combined in a fixed order through LDS
-__global__ __launch_bounds__(kBlock) void k_reduce_partials(ReduceJobs jobs) {
-  __shared__ float red[kNS4][kWave];
+// blockIdx.z picks the job; block = 16 waves.  A wave covers Wc = min(Wd, 64) columns; when Wd < 64 its lanes also
+// split the partials: lane = (sub-slice, column), 64 / Wc sub-slices (Wc a power of two).  (wave w, sub-slice s) sums
+// partials j = w S + s, + 16 S, ... (8 loads in flight); the sub-slices are combined by a fixed xor butterfly, the 16
+// waves in wave order through LDS: a fixed order, bitwise reproducible.  (LayerNorm's backward leaves 2048 partials of 24 columns per
+// relation: with 4 waves and one lane per column that sum took 34 us of dependent loads, twice per training step.)
+constexpr int kRedWaves = 16;
+constexpr int kRedBlock = 64 * kRedWaves;
+
+// columns per wave: Wd rounded up to a power of two, at most 64 (so that the sub-slices combine by xor shuffles)
+__host__ __device__ static inline int red_cols(int Wd) {
+  int c = 1;
+  while (c < Wd && c < kWave) c <<= 1;
+  return c;
+}
+
+__global__ __launch_bounds__(kRedBlock) void k_reduce_partials(ReduceJobs jobs) {
+  __shared__ float red[kRedWaves][kWave];
   const ReduceJob& jb = jobs.job[blockIdx.z];
   const int r = blockIdx.y;
   const int lane = threadIdx.x & (kWave - 1);
   const int w = threadIdx.x >> 6;
-  const int i = blockIdx.x * kWave + lane;
   const int Wd = jb.Wd, J = jb.J;
-  if (r >= jb.R || blockIdx.x * kWave >= Wd) return;  // the grid covers the largest job
+  const int Wc = red_cols(Wd);          // columns per wave
+  const int S = kWave / Wc;             // sub-slices of the partials per wave
+  const int col = lane % Wc, sub = lane / Wc;
+  const int i = blockIdx.x * Wc + col;
+  if (r >= jb.R || blockIdx.x * Wc >= Wd) return;  // the grid covers the largest job
   float acc = 0.f;
   if (i < Wd) {
     const float* p = jb.part + (size_t)r * J * Wd + i;
+    const int step = kRedWaves * S;
     float a[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) a[k] = 0.f;
-    int j = w;
-    for (; j + 28 < J; j += 32) {
+    int j = w * S + sub;
+    for (; j + 7 * step < J; j += 8 * step) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) a[k] += p[(size_t)(j + 4 * k) * Wd];
+      for (int k = 0; k < 8; ++k) a[k] += p[(size_t)(j + k * step) * Wd];
     }
-    for (; j < J; j += 4) a[0] += p[(size_t)j * Wd];
+    for (; j < J; j += step) a[0] += p[(size_t)j * Wd];
     acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   }
+  for (int off = Wc; off < kWave; off <<= 1) acc += __shfl_xor(acc, off);   // sub-slices of this wave
   red[w][lane] = acc;
   __syncthreads();
-  if (w != 0 || i >= Wd) return;
-  const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (w != 0 || sub != 0 || i >= Wd) return;
+  float v = 0.f;
+  for (int ww = 0; ww < kRedWaves; ++ww) v += red[ww][col];
   if (i < jb.n0) {
     if (jb.dst0 != nullptr) jb.dst0[(size_t)r * jb.n0 + i] = v;
   } else if (jb.dst1 != nullptr && i - jb.n0 < jb.n1) {
@@ -55,10 +73,10 @@ int launch_reduce_jobs(const ReduceJobs& jobs, hipStream_t s) {
   if (jobs.n <= 0) return MSGAT_OK;
   int bx = 1, by = 1;
   for (int k = 0; k < jobs.n; ++k) {
-    bx = max(bx, cdiv(jobs.job[k].Wd, kWave));
+    bx = max(bx, cdiv(jobs.job[k].Wd, red_cols(jobs.job[k].Wd)));
     by = max(by, jobs.job[k].R);
   }
-  hipLaunchKernelGGL(k_reduce_partials, dim3(bx, by, jobs.n), dim3(kBlock), 0, s, jobs);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(bx, by, jobs.n), dim3(kRedBlock), 0, s, jobs);
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
