@@ -187,8 +187,10 @@ int launch_project_mfma(const SegList& in, const float* M, int m_in_major, const
                         int P, const MixEpilogue& epi, hipStream_t s);
 int chanpair_mfma_blocks(int R);  // blocks (= partials) per relation
 // b_ones: B's last channel (Cb counts it) is a virtual row of ones: part[a, Cb-1] = sum_p A[a,p]
+// nblk: partial blocks per relation the buffer has room for; *nblk_used: how many the launch wrote (fewer when the
+// channel matrix is cut into several z-blocks, which all run at once)
 int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
-                         int b_ones, hipStream_t s);
+                         int b_ones, hipStream_t s, int* nblk_used);
 int launch_scores(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW, float* lse,
                   float* pq, float* E, float* Ec, int G, int Bg, int N, int T, hipStream_t s);
 // v[g,c,n,:] = sum_{e in ptr[n]..ptr[n+1]} E[g,e] u[g,c,idx[e],:] (+ addvec[r,c]*extra[g,n,:])

@@ -329,7 +329,8 @@ constexpr int kTile = 32 * kCpWaves;   // positions per staged tile (default): 3
 // pass over both operands instead of two z-blocks that each re-read B.
 template <int MA, int NB, bool TWO = true, int TILE = kTile>
 __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
-    SegList A, const float* __restrict__ B, float* __restrict__ part, int Cb, int P, int Bg, int nzb, int b_ones) {
+    SegList A, const float* __restrict__ B, float* __restrict__ part, int Cb, int P, int Bg, int nzb, int b_ones,
+    int nza, int nblk, int R) {
   // b_ones: B's last channel (index Cb-1) is a virtual row of ones, so part[a, Cb-1] = sum_p A[a,p] -- the bias
   // gradient of a 1x1 convolution comes out of the contraction that computes its weight gradient
   const int Cbr = Cb - b_ones;  // channels B really has
@@ -340,21 +341,40 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
   constexpr int kRowF4 = TILE / 4 + 1;  // float4s per LDS row (piece + 16 B pad)
   constexpr int kPPW = TILE / kCpWaves;  // positions per wave and tile: 4 per k-step
   constexpr int RPW = ((MA + NB) * 16 + kCpWaves * kRPI - 1) / (kCpWaves * kRPI);  // load instructions per wave per tile
-  const int r = blockIdx.y;
-  const int nblk = gridDim.x;
+  // Block -> (relation r, run bx of the relation's tile stream, z-block zb of the channel matrix).  A channel matrix
+  // larger than one [MA*16 x NB*16] block is cut into nza x nzb z-blocks that each stream their own A rows and B
+  // columns -- the z-blocks of one A split all re-read the SAME B tiles.  With several z-blocks the grid is
+  // one-dimensional and XCD-aware: workgroups are dealt round-robin over the 8 XCDs (block b on XCD b % 8), so the
+  // z-blocks of one run take consecutive slots of ONE XCD, start together, do equal work (A rows split evenly: 49 + 49
+  // of 98, not 64 + 34) and stay in step -- the second reader of a B tile finds it in that XCD's L2.  (As a 3-D grid
+  // with z slowest, all z = 0 blocks ran first and z = 1 re-read B from HBM 170 us later.)
+  const int nz = nza * nzb;
+  int bx, r, zb;
+  if (nz > 1) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    zb = slot % nz;
+    const int k = (slot / nz) * 8 + xcd;
+    if (k >= nblk * R) return;  // the grid is padded to a multiple of 8 runs
+    r = k / nblk;
+    bx = k - r * nblk;
+  } else {
+    bx = blockIdx.x;
+    r = blockIdx.y;
+    zb = 0;
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = lane & 15, kq = lane >> 4;
-  // blockIdx.z walks the [MA*16 x NB*16] blocks of a channel matrix larger than one block
-  const int a0 = (blockIdx.z / nzb) * (MA * 16);
-  const int c0 = (blockIdx.z % nzb) * (NB * 16);
-  const int ca = min(MA * 16, Ca - a0), cb = min(NB * 16, Cb - c0);
+  const int a_per = cdiv(Ca, nza);  // A rows per z-block (<= MA * 16, host-checked)
+  const int a0 = (zb / nzb) * a_per;
+  const int c0 = (zb % nzb) * (NB * 16);
+  const int ca = min(a_per, Ca - a0), cb = min(NB * 16, Cb - c0);
   const int rows = ca + cb;  // rows [0,ca) = A channels, [ca,rows) = B channels
   constexpr int kZeroRow = (MA + NB) * 16;  // an all-zero row for absent channels
   constexpr int kOnesRow = kZeroRow + 1;    // an all-ones row for the virtual channel
   // this block's run of the relation's tile stream
   const int tpg = cdiv(P, TILE);  // tiles per group (the last one is partial)
   const long long ntot = (long long)Bg * tpg;
-  const int t0 = (int)(ntot * blockIdx.x / nblk), t1 = (int)(ntot * (blockIdx.x + 1) / nblk);
+  const int t0 = (int)(ntot * bx / nblk), t1 = (int)(ntot * (bx + 1) / nblk);
   const int ntile = t1 - t0;
 
   MSGAT_STAMP(0);
@@ -495,7 +515,7 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
   static_assert(kRedTiles >= 1, "tile buffer too small for the reduction");
   float* red = reinterpret_cast<float*>(lds4) + (size_t)wave * (kRedTiles * 256);
   const float* all = reinterpret_cast<const float*>(lds4);
-  float* out = part + ((size_t)r * nblk + blockIdx.x) * ((size_t)Ca * Cb);
+  float* out = part + ((size_t)r * nblk + bx) * ((size_t)Ca * Cb);
 #pragma unroll
   for (int t0r = 0; t0r < kTiles; t0r += kRedTiles) {
     __syncthreads();  // the tile buffer (or the previous pass) is no longer read
@@ -519,7 +539,7 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
       const int ma = tile / NB, nb = tile - ma * NB;
       const int a = a0 + ma * 16 + 4 * (el >> 4) + reg;  // D row = 4*(lane >> 4) + reg
       const int c = c0 + nb * 16 + (el & 15);            // D column = lane & 15
-      if (a < Ca && c < Cb) out[(size_t)a * Cb + c] = v;
+      if (a < a0 + ca && c < c0 + cb) out[(size_t)a * Cb + c] = v;   // this z-block's rows and columns only
     }
   }
   MSGAT_STAMP(5);
@@ -534,10 +554,14 @@ int chanpair_mfma_blocks(int R) {
 }
 
 template <int MA, int NB, bool TWO = true, int TILE = kTile>
-static int launch_chanpair_t(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
-                             int b_ones, hipStream_t s) {
+static int launch_chanpair_t(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk_max,
+                             int b_ones, hipStream_t s, int* nblk_used) {
   const int Ca = A.total();
   const int nza = cdiv(Ca, MA * 16), nzb = cdiv(Cb, NB * 16);
+  const int nz = nza * nzb;
+  // several z-blocks: all of them resident at once (one block per CU), so fewer, longer runs per relation
+  const int nblk = nz > 1 ? max(1, nblk_max / nz) : nblk_max;
+  *nblk_used = nblk;
   // tile rows + the zero row + the ones row; the reduction re-uses the buffer a few tiles at a time
   const size_t lds = sizeof(float4) * (size_t)(((MA + NB) * 16 + 2) * (TILE / 4 + 1));
   if (lds > 64 * 1024) {
@@ -545,14 +569,15 @@ static int launch_chanpair_t(const SegList& A, const float* B, float* part, int 
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
   }
-  dim3 grid(nblk, R, nza * nzb);
-  hipLaunchKernelGGL((k_chanpair_mfma<MA, NB, TWO, TILE>), grid, dim3(kCpBlock), lds, s, A, B, part, Cb, P, Bg, nzb, b_ones);
+  const dim3 grid = nz > 1 ? dim3((unsigned)cdiv(nblk * R, 8) * 8 * nz) : dim3(nblk, R, 1);
+  hipLaunchKernelGGL((k_chanpair_mfma<MA, NB, TWO, TILE>), grid, dim3(kCpBlock), lds, s, A, B, part, Cb, P, Bg, nzb, b_ones,
+                     nza, nblk, R);
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
 
 int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
-                         int b_ones, hipStream_t s) {
+                         int b_ones, hipStream_t s, int* nblk_used) {
   const int Ca = A.total();
   const int MA = min(cdiv(Ca, 16), 3), NB = min(cdiv(Cb, 16), 6);
   // 49..80 A channels against 17..80 B channels: half-length tiles hold all of A and B in LDS at once -- ONE pass over
@@ -561,24 +586,24 @@ int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, i
   // [64 x 80] blocks below) nor for a B of one tile (re-reading it is cheap: 64 -> 84 us).
   if (NB >= 2 && NB <= 5 && Ca > 48 && Ca <= 80) {
     switch (NB) {
-      case 2: return launch_chanpair_t<5, 2, false, 128>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
-      case 3: return launch_chanpair_t<5, 3, false, 128>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
-      case 4: return launch_chanpair_t<5, 4, false, 128>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
-      default: return launch_chanpair_t<5, 5, false, 128>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
+      case 2: return launch_chanpair_t<5, 2, false, 128>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used);
+      case 3: return launch_chanpair_t<5, 3, false, 128>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used);
+      case 4: return launch_chanpair_t<5, 4, false, 128>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used);
+      default: return launch_chanpair_t<5, 5, false, 128>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used);
     }
   }
   // 64 A channels per z-block where that saves a pass over B (and the [64 + 16 NB] rows fit LDS: NB <= 5)
   if (NB <= 5 && cdiv(Ca, 64) < cdiv(Ca, 48)) {
     switch (NB) {
-      case 1: return launch_chanpair_t<4, 1, false>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
-      case 2: return launch_chanpair_t<4, 2, false>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
-      case 3: return launch_chanpair_t<4, 3, false>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
-      case 4: return launch_chanpair_t<4, 4, false>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
-      default: return launch_chanpair_t<4, 5, false>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
+      case 1: return launch_chanpair_t<4, 1, false>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used);
+      case 2: return launch_chanpair_t<4, 2, false>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used);
+      case 3: return launch_chanpair_t<4, 3, false>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used);
+      case 4: return launch_chanpair_t<4, 4, false>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used);
+      default: return launch_chanpair_t<4, 5, false>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used);
     }
   }
 #define MSGAT_CP(ma, nb) \
-  if (MA == ma && NB == nb) return launch_chanpair_t<ma, nb>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
+  if (MA == ma && NB == nb) return launch_chanpair_t<ma, nb>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used);
   MSGAT_CP(1, 1) MSGAT_CP(1, 2) MSGAT_CP(1, 3) MSGAT_CP(1, 4) MSGAT_CP(1, 5) MSGAT_CP(1, 6)
   MSGAT_CP(2, 1) MSGAT_CP(2, 2) MSGAT_CP(2, 3) MSGAT_CP(2, 4) MSGAT_CP(2, 5) MSGAT_CP(2, 6)
   MSGAT_CP(3, 1) MSGAT_CP(3, 2) MSGAT_CP(3, 3) MSGAT_CP(3, 4) MSGAT_CP(3, 5) MSGAT_CP(3, 6)

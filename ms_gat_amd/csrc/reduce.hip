@@ -127,8 +127,8 @@ size_t chanpair_partial_floats(int G, int Bg, int Ca, int Cb) {
 int launch_chanpair_seg(const SegList& A, const float* B, float* part, float* dst0, int n0, float* dst1, int n1,
                         int G, int Bg, int Cb, int P, hipStream_t s, int b_ones, ReduceJobs* defer) {
   const int R = G / Bg;
-  const int nblk = chanpair_mfma_blocks(R);
-  const int st = launch_chanpair_mfma(A, B, part, R, Bg, Cb, P, nblk, b_ones, s);
+  int nblk = 0;
+  const int st = launch_chanpair_mfma(A, B, part, R, Bg, Cb, P, chanpair_mfma_blocks(R), b_ones, s, &nblk);
   if (st) return st;
   return launch_reduce_partials(part, R, nblk, A.total() * Cb, dst0, n0, dst1, n1, s, defer);
 }
