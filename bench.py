@@ -114,6 +114,26 @@ class HotPath:
             return [m(x, self.graph) for m, x in zip(self.layers, self.xs)]
 
 
+SETTLE_MS = 60.0   # see settle()
+
+
+def settle(fn, device, ms=SETTLE_MS):
+    """Runs `fn` untimed for about `ms` milliseconds of GPU time.  Coming out of set-up (input generation on the host,
+    graph build) the first ~25 hot-path steps are up to 10 % slower than the rate the GPU then holds (0.81-0.86 ms
+    falling to 0.775 ms over 20 ms: tools/ramp.py) -- power state, cache and allocator warm-up.  The contract's W
+    warm-up steps follow this; with W = 5 (4 ms) alone the K timed steps would sit inside that ramp."""
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    stream = torch.cuda.current_stream(device)
+    done = 0.0
+    while done < ms:
+        t0.record(stream)
+        for _ in range(8):
+            fn()
+        t1.record(stream)
+        t1.synchronize()
+        done += t0.elapsed_time(t1)
+
+
 def timed_steps(fn, steps, warmup, device, barrier):
     """`warmup` untimed calls, then EXACTLY `steps` timed ones bracketed by barrier + synchronize (the contract's
     wall clock), with a HIP event between consecutive steps on the launch stream for the per-step distribution."""
@@ -497,6 +517,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     hp = HotPath(wl, dev, seed=rank)
+    settle(lambda: hp.step(allreduce=multi), dev)
     hot_wall, hot_steps = timed_steps(lambda: hp.step(allreduce=multi), args.steps, args.warmup, dev, barrier)
     hot_wall = max_over_ranks(hot_wall)
     workload = (f"{args.workload}: N={wl['N']} nodes, {wl['E']} undirected edges (+self loops, sym-normalised), "
@@ -515,6 +536,7 @@ def main():
                       "parallelism": (f"batch-sharded x{world}, one flat all-reduce of the hot path's parameter gradients "
                                       f"per step ({hp.sync.nbytes} bytes)" if world > 1 else "single GPU (batch-sharded x1)")},
            "node_updates_per_s": round(value * wl["R"] * wl["T"] * wl["N"], 1),
+           "settle_ms_before_warmup": SETTLE_MS,   # untimed steps in front of the W warm-up steps (clock / cache ramp)
            "launch": ("torch.distributed.run" if launched else "forced process group" if FORCE_DIST else "plain"),
            "transport": (("gloo, all ranks share cuda:0 (REHEARSAL, not a scaling measurement)" if SHARE_GPU else "rccl")
                          if multi else None)}
