@@ -548,6 +548,7 @@ class Trainer(Engine):
         on_gpu = next(model.parameters()).is_cuda
         if hip_graph and not on_gpu:
             raise ValueError("hip_graph=True needs the model on the GPU")
+        parallel.sync_parameters(model)     # data-parallel replicas start from rank 0's weights (no-op for one process)
         adam = FlatAdam if on_gpu else optim.Adam
         self.optimizer = adam(model.parameters(), lr=1e-3, weight_decay=5e-4)
         self.scheduler = lr_scheduler.StepLR(self.optimizer, step_size=30, gamma=0.1)

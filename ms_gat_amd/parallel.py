@@ -51,6 +51,25 @@ def shard_batch(tensors: Sequence[torch.Tensor], rank: int, world: int) -> List[
     return [t[lo:hi] for t in tensors]
 
 
+def sync_parameters(module: torch.nn.Module, src: int = 0) -> None:
+    """Every rank starts from rank `src`'s parameters and buffers (what `nn.DataParallel` gets for free by replicating
+    the module from device 0 every iteration, main.py:52-55).  One broadcast per dtype over a flat copy."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    tensors = [t.data for t in list(module.parameters()) + list(module.buffers())]
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault((t.dtype, t.device), []).append(t)
+    with torch.no_grad():
+        for group in by_dtype.values():
+            flat = torch.cat([t.reshape(-1) for t in group])
+            dist.broadcast(flat, src)
+            off = 0
+            for t in group:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+
+
 def gather_scaled(flat: torch.Tensor, grads: Sequence[torch.Tensor], offsets: Sequence[int], weight: float,
                   weight_index: int, cache: "OrderedDict") -> None:
     """flat[offsets[i] : ...] = weight * grads[i] for every gradient and flat[weight_index] = weight, in ONE launch

@@ -138,7 +138,12 @@ def test_graph_validate_rejects_corruption():
     import ms_gat_amd
     from ms_gat_amd import _lib
     g = ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(20, 25, 0))
+    g.validate()
     g.col[3] = 99
+    with pytest.raises(_lib.MsgatError):
+        g.validate()
+    g = ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(20, 25, 0))
+    g.cpos[[0, 1]] = g.cpos[[1, 0]]         # the CSR -> CSC map must invert cperm (the forward scatters E through it)
     with pytest.raises(_lib.MsgatError):
         g.validate()
 

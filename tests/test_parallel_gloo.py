@@ -163,6 +163,31 @@ def test_sharded_batch_sampler_partitions_every_epoch():
             assert (list(again) != per_rank[0]) == shuffle                    # a new permutation per epoch
 
 
+def _sync_worker(rank, world, port, out_dir):
+    from ms_gat_amd import engine
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    parallel.init_from_env("gloo")
+    model = _TinyMSGAT()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(float(rank))                       # the replicas disagree before the trainer is built
+    engine.Trainer(model, 50.0, os.path.join(out_dir, f"s{rank}"))
+    torch.save([p.detach().clone() for p in model.parameters()], os.path.join(out_dir, f"sync_r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_starts_every_replica_from_rank_zero_weights(tmp_path):
+    """nn.DataParallel replicates the module from device 0 (main.py:52-55); one process per GPU must do it itself."""
+    out = str(tmp_path)
+    mp.spawn(_sync_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    a, b = (torch.load(os.path.join(out, f"sync_r{r}.pt"), weights_only=False) for r in (0, 1))
+    want = [p.detach() for p in _TinyMSGAT().parameters()]
+    for p, q, w in zip(a, b, want):
+        assert torch.equal(p, q) and torch.equal(p, w)
+
+
 def _loader_worker(rank, world, port, out_dir):
     from ms_gat_amd import data, engine
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
