@@ -19,7 +19,7 @@ One JSON line (rank 0 prints it; see the repo prompt for the contract).  `value`
 * rank 0 adds `roofline` (attention-aggregate kernel, HIP-event timed on the launch stream), `roofline_dense` (the
   score / column passes against the fp32 matrix-core peak) and -- single GPU only -- `cpu_baseline`
   (oracle/dense_torch.py, the reference's op sequence, on the host cores), the eager PyTorch-ROCm baselines,
-  `full_step_cfg3` and `stress` (configs[4]: N = 8192).
+  `full_step_cfg3`, `pemsd4` (configs[1]: N = 307, B = 64, one relation, against eager) and `stress` (configs[4]: N = 8192).
 
 Launch: `python bench.py --gpus N` starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` by itself
 when N > 1 and no process group environment is present (before anything touches the GPU) and exits with its code;
@@ -468,6 +468,29 @@ def respawn_under_torchrun(args):
     return subprocess.call(cmd, env=env)
 
 
+def pemsd4_object(dev):
+    """configs[1] (PEMSD4: N = 307, 3 features, B = 64, ONE relation): the hot-path step and its forward against the same
+    ops in PyTorch-ROCm eager (the dense [B,N,N] sequence of oracle/dense_torch.py)."""
+    wl = WORKLOADS["pemsd4"]
+    hp = HotPath(wl, dev, seed=0)
+    sync = lambda: torch.cuda.synchronize(dev)  # noqa: E731
+    settle(hp.step, dev, 20.0)
+    wall, per_step = timed_steps(hp.step, 50, 10, dev, sync)
+    _, fwd = timed_steps(hp.forward_only, 30, 5, dev, sync)
+    _, eager_fwd = timed_steps(lambda: dense_reference_step(hp, dev, wl["B"], backward=False), 10, 2, dev, sync)
+    _, eager_all = timed_steps(lambda: dense_reference_step(hp, dev, wl["B"], backward=True), 10, 2, dev, sync)
+    return {
+        "workload": (f"pemsd4: N={wl['N']} nodes, {wl['E']} undirected edges (+self loops), T={wl['T']}, B={wl['B']}, "
+                     f"R={wl['R']} relation, GACN {wl['Cin']}->{wl['Co']} and {wl['hidden']}->{wl['Co']}, forward+backward"),
+        "ms_per_step": round(wall / 50 * 1e3, 4), "ms_per_step_median_hip_events": round(statistics.median(per_step), 4),
+        "samples_per_s": round(wl["B"] / (wall / 50), 2), "forward_ms": round(statistics.median(fwd), 4),
+        "eager_rocm_forward_ms": round(statistics.median(eager_fwd), 3),
+        "eager_rocm_fwd_bwd_ms": round(statistics.median(eager_all), 3),
+        "speedup_vs_eager_rocm_forward": round(statistics.median(eager_fwd) / statistics.median(fwd), 2),
+        "speedup_vs_eager_rocm_fwd_bwd": round(statistics.median(eager_all) / statistics.median(per_step), 2),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -613,6 +636,10 @@ def main():
             out["full_model_error"] = str(e).splitlines()[0][:160]
 
         if args.workload == "pemsd7":
+            try:
+                out["pemsd4"] = pemsd4_object(dev)
+            except RuntimeError as e:
+                out["pemsd4"] = {"error": str(e).splitlines()[0][:160]}
             try:
                 out["stress"] = stress_object(dev)
             except RuntimeError as e:
