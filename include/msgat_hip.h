@@ -371,7 +371,8 @@ int msgat_attention_backward(const msgat_shape_t* shape, const msgat_graph_t* gr
  * TPC's Conv2d(T_in -> T_out, kernel [1, C]) over the transposed activation (src/models/msgat.py:153,
  * applied :158-159):  out[b,n,o] = bias[o] + sum_c sum_t W[o,t,0,c] x[b,c,n,t].
  * x [B,C,N,T]; W in the convolution's own layout [T_out,T,1,C]; out [B,N,T_out] (what the reference has after
- * its squeeze + transpose); T_out <= 16.  Backward: dx [B,C,N,T]; dWc [R,C,T_out,T] (the caller permutes to
+ * its squeeze + transpose); T_out <= 16; `partials` (msgat_head_forward_partial_floats floats) is scratch: the weights
+ * re-ordered to [R,C,T,16] by a small pre-pass, so that the kernel stages them with contiguous copies.  Backward: dx [B,C,N,T]; dWc [R,C,T_out,T] (the caller permutes to
  * the convolution layout); partial buffers sized by the *_partial_floats queries. */
 size_t msgat_head_forward_partial_floats(int32_t B, int32_t C, int32_t N, int32_t T_out);
 int msgat_head_forward(const float* x, const float* W, const float* bias, float* out, float* partials,

@@ -340,6 +340,17 @@ constexpr int kHeadTo = 16;  // T_out <= 16
 constexpr int kHeadFwdCC = 32;   // channels of W staged in LDS at a time (24 KB at T = 12: six blocks per CU)
 constexpr int kHeadFwdUn = 8;    // channels whose loads are in flight together
 
+// Wp[r][c][t][o < 16] = W[r][o][t][0][c] (0 for o >= To): the convolution's weights in the order the kernels stage them.
+// Staged straight from the convolution layout, every block gathered its 3 x 6144 weights as 4-byte loads at a
+// stride of T*C floats; from Wp a chunk is one contiguous 24 KB copy.
+__global__ __launch_bounds__(kBlock) void k_head_wperm(const float* __restrict__ W, float* __restrict__ Wp, int C, int T,
+                                                       int To, int total) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= total) return;
+  const int o = i % kHeadTo, t = (i / kHeadTo) % T, c = (i / (kHeadTo * T)) % C, r = i / (kHeadTo * T * C);
+  Wp[i] = (o < To) ? W[(((size_t)r * To + o) * T + t) * C + c] : 0.f;
+}
+
 template <int T>
 __global__ __launch_bounds__(kBlock) void k_head_fwd(const float* __restrict__ x, const float* __restrict__ W,
                                                      const float* __restrict__ bias, float* __restrict__ out,
@@ -348,7 +359,7 @@ __global__ __launch_bounds__(kBlock) void k_head_fwd(const float* __restrict__ x
   constexpr int T4 = T / 4;
   __shared__ float Wl[kHeadFwdCC * T * kHeadTo];
   const int b = blockIdx.y;
-  W += (size_t)(b / Bg) * To * T * C;   // weights [R,To,T,1,C], bias [R,To]: Bg samples per relation
+  W += (size_t)(b / Bg) * C * T * kHeadTo;   // pre-laid-out weights Wp [R,C,T,16] (k_head_wperm), bias [R,To]
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const int m = lane & 15, kq = lane >> 4;
   const int n0 = (blockIdx.x * (kBlock / kWave) + wave) * 16;
@@ -357,10 +368,8 @@ __global__ __launch_bounds__(kBlock) void k_head_fwd(const float* __restrict__ x
   for (int c0 = 0; c0 < C; c0 += kHeadFwdCC) {
     const int cn = min(kHeadFwdCC, C - c0);
     __syncthreads();  // the previous chunk's weights are no longer read
-    for (int i = threadIdx.x; i < kHeadFwdCC * T * kHeadTo; i += kBlock) {
-      const int c = i / (T * kHeadTo), t = (i / kHeadTo) % T, o = i % kHeadTo;
-      Wl[i] = (c < cn && o < To) ? W[((size_t)o * T + t) * C + c0 + c] : 0.f;  // W is [To][T][1][C]
-    }
+    for (int i = threadIdx.x; i < kHeadFwdCC * T * kHeadTo; i += kBlock)   // one contiguous copy (Wp is zero past To)
+      Wl[i] = (i < cn * T * kHeadTo) ? W[(size_t)c0 * T * kHeadTo + i] : 0.f;
     __syncthreads();
     const int kqc = min(kq, T4 - 1);
     const float kmask = kq < T4 ? 1.f : 0.f;
@@ -467,7 +476,12 @@ __global__ __launch_bounds__(kBlock) void k_head_dW(const float* __restrict__ do
   }
 }
 
-size_t head_fwd_partial_floats(int B, int C, int N, int To) { return (size_t)B * cdiv(C, kHeadCC) * N * To; }
+// the buffer holds the pre-laid-out weights [R,C,T,16] (R <= B, T <= 16); never smaller than the channel-chunk partials
+// of the VALU form it was first sized for
+size_t head_fwd_partial_floats(int B, int C, int N, int To) {
+  const size_t old = (size_t)B * cdiv(C, kHeadCC) * N * To, wp = (size_t)B * C * 16 * kHeadTo;
+  return old > wp ? old : wp;
+}
 size_t head_dw_partial_floats(int C, int T, int To, int R) { return (size_t)R * C * kHeadChunks * To * T; }
 
 #define MSGAT_T_SWITCH(T, CALL)                 \
@@ -481,10 +495,14 @@ size_t head_dw_partial_floats(int C, int T, int To, int R) { return (size_t)R * 
 
 int launch_head_fwd(const float* x, const float* W, const float* bias, float* out, float* part, int B, int C, int N,
                     int T, int To, int R, hipStream_t s) {
-  (void)part;  // the matrix-core form needs no partials; the argument stays for the ABI
+  // the matrix-core form needs no channel-chunk partials; the buffer holds the weights in staging order
   const int Bg = B / R;
+  const int total = R * C * T * kHeadTo;
+  if ((size_t)total > head_fwd_partial_floats(B, C, N, To)) return MSGAT_ERR_WORKSPACE;
+  hipLaunchKernelGGL(k_head_wperm, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, s, W, part, C, T, To, total);
+  MSGAT_CHECK_LAUNCH();
   dim3 grid(cdiv(N, 16 * (kBlock / kWave)), B);
-  MSGAT_T_SWITCH(T, hipLaunchKernelGGL(k_head_fwd<TT>, grid, dim3(kBlock), 0, s, x, W, bias, out, C, N, To, Bg));
+  MSGAT_T_SWITCH(T, hipLaunchKernelGGL(k_head_fwd<TT>, grid, dim3(kBlock), 0, s, x, part, bias, out, C, N, To, Bg));
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
