@@ -11,6 +11,7 @@
 //   backward  dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w
 //             dw[t] = sum_rows dy * xhat,  db[t] = sum_rows dy     (per-block partials, fixed-order sum)
 #include "common.hpp"
+#include "rowtile.hpp"
 
 namespace msgat {
 
@@ -51,16 +52,24 @@ __global__ __launch_bounds__(kBlock) void k_ln_fwd(const float* __restrict__ x, 
   // blockIdx.y = relation (parameter set): its `rows` rows are contiguous, its weight / bias are row y of [R,T]
   x += (size_t)blockIdx.y * rows * T;
   y += (size_t)blockIdx.y * rows * T;
+  __shared__ float4 tiles[kBlock / kWave][RowTile<T>::kFloat4s];
+  const int wave = threadIdx.x >> 6;
+  const RowTile<T> rt(tiles[wave], threadIdx.x & (kWave - 1));
   float wv[T], bv[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) { wv[t] = w ? w[blockIdx.y * T + t] : 1.f; bv[t] = b ? b[blockIdx.y * T + t] : 0.f; }
-  for (long long r = (long long)blockIdx.x * kBlock + threadIdx.x; r < rows; r += (long long)gridDim.x * kBlock) {
+  // a wave owns 64 consecutive rows per trip (lane = row), moved in flat order: rowtile.hpp
+  for (long long r0 = ((long long)blockIdx.x * (kBlock / kWave) + wave) * kWave; r0 < rows;
+       r0 += (long long)gridDim.x * kBlock) {
+    const int nf = (int)min((long long)kWave, rows - r0) * (T / 4);
+    float4 in[T / 4];
+    rt.fetch(x + r0 * T, nf, in);
     float v[T];
-    load_row<T>(x + r * T, v);
+    rt.to_row(in, v);
     const float rstd = centre_row<T>(v, eps);
 #pragma unroll
     for (int t = 0; t < T; ++t) v[t] = fmaf(v[t] * rstd, wv[t], bv[t]);
-    store_row<T>(y + r * T, v);
+    rt.store(y + r0 * T, nf, v);
   }
 }
 
@@ -74,13 +83,27 @@ __global__ __launch_bounds__(kBlock) void k_ln_bwd(const float* __restrict__ x, 
   dy += (size_t)blockIdx.y * rows * T;
   dx += (size_t)blockIdx.y * rows * T;
   if (add != nullptr) add += (size_t)blockIdx.y * rows * T;
+  __shared__ float4 tiles[kBlock / kWave][RowTile<T>::kFloat4s];
+  const RowTile<T> rt(tiles[threadIdx.x >> 6], threadIdx.x & (kWave - 1));
   float wv[T], dw[T], db[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) { wv[t] = w ? w[blockIdx.y * T + t] : 1.f; dw[t] = 0.f; db[t] = 0.f; }
-  for (long long r = (long long)blockIdx.x * kBlock + threadIdx.x; r < rows; r += (long long)gridDim.x * kBlock) {
+  for (long long r0 = ((long long)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * kWave; r0 < rows;
+       r0 += (long long)gridDim.x * kBlock) {
+    const int nf = (int)min((long long)kWave, rows - r0) * (T / 4);
+    const bool live = (long long)(threadIdx.x & (kWave - 1)) < rows - r0;   // lanes past the last row contribute nothing
+    // all streams requested before the first one is consumed (flat order, rowtile.hpp)
+    float4 xin[T / 4], gin[T / 4], ain[T / 4];
+    rt.fetch(x + r0 * T, nf, xin);
+    rt.fetch(dy + r0 * T, nf, gin);
+    if (add != nullptr) rt.fetch(add + r0 * T, nf, ain);   // kernel-uniform
     float xv[T], gv[T];
-    load_row<T>(x + r * T, xv);
-    load_row<T>(dy + r * T, gv);
+    rt.to_row(xin, xv);
+    rt.to_row(gin, gv);
+    if (!live) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) { xv[t] = 0.f; gv[t] = 0.f; }
+    }
     unsigned positive = 0;  // x > 0, per element: x is a ReLU output when relu_mask is set
 #pragma unroll
     for (int t = 0; t < T; ++t) positive |= (xv[t] > 0.f ? 1u : 0u) << t;
@@ -101,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void k_ln_bwd(const float* __restrict__ x, 
     for (int t = 0; t < T; ++t) gv[t] = rstd * (gv[t] - s1 - xv[t] * s2);
     if (add != nullptr) {  // the gradient that reached x along its other path (MEAM's residual convolution reads x too)
       float av[T];
-      load_row<T>(add + r * T, av);
+      rt.to_row(ain, av);
 #pragma unroll
       for (int t = 0; t < T; ++t) gv[t] += av[t];
     }
@@ -109,7 +132,7 @@ __global__ __launch_bounds__(kBlock) void k_ln_bwd(const float* __restrict__ x, 
 #pragma unroll
       for (int t = 0; t < T; ++t) gv[t] = ((positive >> t) & 1u) ? gv[t] : 0.f;
     }
-    store_row<T>(dx + r * T, gv);
+    rt.store(dx + r0 * T, nf, gv);
   }
   // block partial of (dw, db): wave shuffle tree, then the 4 waves in a fixed order
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;

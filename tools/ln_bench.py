@@ -24,8 +24,9 @@ def timeit(fn, n=20):
 
 
 dev = torch.device("cuda:0")
+B = int(os.environ.get("LN_BENCH_B", "32"))   # 96 = three stacked relations: 293 MB per tensor, beyond the 256 MB cache
 for C in (3, 72):
-    x = torch.randn(32, C, 883, 12, device=dev, requires_grad=True)
+    x = torch.randn(B, C, 883, 12, device=dev, requires_grad=True)
     w = torch.rand(12, device=dev, requires_grad=True)
     b = torch.rand(12, device=dev, requires_grad=True)
     dy = torch.randn_like(x)
