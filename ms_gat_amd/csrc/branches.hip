@@ -18,6 +18,7 @@
 // Every kernel reads and writes the reference's [B,C,N,T] layout: a lane owns one row of T contiguous
 // floats (T/4 16-byte loads), neighbouring lanes neighbouring rows.  All are HBM-bound.
 #include "common.hpp"
+#include "rowtile.hpp"
 
 namespace msgat {
 
@@ -48,6 +49,7 @@ __global__ __launch_bounds__(kBlock) void k_tmix(const float* __restrict__ src, 
   // src_gs: channels per group of the tensor src is a channel slice of (backward form: the incoming gradient is a
   // slice [:, a:b] of the block's concatenated gradient, read in place)
   __shared__ float Al[K][T][T];
+  __shared__ float4 tiles[kBlock / kWave][RowTile<T>::kFloat4s];
   const int g = blockIdx.y;
   for (int i = threadIdx.x; i < K * T * T; i += kBlock) {
     const int k = i / (T * T), t = (i / T) % T, c = i % T;
@@ -55,10 +57,19 @@ __global__ __launch_bounds__(kBlock) void k_tmix(const float* __restrict__ src, 
     if (BWD) Al[k][c][t] = a; else Al[k][t][c] = a;
   }
   __syncthreads();
-  const int rr = blockIdx.x * kBlock + threadIdx.x;  // row (o, n) of this group
-  if (rr >= Co * N) return;
+  // a wave owns 64 consecutive rows (o, n) of this group, lane = row, moved in flat order (rowtile.hpp)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+  const int rows = Co * N;
+  const int r0 = (blockIdx.x * (kBlock / kWave) + wave) * kWave;
+  if (r0 >= rows) return;                                   // wave-uniform
+  const int nf = min(kWave, rows - r0) * (T / 4);
+  const int rr = min(r0 + lane, rows - 1);                  // lanes past the last row compute it again; nothing is stored
+  const RowTile<T> rt(tiles[wave], lane);
   const int o = rr / N;
   if (!BWD) {
+    float4 in[K][T / 4];
+#pragma unroll
+    for (int k = 0; k < K; ++k) rt.fetch(src + ((size_t)g * K * rows + (size_t)k * rows + r0) * T, nf, in[k]);
     float acc[T];
     const float b = bias ? bias[(g / Bg) * Co + o] : 0.f;  // bias [R,Co], Bg groups per relation
 #pragma unroll
@@ -66,16 +77,18 @@ __global__ __launch_bounds__(kBlock) void k_tmix(const float* __restrict__ src, 
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       float v[T];
-      ld_row<T>(src + ((size_t)g * K * Co * N + (size_t)k * Co * N + rr) * T, v);
+      rt.to_row(in[k], v);
 #pragma unroll
       for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int i = 0; i < T; ++i) acc[t] = fmaf(Al[k][t][i], v[i], acc[t]);
     }
-    st_row<T>(dst + ((size_t)g * Co * N + rr) * T, acc);
+    rt.store(dst + ((size_t)g * rows + r0) * T, nf, acc);
   } else {
+    float4 in[T / 4];
+    rt.fetch(src + ((size_t)g * src_gs * N + r0) * T, nf, in);
     float v[T];
-    ld_row<T>(src + ((size_t)g * src_gs * N + rr) * T, v);
+    rt.to_row(in, v);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       float acc[T];
@@ -85,7 +98,7 @@ __global__ __launch_bounds__(kBlock) void k_tmix(const float* __restrict__ src, 
 #pragma unroll
         for (int t = 0; t < T; ++t) acc[i] = fmaf(Al[k][i][t], v[t], acc[i]);
       }
-      st_row<T>(dst + ((size_t)g * K * Co * N + (size_t)k * Co * N + rr) * T, acc);
+      rt.store(dst + ((size_t)g * K * rows + (size_t)k * rows + r0) * T, nf, acc);
     }
   }
 }

@@ -92,14 +92,13 @@ __global__ __launch_bounds__(kBlock) void k_ln_bwd(const float* __restrict__ x, 
        r0 += (long long)gridDim.x * kBlock) {
     const int nf = (int)min((long long)kWave, rows - r0) * (T / 4);
     const bool live = (long long)(threadIdx.x & (kWave - 1)) < rows - r0;   // lanes past the last row contribute nothing
-    // all streams requested before the first one is consumed (flat order, rowtile.hpp)
-    float4 xin[T / 4], gin[T / 4], ain[T / 4];
-    rt.fetch(x + r0 * T, nf, xin);
-    rt.fetch(dy + r0 * T, nf, gin);
-    if (add != nullptr) rt.fetch(add + r0 * T, nf, ain);   // kernel-uniform
+    // the three input streams are read row-wise (a lane's own row, clamped): routing them through the tile as well
+    // costs 36 more registers in flight and halves the occupancy (52 -> 108 VGPRs: 125 -> 137 us in the step); the
+    // gradient leaves in flat order
+    const long long r = min(r0 + (long long)(threadIdx.x & (kWave - 1)), rows - 1);
     float xv[T], gv[T];
-    rt.to_row(xin, xv);
-    rt.to_row(gin, gv);
+    load_row<T>(x + r * T, xv);
+    load_row<T>(dy + r * T, gv);
     if (!live) {
 #pragma unroll
       for (int t = 0; t < T; ++t) { xv[t] = 0.f; gv[t] = 0.f; }
@@ -124,7 +123,7 @@ __global__ __launch_bounds__(kBlock) void k_ln_bwd(const float* __restrict__ x, 
     for (int t = 0; t < T; ++t) gv[t] = rstd * (gv[t] - s1 - xv[t] * s2);
     if (add != nullptr) {  // the gradient that reached x along its other path (MEAM's residual convolution reads x too)
       float av[T];
-      rt.to_row(ain, av);
+      load_row<T>(add + r * T, av);
 #pragma unroll
       for (int t = 0; t < T; ++t) gv[t] += av[t];
     }
