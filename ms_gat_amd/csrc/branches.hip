@@ -22,21 +22,6 @@
 
 namespace msgat {
 
-template <int T>
-__device__ __forceinline__ void ld_row(const float* __restrict__ p, float (&v)[T]) {
-#pragma unroll
-  for (int t4 = 0; t4 < T / 4; ++t4) {
-    const float4 a = reinterpret_cast<const float4*>(p)[t4];
-    v[4 * t4 + 0] = a.x; v[4 * t4 + 1] = a.y; v[4 * t4 + 2] = a.z; v[4 * t4 + 3] = a.w;
-  }
-}
-template <int T>
-__device__ __forceinline__ void st_row(float* __restrict__ p, const float (&v)[T]) {
-#pragma unroll
-  for (int t4 = 0; t4 < T / 4; ++t4)
-    reinterpret_cast<float4*>(p)[t4] = make_float4(v[4 * t4], v[4 * t4 + 1], v[4 * t4 + 2], v[4 * t4 + 3]);
-}
-
 // ---- time mixing --------------------------------------------------------------------------------------
 // forward  (BWD = false): dst[g,o,n,t]        = bias[o] + sum_k sum_i A[ga,k,t,i] src[g,k*Co+o,n,i]
 // backward (BWD = true):  dst[g,k*Co+o,n,i]   =           sum_t  A[ga,k,t,i] src[g,o,n,t]
@@ -218,17 +203,24 @@ __global__ __launch_bounds__(kBlock) void k_node_pool(const float* __restrict__ 
   w += (size_t)(blockIdx.x / spr) * N;  // weights [R,N]: spr slabs per relation
   // C > 0: slab (g, c) of a channel slice of a [G, gs, N, T] tensor, read in place
   const size_t xs = (C > 0) ? (size_t)(blockIdx.x / C) * gs + (blockIdx.x % C) : sl;
+  __shared__ float4 tiles[kBlock / kWave][RowTile<T>::kFloat4s];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const RowTile<T> rt(tiles[wave], lane);
   float acc[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) acc[t] = 0.f;
-  for (int n = threadIdx.x; n < N; n += kBlock) {
+  // a wave takes 64 consecutive nodes = rows per trip, read in flat order (rowtile.hpp)
+  for (int n0 = wave * kWave; n0 < N; n0 += kBlock) {
+    const int nf = min(kWave, N - n0) * (T / 4);
+    float4 in[T / 4];
+    rt.fetch(x + (xs * N + n0) * T, nf, in);
+    const float wl = w[min(n0 + lane, N - 1)];
+    const float wn = n0 + lane < N ? wl : 0.f;
     float v[T];
-    ld_row<T>(x + (xs * N + n) * T, v);
-    const float wn = w[n];
+    rt.to_row(in, v);
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = fmaf(wn, v[t], acc[t]);
   }
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     float a = acc[t];
@@ -247,21 +239,28 @@ template <int T>
 __global__ __launch_bounds__(kBlock) void k_node_pool_dx(const float* __restrict__ w, const float* __restrict__ dp,
                                                          const float* __restrict__ add, float* __restrict__ dx, int N,
                                                          int spr) {
+  __shared__ float4 tiles[kBlock / kWave][RowTile<T>::kFloat4s];
   const size_t sl = blockIdx.x;
   w += (size_t)(blockIdx.x / spr) * N;
-  const int n = blockIdx.y * kBlock + threadIdx.x;
-  if (n >= N) return;
+  // a wave owns 64 consecutive nodes = rows of this slab, moved in flat order (rowtile.hpp)
+  const int lane = threadIdx.x & (kWave - 1);
+  const int n0 = blockIdx.y * kBlock + (int)(threadIdx.x - lane);
+  if (n0 >= N) return;                                      // wave-uniform
+  const int nf = min(kWave, N - n0) * (T / 4);
+  const RowTile<T> rt(tiles[threadIdx.x >> 6], lane);
   float v[T];
-  const float wn = w[n];
+  const float wn = w[min(n0 + lane, N - 1)];
   if (add != nullptr) {
-    ld_row<T>(add + (sl * N + n) * T, v);
+    float4 in[T / 4];
+    rt.fetch(add + (sl * N + n0) * T, nf, in);
+    rt.to_row(in, v);
 #pragma unroll
     for (int t = 0; t < T; ++t) v[t] = fmaf(wn, dp[sl * T + t], v[t]);
   } else {
 #pragma unroll
     for (int t = 0; t < T; ++t) v[t] = wn * dp[sl * T + t];
   }
-  st_row<T>(dx + (sl * N + n) * T, v);
+  rt.store(dx + (sl * N + n0) * T, nf, v);
 }
 
 // dw partial[g*nck + ck, n] = sum_{c in chunk ck} sum_t x[g,c,n,t] dpooled[g,c,t]
@@ -275,16 +274,22 @@ __global__ __launch_bounds__(kBlock) void k_node_pool_dw(const float* __restrict
   const int c0 = ck * kPoolCC, cn = min(kPoolCC, C - c0);
   for (int i = threadIdx.x; i < cn * T; i += kBlock) dl[i / T][i % T] = dp[((size_t)g * C + c0) * T + i];
   __syncthreads();
-  const int n = blockIdx.x * kBlock + threadIdx.x;
-  if (n >= N) return;
+  __shared__ float4 tiles[kBlock / kWave][RowTile<T>::kFloat4s];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int n0 = blockIdx.x * kBlock + (int)(threadIdx.x - lane);   // the wave's 64 nodes: rows read in flat order
+  if (n0 >= N) return;                                              // wave-uniform, after the barrier
+  const int nf = min(kWave, N - n0) * (T / 4);
+  const RowTile<T> rt(tiles[threadIdx.x >> 6], lane);
   float acc = 0.f;
   for (int c = 0; c < cn; ++c) {
+    float4 in[T / 4];
+    rt.fetch(x + (((size_t)g * C + c0 + c) * N + n0) * T, nf, in);
     float v[T];
-    ld_row<T>(x + (((size_t)g * C + c0 + c) * N + n) * T, v);
+    rt.to_row(in, v);
 #pragma unroll
     for (int t = 0; t < T; ++t) acc = fmaf(v[t], dl[c][t], acc);
   }
-  part[((size_t)g * gridDim.y + ck) * N + n] = acc;
+  if (n0 + lane < N) part[((size_t)g * gridDim.y + ck) * N + n0 + lane] = acc;
 }
 
 int launch_node_pool(const float* x, const float* w, float* pooled, long long slabs, int N, int T, int R,
@@ -416,6 +421,7 @@ template <int T>
 __global__ __launch_bounds__(kBlock) void k_head_dx(const float* __restrict__ dout, const float* __restrict__ W,
                                                     float* __restrict__ dx, int C, int N, int To, int Bg) {
   __shared__ float Wl[kHeadCC][T][kHeadTo];
+  __shared__ float4 tiles[kBlock / kWave][RowTile<T>::kFloat4s];
   const int b = blockIdx.z, ck = blockIdx.y;
   W += (size_t)(b / Bg) * To * T * C;
   const int c0 = ck * kHeadCC, cn = min(kHeadCC, C - c0);
@@ -445,7 +451,11 @@ __global__ __launch_bounds__(kBlock) void k_head_dx(const float* __restrict__ do
     if (i < kHeadCC * kHeadTo * T) (&Wl[0][0][0])[i] = wv[k];
   }
   __syncthreads();
-  if (n >= N) return;
+  // a wave's 64 nodes are 64 consecutive rows of every channel: stored in flat order (rowtile.hpp)
+  const int n0 = n - (int)(threadIdx.x & (kWave - 1));
+  if (n0 >= N) return;                                      // wave-uniform
+  const int nf = min(kWave, N - n0) * (T / 4);
+  const RowTile<T> rt(tiles[threadIdx.x >> 6], threadIdx.x & (kWave - 1));
   for (int c = 0; c < cn; ++c) {
     float v[T];
 #pragma unroll
@@ -454,7 +464,7 @@ __global__ __launch_bounds__(kBlock) void k_head_dx(const float* __restrict__ do
 #pragma unroll
       for (int o = 0; o < kHeadTo; ++o) v[t] = fmaf(Wl[c][t][o], d[o], v[t]);
     }
-    st_row<T>(dx + (((size_t)b * C + c0 + c) * N + n) * T, v);
+    rt.store(dx + (((size_t)b * C + c0 + c) * N + n0) * T, nf, v);
   }
 }
 
