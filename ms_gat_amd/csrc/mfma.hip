@@ -545,6 +545,233 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
   MSGAT_STAMP(5);
 }
 
+// ---- the same contraction with LDS-DMA staging ---------------------------------------------------------------------
+// k_chanpair_mfma keeps a tile in flight in REGISTERS, and its wide channel blocks have registers for one tile only:
+// the next fetch cannot be issued before the previous tile has been written to LDS, so each tile pays its whole load
+// time (5-7 us under load) plus the write pass in series with nothing -- 269 us for the [98 x 73] contraction whose
+// load side alone takes 160 us and whose multiply side alone 180 us (profiles/r03/contraction_lab.txt).  Here the
+// tiles go from global memory straight into LDS (global_load_lds_dwordx4: no destination registers) into a ring of
+// NBUF buffers of TILE positions: while tile t is multiplied, tiles t+1 .. t+NBUF-2 are landing, and the accumulators
+// are all the registers the kernel needs -- a [112 x 80] channel block fits, so the 98-channel gradient is ONE pass.
+//   - one wave-instruction moves 1 KiB = the 4*TILE-byte pieces of 1024 / (4 TILE) consecutive rows (a "row group").
+//     The LDS image of an instruction is lane-linear (base in M0 + 16 B x lane), so the group's pieces are adjacent;
+//     a 16-B pad follows each group.  Rows of a group would hit the same banks: the float4 slots of row r are
+//     XOR-swizzled on the SOURCE side (lane l of the piece fetches float4 l ^ swz(r)), and the fragment reads apply
+//     the same XOR -- conflict-free;
+//   - order (NBUF >= 3): counted s_waitcnt vmcnt (own pieces of tile t landed, later tiles may still fly), barrier
+//     (everyone's pieces landed, everyone is done with tile t-1), re-issue into tile t-1's buffer, multiply.  With
+//     two buffers a second barrier separates the multiply from the re-issue.  Raw s_barrier with lgkmcnt(0) only:
+//     __syncthreads() would drain vmcnt;
+//   - positions past the end of a row cannot be zeroed on the way (no registers): their lanes re-read in-row data and
+//     the A fragment of those k-steps is zeroed instead (partial tiles only: the last tile of a group);
+//   - row groups past the block's last row are not staged: their instructions (kept, so that every wave's vmcnt
+//     arithmetic is the same) fetch one 16-B word into a dump group.
+constexpr int kGGroupF4 = 64 + 1;  // float4s per row group: 1 KiB + 16 B
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int MA, int NB, int TILE, int NBUF>
+__global__ __launch_bounds__(kCpBlock) void k_chanpair_glds(
+    SegList A, const float* __restrict__ B, float* __restrict__ part, int Cb, int P, int Bg, int nzb, int b_ones,
+    int nza, int nblk, int R) {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+  static_assert(TILE == 64 || TILE == 128, "row pieces of 256 or 512 bytes");
+  constexpr int kRPI = 256 / TILE;                 // rows per wave-instruction (row group)
+  constexpr int kLPR = TILE / 4;                   // lanes (float4s) per row piece
+  constexpr int kPPW = TILE / kCpWaves;            // positions per wave and tile
+  constexpr int kMaxGroups = (MA + NB) * 16 / kRPI;
+  constexpr int RPW = (kMaxGroups + kCpWaves - 1) / kCpWaves;  // LDS-DMA instructions per wave and tile
+  const int Cbr = Cb - b_ones;
+  const int Ca = A.total();
+  extern __shared__ float4 lds4[];
+  const int nz = nza * nzb;
+  int bx, r, zb;
+  if (nz > 1) {  // XCD-paired one-dimensional grid: see k_chanpair_mfma
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    zb = slot % nz;
+    const int k = (slot / nz) * 8 + xcd;
+    if (k >= nblk * R) return;
+    r = k / nblk;
+    bx = k - r * nblk;
+  } else {
+    bx = blockIdx.x;
+    r = blockIdx.y;
+    zb = 0;
+  }
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int j = lane & 15, kq = lane >> 4;
+  const int a_per = cdiv(Ca, nza);
+  const int a0 = (zb / nzb) * a_per;
+  const int c0 = (zb % nzb) * (NB * 16);
+  const int ca = min(a_per, Ca - a0), cb = min(NB * 16, Cb - c0);
+  const int rows = ca + cb;
+  // buffer = the groups of the block's largest z-block (the host sized LDS for that), a constant group (zero row,
+  // ones row), a dump group
+  const int ngroups = cdiv(min(a_per, Ca) + min(NB * 16, Cb), kRPI);
+  const int bufF4 = (ngroups + 2) * kGGroupF4;
+  const int zero_row = ngroups * kRPI, ones_row = zero_row + 1;
+  const int tpg = cdiv(P, TILE);
+  const long long ntot = (long long)Bg * tpg;
+  const int t0 = (int)(ntot * bx / nblk), t1 = (int)(ntot * (bx + 1) / nblk);
+  const int ntile = t1 - t0;
+  float* out = part + ((size_t)r * nblk + bx) * ((size_t)Ca * Cb);
+  if (ntile <= 0) {  // (never with the launcher's block counts) this block's partial is zero
+    for (int e = threadIdx.x; e < ca * cb; e += kCpBlock) out[(size_t)(a0 + e / cb) * Cb + c0 + e % cb] = 0.f;
+    return;
+  }
+
+  if (threadIdx.x < 2 * kLPR) {  // the constant rows, in every buffer
+    const float4 v = (int)threadIdx.x < kLPR ? f4zero() : make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+    for (int b = 0; b < NBUF; ++b) lds4[b * bufF4 + ngroups * kGGroupF4 + threadIdx.x] = v;
+  }
+
+  // staging plan: instruction k of this wave fills group wave + 8k; lane l fetches float4 ((l % kLPR) ^ swz(row)) of
+  // row group * kRPI + l / kLPR
+  auto swz = [](int row) { return (row % kRPI) * (16 / kRPI); };   // in float4 slots: row i of a group sits 64 i / kRPI banks further
+  const int lrow = lane / kLPR, lcol = lane % kLPR;
+  const float* src[RPW];
+  int gstride[RPW], lcs[RPW], grp[RPW];
+#pragma unroll
+  for (int k = 0; k < RPW; ++k) {
+    const int g = wave + kCpWaves * k;
+    const int rr = g * kRPI + lrow;
+    const bool live = rr < rows;
+    const int row = live ? rr : 0;
+    const size_t g0 = (size_t)r * Bg;
+    const float* p;
+    if (row < ca) {
+      const int a = a0 + row;
+      int sk = 0;
+#pragma unroll
+      for (int i = 1; i < kMaxSeg; ++i) sk += (i < A.n && a >= A.begin[i]) ? 1 : 0;
+      p = A.row((int)g0, a, P);
+      int gs = A.gstride[0];
+#pragma unroll
+      for (int i = 1; i < kMaxSeg; ++i) gs = (i == sk) ? A.gstride[i] : gs;
+      gstride[k] = gs * P;
+    } else {
+      p = B + (g0 * Cbr + min(c0 + row - ca, Cbr - 1)) * P;
+      gstride[k] = Cbr * P;
+    }
+    src[k] = p;
+    lcs[k] = live ? 4 * (lcol ^ swz(rr)) : -1;              // float offset inside the piece; -1: fetch one word only
+    grp[k] = g * kRPI < rows ? g : ngroups + 1;             // wave-uniform: groups without a live row go to the dump
+  }
+  auto issue = [&](int t) {  // t relative to t0, clamped to the run; buffer t % NBUF
+    const int tau = t0 + min(t, ntile - 1);
+    const int b = tau / tpg;
+    const int p0 = (tau - b * tpg) * TILE;
+    float4* buf = lds4 + (t % NBUF) * bufF4;
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+      const int poff = lcs[k] < 0 ? 0 : min(p0 + lcs[k], P - 4);   // inside the row (P % 4 == 0); masked in multiply()
+      const float* gp = src[k] + (size_t)b * gstride[k] + poff;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)gp, (lds_ptr_t)(buf + grp[k] * kGGroupF4), 16, 0, 0);
+    }
+  };
+
+  // fragment words: row `row`, positions kPPW * wave + 4 qq + kq -> float4 slot ((kPPW / 4) * wave ^ swz) + qq
+  const float* ldsw = reinterpret_cast<const float*>(lds4);
+  auto frag_word = [&](int row) {
+    return (row / kRPI) * (kGGroupF4 * 4) + (row % kRPI) * TILE + 4 * (((kPPW / 4) * wave) ^ swz(row)) + kq;
+  };
+  int aw[MA], bw[NB];
+#pragma unroll
+  for (int ma = 0; ma < MA; ++ma) aw[ma] = frag_word((ma * 16 + j < ca) ? ma * 16 + j : zero_row);
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int cl = nb * 16 + j;
+    bw[nb] = frag_word((cl < cb) ? ((b_ones && c0 + cl == Cbr) ? ones_row : ca + cl) : zero_row);
+  }
+
+  f32x4 acc[MA][NB];
+#pragma unroll
+  for (int ma = 0; ma < MA; ++ma)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[ma][nb] = zero4();
+
+  auto multiply = [&](int t) {
+    const int tau = t0 + t;
+    const int p0 = (tau - (tau / tpg) * tpg) * TILE;
+    const bool partial = p0 + TILE > P;   // wave-uniform: the last tile of a group
+    const float* w = ldsw + (t % NBUF) * (bufF4 * 4);
+#pragma unroll
+    for (int qq = 0; qq < kPPW / 4; ++qq) {
+      float av[MA], bv[NB];
+#pragma unroll
+      for (int ma = 0; ma < MA; ++ma) av[ma] = w[aw[ma] + 4 * qq];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) bv[nb] = w[bw[nb] + 4 * qq];
+      if (partial) {
+        const float keep = (p0 + kPPW * wave + 4 * qq + kq < P) ? 1.f : 0.f;
+#pragma unroll
+        for (int ma = 0; ma < MA; ++ma) av[ma] *= keep;
+      }
+#pragma unroll
+      for (int ma = 0; ma < MA; ++ma)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[ma][nb] = mfma16(av[ma], bv[nb], acc[ma][nb]);
+    }
+  };
+
+#pragma unroll
+  for (int t = 0; t < NBUF - 1; ++t) issue(t);
+  if (NBUF == 2) {
+    issue(1);
+    for (int t = 0; t < ntile; ++t) {
+      wait_vmcnt<RPW>();   // tile t landed, tile t + 1 may be in flight
+      lds_barrier();
+      multiply(t);
+      lds_barrier();       // the buffer is free
+      issue(t + 2);
+    }
+  } else {
+    for (int t = 0; t < ntile; ++t) {
+      wait_vmcnt<(NBUF - 2) * RPW>();   // this wave's pieces of tile t are in LDS (later tiles may be in flight)
+      lds_barrier();                    // ... and every other wave's; and nobody reads tile t-1's buffer any more
+      issue(t + NBUF - 1);              // into tile t-1's buffer (clamped index: the last trips re-read the last tile)
+      multiply(t);
+    }
+  }
+  wait_vmcnt<0>();
+
+  // sum the 8 waves' accumulators in a fixed order, kRedTiles 16x16 tiles at a time (the launcher checks that
+  // kRedTiles * 8 KiB fit the staging buffers)
+  constexpr int kTiles = MA * NB;
+  constexpr int kRedTiles = kTiles < 8 ? kTiles : 8;
+  float* red = reinterpret_cast<float*>(lds4) + (size_t)wave * (kRedTiles * 256);
+  const float* all = reinterpret_cast<const float*>(lds4);
+#pragma unroll
+  for (int t0r = 0; t0r < kTiles; t0r += kRedTiles) {
+    __syncthreads();
+#pragma unroll
+    for (int ma = 0; ma < MA; ++ma)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int tile = ma * NB + nb;
+        if (tile >= t0r && tile < t0r + kRedTiles) {
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) red[((tile - t0r) * 4 + reg) * 64 + lane] = acc[ma][nb][reg];
+        }
+      }
+    __syncthreads();
+    const int ntl = (kTiles - t0r < kRedTiles) ? kTiles - t0r : kRedTiles;
+    for (int e = threadIdx.x; e < ntl * 256; e += kCpBlock) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < kCpWaves; ++w) v += all[w * (kRedTiles * 256) + e];
+      const int el = e & 63, reg = (e >> 6) & 3, tile = t0r + (e >> 8);
+      const int ma = tile / NB, nb = tile - ma * NB;
+      const int a = a0 + ma * 16 + 4 * (el >> 4) + reg;
+      const int c = c0 + nb * 16 + (el & 15);
+      if (a < a0 + ca && c < c0 + cb) out[(size_t)a * Cb + c] = v;
+    }
+  }
+}
+
 // blocks per relation: one block per CU in total (the kernel is built for one resident block per CU)
 int chanpair_mfma_blocks(int R) {
   int dev = 0, ncu = 0;
@@ -576,10 +803,54 @@ static int launch_chanpair_t(const SegList& A, const float* B, float* part, int 
   return MSGAT_OK;
 }
 
+// LDS bytes of the LDS-DMA form for a channel matrix cut into nza x nzb z-blocks
+template <int MA, int NB, int TILE, int NBUF>
+static size_t chanpair_glds_lds(int Ca, int Cb) {
+  const int nza = cdiv(Ca, MA * 16);
+  const int rows = min(cdiv(Ca, nza), Ca) + min(NB * 16, Cb);
+  return sizeof(float4) * (size_t)NBUF * (cdiv(rows, 256 / TILE) + 2) * kGGroupF4;
+}
+
+template <int MA, int NB, int TILE, int NBUF>
+static int launch_chanpair_glds_t(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P,
+                                  int nblk_max, int b_ones, hipStream_t s, int* nblk_used) {
+  const int Ca = A.total();
+  const int nza = cdiv(Ca, MA * 16), nzb = cdiv(Cb, NB * 16);
+  const int nz = nza * nzb;
+  const int nblk = nz > 1 ? max(1, nblk_max / nz) : nblk_max;
+  *nblk_used = nblk;
+  const size_t lds = chanpair_glds_lds<MA, NB, TILE, NBUF>(Ca, Cb);
+  if (lds > (size_t)kLdsMax || lds < (size_t)(MA * NB < 8 ? MA * NB : 8) * kCpWaves * 1024) return MSGAT_ERR_UNSUPPORTED;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chanpair_glds<MA, NB, TILE, NBUF>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
+  }
+  const dim3 grid = nz > 1 ? dim3((unsigned)cdiv(nblk * R, 8) * 8 * nz) : dim3(nblk, R, 1);
+  hipLaunchKernelGGL((k_chanpair_glds<MA, NB, TILE, NBUF>), grid, dim3(kCpBlock), lds, s, A, B, part, Cb, P, Bg, nzb,
+                     b_ones, nza, nblk, R);
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
+}
+
 int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
                          int b_ones, hipStream_t s, int* nblk_used) {
   const int Ca = A.total();
   const int MA = min(cdiv(Ca, 16), 3), NB = min(cdiv(Cb, 16), 6);
+#ifndef MSGAT_NO_GLDS
+  // LDS-DMA staging where two half-length tiles of all rows fit LDS (MA + NB <= 9) and every group spans several tiles
+  if (P % 4 == 0 && P >= 512 && Cb > 64 && Cb <= 80) {
+    // 17..32 against 65..80 channels (dW, dalpha of the GACN projection): three 128-position buffers
+    if (Ca > 16 && Ca <= 32 && chanpair_glds_lds<2, 5, 128, 3>(Ca, Cb) <= (size_t)kLdsMax)
+      return launch_chanpair_glds_t<2, 5, 128, 3>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used);
+    // 49..80 against 65..80 (the residual convolution's weight gradient, 72 x 73): one [80 x 80] block
+    if (Ca > 48 && Ca <= 80 && chanpair_glds_lds<5, 5, 64, 3>(Ca, Cb) <= (size_t)kLdsMax)
+      return launch_chanpair_glds_t<5, 5, 64, 3>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used);
+    // 81..112 against 65..80 (the merged channel mixing of a MEAM block): ONE [112 x 80] block, three 64-position buffers
+    if (Ca > 80 && Ca <= 112 && chanpair_glds_lds<7, 5, 64, 3>(Ca, Cb) <= (size_t)kLdsMax)
+      return launch_chanpair_glds_t<7, 5, 64, 3>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used);
+  }
+#endif
   // 49..80 A channels against 17..80 B channels: half-length tiles hold all of A and B in LDS at once -- ONE pass over
   // both operands where the [48 x 96] blocks take two z-blocks that each re-read B (72 x 73, the residual tail's weight
   // gradient: 286 -> 174 us).  Not for wider A (a [112 x 80] block spills and ran at 372 us against 344 for the two
