@@ -6,7 +6,7 @@ CACN :83-100, MEAM tail :130-131.  Tolerance 1e-4 relative (the path's bar)."""
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import record_err, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -386,3 +386,53 @@ def test_temporal_attention_taps_are_one_launch_each_way(R, Bg, N, K, T, dil):
     assert ops.causal_shift_taps(T, 2, _dev()) is ops.causal_shift_taps(T, 2, _dev())
     eye = torch.eye(T)
     assert torch.equal(ops.causal_shift_taps(T, 2, _dev()).cpu()[0, 0], torch.nn.functional.pad(eye[: T - 2], (0, 0, 2, 0)))
+
+
+# ---- channel-pair contraction (the weight gradients of the channel mixings) through the C ABI ------------------------
+# (Ca segments, Cb, ones, N): every staging form of launch_chanpair_mfma -- LDS-DMA rings of 128- and 64-position tiles
+# ([32 x 80], [80 x 80], [112 x 80] channel blocks), the register-staged kernel (narrow B, short rows) -- with rows whose
+# length is no multiple of the tile (N T = 10596 = 82 x 128 + 100 = 165 x 64 + 36; 13 x 12 = 156) and channel counts
+# that leave rows of the last 16-row fragment and whole row groups empty.
+@pytest.mark.parametrize("segs,Cb,ones,N,Bg", [
+    ((24, 1), 72, 0, 883, 2),             # dW | dalpha of the GACN projection: k_chanpair_glds<2,5,128,3>
+    ((24, 48, 24, 1, 1), 72, 1, 883, 2),  # merged channel mixing of a MEAM block (98 x 73): <7,5,64,3>
+    ((72,), 72, 1, 883, 1),               # residual convolution (72 x 73): <5,5,64,3>
+    ((17,), 65, 0, 307, 3),               # lower edges of the [32 x 80] form
+    ((81,), 79, 1, 64, 2),                # P = 768: six tiles per group; 81 rows = five full fragments + 1
+    ((24, 1), 72, 0, 13, 2),              # P = 156 < 512: register-staged kernel
+    ((48,), 24, 1, 883, 2),               # narrow B: register-staged kernel
+])
+def test_contract_segments_matches_float64_and_repeats_bit_for_bit(segs, Cb, ones, N, Bg):
+    import ctypes as C
+    from ms_gat_amd import _lib
+    L = _lib.lib()
+    dev, R, T = _dev(), 2, 12
+    G, Ca = R * Bg, sum(segs)
+    g = torch.Generator().manual_seed(11)
+    # every segment is a channel slice of a wider tensor (group stride > channels), as the model passes them
+    wide = [torch.randn(G, c + 3, N, T, generator=g).to(dev) for c in segs]
+    B = torch.randn(G, Cb, N, T, generator=g).to(dev)
+    arr = (_lib.Seg * len(segs))()
+    for i, (t, c) in enumerate(zip(wide, segs)):
+        arr[i] = _lib.Seg(t[:, 1:].data_ptr(), c, c + 3)
+    nfl = int(L.msgat_contract_segments_partial_floats(R, Ca, Cb + ones))
+    part = torch.empty(max(nfl, 1), device=dev)
+    outs = []
+    for rep in range(4):   # a race between the LDS-DMA ring and its readers would differ from run to run
+        part.fill_(float("nan"))
+        dst = torch.full((R, Ca, Cb + ones), float("nan"), device=dev)
+        st = L.msgat_contract_segments(R, Bg, N, T, arr, len(segs), B.data_ptr(), Cb, ones, part.data_ptr(),
+                                       dst.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(st, "msgat_contract_segments")
+        outs.append(dst)
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    A64 = torch.cat([t[:, 1:1 + c] for t, c in zip(wide, segs)], dim=1).double().view(R, Bg, Ca, N * T)
+    B64 = B.double().view(R, Bg, Cb, N * T)
+    if ones:
+        B64 = torch.cat([B64, torch.ones(R, Bg, 1, N * T, device=dev, dtype=torch.float64)], dim=2)
+    want = torch.einsum("rgap,rgcp->rac", A64, B64)
+    err = rel_err(outs[0], want)
+    record_err(f"contract_segments {segs}x{Cb}+{ones} N={N}", "dst", err, 1e-5)
+    assert err < 1e-5
