@@ -673,10 +673,18 @@ extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t*
     }
     // the contraction (reads only) goes first: behind the projection it would stream x while the 72-channel dx the
     // projection has just written is still draining to HBM
-    st = launch_chanpair(dvb, dq, io->x, cpp, io->dW, Co * C, io->dalpha, C, G, Bg, Co + 1, C, P, s, &jobs);
+    // ... and where its channel block leaves the registers (LDS-DMA staging), the same pass also writes dx: du and dq
+    // are read once
+    int both = 0;
+    st = launch_chanpair_mix(dvb, dq, io->x, io->W, io->alpha, io->dx, cpp, io->dW, io->dalpha, G, Bg, Co, C, P, s, &jobs,
+                             &both);
     if (st) return st;
-    st = launch_project(dvb, io->W, 1, nullptr, io->alpha, dq, io->dx, nullptr, G, Bg, Co, C, P, s);
-    if (st) return st;
+    if (!both) {
+      st = launch_chanpair(dvb, dq, io->x, cpp, io->dW, Co * C, io->dalpha, C, G, Bg, Co + 1, C, P, s, &jobs);
+      if (st) return st;
+      st = launch_project(dvb, io->W, 1, nullptr, io->alpha, dq, io->dx, nullptr, G, Bg, Co, C, P, s);
+      if (st) return st;
+    }
     return launch_reduce_jobs(jobs, s);
   }
   // PLAIN / AGG_FIRST:  dx = E^T dv + alpha (x) dq;  dalpha = dq . x -- from the same kernel (it holds dq) when the

@@ -189,6 +189,8 @@ int chanpair_mfma_blocks(int R);  // blocks (= partials) per relation
 // b_ones: B's last channel (Cb counts it) is a virtual row of ones: part[a, Cb-1] = sum_p A[a,p]
 // nblk: partial blocks per relation the buffer has room for; *nblk_used: how many the launch wrote (fewer when the
 // channel matrix is cut into several z-blocks, which all run at once)
+int launch_chanpair_mix(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
+                        const float* Mw, const float* Mlast, float* mixout, hipStream_t s, int* nblk_used, int* done);
 int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
                          int b_ones, hipStream_t s, int* nblk_used);
 int launch_scores(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW, float* lse,
@@ -255,6 +257,11 @@ size_t chanpair_partial_floats(int G, int Bg, int Ca, int Cb);
 int launch_chanpair(const float* A, const float* Aextra, const float* B, float* part, float* dst0,
                     int n0, float* dst1, int n1, int G, int Bg, int Ca, int Cb, int P,
                     hipStream_t s, ReduceJobs* defer = nullptr);
+// dW | dalpha = [du | dq] x^T and dx = W^T du + alpha (x) dq in ONE pass over du, dq and x (PROJ_FIRST backward); *done = 0
+// and nothing launched when the fused form does not cover the shape
+int launch_chanpair_mix(const float* du, const float* dq, const float* x, const float* W, const float* alpha, float* dx,
+                        float* part, float* dW, float* dalpha, int G, int Bg, int Co, int C, int P, hipStream_t s,
+                        ReduceJobs* defer, int* done);
 int launch_chanpair_seg(const SegList& A, const float* B, float* part, float* dst0, int n0, float* dst1, int n1,
                         int G, int Bg, int Cb, int P, hipStream_t s, int b_ones = 0, ReduceJobs* defer = nullptr);
 // AGG_FIRST backward with few input channels (C <= kAggFirstMaxC): dy = W^T dz and the partials of dW = dz y^T in ONE

@@ -571,10 +571,23 @@ constexpr int kGGroupF4 = 64 + 1;  // float4s per row group: 1 KiB + 16 B
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int MA, int NB, int TILE, int NBUF>
+// MIX: the pass also writes mix[g,c,p] = sum_a Mx[r,a,c] A[g,a,p] -- with A = [du | dq] and Mx = [W | alpha] that is
+// dx = W^T du + alpha (x) dq of the PROJ_FIRST backward (msgat.py:27's autograd), computed from the A tile the
+// contraction has in LDS anyway: du and dq are read once for dW, dalpha AND dx.  Wave w owns positions 16 w .. 16 w + 15
+// of a tile for all channels: D[i = channel][j = position] = sum_a Mx[a][channel] A[a][position], Mx fragments held in
+// registers for the whole run.  The stores count on vmcnt like the LDS-DMA loads (in issue order), so EVERY lane
+// stores every time -- lanes without a valid (channel, position) into `dump` -- and the waits are counted over both.
+struct ChanMix {
+  const float* Mw = nullptr;     // [R, Ca - 1, Cb]
+  const float* Mlast = nullptr;  // [R, Cb]: row Ca - 1 of the matrix
+  float* out = nullptr;          // [G, Cb, P]
+  float* dump = nullptr;         // >= 64 floats nobody reads
+};
+
+template <int MA, int NB, int TILE, int NBUF, bool MIX = false>
 __global__ __launch_bounds__(kCpBlock) void k_chanpair_glds(
     SegList A, const float* __restrict__ B, float* __restrict__ part, int Cb, int P, int Bg, int nzb, int b_ones,
-    int nza, int nblk, int R) {
+    int nza, int nblk, int R, ChanMix mix) {
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef const __attribute__((address_space(1))) void* glb_ptr_t;
   static_assert(TILE == 64 || TILE == 128, "row pieces of 256 or 512 bytes");
@@ -693,6 +706,55 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_glds(
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[ma][nb] = zero4();
 
+  // MIX: matrix fragments A2[i = channel 16 nb + j][k = a = 4 s + kq], and the words of the B2 operand
+  // B2[k = a][j = position kPPW w + j] in the A rows of the tile
+  constexpr int KS = MIX ? MA * 4 : 1;
+  constexpr int kStores = MIX ? 4 * NB : 0;   // per lane and tile
+  static_assert(!MIX || kPPW == 16, "one 16-position tile per wave");
+  float mfrag[KS][NB];
+  int mword[KS];
+  if (MIX) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int a = 4 * s + kq;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int c = nb * 16 + j;
+        const int ac = min(a, Ca - 2), cc = min(c, Cb - 1);
+        const float wv = mix.Mw[((size_t)r * (Ca - 1) + max(ac, 0)) * Cb + cc];
+        const float lv = mix.Mlast[(size_t)r * Cb + cc];
+        mfrag[s][nb] = (c < Cb && a < Ca) ? (a == Ca - 1 ? lv : wv) : 0.f;
+      }
+      const int row = a < ca ? a : zero_row;
+      mword[s] = (row / kRPI) * (kGGroupF4 * 4) + (row % kRPI) * TILE + 4 * (((kPPW / 4) * wave + (j >> 2)) ^ swz(row)) + (j & 3);
+    }
+  }
+  auto mix_tile = [&](int t) {
+    const int tau = t0 + t;
+    const int b = tau / tpg;
+    const int p0 = (tau - b * tpg) * TILE;
+    const float* w = ldsw + (t % NBUF) * (bufF4 * 4);
+    f32x4 d[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) d[nb] = zero4();
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float bv = w[mword[s]];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) d[nb] = mfma16(mfrag[s][nb], bv, d[nb]);
+    }
+    const int pos = p0 + kPPW * wave + j;
+    float* og = mix.out + ((size_t)r * Bg + b) * Cb * P + pos;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int c = nb * 16 + 4 * kq + reg;
+        float* dst = (c < Cb && pos < P) ? og + (size_t)c * P : mix.dump + lane;   // a select on the address: no branch
+        *dst = d[nb][reg];
+      }
+  };
+
   auto multiply = [&](int t) {
     const int tau = t0 + t;
     const int p0 = (tau - (tau / tpg) * tpg) * TILE;
@@ -729,11 +791,19 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_glds(
       issue(t + 2);
     }
   } else {
+    static_assert(!MIX || NBUF == 3, "the counted waits of the MIX form are written for three buffers");
+    constexpr int kSteady = (NBUF - 2) * RPW + (NBUF - 1) * kStores;   // younger than tile t's loads: see below
+    static_assert(kSteady < 64, "vmcnt is a 6-bit counter");
     for (int t = 0; t < ntile; ++t) {
-      wait_vmcnt<(NBUF - 2) * RPW>();   // this wave's pieces of tile t are in LDS (later tiles may be in flight)
+      // this wave's pieces of tile t are in LDS; later tiles (and, MIX, the stores of the last NBUF - 1 trips, issued
+      // after tile t's loads) may be in flight.  The first trips have fewer operations behind them.
+      if (MIX && t == 0) wait_vmcnt<RPW>();
+      else if (MIX && t == 1) wait_vmcnt<RPW + kStores>();
+      else wait_vmcnt<kSteady>();
       lds_barrier();                    // ... and every other wave's; and nobody reads tile t-1's buffer any more
       issue(t + NBUF - 1);              // into tile t-1's buffer (clamped index: the last trips re-read the last tile)
       multiply(t);
+      if (MIX) mix_tile(t);
     }
   }
   wait_vmcnt<0>();
@@ -811,9 +881,9 @@ static size_t chanpair_glds_lds(int Ca, int Cb) {
   return sizeof(float4) * (size_t)NBUF * (cdiv(rows, 256 / TILE) + 2) * kGGroupF4;
 }
 
-template <int MA, int NB, int TILE, int NBUF>
+template <int MA, int NB, int TILE, int NBUF, bool MIX = false>
 static int launch_chanpair_glds_t(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P,
-                                  int nblk_max, int b_ones, hipStream_t s, int* nblk_used) {
+                                  int nblk_max, int b_ones, hipStream_t s, int* nblk_used, ChanMix mix = ChanMix()) {
   const int Ca = A.total();
   const int nza = cdiv(Ca, MA * 16), nzb = cdiv(Cb, NB * 16);
   const int nz = nza * nzb;
@@ -822,15 +892,30 @@ static int launch_chanpair_glds_t(const SegList& A, const float* B, float* part,
   const size_t lds = chanpair_glds_lds<MA, NB, TILE, NBUF>(Ca, Cb);
   if (lds > (size_t)kLdsMax || lds < (size_t)(MA * NB < 8 ? MA * NB : 8) * kCpWaves * 1024) return MSGAT_ERR_UNSUPPORTED;
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chanpair_glds<MA, NB, TILE, NBUF>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chanpair_glds<MA, NB, TILE, NBUF, MIX>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
   }
   const dim3 grid = nz > 1 ? dim3((unsigned)cdiv(nblk * R, 8) * 8 * nz) : dim3(nblk, R, 1);
-  hipLaunchKernelGGL((k_chanpair_glds<MA, NB, TILE, NBUF>), grid, dim3(kCpBlock), lds, s, A, B, part, Cb, P, Bg, nzb,
-                     b_ones, nza, nblk, R);
+  hipLaunchKernelGGL((k_chanpair_glds<MA, NB, TILE, NBUF, MIX>), grid, dim3(kCpBlock), lds, s, A, B, part, Cb, P, Bg,
+                     nzb, b_ones, nza, nblk, R, mix);
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
+}
+
+// The contraction of [A | Alast] against B AND mixout = [Mw | Mlast]^T [A | Alast] in one pass (k_chanpair_glds<MIX>).
+// *done = 0 (nothing launched) when the shape is not one the fused form covers: the caller runs the two passes.
+int launch_chanpair_mix(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
+                        const float* Mw, const float* Mlast, float* mixout, hipStream_t s, int* nblk_used, int* done) {
+  const int Ca = A.total();
+  *done = 0;
+  if (!(P % 4 == 0 && P >= 512 && Cb > 64 && Cb <= 80 && Ca > 16 && Ca <= 32)) return MSGAT_OK;
+  if (chanpair_glds_lds<2, 5, 128, 3>(Ca, Cb) > (size_t)kLdsMax) return MSGAT_OK;
+  ChanMix mix;
+  mix.Mw = Mw; mix.Mlast = Mlast; mix.out = mixout;
+  mix.dump = part + (size_t)R * nblk * Ca * Cb;   // chanpair_partial_floats() leaves 64 floats behind the partials
+  *done = 1;
+  return launch_chanpair_glds_t<2, 5, 128, 3, true>(A, B, part, R, Bg, Cb, P, nblk, 0, s, nblk_used, mix);
 }
 
 int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,

@@ -121,7 +121,7 @@ int launch_reduce_groups(const float* part, int R, int J, int Wd, float* dst, hi
 // fixed-order sum over a relation's blocks happens here.
 size_t chanpair_partial_floats(int G, int Bg, int Ca, int Cb) {
   const int R = G / Bg;
-  return (size_t)R * chanpair_mfma_blocks(R) * Ca * Cb;
+  return (size_t)R * chanpair_mfma_blocks(R) * Ca * Cb + 64;   // + the dump words of the fused contraction-and-mix form
 }
 
 int launch_chanpair_seg(const SegList& A, const float* B, float* part, float* dst0, int n0, float* dst1, int n1,
@@ -131,6 +131,19 @@ int launch_chanpair_seg(const SegList& A, const float* B, float* part, float* ds
   const int st = launch_chanpair_mfma(A, B, part, R, Bg, Cb, P, chanpair_mfma_blocks(R), b_ones, s, &nblk);
   if (st) return st;
   return launch_reduce_partials(part, R, nblk, A.total() * Cb, dst0, n0, dst1, n1, s, defer);
+}
+
+// dW | dalpha = [du | dq] x^T and dx = W^T du + alpha (x) dq in one pass over du, dq and x; *done = 0 when the fused
+// form does not cover the shape (nothing launched)
+int launch_chanpair_mix(const float* du, const float* dq, const float* x, const float* W, const float* alpha, float* dx,
+                        float* part, float* dW, float* dalpha, int G, int Bg, int Co, int C, int P, hipStream_t s,
+                        ReduceJobs* defer, int* done) {
+  const int R = G / Bg;
+  int nblk = 0;
+  const int st = launch_chanpair_mix(seg_pair(du, Co, dq, 1), x, part, R, Bg, C, P, chanpair_mfma_blocks(R), W, alpha, dx,
+                                     s, &nblk, done);
+  if (st || !*done) return st;
+  return launch_reduce_partials(part, R, nblk, (Co + 1) * C, dW, Co * C, dalpha, C, s, defer);
 }
 
 int launch_chanpair(const float* A, const float* Aextra, const float* B, float* part, float* dst0,
