@@ -473,10 +473,14 @@ def test_mid_size_graph_uses_a_large_lds_slab():
 
 def test_results_are_bitwise_reproducible():
     """No float atomics anywhere: two runs give identical bits."""
-    prob = random_problem(2, 4, 72, 24, 307, 12, 340, seed=77)
-    a, b = run_ours(*prob), run_ours(*prob)
-    for k in a:
-        assert np.array_equal(a[k], b[k]), k
+    # the second problem has rows of 883 x 12 positions: partial last tiles in the LDS-DMA ring of the fused
+    # dW / dalpha / dx pass, whose counted waits a race would show up in as run-to-run differences
+    for prob in (random_problem(2, 4, 72, 24, 307, 12, 340, seed=77), random_problem(3, 8, 72, 24, 883, 12, 866, seed=78)):
+        a = run_ours(*prob)
+        for _ in range(3):
+            b = run_ours(*prob)
+            for k in a:
+                assert np.array_equal(a[k], b[k]), k
 
 
 def test_cpu_tensors_are_refused_not_silently_computed():
