@@ -351,6 +351,16 @@ int msgat_mix_segments(int32_t R, int32_t Bg, int32_t N, int32_t T, const msgat_
 size_t msgat_contract_segments_partial_floats(int32_t R, int32_t Ca, int32_t Cb);
 int msgat_contract_segments(int32_t R, int32_t Bg, int32_t N, int32_t T, const msgat_seg_t* A, int32_t n_a,
                             const float* B, int32_t Cb, int32_t with_ones, float* partials, float* dst, void* stream);
+/* msgat_contract_mix_segments: the whole backward of a 1x1 convolution y = M x (+ bias) in ONE pass over its
+ * operands -- the autograd of the reference's nn.Conv2d(kernel_size=1) / GACN projection calls, msgat.py:27,63-66,
+ * 92,116.  With A = cat(A_segments) the gradient at y [G,Ca,N,T], B = x [G,Cb,N,T], M [R,Ca,Cb]:
+ *   dst[r,a,c]     = sum_{g in r, p} A[g,a,p] B[g,c,p]      (dM; with_ones: column Cb = sum A, the bias gradient)
+ *   mixout[g,c,p]  = sum_a M[r,a,c] A[g,a,p]                (dx, [G,Cb,N,T] contiguous)
+ * i.e. msgat_contract_segments + msgat_mix_segments(m_in_major = 1) with A streamed once; shapes without a fused
+ * form run those two passes.  partials: msgat_contract_segments_partial_floats(R, Ca, Cb + with_ones). */
+int msgat_contract_mix_segments(int32_t R, int32_t Bg, int32_t N, int32_t T, const msgat_seg_t* A, int32_t n_a,
+                                const float* B, int32_t Cb, int32_t with_ones, const float* M, float* partials,
+                                float* dst, float* mixout, void* stream);
 
 /* ---- device: the attention core on already projected features ----
  * Forward = msgat_stage_scores(q) + msgat_stage_aggregate(u) (above).  Backward of exactly that pair, for

@@ -379,6 +379,28 @@ extern "C" int msgat_contract_segments(int32_t R, int32_t Bg, int32_t N, int32_t
                              (hipStream_t)stream, with_ones);
 }
 
+extern "C" int msgat_contract_mix_segments(int32_t R, int32_t Bg, int32_t N, int32_t T, const msgat_seg_t* A, int32_t n_a,
+                                           const float* B, int32_t Cb, int32_t with_ones, const float* M, float* partials,
+                                           float* dst, float* mixout, void* stream) {
+  int st = check_rgnt(R, Bg, N, T);
+  if (st) return st;
+  if (!B || !partials || !dst || !M || !mixout) return MSGAT_ERR_NULL;
+  if (Cb <= 0 || Cb > kMaxC || (with_ones != 0 && with_ones != 1)) return MSGAT_ERR_SHAPE;
+  SegList sa;
+  if ((st = to_seglist(A, n_a, &sa))) return st;
+  if (sa.n == 0) return MSGAT_ERR_SHAPE;
+  const int Cbx = Cb + with_ones, Ca = sa.total(), P = N * T;
+  hipStream_t s = (hipStream_t)stream;
+  int nblk = 0, both = 0;
+  st = launch_chanpair_mix_wide(sa, B, partials, R, Bg, Cbx, P, chanpair_mfma_blocks(R), with_ones, M, mixout, s, &nblk, &both);
+  if (st) return st;
+  if (both) return launch_reduce_groups(partials, R, nblk, Ca * Cbx, dst, s);
+  // no fused form for this shape: the two passes
+  st = launch_chanpair_seg(sa, B, partials, dst, Ca * Cbx, nullptr, 0, R * Bg, Bg, Cbx, P, s, with_ones);
+  if (st) return st;
+  return launch_project_seg(sa, M, 1, nullptr, nullptr, nullptr, seg_single(mixout, Cb), nullptr, R * Bg, Bg, P, MixEpilogue(), s);
+}
+
 // ---- attention core on projected features: backward --------------------------------------------------------
 static msgat_shape_t plain_shape(const msgat_shape_t* sh) {
   msgat_shape_t s = *sh;

@@ -191,6 +191,8 @@ int chanpair_mfma_blocks(int R);  // blocks (= partials) per relation
 // channel matrix is cut into several z-blocks, which all run at once)
 int launch_chanpair_mix(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
                         const float* Mw, const float* Mlast, float* mixout, hipStream_t s, int* nblk_used, int* done);
+int launch_chanpair_mix_wide(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
+                             int b_ones, const float* M, float* mixout, hipStream_t s, int* nblk_used, int* done);
 int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
                          int b_ones, hipStream_t s, int* nblk_used);
 int launch_scores(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW, float* lse,

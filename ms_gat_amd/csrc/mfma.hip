@@ -574,26 +574,33 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // MIX: the pass also writes mix[g,c,p] = sum_a Mx[r,a,c] A[g,a,p] -- with A = [du | dq] and Mx = [W | alpha] that is
 // dx = W^T du + alpha (x) dq of the PROJ_FIRST backward (msgat.py:27's autograd), computed from the A tile the
 // contraction has in LDS anyway: du and dq are read once for dW, dalpha AND dx.  Wave w owns positions 16 w .. 16 w + 15
-// of a tile for all channels: D[i = channel][j = position] = sum_a Mx[a][channel] A[a][position], Mx fragments held in
-// registers for the whole run.  The stores count on vmcnt like the LDS-DMA loads (in issue order), so EVERY lane
+// of a tile for all channels: D[i = position][j = channel] = sum_a A[a][position] Mx[a][channel], Mx fragments held in
+// registers for the whole run (positions as D's rows: a lane ends up with four consecutive positions of a channel, one
+// 16-B store; with channels as rows it was four 4-B stores: the [98 x 73] pass 456 instead of 415 us in the step).  The stores count on vmcnt like the LDS-DMA loads (in issue order), so EVERY lane
 // stores every time -- lanes without a valid (channel, position) into `dump` -- and the waits are counted over both.
 struct ChanMix {
   const float* Mw = nullptr;     // [R, Ca - 1, Cb]
   const float* Mlast = nullptr;  // [R, Cb]: row Ca - 1 of the matrix
   float* out = nullptr;          // [G, Cb, P]
-  float* dump = nullptr;         // >= 64 floats nobody reads
+  float* dump = nullptr;         // >= 256 floats (16-B aligned) nobody reads
 };
 
-template <int MA, int NB, int TILE, int NBUF, bool MIX = false>
+// MODE 0: the contraction.  MODE 1 (MIX): every wave also computes the mix output of its 16 positions.  MODE 2 (SPLIT, for
+// the wide channel blocks whose accumulators leave no registers for the matrix fragments): waves 0-3 contract (16
+// positions of a 64-position tile each), waves 4-7 compute the mix output from the same LDS tiles -- two roles with
+// equal MFMA counts, one wave of each per SIMD; all eight stage.
+template <int MA, int NB, int TILE, int NBUF, int MODE = 0>
 __global__ __launch_bounds__(kCpBlock) void k_chanpair_glds(
     SegList A, const float* __restrict__ B, float* __restrict__ part, int Cb, int P, int Bg, int nzb, int b_ones,
     int nza, int nblk, int R, ChanMix mix) {
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef const __attribute__((address_space(1))) void* glb_ptr_t;
   static_assert(TILE == 64 || TILE == 128, "row pieces of 256 or 512 bytes");
+  constexpr bool MIX = MODE != 0, SPLIT = MODE == 2;
   constexpr int kRPI = 256 / TILE;                 // rows per wave-instruction (row group)
   constexpr int kLPR = TILE / 4;                   // lanes (float4s) per row piece
-  constexpr int kPPW = TILE / kCpWaves;            // positions per wave and tile
+  constexpr int kCWaves = SPLIT ? kCpWaves / 2 : kCpWaves;   // waves that contract
+  constexpr int kPPW = TILE / kCWaves;             // positions per (contracting) wave and tile
   constexpr int kMaxGroups = (MA + NB) * 16 / kRPI;
   constexpr int RPW = (kMaxGroups + kCpWaves - 1) / kCpWaves;  // LDS-DMA instructions per wave and tile
   const int Cbr = Cb - b_ones;
@@ -688,8 +695,9 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_glds(
 
   // fragment words: row `row`, positions kPPW * wave + 4 qq + kq -> float4 slot ((kPPW / 4) * wave ^ swz) + qq
   const float* ldsw = reinterpret_cast<const float*>(lds4);
+  const int rwave = SPLIT ? (wave & (kCWaves - 1)) : wave;   // index within the wave's role: its slice of the tile
   auto frag_word = [&](int row) {
-    return (row / kRPI) * (kGGroupF4 * 4) + (row % kRPI) * TILE + 4 * (((kPPW / 4) * wave) ^ swz(row)) + kq;
+    return (row / kRPI) * (kGGroupF4 * 4) + (row % kRPI) * TILE + 4 * (((kPPW / 4) * rwave) ^ swz(row)) + kq;
   };
   int aw[MA], bw[NB];
 #pragma unroll
@@ -700,35 +708,47 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_glds(
     bw[nb] = frag_word((cl < cb) ? ((b_ones && c0 + cl == Cbr) ? ones_row : ca + cl) : zero_row);
   }
 
+  // The two roles of SPLIT are the two arms of ONE if: the accumulators exist only in the first, the matrix fragments
+  // only in the second -- as two independent conditions hipcc kept both sets alive everywhere (256 VGPRs + 142 spilled).
   f32x4 acc[MA][NB];
+  const bool contracts = !SPLIT || wave < kCWaves;   // wave-uniform
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int ma = 0; ma < MA; ++ma)
+    for (int ma = 0; ma < MA; ++ma)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) acc[ma][nb] = zero4();
+      for (int nb = 0; nb < NB; ++nb) acc[ma][nb] = zero4();
+  };
 
   // MIX: matrix fragments A2[i = channel 16 nb + j][k = a = 4 s + kq], and the words of the B2 operand
   // B2[k = a][j = position kPPW w + j] in the A rows of the tile
   constexpr int KS = MIX ? MA * 4 : 1;
-  constexpr int kStores = MIX ? 4 * NB : 0;   // per lane and tile
+  constexpr int kStores = MIX ? NB : 0;       // per lane and tile
   static_assert(!MIX || kPPW == 16, "one 16-position tile per wave");
   float mfrag[KS][NB];
-  int mword[KS];
-  if (MIX) {
+  // B2 word of k-step s: row 4 s + kq of the tile = group (4 s + kq) / kRPI -- linear in s, so one register and an
+  // immediate offset per read.  Rows a >= Ca of the last k-step are other channels' finite data times a zero fragment.
+  constexpr int kMStep = (4 / kRPI) * (kGGroupF4 * 4);
+  const int mbase = (kq / kRPI) * (kGGroupF4 * 4) + (kq % kRPI) * TILE + 4 * (((kPPW / 4) * rwave + (j >> 2)) ^ swz(kq)) + (j & 3);
+  auto load_mfrag = [&]() {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int a = 4 * s + kq;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const int c = nb * 16 + j;
-        const int ac = min(a, Ca - 2), cc = min(c, Cb - 1);
-        const float wv = mix.Mw[((size_t)r * (Ca - 1) + max(ac, 0)) * Cb + cc];
-        const float lv = mix.Mlast[(size_t)r * Cb + cc];
-        mfrag[s][nb] = (c < Cb && a < Ca) ? (a == Ca - 1 ? lv : wv) : 0.f;
+        const int cc = min(c, Cbr - 1);
+        float v;
+        if (mix.Mlast != nullptr) {   // kernel-uniform: the matrix's last row lives in another array
+          const float wv = mix.Mw[((size_t)r * (Ca - 1) + max(min(a, Ca - 2), 0)) * Cbr + cc];
+          const float lv = mix.Mlast[(size_t)r * Cbr + cc];
+          v = a == Ca - 1 ? lv : wv;
+        } else {
+          v = mix.Mw[((size_t)r * Ca + min(a, Ca - 1)) * Cbr + cc];
+        }
+        mfrag[s][nb] = (c < Cbr && a < Ca) ? v : 0.f;
       }
-      const int row = a < ca ? a : zero_row;
-      mword[s] = (row / kRPI) * (kGGroupF4 * 4) + (row % kRPI) * TILE + 4 * (((kPPW / 4) * wave + (j >> 2)) ^ swz(row)) + (j & 3);
     }
-  }
+  };
   auto mix_tile = [&](int t) {
     const int tau = t0 + t;
     const int b = tau / tpg;
@@ -739,20 +759,19 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_glds(
     for (int nb = 0; nb < NB; ++nb) d[nb] = zero4();
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const float bv = w[mword[s]];
+      const float bv = w[mbase + s * kMStep];
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) d[nb] = mfma16(mfrag[s][nb], bv, d[nb]);
+      for (int nb = 0; nb < NB; ++nb) d[nb] = mfma16(bv, mfrag[s][nb], d[nb]);
     }
-    const int pos = p0 + kPPW * wave + j;
-    float* og = mix.out + ((size_t)r * Bg + b) * Cb * P + pos;
+    // D[i = position 4 kq + reg][j = channel]: a lane holds four consecutive positions of one channel -- one 16-B store
+    const int pos = p0 + kPPW * rwave + 4 * kq;
+    float* og = mix.out + ((size_t)r * Bg + b) * Cbr * P + pos;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int c = nb * 16 + 4 * kq + reg;
-        float* dst = (c < Cb && pos < P) ? og + (size_t)c * P : mix.dump + lane;   // a select on the address: no branch
-        *dst = d[nb][reg];
-      }
+    for (int nb = 0; nb < NB; ++nb) {
+      const int c = nb * 16 + j;
+      float* dst = (c < Cbr && pos < P) ? og + (size_t)c * P : mix.dump + 4 * lane;   // a select on the address: no branch
+      *reinterpret_cast<f32x4*>(dst) = d[nb];
+    }
   };
 
   auto multiply = [&](int t) {
@@ -768,7 +787,7 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_glds(
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) bv[nb] = w[bw[nb] + 4 * qq];
       if (partial) {
-        const float keep = (p0 + kPPW * wave + 4 * qq + kq < P) ? 1.f : 0.f;
+        const float keep = (p0 + kPPW * rwave + 4 * qq + kq < P) ? 1.f : 0.f;
 #pragma unroll
         for (int ma = 0; ma < MA; ++ma) av[ma] *= keep;
       }
@@ -782,6 +801,7 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_glds(
 #pragma unroll
   for (int t = 0; t < NBUF - 1; ++t) issue(t);
   if (NBUF == 2) {
+    zero_acc();
     issue(1);
     for (int t = 0; t < ntile; ++t) {
       wait_vmcnt<RPW>();   // tile t landed, tile t + 1 may be in flight
@@ -791,19 +811,36 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_glds(
       issue(t + 2);
     }
   } else {
-    static_assert(!MIX || NBUF == 3, "the counted waits of the MIX form are written for three buffers");
+    static_assert(!MIX || NBUF == 3, "the counted waits of the MIX forms are written for three buffers");
     constexpr int kSteady = (NBUF - 2) * RPW + (NBUF - 1) * kStores;   // younger than tile t's loads: see below
     static_assert(kSteady < 64, "vmcnt is a 6-bit counter");
-    for (int t = 0; t < ntile; ++t) {
-      // this wave's pieces of tile t are in LDS; later tiles (and, MIX, the stores of the last NBUF - 1 trips, issued
-      // after tile t's loads) may be in flight.  The first trips have fewer operations behind them.
-      if (MIX && t == 0) wait_vmcnt<RPW>();
-      else if (MIX && t == 1) wait_vmcnt<RPW + kStores>();
-      else wait_vmcnt<kSteady>();
-      lds_barrier();                    // ... and every other wave's; and nobody reads tile t-1's buffer any more
-      issue(t + NBUF - 1);              // into tile t-1's buffer (clamped index: the last trips re-read the last tile)
-      multiply(t);
-      if (MIX) mix_tile(t);
+    // Per trip: this wave's pieces of tile t are in LDS (later tiles and -- waves that mix -- the stores of the last
+    // NBUF - 1 trips, issued after tile t's loads, may be in flight; the first trips have fewer operations behind
+    // them); barrier: ... and every other wave's, and nobody reads tile t-1's buffer any more; re-issue into that
+    // buffer (clamped index: the last trips re-read the last tile); the wave's role(s).  Both roles pass the same
+    // barriers.
+    if (contracts) {
+      zero_acc();
+      if (MODE == 1) load_mfrag();
+      for (int t = 0; t < ntile; ++t) {
+        if (MODE == 1 && t == 0) wait_vmcnt<RPW>();
+        else if (MODE == 1 && t == 1) wait_vmcnt<RPW + kStores>();
+        else wait_vmcnt<MODE == 1 ? kSteady : (NBUF - 2) * RPW>();
+        lds_barrier();
+        issue(t + NBUF - 1);
+        multiply(t);
+        if (MODE == 1) mix_tile(t);
+      }
+    } else {   // SPLIT, waves that mix
+      load_mfrag();
+      for (int t = 0; t < ntile; ++t) {
+        if (t == 0) wait_vmcnt<RPW>();
+        else if (t == 1) wait_vmcnt<RPW + kStores>();
+        else wait_vmcnt<kSteady>();
+        lds_barrier();
+        issue(t + NBUF - 1);
+        mix_tile(t);
+      }
     }
   }
   wait_vmcnt<0>();
@@ -817,22 +854,24 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_glds(
 #pragma unroll
   for (int t0r = 0; t0r < kTiles; t0r += kRedTiles) {
     __syncthreads();
+    if (contracts) {
 #pragma unroll
-    for (int ma = 0; ma < MA; ++ma)
+      for (int ma = 0; ma < MA; ++ma)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const int tile = ma * NB + nb;
-        if (tile >= t0r && tile < t0r + kRedTiles) {
+        for (int nb = 0; nb < NB; ++nb) {
+          const int tile = ma * NB + nb;
+          if (tile >= t0r && tile < t0r + kRedTiles) {
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) red[((tile - t0r) * 4 + reg) * 64 + lane] = acc[ma][nb][reg];
+            for (int reg = 0; reg < 4; ++reg) red[((tile - t0r) * 4 + reg) * 64 + lane] = acc[ma][nb][reg];
+          }
         }
-      }
+    }
     __syncthreads();
     const int ntl = (kTiles - t0r < kRedTiles) ? kTiles - t0r : kRedTiles;
     for (int e = threadIdx.x; e < ntl * 256; e += kCpBlock) {
       float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < kCpWaves; ++w) v += all[w * (kRedTiles * 256) + e];
+      for (int w = 0; w < kCWaves; ++w) v += all[w * (kRedTiles * 256) + e];
       const int el = e & 63, reg = (e >> 6) & 3, tile = t0r + (e >> 8);
       const int ma = tile / NB, nb = tile - ma * NB;
       const int a = a0 + ma * 16 + 4 * (el >> 4) + reg;
@@ -881,7 +920,7 @@ static size_t chanpair_glds_lds(int Ca, int Cb) {
   return sizeof(float4) * (size_t)NBUF * (cdiv(rows, 256 / TILE) + 2) * kGGroupF4;
 }
 
-template <int MA, int NB, int TILE, int NBUF, bool MIX = false>
+template <int MA, int NB, int TILE, int NBUF, int MODE = 0>
 static int launch_chanpair_glds_t(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P,
                                   int nblk_max, int b_ones, hipStream_t s, int* nblk_used, ChanMix mix = ChanMix()) {
   const int Ca = A.total();
@@ -892,12 +931,12 @@ static int launch_chanpair_glds_t(const SegList& A, const float* B, float* part,
   const size_t lds = chanpair_glds_lds<MA, NB, TILE, NBUF>(Ca, Cb);
   if (lds > (size_t)kLdsMax || lds < (size_t)(MA * NB < 8 ? MA * NB : 8) * kCpWaves * 1024) return MSGAT_ERR_UNSUPPORTED;
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chanpair_glds<MA, NB, TILE, NBUF, MIX>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chanpair_glds<MA, NB, TILE, NBUF, MODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
   }
   const dim3 grid = nz > 1 ? dim3((unsigned)cdiv(nblk * R, 8) * 8 * nz) : dim3(nblk, R, 1);
-  hipLaunchKernelGGL((k_chanpair_glds<MA, NB, TILE, NBUF, MIX>), grid, dim3(kCpBlock), lds, s, A, B, part, Cb, P, Bg,
+  hipLaunchKernelGGL((k_chanpair_glds<MA, NB, TILE, NBUF, MODE>), grid, dim3(kCpBlock), lds, s, A, B, part, Cb, P, Bg,
                      nzb, b_ones, nza, nblk, R, mix);
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
@@ -913,9 +952,29 @@ int launch_chanpair_mix(const SegList& A, const float* B, float* part, int R, in
   if (chanpair_glds_lds<2, 5, 128, 3>(Ca, Cb) > (size_t)kLdsMax) return MSGAT_OK;
   ChanMix mix;
   mix.Mw = Mw; mix.Mlast = Mlast; mix.out = mixout;
-  mix.dump = part + (size_t)R * nblk * Ca * Cb;   // chanpair_partial_floats() leaves 64 floats behind the partials
+  mix.dump = part + (((size_t)R * nblk * Ca * Cb + 3) & ~(size_t)3);   // chanpair_partial_floats() leaves 260 floats behind the partials
   *done = 1;
-  return launch_chanpair_glds_t<2, 5, 128, 3, true>(A, B, part, R, Bg, Cb, P, nblk, 0, s, nblk_used, mix);
+  return launch_chanpair_glds_t<2, 5, 128, 3, 1>(A, B, part, R, Bg, Cb, P, nblk, 0, s, nblk_used, mix);
+}
+
+// The same for the wide channel blocks: part[a, c] (c < Cb; with b_ones a virtual last channel of ones in B) and
+// mixout[g, c, p] = sum_a M[r, a, c] A[g, a, p] over B's Cb - b_ones real channels, M = [R, Ca, Cb - b_ones].
+int launch_chanpair_mix_wide(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
+                             int b_ones, const float* M, float* mixout, hipStream_t s, int* nblk_used, int* done) {
+  const int Ca = A.total();
+  *done = 0;
+  if (!(P % 4 == 0 && P >= 512 && Cb > 64 && Cb <= 80 && Ca > 48 && Ca <= 112)) return MSGAT_OK;
+  ChanMix mix;
+  mix.Mw = M; mix.out = mixout;
+  mix.dump = part + (((size_t)R * nblk * Ca * Cb + 3) & ~(size_t)3);
+  if (Ca <= 80) {
+    if (chanpair_glds_lds<5, 5, 64, 3>(Ca, Cb) > (size_t)kLdsMax) return MSGAT_OK;
+    *done = 1;
+    return launch_chanpair_glds_t<5, 5, 64, 3, 2>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used, mix);
+  }
+  if (chanpair_glds_lds<7, 5, 64, 3>(Ca, Cb) > (size_t)kLdsMax) return MSGAT_OK;
+  *done = 1;
+  return launch_chanpair_glds_t<7, 5, 64, 3, 2>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used, mix);
 }
 
 int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,

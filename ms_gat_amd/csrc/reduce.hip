@@ -121,7 +121,7 @@ int launch_reduce_groups(const float* part, int R, int J, int Wd, float* dst, hi
 // fixed-order sum over a relation's blocks happens here.
 size_t chanpair_partial_floats(int G, int Bg, int Ca, int Cb) {
   const int R = G / Bg;
-  return (size_t)R * chanpair_mfma_blocks(R) * Ca * Cb + 64;   // + the dump words of the fused contraction-and-mix form
+  return (size_t)R * chanpair_mfma_blocks(R) * Ca * Cb + 260;   // + the dump words of the fused contraction-and-mix form
 }
 
 int launch_chanpair_seg(const SegList& A, const float* B, float* part, float* dst0, int n0, float* dst1, int n1,

@@ -725,8 +725,11 @@ class _MixMultiFunction(torch.autograd.Function):
         need = ctx.needs_input_grad
         dM = dbias = None
         d_ins = [None] * n_in
-        if any(need[7:7 + n_in]):   # one pass: d cat(ins) = M^T cat(dpre), each input's range to its own tensor
+        # one input, its gradient and the matrix gradient both wanted: ONE pass over cat(dpre) and the input gives both
+        both = n_in == 1 and need[0] and need[7]
+        if any(need[7:7 + n_in]):   # d cat(ins) = M^T cat(dpre), each input's range to its own tensor
             d_ins = [_new(like, G, c, N, T) for c in in_channels]
+        if any(need[7:7 + n_in]) and not both:
             _, ai, _ = _seg_array(d_ins)
             st = L.msgat_mix_segments(R, G // R, N, T, ad, nd, _ptr(M), 1, None, 0, None, 0, 0, ai, n_in, stream)
             _lib.check(st, "msgat_mix_segments (backward)")
@@ -739,8 +742,13 @@ class _MixMultiFunction(torch.autograd.Function):
                 ones = int(want_bias and i == 0)   # the bias gradient = contraction with a virtual channel of ones
                 dMi = _new(like, R, Co, c + ones)
                 part = _new(like, max(int(L.msgat_contract_segments_partial_floats(R, Co, c + ones)), 1))
-                st = L.msgat_contract_segments(R, G // R, N, T, ad, nd, _ptr(x), c, ones, _ptr(part), _ptr(dMi), stream)
-                _lib.check(st, "msgat_contract_segments")
+                if both:
+                    st = L.msgat_contract_mix_segments(R, G // R, N, T, ad, nd, _ptr(x), c, ones, _ptr(M), _ptr(part),
+                                                       _ptr(dMi), _ptr(d_ins[0]), stream)
+                    _lib.check(st, "msgat_contract_mix_segments")
+                else:
+                    st = L.msgat_contract_segments(R, G // R, N, T, ad, nd, _ptr(x), c, ones, _ptr(part), _ptr(dMi), stream)
+                    _lib.check(st, "msgat_contract_segments")
                 if ones:
                     # contiguous once per stacked tensor (see the head's weight gradient): a column slice handed down to the
                     # components' parameters costs one copy per component in AccumulateGrad
