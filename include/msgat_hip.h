@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MSGAT_ABI_VERSION 4
+#define MSGAT_ABI_VERSION 5
 
 enum {
   MSGAT_OK = 0,

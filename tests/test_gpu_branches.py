@@ -436,3 +436,53 @@ def test_contract_segments_matches_float64_and_repeats_bit_for_bit(segs, Cb, one
     err = rel_err(outs[0], want)
     record_err(f"contract_segments {segs}x{Cb}+{ones} N={N}", "dst", err, 1e-5)
     assert err < 1e-5
+
+
+@pytest.mark.parametrize("segs,Cb,ones,N,Bg", [
+    ((24, 48, 24, 1, 1), 72, 1, 883, 2),  # merged channel mixing of a MEAM block: SPLIT form <7,5>
+    ((72,), 72, 1, 883, 1),               # residual convolution: SPLIT form <5,5>
+    ((49,), 65, 0, 307, 3),               # lower edges of the <5,5> form, no bias column
+    ((81,), 79, 1, 64, 2),                # lower edge of <7,5>; P = 768
+    ((24,), 72, 0, 883, 2),               # no fused form for 24 x 72 behind this entry point: the two passes
+    ((72,), 72, 1, 13, 2),                # P = 156: the two passes
+])
+def test_contract_mix_segments_gives_matrix_bias_and_input_gradients_in_one_pass(segs, Cb, ones, N, Bg):
+    """msgat_contract_mix_segments = the backward of y = M x (+ bias): dM (| dbias) AND dx from one pass over dy and x,
+    against float64; four repeats must agree bit for bit (the dx stores count on vmcnt next to the LDS-DMA loads: a
+    miscounted wait would read a tile that has not landed, differently from run to run)."""
+    from ms_gat_amd import _lib
+    L = _lib.lib()
+    dev, R, T = _dev(), 2, 12
+    G, Ca = R * Bg, sum(segs)
+    g = torch.Generator().manual_seed(13)
+    wide = [torch.randn(G, c + 2, N, T, generator=g).to(dev) for c in segs]
+    B = torch.randn(G, Cb, N, T, generator=g).to(dev)
+    M = (torch.randn(R, Ca, Cb, generator=g) * 0.2).to(dev)
+    arr = (_lib.Seg * len(segs))()
+    for i, (t, c) in enumerate(zip(wide, segs)):
+        arr[i] = _lib.Seg(t[:, 2:].data_ptr(), c, c + 2)
+    part = torch.empty(max(int(L.msgat_contract_segments_partial_floats(R, Ca, Cb + ones)), 1), device=dev)
+    outs = []
+    for rep in range(4):
+        part.fill_(float("nan"))
+        dst = torch.full((R, Ca, Cb + ones), float("nan"), device=dev)
+        dx = torch.full((G, Cb, N, T), float("nan"), device=dev)
+        st = L.msgat_contract_mix_segments(R, Bg, N, T, arr, len(segs), B.data_ptr(), Cb, ones, M.data_ptr(),
+                                           part.data_ptr(), dst.data_ptr(), dx.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream)
+        _lib.check(st, "msgat_contract_mix_segments")
+        outs.append((dst, dx))
+    torch.cuda.synchronize()
+    for dst, dx in outs[1:]:
+        assert torch.equal(dst, outs[0][0]) and torch.equal(dx, outs[0][1])
+    A64 = torch.cat([t[:, 2:2 + c] for t, c in zip(wide, segs)], dim=1).double().view(R, Bg, Ca, N * T)
+    B64 = B.double().view(R, Bg, Cb, N * T)
+    want_dx = torch.einsum("rac,rgap->rgcp", M.double(), A64).reshape(G, Cb, N, T)
+    if ones:
+        B64 = torch.cat([B64, torch.ones(R, Bg, 1, N * T, device=dev, dtype=torch.float64)], dim=2)
+    want = torch.einsum("rgap,rgcp->rac", A64, B64)
+    what = f"contract_mix_segments {segs}x{Cb}+{ones} N={N}"
+    for key, got, ref in (("dM", outs[0][0], want), ("dx", outs[0][1], want_dx)):
+        err = rel_err(got, ref)
+        record_err(what, key, err, 1e-5)
+        assert err < 1e-5, key
