@@ -16,7 +16,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--R", type=int, default=5)
 ap.add_argument("--steps", type=int, default=6)
 ap.add_argument("--graph", action="store_true")
+ap.add_argument("--lib", default="", help="another build of libmsgat_hip.so (A/B runs)")
 a = ap.parse_args()
+if a.lib:
+    from ms_gat_amd import _lib
+    _lib.LIB_PATH = os.path.abspath(a.lib)
 dev = torch.device("cuda:0")
 ts = bench.TrainStep(dict(bench.CFG4, R=a.R), dev, hip_graph=a.graph)
 wall, per = bench.time_train_step(ts, a.steps, 4, lambda: torch.cuda.synchronize(dev))
