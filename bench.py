@@ -100,11 +100,15 @@ class HotPath:
         self.sync = parallel.FlatGradAllReduce(self.params)
 
     def step(self, allreduce=False):
-        for m, x, dz in zip(self.layers, self.xs, self.dzs):
+        # the order of a training step of the model that holds these layers (msgat.py:143-150: the two MEAMs of a TPC
+        # in sequence): forward of the first depth, forward of the second, then backward second depth first
+        for m, x in zip(self.layers, self.xs):
             x.grad = None
             for p in m.parameters():
                 p.grad = None
-            z = m(x, self.graph)
+        # (each depth's forward and backward back to back measures the same: 0.737 vs 0.730-0.740 ms)
+        zs = [m(x, self.graph) for m, x in zip(self.layers, self.xs)]
+        for z, dz in zip(reversed(zs), reversed(self.dzs)):
             z.backward(dz)
         if allreduce:  # one flat bucket: the payload is KBs, the collective is latency-bound
             self.sync(weight=float(self.wl["B"]))
