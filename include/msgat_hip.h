@@ -257,6 +257,13 @@ size_t msgat_contract_partial_floats(const msgat_shape_t* shape, int32_t Ca, int
 int msgat_stage_contract(const msgat_shape_t* shape, int32_t Ca, int32_t Cb, const float* A,
                          const float* Aextra, const float* B, float* partials, float* dst0, int32_t n0,
                          float* dst1, int32_t n1, void* stream);
+/* msgat_stage_project_backward: the last stage of the PROJ_FIRST backward as msgat_gacn_backward enqueues it --
+ *   dW[r,o,c] = sum du[g,o,p] x[g,c,p],  dalpha[r,c] = sum dq[g,p] x[g,c,p],  dx = W^T du + alpha (x) dq
+ * (the autograd of msgat.py:27 and attention.py:33) in ONE pass over du, dq and x where the shape has a fused form,
+ * as msgat_stage_contract + msgat_stage_mix otherwise.  partials: msgat_contract_partial_floats(shape, Co + 1, C). */
+int msgat_stage_project_backward(const msgat_shape_t* shape, const float* du, const float* dq, const float* x,
+                                 const float* W, const float* alpha, float* partials, float* dW, float* dalpha,
+                                 float* dx, void* stream);
 
 /* ---- device: the producer of every GACN input -- LayerNorm over the timestep axis ----
  * Replaces nn.LayerNorm([n_timesteps]) of the callers (src/models/msgat.py:114 applied at :122,

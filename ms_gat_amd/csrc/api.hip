@@ -229,6 +229,28 @@ extern "C" int msgat_stage_contract(const msgat_shape_t* sh, int32_t Ca, int32_t
                          sh->N * sh->T, (hipStream_t)stream);
 }
 
+extern "C" int msgat_stage_project_backward(const msgat_shape_t* sh, const float* du, const float* dq, const float* x,
+                                            const float* W, const float* alpha, float* partials, float* dW,
+                                            float* dalpha, float* dx, void* stream) {
+  int st = check_shape(sh);
+  if (st) return st;
+  if (!du || !dq || !x || !W || !alpha || !partials || !dW || !dalpha || !dx) return MSGAT_ERR_NULL;
+  if (sh->Co <= 0) return MSGAT_ERR_SHAPE;
+  const int G = sh->R * sh->Bg, Bg = sh->Bg, C = sh->C, Co = sh->Co, P = sh->N * sh->T;
+  hipStream_t s = (hipStream_t)stream;
+  ReduceJobs jobs{};
+  int both = 0;
+  st = launch_chanpair_mix(du, dq, x, W, alpha, dx, partials, dW, dalpha, G, Bg, Co, C, P, s, &jobs, &both);
+  if (st) return st;
+  if (!both) {
+    st = launch_chanpair(du, dq, x, partials, dW, Co * C, dalpha, C, G, Bg, Co + 1, C, P, s, &jobs);
+    if (st) return st;
+    st = launch_project(du, W, 1, nullptr, alpha, dq, dx, nullptr, G, Bg, Co, C, P, s);
+    if (st) return st;
+  }
+  return launch_reduce_jobs(jobs, s);
+}
+
 // ---- temporal / channel branches -------------------------------------------------------------------------
 extern "C" int msgat_stage_mix_epilogue(const msgat_shape_t* sh, int32_t Ci, int32_t Co, const float* in,
                                         const float* M, int32_t m_in_major, const float* bias,
@@ -697,7 +719,7 @@ extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t*
     // projection has just written is still draining to HBM
     // ... and where its channel block leaves the registers (LDS-DMA staging), the same pass also writes dx: du and dq
     // are read once
-    int both = 0;
+    int both = 0;   // (msgat_stage_project_backward is this stage on its own)
     st = launch_chanpair_mix(dvb, dq, io->x, io->W, io->alpha, io->dx, cpp, io->dW, io->dalpha, G, Bg, Co, C, P, s, &jobs,
                              &both);
     if (st) return st;

@@ -486,3 +486,39 @@ def test_contract_mix_segments_gives_matrix_bias_and_input_gradients_in_one_pass
         err = rel_err(got, ref)
         record_err(what, key, err, 1e-5)
         assert err < 1e-5, key
+
+
+@pytest.mark.parametrize("R,Bg,C,Co,N", [(3, 2, 72, 24, 883), (2, 2, 72, 24, 13), (1, 3, 48, 16, 307), (2, 1, 80, 31, 64)])
+def test_stage_project_backward_matches_float64(R, Bg, C, Co, N):
+    """msgat_stage_project_backward: dW = du x^T, dalpha = dq . x, dx = W^T du + alpha (x) dq -- the fused one-pass
+    form (C in 65..80, Co + 1 in 17..32, rows of >= 512 positions) and the two-pass form behind the same entry point."""
+    import ctypes as C_
+    from ms_gat_amd import _lib
+    L = _lib.lib()
+    dev, T = _dev(), 12
+    G = R * Bg
+    g = torch.Generator().manual_seed(17)
+    du, dq = torch.randn(G, Co, N, T, generator=g).to(dev), torch.randn(G, N, T, generator=g).to(dev)
+    x = torch.randn(G, C, N, T, generator=g).to(dev)
+    W, alpha = (torch.randn(R, Co, C, generator=g) * 0.2).to(dev), (torch.randn(R, C, generator=g) * 0.2).to(dev)
+    shape = _lib.Shape(R, Bg, C, Co, N, T)
+    part = torch.empty(int(L.msgat_contract_partial_floats(C_.byref(shape), Co + 1, C)), device=dev)
+    res = []
+    for rep in range(3):
+        dW, da, dx = (torch.full(s, float("nan"), device=dev) for s in ((R, Co, C), (R, C), (G, C, N, T)))
+        st = L.msgat_stage_project_backward(C_.byref(shape), du.data_ptr(), dq.data_ptr(), x.data_ptr(), W.data_ptr(),
+                                            alpha.data_ptr(), part.data_ptr(), dW.data_ptr(), da.data_ptr(), dx.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream)
+        _lib.check(st, "msgat_stage_project_backward")
+        res.append((dW, da, dx))
+    torch.cuda.synchronize()
+    for r_ in res[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(r_, res[0]))
+    du64, dq64, x64 = (t.double().view(R, Bg, -1, N * T) for t in (du, dq.unsqueeze(1), x))
+    want = (torch.einsum("rgop,rgcp->roc", du64, x64), torch.einsum("rgop,rgcp->rc", dq64, x64),
+            (torch.einsum("roc,rgop->rgcp", W.double(), du64)
+             + torch.einsum("rc,rgop->rgcp", alpha.double(), dq64)).reshape(G, C, N, T))
+    for key, got, ref in zip(("dW", "dalpha", "dx"), res[0], want):
+        err = rel_err(got, ref)
+        record_err(f"stage_project_backward R={R} C={C} Co={Co} N={N}", key, err, 1e-5)
+        assert err < 1e-5, key

@@ -120,6 +120,9 @@ def main():
         lambda: _lib.check(L.msgat_stage_aggregate(sp, gp, Co, ptr(rot(us)), ptr(E), ptr(rot(ous)), ptr(escr), st()), "a"))
     reg("mix_bwd      du,dq->dx", 4 * G * P * (Co + 1 + Cc),
         lambda: _lib.check(L.msgat_stage_mix(sp, Co, Cc, ptr(rot(us)), ptr(W), 1, ptr(alpha), ptr(dq), ptr(rot(oxs)), st()), "m"))
+    reg("project_bwd  du,dq,x->dW,dalpha,dx", 4 * G * P * (Co + 1 + 2 * Cc),
+        lambda: _lib.check(L.msgat_stage_project_backward(sp, ptr(rot(us)), ptr(dq), ptr(rot(xs)), ptr(W), ptr(alpha),
+                                                          ptr(part), ptr(dW), ptr(da), ptr(rot(oxs)), st()), "pb"))
     # the merged channel mixing of a MEAM block (stacked.py): 72 -> 98 channels forward, 98 -> 72 backward
     Cm = 98
     ys = [rnd(G, Cm, N, T) for _ in range(min(a.sets, 2))]
