@@ -174,8 +174,11 @@ def dense_reference_step(hp, device, B, backward=True):
 
 
 def aggregate_kernel_name(wl):
-    """The library picks the aggregate variant by slab size (aggregate.hip): whole [N,T] slab in LDS; one
-    4-timestep column of it with the edges in the SELL layout; or gather from L2."""
+    """The library picks the aggregate variant by slab size (aggregate.hip): three [N,T] slabs in an LDS-DMA ring
+    (one persistent block per CU); one whole slab in LDS; one 4-timestep column of it with the edges in the SELL layout;
+    or gather from L2."""
+    if wl["N"] * wl["T"] // 4 <= 3 * 1024 and wl["R"] * wl["B"] * wl["Co"] >= 512:
+        return "k_agg_ring"
     if wl["N"] * wl["T"] * 4 <= 159 * 1024:
         return "k_agg_lds"
     return "k_agg_sell" if wl["N"] * 16 <= 159 * 1024 else "k_agg_glb"

@@ -126,6 +126,109 @@ __global__ __launch_bounds__(kAggBlock) void k_agg_lds(
   }
 }
 
+// ---- LDS aggregate as a persistent ring (small graphs: three [N,T] slabs fit LDS) ---------------------------------
+// k_agg_lds gives every slab its own block: stage, barrier, row extents -> edge windows -> gather, store -- a chain of
+// dependent round trips per slab that two resident blocks per CU only half hide (3.8 TB/s on cold operands, 72 % of
+// what a plain copy gets).  Here ONE block per CU walks a run of consecutive slabs:
+//   - slabs land in a ring of three LDS buffers by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, the
+//     slab's flat order = the LDS order): while slab t is gathered, slabs t+1 and t+2 are in flight, with no
+//     registers and no ds_write pass; counted s_waitcnt vmcnt + one raw barrier per slab;
+//   - a run stays within one or two groups, and the edge windows of a lane's slots (8 indices, 8 coefficients, masked
+//     once) live in registers for all channels of a group: the per-slab work is LDS gathers and one store per slot;
+//   - stores count on vmcnt next to the LDS-DMA loads, in issue order, so the counted waits need every lane to store
+//     every time: a slot past the slab's end recomputes the slab's LAST slot (same inputs, same bits) and stores that.
+#ifndef MSGAT_RING_AUX
+#define MSGAT_RING_AUX 0
+#endif
+template <int T4, int KI>
+__global__ __launch_bounds__(kAggBlock) void k_agg_ring(
+    const int* __restrict__ ptr, const int* __restrict__ idx, const float4* __restrict__ u4,
+    const float* __restrict__ E, float4* __restrict__ v4, int Cu, int N, int nnz, int nslab, int per) {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+  extern __shared__ float4 ring[];             // 3 x kBufF4
+  constexpr int kWaves = kAggBlock / 64;
+  constexpr int kBufF4 = KI * kAggBlock;        // >= N * T4 (host-checked)
+  const int NT4 = N * T4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int s0 = blockIdx.x * per, ns = min(per, nslab - s0);
+  if (ns <= 0) return;
+
+  auto issue = [&](int t) {   // slab s0 + t (clamped to the run) into buffer t % 3
+    const float4* src = u4 + (size_t)(s0 + min(t, ns - 1)) * NT4;
+    float4* buf = ring + (t % 3) * kBufF4;
+#pragma unroll
+    for (int k = 0; k < KI; ++k) {
+      const int i0 = (wave + kWaves * k) * 64;   // wave-uniform
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + min(i0 + lane, NT4 - 1)), (lds_ptr_t)(buf + i0), 16, 0, MSGAT_RING_AUX);
+    }
+  };
+
+  // the first two slabs are requested before anything else: the edge windows below are three dependent round trips
+  // that then run under the slabs' flight (hipcc drains vmcnt before the windows' first use -- slab 0 is needed by then)
+  issue(0);
+  issue(1);
+
+  // this lane's slots: float4 number tid + 1024 k of a slab = (node, 4 timesteps)
+  int slot[KI], jof[KI], e0s[KI], e1s[KI], b0s[KI];
+  int m[KI][8];
+  float w[KI][8];
+#pragma unroll
+  for (int k = 0; k < KI; ++k) {
+    slot[k] = min((int)threadIdx.x + kAggBlock * k, NT4 - 1);
+    const int n = slot[k] / T4;
+    jof[k] = slot[k] - n * T4;
+    e0s[k] = ptr[n];
+    e1s[k] = ptr[n + 1];
+    b0s[k] = min(e0s[k], nnz - 8);
+    const int4u ia = *reinterpret_cast<const int4u*>(idx + b0s[k]), ib = *reinterpret_cast<const int4u*>(idx + b0s[k] + 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {   // rows of edges outside [e0, e1) read row 0 with coefficient 0
+      m[k][q] = (b0s[k] + q >= e0s[k] && b0s[k] + q < e1s[k]) ? ia.v[q] * T4 + jof[k] : jof[k];
+      m[k][4 + q] = (b0s[k] + 4 + q >= e0s[k] && b0s[k] + 4 + q < e1s[k]) ? ib.v[q] * T4 + jof[k] : jof[k];
+    }
+  }
+  auto load_weights = [&](int g) {
+    const float* Eg = E + (size_t)g * nnz;
+#pragma unroll
+    for (int k = 0; k < KI; ++k) {
+      const float4u wa = *reinterpret_cast<const float4u*>(Eg + b0s[k]), wb = *reinterpret_cast<const float4u*>(Eg + b0s[k] + 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        w[k][q] = (b0s[k] + q >= e0s[k] && b0s[k] + q < e1s[k]) ? wa.v[q] : 0.f;
+        w[k][4 + q] = (b0s[k] + 4 + q >= e0s[k] && b0s[k] + 4 + q < e1s[k]) ? wb.v[q] : 0.f;
+      }
+    }
+  };
+  int gcur = s0 / Cu;
+  load_weights(gcur);
+
+  for (int t = 0; t < ns; ++t) {
+    // slab t has landed: behind its loads the wave issued the stores of slab t-2, the loads of t+1 and the stores of t-1
+    if (t == 0) wait_vmcnt<KI>();
+    else if (t == 1) wait_vmcnt<2 * KI>();
+    else wait_vmcnt<3 * KI>();
+    lds_barrier();    // ... everyone's pieces too; and nobody gathers from slab t-1's buffer any more
+    issue(t + 2);
+    const int g = (s0 + t) / Cu;
+    if (g != gcur) {  // block-uniform; the coefficients of the next group (these loads make hipcc drain vmcnt: once per group)
+      gcur = g;
+      load_weights(g);
+    }
+    const float4* buf = ring + (t % 3) * kBufF4;
+    float4* out = v4 + (size_t)(s0 + t) * NT4;
+    const float* Eg = E + (size_t)g * nnz;
+#pragma unroll
+    for (int k = 0; k < KI; ++k) {
+      float4 acc = f4zero();
+#pragma unroll
+      for (int q = 0; q < 8; ++q) f4fma(w[k][q], buf[m[k][q]], acc);
+      for (int e = b0s[k] + 8; e < e1s[k]; ++e) f4fma(Eg[e], buf[idx[e] * T4 + jof[k]], acc);   // rows with more than 8 edges
+      out[slot[k]] = acc;
+    }
+  }
+}
+
 // ---- LDS aggregate for slabs larger than LDS: one 4-timestep column of the slab at a time --------------
 // N*T*4 bytes exceed the CU's LDS from N ~ 3400 (T = 12), but one float4 column of the slab (N*16 B)
 // fits up to N ~ 10 000 (the N = 8192 stress graph: 128 KB).  The block walks the T/4 columns: stage
@@ -285,6 +388,24 @@ static int launch_aggregate_t(const int* ptr, const int* idx, int nnz, const msg
     hipLaunchKernelGGL((k_agg_sell<T4>), dim3((unsigned)cdiv(G, 8) * 8 * Cu * T4), dim3(kAggBlock), lds, s,
                        sell->slice_off, sell->lane_row, sell->idx, (const float4*)u, E, addvec, (const float4*)extra,
                        (float4*)v, G, Bg, Cu, N, sell->n_pos, sell->n_slices);
+  } else if (addvec == nullptr && xdot == nullptr && nnz >= 8 && N * T4 <= 3 * kAggBlock && G * Cu >= 512) {
+    // plain aggregate on a small graph: the persistent LDS-DMA ring, one block per CU
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+      ncu = 256;  // MI355X
+    const int nslab = G * Cu, per = cdiv(nslab, ncu), nb = cdiv(nslab, per);
+    const int KI = cdiv(N * T4, kAggBlock);
+    const size_t lds = (size_t)3 * KI * kAggBlock * sizeof(float4);
+#define MSGAT_RING(ki)                                                                                            \
+    {                                                                                                               \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_ring<T4, ki>),                        \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+      if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;                                                      \
+      hipLaunchKernelGGL((k_agg_ring<T4, ki>), dim3(nb), dim3(kAggBlock), lds, s, ptr, idx, (const float4*)u, E,    \
+                         (float4*)v, Cu, N, nnz, nslab, per);                                                       \
+    }
+    if (KI == 1) MSGAT_RING(1) else if (KI == 2) MSGAT_RING(2) else MSGAT_RING(3)
+#undef MSGAT_RING
   } else if (CH >= 1) {
     const size_t lds = (size_t)CH * N * T * sizeof(float);
     if (lds > 64 * 1024) {

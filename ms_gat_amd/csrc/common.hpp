@@ -62,6 +62,16 @@ inline bool sell_usable(const msgat_sell_t& j, int nnz, int N, int T) {
   return j.prefer != 0 || slab_channels(N, T, 1, kLdsBudget) == 0;
 }
 
+#if defined(__HIPCC__)
+// Workgroup barrier for LDS hand-offs that leaves global loads in flight: __syncthreads() makes hipcc drain vmcnt(0)
+// first, which would serialise a register prefetch -- or an LDS-DMA ring -- against the barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Counted wait: until all but the wave's N youngest vector-memory operations (loads, LDS-DMA and stores, in issue order)
+// are done.  Safe as long as at least N operations were really issued behind the one that is waited for.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#endif
+
 // Diagnostic builds only (tools/*_stamps.hip compile a kernel file with -DMSGAT_STAMPS): s_memtime
 // stamps of the phases of a block, written to a buffer nothing else reads.  The product library is
 // built without the macro and contains no stamp.

@@ -313,9 +313,7 @@ int launch_project_mfma(const SegList& in, const float* M, int m_in_major, const
 // stamps showed the alternative -- one block per (group, 1024 positions) -- spending 45% of a
 // block in its exposed prologue, first-tile wait and reduction.
 
-// Workgroup barrier for LDS hand-offs that leaves global loads in flight: __syncthreads() makes
-// hipcc drain vmcnt(0) first, which would serialise the register prefetch against the barrier.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// lds_barrier() (common.hpp): the workgroup barrier for LDS hand-offs that leaves global loads in flight.
 
 constexpr int kCpWaves = 8;
 constexpr int kCpBlock = 64 * kCpWaves;
@@ -567,9 +565,6 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
 //   - row groups past the block's last row are not staged: their instructions (kept, so that every wave's vmcnt
 //     arithmetic is the same) fetch one 16-B word into a dump group.
 constexpr int kGGroupF4 = 64 + 1;  // float4s per row group: 1 KiB + 16 B
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // MIX: the pass also writes mix[g,c,p] = sum_a Mx[r,a,c] A[g,a,p] -- with A = [du | dq] and Mx = [W | alpha] that is
 // dx = W^T du + alpha (x) dq of the PROJ_FIRST backward (msgat.py:27's autograd), computed from the A tile the

@@ -14,6 +14,7 @@ src, out = sys.argv[1], sys.argv[2]
 G, N, T, C, Co, nnz = 96, 883, 12, 72, 24, 2615
 sG, sN, sCu, snnz = 256, 8192, 24, 139264
 ALG = {  # algorithmic bytes per launch, the workloads of tools/kbench.py / tools/stress_kernels.py
+    "msgat::k_agg_ring<3, 3>": 2 * 4 * G * Co * N * T + 4 * G * nnz + 8 * nnz + 4 * (N + 1),
     "msgat::k_agg_lds<3, false>": 2 * 4 * G * Co * N * T + 4 * G * nnz + 8 * nnz + 4 * (N + 1),
     "msgat::k_agg_sell<3>": 2 * 4 * sG * sCu * sN * T + 4 * sG * snnz + 8 * snnz + 4 * (sN + 1),
     "msgat::k_sddmm_sellreg<3>": 2 * 4 * sG * sCu * sN * T,

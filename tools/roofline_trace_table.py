@@ -3,7 +3,7 @@
 the launches inside the timed steps, the roofline loop on four operand sets (cold operands: the figure `roofline.frac`
 is computed from) and the loop on one operand set (cache-resident operands).
 
-usage: roofline_trace_table.py <kernel_trace.csv> [kernel-substring=k_agg_lds] [loop-launches=44]
+usage: roofline_trace_table.py <kernel_trace.csv> [kernel-substring=k_agg_ring] [loop-launches=44]
 
 bench.py's roofline_object() runs 4 warm-up + 40 timed launches per loop, cold loop first; they are the last
 2 x 44 launches of the kernel with the second-depth grid (the largest grid of that kernel in the trace)."""
@@ -12,7 +12,7 @@ import sys
 from collections import defaultdict
 
 path = sys.argv[1]
-name = sys.argv[2] if len(sys.argv) > 2 else "k_agg_lds"
+name = sys.argv[2] if len(sys.argv) > 2 else "k_agg_ring"
 per_loop = int(sys.argv[3]) if len(sys.argv) > 3 else 44
 rows = [r for r in csv.DictReader(open(path)) if name in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
