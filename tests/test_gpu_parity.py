@@ -505,3 +505,49 @@ def test_randomised_shape_sweep():
         E = int(min(N * (N - 1) // 2, rng.choice([0, 1, N // 2, N, 3 * N, 8 * N])))
         prob = random_problem(R, Bg, C, Co, N, T, E, seed=1000 + it)
         assert_close(run_ours(*prob), oracle_f64(*prob), what=f"T{T} N{N} C{C} Co{Co} R{R} Bg{Bg} E{E}")
+
+
+@pytest.mark.parametrize("R,Bg,Cu,N,T,E", [
+    (3, 8, 24, 883, 12, 866),     # headline shape: three 1024-slot trips per slab, runs of 9 slabs that cross groups
+    (2, 8, 32, 1024, 12, 4000),   # N T / 4 = 3072: exactly the three buffers' size; rows with more than 8 edges
+    (2, 16, 16, 307, 12, 340),    # one trip per slab
+    (1, 16, 32, 500, 8, 600),     # T = 8 (two float4 per row), two trips
+    (4, 8, 16, 700, 16, 900),     # T = 16
+    (2, 16, 16, 2000, 4, 9000),   # T = 4, dense-ish rows (mean degree 10)
+])
+def test_aggregate_ring_against_float64(R, Bg, Cu, N, T, E):
+    """msgat_stage_aggregate on shapes that take the persistent LDS-DMA ring (k_agg_ring: G Cu >= 512 slabs of at most
+    3072 float4), v[g,c,n,:] = sum_e E[g,e] u[g,c,col_e,:] against float64; repeated runs must agree bit for bit (a
+    miscounted wait of the ring would not)."""
+    import ctypes as C_
+    import ms_gat_amd
+    from ms_gat_amd import _lib
+    L = _lib.lib()
+    dev = _dev()
+    G = R * Bg
+    graph = ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(N, E, 3))
+    gs, _keep = graph.on(dev)
+    nnz = graph.nnz
+    g = torch.Generator().manual_seed(23)
+    u = torch.randn(G, Cu, N, T, generator=g).to(dev)
+    Ee = torch.rand(G, nnz, generator=g).to(dev)
+    shape = _lib.Shape(R, Bg, Cu, Cu, N, T)
+    nscr = int(L.msgat_edge_scratch_floats(C_.byref(shape), C_.byref(gs)))
+    escr = torch.empty(max(nscr, 1), device=dev)
+    outs = []
+    for _ in range(3):
+        v = torch.full((G, Cu, N, T), float("nan"), device=dev)
+        st = L.msgat_stage_aggregate(C_.byref(shape), C_.byref(gs), Cu, u.data_ptr(), Ee.data_ptr(), v.data_ptr(),
+                                     escr.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(st, "msgat_stage_aggregate")
+        outs.append(v)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    rowptr = graph.rowptr.long()
+    col = graph.col[:nnz].long().to(dev)
+    rows = torch.repeat_interleave(torch.arange(N), rowptr[1:] - rowptr[:-1]).to(dev)
+    want = torch.zeros(G, Cu, N, T, device=dev, dtype=torch.float64)
+    want.index_add_(2, rows, u.double()[:, :, col, :] * Ee.double()[:, None, :, None])
+    err = rel_err(outs[0], want)
+    record_err(f"aggregate ring R={R} Bg={Bg} Cu={Cu} N={N} T={T}", "v", err, 1e-5)
+    assert err < 1e-5
