@@ -182,7 +182,7 @@ def main():
         lambda: _lib.check(L.msgat_stage_contract(sp, Cm, Cc, ptr(rot(ys)), None, ptr(rot(xs)), ptr(part98), ptr(dW98),
                                                   Cm * Cc, None, 0, st()), "c"))
     # the whole backward of a 1x1 convolution in one pass (msgat_contract_mix_segments): dM, dbias and dx
-    def cmix(Ca, srcs):
+    def cmix(Ca, srcs, outs):   # gradient from `srcs`, input from xs, dx into `outs`: three distinct pools
         nf = L.msgat_contract_segments_partial_floats(R, Ca, Cc + 1)
         pt, dM = torch.empty(nf, device=dev), torch.empty(R, Ca, Cc + 1, device=dev)
         Mx = rnd(R, Ca, Cc) * 0.1
@@ -191,10 +191,10 @@ def main():
             t = rot(srcs)
             arr = (_lib.Seg * 1)(_lib.Seg(t.data_ptr(), Ca, 0))
             _lib.check(L.msgat_contract_mix_segments(R, B, N, T, arr, 1, ptr(rot(xs)), Cc, 1, ptr(Mx), ptr(pt), ptr(dM),
-                                                     ptr(rot(oxs)), st()), "cm")
+                                                     ptr(rot(outs)), st()), "cm")
         return run
-    reg("cmix98       d98,x->dW[98,73],dx", 4 * G * P * (Cm + 2 * Cc), cmix(Cm, ys))
-    reg("cmix72       d72,x->dW[72,73],dx", 4 * G * P * (3 * Cc), cmix(Cc, xs))
+    reg("cmix98       d98,x->dW[98,73],dx", 4 * G * P * (Cm + 2 * Cc), cmix(Cm, ys, oxs))
+    reg("cmix72       d72,x->dW[72,73],dx", 4 * G * P * (3 * Cc), cmix(Cc, oxs, ys))
     only = [s for s in a.only.split(",") if s]
     for name, (nbytes, fn) in stages.items():
         if only and not any(o in name for o in only):

@@ -18,7 +18,7 @@ if has hot; then
   KT=$(ls $O/bench_kt/*/*kernel_trace.csv | head -1)
   python3 $R/tools/trace_summary.py $KT k_qonly 1 15 40 > $O/hot_path_per_step.txt
   python3 $R/tools/trace_one_step.py $O/bench_kt --anchor k_qonly > $O/hot_path_launches.txt 2>&1
-  python3 $R/tools/roofline_trace_table.py $KT > $O/agg_lds_by_phase.txt
+  python3 $R/tools/roofline_trace_table.py $KT > $O/aggregate_by_phase.txt
   cp $(ls $O/bench_kt/*/*kernel_stats.csv | head -1) $O/hot_path_kernel_stats.csv 2>/dev/null
   rm -rf $O/bench_kt
 fi
