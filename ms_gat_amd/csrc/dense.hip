@@ -67,9 +67,16 @@ static size_t balance_pad_bytes(int nblocks, size_t static_lds) {
 #else
   const int per_cu = cdiv(nblocks, ncu);
 #endif
-  const size_t share = (size_t)kLdsMax / per_cu;  // LDS a block may occupy so that exactly per_cu fit
+#ifndef MSGAT_LDS_GRAIN
+#define MSGAT_LDS_GRAIN 4096
+#endif
+  // LDS a block may occupy so that exactly per_cu fit: rounded DOWN to a coarse grain -- the allocator rounds a block's
+  // request up, and with 3 x 54 016 B of the 163 840 only TWO blocks were resident (in-kernel stamps: the third block of
+  // 160 CUs started when the first had finished; k_scores 61.7 us)
+  const size_t share = ((size_t)kLdsMax / per_cu) / MSGAT_LDS_GRAIN * MSGAT_LDS_GRAIN;
   if (share <= static_lds + 1024) return 0;        // already limited by its own LDS
-  size_t pad = share - static_lds - 512;
+  if ((size_t)(per_cu + 1) * share <= (size_t)kLdsMax) return 0;   // (cannot happen for grains below 160 KB / per_cu^2)
+  size_t pad = share - static_lds;
   if (pad > 64 * 1024 - 256) pad = 64 * 1024 - 256;  // stay under the default dynamic-LDS limit
   return pad & ~(size_t)255;
 }

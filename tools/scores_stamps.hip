@@ -21,13 +21,15 @@ int main() {
   for (auto& v : hq) v = nd(rng); for (auto& v : hw) v = 0.3f * nd(rng);
   hipMemcpy(q, hq.data(), hq.size() * 4, hipMemcpyHostToDevice); hipMemcpy(Wg, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(val, hv.data(), nnz * 4, hipMemcpyHostToDevice);
-  msgat_graph_t gr{N, nnz, rowptr, col, val, erow, rowptr, erow, col};
+  msgat_graph_t gr{};
+  gr.n_nodes = N; gr.nnz = nnz; gr.rowptr = rowptr; gr.col = col; gr.val = val; gr.erow = erow;
+  gr.colptr = rowptr; gr.crow = erow; gr.cperm = col; gr.cpos = col;
   for (size_t l : {0, 8192, 13056, 16384, 32768}) {
     int nblk = -1;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)msgat::k_scores<12, true>, msgat::kDBlock, l);
     printf("occupancy API: dynamic LDS %zu -> %d blocks/CU\n", l, nblk);
   }
-  for (int i = 0; i < 3; ++i) msgat::launch_scores(gr, q, Wg, kW, lse, pq, E, G, Bg, N, T, 0);
+  for (int i = 0; i < 3; ++i) msgat::launch_scores(gr, q, Wg, kW, lse, pq, E, nullptr, G, Bg, N, T, 0);
   hipDeviceSynchronize();
   std::vector<unsigned long long> st(8 * 4096);
   hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(msgat::g_stamps), st.size() * 8);
