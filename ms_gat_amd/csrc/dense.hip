@@ -270,9 +270,273 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
   MSGAT_STAMP(5);
 }
 
+// ---- forward, 7 owner waves + 1 helper wave ---------------------------------------------------------------------
+// At N = 883 k_scores has 7 x 96 = 672 blocks of 8 waves for 256 CUs: 5.25 waves per SIMD, i.e. some SIMDs carry 6
+// and the kernel takes what those take (87.5 % balance, dense_lab.txt).  Here a block owns 112 rows (7 waves x 16) and
+// its eighth wave takes the LAST columns of all seven row groups: 8 x 96 = 768 blocks are exactly 3 per CU, every wave
+// does the same number of score tiles (owner: Ta column tiles of its row group; helper: 7 x Th with Ta + Th = N / 16,
+// Ta ~ 7 Th), and every SIMD carries 6 waves of 7/8 of the old work.  The helper's columns (at most 128) are staged once;
+// it keeps step with the owners' chunk barriers, leaves its partial (running max, payload sums) per row group in LDS, and
+// each owner folds that into its own before the logsumexp.  Same products in the same k order per tile as k_scores.
+constexpr int kHOwners = 7;
+constexpr int kHRows = 16 * kHOwners;
+
+template <int T, bool WITH_PQ>
+__global__ __launch_bounds__(kDBlock) void k_scores7(
+    const float* __restrict__ q, const float* __restrict__ Wg, const int* __restrict__ rowptr,
+    const int* __restrict__ col, const float* __restrict__ val, const int* __restrict__ erow,
+    float* __restrict__ kW, float* __restrict__ lse, float* __restrict__ pq, float* __restrict__ E,
+    const int* __restrict__ cpos, float* __restrict__ Ec, int Bg, int N, int nnz, int Ca) {
+  constexpr int T4 = T / 4;
+  constexpr bool ONES = WITH_PQ && T < 16;
+  constexpr int kOThreads = 64 * kHOwners;                      // lanes that stage the owners' chunks
+  __shared__ float4 qs4[kDMC * kPS / 4];  // owners' chunk of columns [0, Ca)
+  __shared__ float4 qh4[kDMC * kPS / 4];  // the helper's columns [Ca, N), staged once
+  __shared__ float kw2s[kHRows][T];
+  __shared__ float lse2s[kHRows];
+  __shared__ float hmax[kHRows];          // helper partial: running max of the row over its columns
+  __shared__ float hsum[kHRows];          //                 sum of 2^(S - max) (when the payload tile has no ones row)
+  __shared__ float hpay[kHRows][17];      //                 payload sums D2[s][row], [row][s] padded
+  const float* qsw = reinterpret_cast<const float*>(qs4);
+  const float* qhw = reinterpret_cast<const float*>(qh4);
+
+  const int g = blockIdx.y;
+  const int r = g / Bg;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = lane & 15, quad = lane >> 4;
+  const bool owner = wave < kHOwners;   // wave-uniform
+  const int n0 = blockIdx.x * kHRows;
+  const int n = n0 + 16 * wave + j;
+  const bool valid = owner && n < N;
+  const float* qg = q + (size_t)g * N * T;
+  const float* wg = Wg + (size_t)r * T * T;
+  const int colsh = N - Ca;             // 1 .. kDMC (host-checked)
+  const int nchunk = cdiv(Ca, kDMC);
+
+  // the helper's columns, by every lane of the block
+  constexpr int kF4 = kPS / 4;
+  for (int i = threadIdx.x; i < kDMC * kF4; i += kDBlock) {
+    const int c = i / kF4, f = i - c * kF4;
+    const bool live = (c < colsh) && (f < T4);
+    const float4 v = reinterpret_cast<const float4*>(qg + (size_t)(Ca + (live ? c : 0)) * T)[live ? f : 0];
+    const float keep = live ? 1.f : 0.f;
+    const float one = (ONES && c < colsh && f == T4) ? 1.f : 0.f;
+    qh4[i] = make_float4(fmaf(v.x, keep, one), v.y * keep, v.z * keep, v.w * keep);
+  }
+
+  float bfrag[T4];
+  if (owner) {
+    float qr[T];
+#pragma unroll
+    for (int t4 = 0; t4 < T4; ++t4) {
+      float4 v = f4zero();
+      if (valid) v = reinterpret_cast<const float4*>(qg + (size_t)n * T)[t4];
+      qr[4 * t4 + 0] = v.x; qr[4 * t4 + 1] = v.y; qr[4 * t4 + 2] = v.z; qr[4 * t4 + 3] = v.w;
+    }
+#pragma unroll
+    for (int kk = 0; kk < T4; ++kk) {
+      const int s = 4 * kk + quad;
+      float a = 0.f;
+#pragma unroll
+      for (int t = 0; t < T; ++t) a = fmaf(qr[t], wg[t * T + s], a);
+      if (valid) kW[((size_t)g * N + n) * T + s] = a;
+      bfrag[kk] = a * kLog2e;
+      kw2s[16 * wave + j][s] = bfrag[kk];
+    }
+  }
+
+  float m = -3.0e38f;
+  float lsum = 0.f;
+  f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = da, dc = da, dd = da;
+
+  // one trip = two score tiles of the staged columns m0 .. m0 + 31 of `buf` (k_scores' inner trip)
+  auto trip = [&](const float* buf, int m0, int cols) {
+    f32x4 S0 = {0.f, 0.f, 0.f, 0.f}, S1 = S0;
+#pragma unroll
+    for (int kk = 0; kk < T4; ++kk) S0 = mfma16(buf[(m0 + j) * kPS + 4 * kk + quad], bfrag[kk], S0);
+#pragma unroll
+    for (int kk = 0; kk < T4; ++kk) S1 = mfma16(buf[(m0 + 16 + j) * kPS + 4 * kk + quad], bfrag[kk], S1);
+    const int mq = m0 + 4 * quad;
+    float sv[8];
+    if (m0 + 32 > cols) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        sv[rr] = (mq + rr < cols) ? S0[rr] : -3.0e38f;
+        sv[4 + rr] = (mq + 16 + rr < cols) ? S1[rr] : -3.0e38f;
+      }
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) { sv[rr] = S0[rr]; sv[4 + rr] = S1[rr]; }
+    }
+    const float cm = max3(max3(sv[0], sv[1], sv[2]), max3(sv[3], sv[4], sv[5]), fmaxf(sv[6], sv[7]));
+    if (__any(cm > m + kDefer)) {
+      float cx = fmaxf(cm, __shfl_xor(cm, 16));
+      cx = fmaxf(cx, __shfl_xor(cx, 32));
+      const float mn = fmaxf(m, cx);
+      const float sc = fast_exp2(m - mn);
+      m = mn;
+      lsum *= sc;
+      if (WITH_PQ) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) { da[rr] *= sc; db[rr] *= sc; dc[rr] *= sc; dd[rr] *= sc; }
+      }
+    }
+    float p[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) p[rr] = fast_exp2(sv[rr] - m);
+    if (!ONES) lsum += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+    if (WITH_PQ) {
+      da = mfma16(buf[(mq + 0) * kPS + j], p[0], da);
+      db = mfma16(buf[(mq + 1) * kPS + j], p[1], db);
+      dc = mfma16(buf[(mq + 2) * kPS + j], p[2], dc);
+      dd = mfma16(buf[(mq + 3) * kPS + j], p[3], dd);
+      da = mfma16(buf[(mq + 16) * kPS + j], p[4], da);
+      db = mfma16(buf[(mq + 17) * kPS + j], p[5], db);
+      dc = mfma16(buf[(mq + 18) * kPS + j], p[6], dc);
+      dd = mfma16(buf[(mq + 19) * kPS + j], p[7], dd);
+    }
+  };
+
+  if (owner) {
+    // columns [0, Ca) in chunks, register-prefetched staging by the owners' lanes (see k_scores)
+    constexpr int kSt = (kDMC * kF4 + kOThreads - 1) / kOThreads;
+    float4 pre[kSt];
+    auto prefetch = [&](int c0) {
+      const int cols = min(kDMC, Ca - c0);
+#pragma unroll
+      for (int k = 0; k < kSt; ++k) {
+        const int i = threadIdx.x + k * kOThreads;
+        const int c = i / kF4, f = i - c * kF4;
+        const bool live = (c < cols) && (f < T4);
+        const float4 v = reinterpret_cast<const float4*>(qg + (size_t)(c0 + (live ? c : 0)) * T)[live ? f : 0];
+        const float keep = live ? 1.f : 0.f;
+        const float one = (ONES && c < cols && f == T4) ? 1.f : 0.f;
+        pre[k] = make_float4(fmaf(v.x, keep, one), v.y * keep, v.z * keep, v.w * keep);
+      }
+    };
+    prefetch(0);
+    for (int c0 = 0; c0 < Ca; c0 += kDMC) {
+      const int cols = min(kDMC, Ca - c0);
+      const int cols16 = (cols + 15) & ~15;
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < kSt; ++k) {
+        const int i = threadIdx.x + k * kOThreads;
+        if (i < kDMC * kF4) qs4[i] = pre[k];
+      }
+      __syncthreads();
+      prefetch(min(c0 + kDMC, max(Ca - 1, 0) / kDMC * kDMC));
+      for (int m0 = 0; m0 < cols16; m0 += 32) trip(qsw, m0, cols);
+    }
+  } else {
+    // the helper: row group rg's last columns during the owners' chunk rg (two barriers per chunk, like them)
+    const int colsh16 = (colsh + 15) & ~15;
+    int nbar = 0;
+    for (int rg = 0; rg < kHOwners; ++rg) {
+      if (nbar < 2 * nchunk) { __syncthreads(); __syncthreads(); nbar += 2; }
+#pragma unroll
+      for (int kk = 0; kk < T4; ++kk) bfrag[kk] = kw2s[16 * rg + j][4 * kk + quad];
+      m = -3.0e38f;
+      lsum = 0.f;
+      da = db = dc = dd = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int m0 = 0; m0 < colsh16; m0 += 32) trip(qhw, m0, colsh);
+      if (!ONES) {
+        lsum += __shfl_xor(lsum, 16);
+        lsum += __shfl_xor(lsum, 32);
+      }
+      if (quad == 0) { hmax[16 * rg + j] = m; hsum[16 * rg + j] = lsum; }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) hpay[16 * rg + j][4 * quad + rr] = (da[rr] + db[rr]) + (dc[rr] + dd[rr]);
+    }
+    for (; nbar < 2 * nchunk; ++nbar) __syncthreads();
+  }
+  __syncthreads();   // the helper's partials are in LDS
+
+  if (owner) {
+    // fold the helper's share of this row group in: both parts re-based to the common maximum
+    const int row = 16 * wave + j;
+    const float mh = hmax[row];
+    const float mt = fmaxf(m, mh);
+    const float so = fast_exp2(m - mt), sh = fast_exp2(mh - mt);
+    float tot[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) tot[rr] = ((da[rr] + db[rr]) + (dc[rr] + dd[rr])) * so + hpay[row][4 * quad + rr] * sh;
+    if (ONES) {
+      lsum = __shfl(tot[T % 4], j + 16 * (T / 4));
+    } else {
+      lsum += __shfl_xor(lsum, 16);
+      lsum += __shfl_xor(lsum, 32);
+      lsum = lsum * so + hsum[row] * sh;
+    }
+    const float lse2 = mt + fast_log2(lsum);
+    if (quad == 0) {
+      lse2s[row] = lse2;
+      if (valid) lse[(size_t)g * N + n] = lse2;
+    }
+    if (WITH_PQ && valid && quad < T4) {
+      const float inv = 1.0f / lsum;
+      reinterpret_cast<float4*>(pq + ((size_t)g * N + n) * T)[quad] =
+          make_float4(tot[0] * inv, tot[1] * inv, tot[2] * inv, tot[3] * inv);
+    }
+  }
+  __syncthreads();
+
+  // edge coefficients of this block's rows (see k_scores)
+  const int e0 = rowptr[min(n0, N)];
+  const int e1 = rowptr[min(n0 + kHRows, N)];
+  for (int e = e0 + threadIdx.x; e < e1; e += kDBlock) {
+    const int nl = erow[e] - n0;
+    const float4* qm = reinterpret_cast<const float4*>(qg + (size_t)col[e] * T);
+    float a = 0.f;
+#pragma unroll
+    for (int t4 = 0; t4 < T4; ++t4) {
+      const float4 v = qm[t4];
+      a = fmaf(v.x, kw2s[nl][4 * t4 + 0], a);
+      a = fmaf(v.y, kw2s[nl][4 * t4 + 1], a);
+      a = fmaf(v.z, kw2s[nl][4 * t4 + 2], a);
+      a = fmaf(v.w, kw2s[nl][4 * t4 + 3], a);
+    }
+    const float ev = fast_exp2(a - lse2s[nl]) * val[e];
+    E[(size_t)g * nnz + e] = ev;
+    if (Ec != nullptr) Ec[(size_t)g * nnz + cpos[e]] = ev;
+  }
+}
+
+// Column split of the 7 + 1 form: the helper takes Th = 2 round(Tn / 18) of the Tn = ceil(N / 16) column tiles (an even
+// count: trips are two tiles; a helper tile costs about what an owner tile costs, and 7 Th ~ Tn - Th).  Returns the owners'
+// column count Ca (a multiple of 32), or 0 when the form does not apply: helper columns must fit one staged chunk, and
+// it only pays where the 128-row blocks leave the CUs unevenly loaded while the 112-row blocks do not.
+static int scores7_owner_columns(int N, int G) {
+  int dev = 0, ncu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+    ncu = 256;
+  const int Tn = cdiv(N, 16);
+  const int Th = 2 * ((Tn + 9) / 18);
+  if (Th < 2 || Th * 16 > kDMC || Tn - Th < 2) return 0;
+  const double b8 = (double)cdiv(N, kDRows) * G / ncu, b7 = (double)cdiv(N, kHRows) * G / ncu;
+  const double eff8 = b8 / ceil(b8), eff7 = b7 / ceil(b7) * (7.0 * Tn / (8.0 * (Tn - Th)));   // useful share of the busiest CU's time
+  if (b7 > 6.0 || eff7 <= eff8 + 0.03) return 0;
+  return (Tn - Th) * 16;
+}
+
 template <int T>
 static int launch_scores_t(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW,
                            float* lse, float* pq, float* E, float* Ec, int G, int Bg, int N, hipStream_t s) {
+#ifndef MSGAT_NO_SCORES7
+  if (const int Ca = scores7_owner_columns(N, G)) {
+    dim3 grid7(cdiv(N, kHRows), G);
+    const size_t lds7 = sizeof(float) * (2 * kDMC * kPS + kHRows * T + 3 * kHRows + kHRows * 17);
+    const size_t pad7 = balance_pad_bytes((int)(grid7.x * grid7.y), lds7);
+    if (pq != nullptr)
+      hipLaunchKernelGGL((k_scores7<T, true>), grid7, dim3(kDBlock), pad7, s, q, Wg, gr.rowptr, gr.col, gr.val,
+                         gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, Ca);
+    else
+      hipLaunchKernelGGL((k_scores7<T, false>), grid7, dim3(kDBlock), pad7, s, q, Wg, gr.rowptr, gr.col, gr.val,
+                         gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, Ca);
+    MSGAT_CHECK_LAUNCH();
+    return MSGAT_OK;
+  }
+#endif
   dim3 grid(cdiv(N, kDRows), G);
   const size_t static_lds = sizeof(float) * (kDMC * kPS + kDRows * T + kDRows);
   const size_t pad = balance_pad_bytes((int)(grid.x * grid.y), static_lds);
