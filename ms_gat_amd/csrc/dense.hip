@@ -679,9 +679,198 @@ __global__ __launch_bounds__(kDBlock) void k_bwd_dense_col(
   *dst = v;
 }
 
+// ---- backward column pass, 7 owner waves + 1 helper wave (see k_scores7) -------------------------------------------
+// A block owns 112 columns; owner w streams rows [0, Ra) for its 16 columns, the helper the LAST rows [Ra, N) (at most
+// 128, staged once) for all seven column groups.  The partial column sums simply add: owner total = own + helper's.
+template <int T>
+__global__ __launch_bounds__(kDBlock) void k_bwd_dense_col7(
+    const float* __restrict__ q, const float* __restrict__ kW, const float* __restrict__ lse,
+    const float* __restrict__ delta, const float* __restrict__ gE, const int* __restrict__ colptr,
+    const int* __restrict__ crow, const int* __restrict__ cperm, float* __restrict__ dq, int N,
+    int nnz, int Ra) {
+  constexpr int T4 = T / 4;
+  constexpr int kOThreads = 64 * kHOwners;
+  __shared__ float4 kwr4[kDMC * T4];        // owners' chunk: [row][kW2(T)]
+  __shared__ float4 dkr4[kDMC * kPS / 4];   //                [row][delta*kW(T) | zeros]
+  __shared__ float4 lse4[kDMC / 4];         //                [row] lse2 (+inf past the end)
+  __shared__ float4 kwh4[kDMC * T4];        // the helper's rows [Ra, N), staged once
+  __shared__ float4 dkh4[kDMC * kPS / 4];
+  __shared__ float4 lsh4[kDMC / 4];
+  __shared__ float qfs[kHRows][T];          // q rows of the block's columns (the helper's B fragments)
+  __shared__ float hpay[kHRows][17];        // helper partial: D2[s][column]
+  const float* kwr = reinterpret_cast<const float*>(kwr4);
+  const float* dkr = reinterpret_cast<const float*>(dkr4);
+  float* lsew = reinterpret_cast<float*>(lse4);
+  const float* kwh = reinterpret_cast<const float*>(kwh4);
+  const float* dkh = reinterpret_cast<const float*>(dkh4);
+  float* lshw = reinterpret_cast<float*>(lsh4);
+
+  const int g = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = lane & 15, quad = lane >> 4;
+  const bool owner = wave < kHOwners;
+  const int m0c = blockIdx.x * kHRows;
+  const int mcol = m0c + 16 * wave + j;
+  const bool valid = owner && mcol < N;
+  const float* qg = q + (size_t)g * N * T;
+  const float* kWg = kW + (size_t)g * N * T;
+  const int rowsh = N - Ra;   // 1 .. kDMC
+  const int nchunk = cdiv(Ra, kDMC);
+
+  // the helper's rows and the block's q rows, by every lane
+  if (threadIdx.x < kDMC) {
+    const int i = threadIdx.x;
+    const bool live = i < rowsh;
+    const int nr = Ra + (live ? i : 0);
+    const float keep = live ? 1.f : 0.f;
+    const float pd = delta[(size_t)g * N + nr] * keep;
+    const float lv = lse[(size_t)g * N + nr];
+    const float4* kr = reinterpret_cast<const float4*>(kWg + (size_t)nr * T);
+#pragma unroll
+    for (int t4 = 0; t4 < kPS / 4; ++t4) {
+      float4 v = f4zero();
+      if (t4 < T4) {
+        v = kr[t4 < T4 ? t4 : 0];
+        v = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
+        kwh4[i * T4 + t4] = make_float4(v.x * kLog2e, v.y * kLog2e, v.z * kLog2e, v.w * kLog2e);
+      }
+      dkh4[i * (kPS / 4) + t4] = make_float4(v.x * pd, v.y * pd, v.z * pd, v.w * pd);
+    }
+    lshw[i] = live ? lv : INFINITY;
+  }
+  for (int i = threadIdx.x; i < kHRows * T; i += kDBlock) {
+    const int cl = i / T, t = i - cl * T;
+    qfs[cl][t] = (m0c + cl < N) ? qg[(size_t)(m0c + cl) * T + t] : 0.f;
+  }
+
+  float bfrag[T4];
+  if (owner) {
+#pragma unroll
+    for (int kk = 0; kk < T4; ++kk) bfrag[kk] = valid ? qg[(size_t)mcol * T + 4 * kk + quad] : 0.f;
+  }
+  f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = da, dc = da, dd = da;
+
+  // one trip = two row tiles rb .. rb + 31 of the staged rows (k_bwd_dense_col's inner trip)
+  auto trip = [&](const float* kw, const float* dk, const float4* l4s, int rb) {
+    f32x4 S0 = {0.f, 0.f, 0.f, 0.f}, S1 = S0;
+#pragma unroll
+    for (int kk = 0; kk < T4; ++kk) S0 = mfma16(kw[(rb + j) * T + 4 * kk + quad], bfrag[kk], S0);
+#pragma unroll
+    for (int kk = 0; kk < T4; ++kk) S1 = mfma16(kw[(rb + 16 + j) * T + 4 * kk + quad], bfrag[kk], S1);
+    const int rq = rb + 4 * quad;
+    const float4 l4 = l4s[rq >> 2], l5 = l4s[(rq + 16) >> 2];
+    const float p0 = fast_exp2(S0[0] - l4.x), p1 = fast_exp2(S0[1] - l4.y);
+    const float p2 = fast_exp2(S0[2] - l4.z), p3 = fast_exp2(S0[3] - l4.w);
+    const float p4 = fast_exp2(S1[0] - l5.x), p5 = fast_exp2(S1[1] - l5.y);
+    const float p6 = fast_exp2(S1[2] - l5.z), p7 = fast_exp2(S1[3] - l5.w);
+    da = mfma16(dk[(rq + 0) * kPS + j], p0, da);
+    db = mfma16(dk[(rq + 1) * kPS + j], p1, db);
+    dc = mfma16(dk[(rq + 2) * kPS + j], p2, dc);
+    dd = mfma16(dk[(rq + 3) * kPS + j], p3, dd);
+    da = mfma16(dk[(rq + 16) * kPS + j], p4, da);
+    db = mfma16(dk[(rq + 17) * kPS + j], p5, db);
+    dc = mfma16(dk[(rq + 18) * kPS + j], p6, dc);
+    dd = mfma16(dk[(rq + 19) * kPS + j], p7, dd);
+  };
+
+  if (owner) {
+    // rows [0, Ra) in chunks, one staged row per lane of the first two owner waves (see k_bwd_dense_col)
+    static_assert(kDMC <= kOThreads, "at most one staged row per owner lane");
+    float4 prek[T4];
+    float pred = 0.f, prel = 0.f;
+    auto prefetch = [&](int r0) {
+      const int rows = min(kDMC, Ra - r0);
+      const bool live = (int)threadIdx.x < rows;
+      const int nr = r0 + (live ? (int)threadIdx.x : 0);
+      const float keep = live ? 1.f : 0.f;
+      const float4* kr = reinterpret_cast<const float4*>(kWg + (size_t)nr * T);
+#pragma unroll
+      for (int t4 = 0; t4 < T4; ++t4) {
+        const float4 v = kr[t4];
+        prek[t4] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
+      }
+      pred = delta[(size_t)g * N + nr] * keep;
+      const float lv = lse[(size_t)g * N + nr];
+      prel = live ? lv : INFINITY;
+    };
+    prefetch(0);
+    for (int r0 = 0; r0 < Ra; r0 += kDMC) {
+      const int rows = min(kDMC, Ra - r0);
+      const int rows16 = (rows + 15) & ~15;
+      __syncthreads();
+      if (threadIdx.x < kDMC) {
+        const int i = threadIdx.x;
+#pragma unroll
+        for (int t4 = 0; t4 < kPS / 4; ++t4) {
+          const float4 v = (t4 < T4) ? prek[t4 < T4 ? t4 : 0] : f4zero();
+          if (t4 < T4) kwr4[i * T4 + t4] = make_float4(v.x * kLog2e, v.y * kLog2e, v.z * kLog2e, v.w * kLog2e);
+          dkr4[i * (kPS / 4) + t4] = make_float4(v.x * pred, v.y * pred, v.z * pred, v.w * pred);
+        }
+        lsew[i] = prel;
+      }
+      __syncthreads();
+      prefetch(min(r0 + kDMC, max(Ra - 1, 0) / kDMC * kDMC));
+      for (int rb = 0; rb < rows16; rb += 32) trip(kwr, dkr, lse4, rb);
+    }
+  } else {
+    const int rowsh16 = (rowsh + 15) & ~15;
+    int nbar = 0;
+    for (int cg = 0; cg < kHOwners; ++cg) {
+      if (nbar < 2 * nchunk) { __syncthreads(); __syncthreads(); nbar += 2; }
+#pragma unroll
+      for (int kk = 0; kk < T4; ++kk) bfrag[kk] = qfs[16 * cg + j][4 * kk + quad];
+      da = db = dc = dd = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int rb = 0; rb < rowsh16; rb += 32) trip(kwh, dkh, lsh4, rb);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) hpay[16 * cg + j][4 * quad + rr] = (da[rr] + db[rr]) + (dc[rr] + dd[rr]);
+    }
+    for (; nbar < 2 * nchunk; ++nbar) __syncthreads();
+  }
+  __syncthreads();   // the helper's partials are in LDS
+  if (!valid || quad >= T4) return;
+
+  const int cl = 16 * wave + j;
+  float4 sp = f4zero();
+  for (int k = colptr[mcol]; k < colptr[mcol + 1]; ++k) {
+    const float ge = gE[(size_t)g * nnz + cperm[k]];
+    const float4 v = reinterpret_cast<const float4*>(kWg + (size_t)crow[k] * T)[quad];
+    sp.x = fmaf(ge, v.x, sp.x);
+    sp.y = fmaf(ge, v.y, sp.y);
+    sp.z = fmaf(ge, v.z, sp.z);
+    sp.w = fmaf(ge, v.w, sp.w);
+  }
+  float4* dst = reinterpret_cast<float4*>(dq + ((size_t)g * N + mcol) * T) + quad;
+  float4 v = *dst;
+  v.x += sp.x - (((da[0] + db[0]) + (dc[0] + dd[0])) + hpay[cl][4 * quad + 0]);
+  v.y += sp.y - (((da[1] + db[1]) + (dc[1] + dd[1])) + hpay[cl][4 * quad + 1]);
+  v.z += sp.z - (((da[2] + db[2]) + (dc[2] + dd[2])) + hpay[cl][4 * quad + 2]);
+  v.w += sp.w - (((da[3] + db[3]) + (dc[3] + dd[3])) + hpay[cl][4 * quad + 3]);
+  *dst = v;
+}
+
 int launch_bwd_dense_col(const msgat_graph_t& gr, const float* q, const float* kW,
                          const float* lse, const float* delta, const float* gE, float* dq, int G,
                          int N, int T, hipStream_t s) {
+#ifndef MSGAT_NO_SCORES7
+  if (const int Ra = scores7_owner_columns(N, G)) {   // the same split, over rows
+    dim3 grid7(cdiv(N, kHRows), G);
+    const size_t lds7 = sizeof(float) * (2 * (kDMC * T + kDMC * kPS + kDMC) + kHRows * T + kHRows * 17);
+    const size_t pad7 = balance_pad_bytes((int)(grid7.x * grid7.y), lds7);
+#define MSGAT_DCOL7(TT)                                                                                    \
+  hipLaunchKernelGGL(k_bwd_dense_col7<TT>, grid7, dim3(kDBlock), pad7, s, q, kW, lse, delta, gE, gr.colptr, \
+                     gr.crow, gr.cperm, dq, N, gr.nnz, Ra)
+    switch (T) {
+      case 4: MSGAT_DCOL7(4); break;
+      case 8: MSGAT_DCOL7(8); break;
+      case 12: MSGAT_DCOL7(12); break;
+      case 16: MSGAT_DCOL7(16); break;
+      default: return MSGAT_ERR_UNSUPPORTED;
+    }
+#undef MSGAT_DCOL7
+    MSGAT_CHECK_LAUNCH();
+    return MSGAT_OK;
+  }
+#endif
   dim3 grid(cdiv(N, kDRows), G);
   const size_t static_lds = sizeof(float) * (kDMC * T + kDMC * kPS + kDMC);
   const size_t pad = balance_pad_bytes((int)(grid.x * grid.y), static_lds);
