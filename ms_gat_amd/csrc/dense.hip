@@ -325,25 +325,6 @@ __global__ __launch_bounds__(kDBlock) void k_scores7(
   }
 
   float bfrag[T4];
-  if (owner) {
-    float qr[T];
-#pragma unroll
-    for (int t4 = 0; t4 < T4; ++t4) {
-      float4 v = f4zero();
-      if (valid) v = reinterpret_cast<const float4*>(qg + (size_t)n * T)[t4];
-      qr[4 * t4 + 0] = v.x; qr[4 * t4 + 1] = v.y; qr[4 * t4 + 2] = v.z; qr[4 * t4 + 3] = v.w;
-    }
-#pragma unroll
-    for (int kk = 0; kk < T4; ++kk) {
-      const int s = 4 * kk + quad;
-      float a = 0.f;
-#pragma unroll
-      for (int t = 0; t < T; ++t) a = fmaf(qr[t], wg[t * T + s], a);
-      if (valid) kW[((size_t)g * N + n) * T + s] = a;
-      bfrag[kk] = a * kLog2e;
-      kw2s[16 * wave + j][s] = bfrag[kk];
-    }
-  }
 
   float m = -3.0e38f;
   float lsum = 0.f;
@@ -414,7 +395,26 @@ __global__ __launch_bounds__(kDBlock) void k_scores7(
         pre[k] = make_float4(fmaf(v.x, keep, one), v.y * keep, v.z * keep, v.w * keep);
       }
     };
-    prefetch(0);
+    prefetch(0);   // in flight while the rows' kW is computed
+    {
+      float qr[T];
+#pragma unroll
+      for (int t4 = 0; t4 < T4; ++t4) {
+        float4 v = f4zero();
+        if (valid) v = reinterpret_cast<const float4*>(qg + (size_t)n * T)[t4];
+        qr[4 * t4 + 0] = v.x; qr[4 * t4 + 1] = v.y; qr[4 * t4 + 2] = v.z; qr[4 * t4 + 3] = v.w;
+      }
+#pragma unroll
+      for (int kk = 0; kk < T4; ++kk) {
+        const int s = 4 * kk + quad;
+        float a = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) a = fmaf(qr[t], wg[t * T + s], a);
+        if (valid) kW[((size_t)g * N + n) * T + s] = a;
+        bfrag[kk] = a * kLog2e;
+        kw2s[16 * wave + j][s] = bfrag[kk];
+      }
+    }
     for (int c0 = 0; c0 < Ca; c0 += kDMC) {
       const int cols = min(kDMC, Ca - c0);
       const int cols16 = (cols + 15) & ~15;
