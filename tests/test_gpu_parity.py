@@ -551,3 +551,21 @@ def test_aggregate_ring_against_float64(R, Bg, Cu, N, T, E):
     err = rel_err(outs[0], want)
     record_err(f"aggregate ring R={R} Bg={Bg} Cu={Cu} N={N} T={T}", "v", err, 1e-5)
     assert err < 1e-5
+
+
+@pytest.mark.parametrize("T,N,Bg,x_scale", [(4, 883, 8, 1.0), (8, 900, 8, 1.0), (16, 883, 8, 1.0), (12, 883, 8, 6.0),
+                                            (12, 1009, 6, 1.0)])
+def test_dense_passes_with_a_helper_wave_at_every_timestep_count(T, N, Bg, x_scale):
+    """Shapes whose dense passes take the 7 owner waves + 1 helper wave form (k_scores7 / k_bwd_dense_col7: the 128-row
+    grid would load the CUs unevenly, the 112-row grid does not) for every supported T, with large scores (the helper's
+    partial maximum differs from the owners': the fold re-bases both) and with a column count whose split leaves the
+    helper a partial last tile; against the dense reference ops on the GPU."""
+    prob = random_problem(3, Bg, 6, 24, N, T, N, seed=90 + T, x_scale=x_scale)
+    got, want = run_ours(*prob), _dense_oracle_gpu(*prob)
+    if x_scale == 1.0:
+        assert_close(got, want, what=f"helper-wave dense passes T={T} N={N}")
+    else:   # partly saturated rows: the yardstick of test_large_scores_need_the_running_max
+        f64, ref32 = oracle_f64(*prob), _ref32_cpu(*prob)
+        for k in f64:
+            bar = max(TOL, 3.0 * rel_err(ref32[k], f64[k]))
+            assert rel_err(got[k], f64[k]) < bar, (k, rel_err(got[k], f64[k]), bar)
