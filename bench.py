@@ -121,11 +121,15 @@ class HotPath:
 SETTLE_MS = 60.0   # see settle()
 
 
-def settle(fn, device, ms=SETTLE_MS):
+def settle(fn, device, ms=SETTLE_MS, agree=None):
     """Runs `fn` untimed for about `ms` milliseconds of GPU time.  Coming out of set-up (input generation on the host,
     graph build) the first ~25 hot-path steps are up to 10 % slower than the rate the GPU then holds (0.81-0.86 ms
     falling to 0.775 ms over 20 ms: tools/ramp.py) -- power state, cache and allocator warm-up.  The contract's W
-    warm-up steps follow this; with W = 5 (4 ms) alone the K timed steps would sit inside that ramp."""
+    warm-up steps follow this; with W = 5 (4 ms) alone the K timed steps would sit inside that ramp.
+
+    With several ranks `fn` may hold a collective, so every rank must leave the loop on the same trip: `agree(x)`
+    (MAX over ranks) makes the elapsed time the ranks compare identical -- a rank must never issue a batch of
+    all-reduces its peers do not."""
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     stream = torch.cuda.current_stream(device)
     done = 0.0
@@ -135,7 +139,8 @@ def settle(fn, device, ms=SETTLE_MS):
             fn()
         t1.record(stream)
         t1.synchronize()
-        done += t0.elapsed_time(t1)
+        batch = t0.elapsed_time(t1)
+        done += batch if agree is None else agree(batch)
 
 
 def timed_steps(fn, steps, warmup, device, barrier):
@@ -460,6 +465,19 @@ def time_dense_kernels(hp, reps=20):
             "kernels": out}
 
 
+def collective_us(last):
+    """Median duration (us, HIP events on the launch stream, this rank) of the last `last` flat all-reduces recorded by
+    `parallel.all_reduce_flat`; None when nothing was recorded (single process).  Clears the record."""
+    from ms_gat_amd import parallel
+    rec = parallel.collective_events
+    if not rec:
+        return None
+    torch.cuda.synchronize()
+    us = [a.elapsed_time(b) * 1e3 for a, b in rec[-last:]]
+    rec.clear()
+    return round(statistics.median(us), 1)
+
+
 def respawn_under_torchrun(args):
     """`python bench.py --gpus N` with N > 1 and no process-group environment: become the launcher -- start one rank per
     GPU with torch.distributed.run as a CHILD process (nothing here has touched the GPU yet) and exit with its code.
@@ -475,26 +493,75 @@ def respawn_under_torchrun(args):
     return subprocess.call(cmd, env=env)
 
 
-def pemsd4_object(dev):
-    """configs[1] (PEMSD4: N = 307, 3 features, B = 64, ONE relation): the hot-path step and its forward against the same
-    ops in PyTorch-ROCm eager (the dense [B,N,N] sequence of oracle/dense_torch.py)."""
-    wl = WORKLOADS["pemsd4"]
+def capture(fn, dev, warm=3):
+    """`fn` (launches only: no host synchronisation, no allocation outside the graph pool) as one HIP graph; returns the
+    replay callable.  Warm-up runs on a side stream first, as torch requires before a capture."""
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(warm):
+            fn()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize(dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    return g.replay, g
+
+
+def gpu_busy_us(fn, dev, steps=20):
+    """Sum of the kernel durations of one call of `fn` (torch's profiler, device activity only): what the step costs when
+    the host never makes the GPU wait."""
+    from torch.profiler import ProfilerActivity, profile
+    torch.cuda.synchronize(dev)
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize(dev)
+    ev = [e for e in prof.key_averages() if e.device_time_total > 0]
+    return sum(e.device_time_total for e in ev) / steps, sum(e.count for e in ev) / steps
+
+
+def small_graph_object(name, dev, steps=100):
+    """A workload whose step is ~0.2 ms of GPU work in 17 launches (configs[1], PEMSD4: N = 307, 3 features, B = 64, ONE
+    relation): launched kernel by kernel the host cannot keep the GPU busy, so the step is also captured once and
+    replayed as ONE HIP graph (what `engine.Trainer(hip_graph=True)` does for the training step) -- `ms_per_step` is the
+    replay; the eager-launch figure and the GPU-busy time (sum of kernel durations) stand next to it.  Forward alone
+    likewise, against the same ops in PyTorch-ROCm eager (the dense [B,N,N] sequence of oracle/dense_torch.py)."""
+    wl = WORKLOADS[name]
     hp = HotPath(wl, dev, seed=0)
     sync = lambda: torch.cuda.synchronize(dev)  # noqa: E731
     settle(hp.step, dev, 20.0)
-    wall, per_step = timed_steps(hp.step, 50, 10, dev, sync)
-    _, fwd = timed_steps(hp.forward_only, 30, 5, dev, sync)
+    wall_e, per_e = timed_steps(hp.step, steps, 10, dev, sync)
+    _, fwd_e = timed_steps(hp.forward_only, 50, 5, dev, sync)
+    busy, launches = gpu_busy_us(hp.step, dev)
+    busy_f, launches_f = gpu_busy_us(hp.forward_only, dev)
+    step_replay, _g1 = capture(hp.step, dev)
+    fwd_replay, _g2 = capture(hp.forward_only, dev)
+    settle(step_replay, dev, 20.0)
+    wall_g, per_g = timed_steps(step_replay, steps, 10, dev, sync)
+    _, fwd_g = timed_steps(fwd_replay, 50, 5, dev, sync)
     _, eager_fwd = timed_steps(lambda: dense_reference_step(hp, dev, wl["B"], backward=False), 10, 2, dev, sync)
     _, eager_all = timed_steps(lambda: dense_reference_step(hp, dev, wl["B"], backward=True), 10, 2, dev, sync)
+    fwd = statistics.median(fwd_g)
     return {
-        "workload": (f"pemsd4: N={wl['N']} nodes, {wl['E']} undirected edges (+self loops), T={wl['T']}, B={wl['B']}, "
-                     f"R={wl['R']} relation, GACN {wl['Cin']}->{wl['Co']} and {wl['hidden']}->{wl['Co']}, forward+backward"),
-        "ms_per_step": round(wall / 50 * 1e3, 4), "ms_per_step_median_hip_events": round(statistics.median(per_step), 4),
-        "samples_per_s": round(wl["B"] / (wall / 50), 2), "forward_ms": round(statistics.median(fwd), 4),
+        "workload": (f"{name}: N={wl['N']} nodes, {wl['E']} undirected edges (+self loops), T={wl['T']}, B={wl['B']}, "
+                     f"R={wl['R']} relation{'s' if wl['R'] > 1 else ''}, GACN {wl['Cin']}->{wl['Co']} and "
+                     f"{wl['hidden']}->{wl['Co']}, forward+backward"),
+        "launch_mode": "hip_graph_replay (one graph = one step: both depths, forward + backward)",
+        "ms_per_step": round(wall_g / steps * 1e3, 4), "ms_per_step_median_hip_events": round(statistics.median(per_g), 4),
+        "hip_graph_replay_ms_per_step": round(wall_g / steps * 1e3, 4),
+        "eager_launch_ms_per_step": round(wall_e / steps * 1e3, 4),
+        "eager_launch_ms_per_step_median_hip_events": round(statistics.median(per_e), 4),
+        "gpu_busy_ms_per_step": round(busy * 1e-3, 4), "launches_per_step": round(launches, 1),
+        "samples_per_s": round(wl["B"] / (wall_g / steps), 2),
+        "forward_ms": round(fwd, 4), "forward_eager_launch_ms": round(statistics.median(fwd_e), 4),
+        "forward_gpu_busy_ms": round(busy_f * 1e-3, 4), "forward_launches": round(launches_f, 1),
         "eager_rocm_forward_ms": round(statistics.median(eager_fwd), 3),
         "eager_rocm_fwd_bwd_ms": round(statistics.median(eager_all), 3),
-        "speedup_vs_eager_rocm_forward": round(statistics.median(eager_fwd) / statistics.median(fwd), 2),
-        "speedup_vs_eager_rocm_fwd_bwd": round(statistics.median(eager_all) / statistics.median(per_step), 2),
+        "speedup_vs_eager_rocm_forward": round(statistics.median(eager_fwd) / fwd, 2),
+        "speedup_vs_eager_rocm_forward_eager_launch": round(statistics.median(eager_fwd) / statistics.median(fwd_e), 2),
+        "speedup_vs_eager_rocm_fwd_bwd": round(statistics.median(eager_all) / statistics.median(per_g), 2),
     }
 
 
@@ -547,9 +614,13 @@ def main():
 
     wl = WORKLOADS[args.workload]
     hp = HotPath(wl, dev, seed=rank)
-    settle(lambda: hp.step(allreduce=multi), dev)
+    settle(lambda: hp.step(allreduce=multi), dev, agree=max_over_ranks if multi else None)
+    from ms_gat_amd import parallel
+    if multi:
+        parallel.collective_events = []     # HIP events around every flat all-reduce (launch stream)
     hot_wall, hot_steps = timed_steps(lambda: hp.step(allreduce=multi), args.steps, args.warmup, dev, barrier)
     hot_wall = max_over_ranks(hot_wall)
+    hot_allreduce_us = collective_us(args.steps)
     workload = (f"{args.workload}: N={wl['N']} nodes, {wl['E']} undirected edges (+self loops, sym-normalised), "
                 f"T={wl['T']}, B={wl['B']}/GPU, R={wl['R']} relations, GACN {wl['Cin']}->{wl['Co']} and "
                 f"{wl['hidden']}->{wl['Co']} (msgat72 widths), forward+backward of the hot path"
@@ -566,6 +637,9 @@ def main():
                       "parallelism": (f"batch-sharded x{world}, one flat all-reduce of the hot path's parameter gradients "
                                       f"per step ({hp.sync.nbytes} bytes)" if world > 1 else "single GPU (batch-sharded x1)")},
            "node_updates_per_s": round(value * wl["R"] * wl["T"] * wl["N"], 1),
+           # the step's one collective, this rank's median over the timed steps (null without a process group): what
+           # separates transport from compute in a scaling curve
+           "allreduce_us": hot_allreduce_us,
            "settle_ms_before_warmup": SETTLE_MS,   # untimed steps in front of the W warm-up steps (clock / cache ramp)
            "launch": ("torch.distributed.run" if launched else "forced process group" if FORCE_DIST else "plain"),
            "transport": (("gloo, all ranks share cuda:0 (REHEARSAL, not a scaling measurement)" if SHARE_GPU else "rccl")
@@ -579,11 +653,14 @@ def main():
     if with_secondary:
         # configs[3]: the whole training step, B = 32 per GPU, all gradients in one flat all-reduce.  Every rank runs
         # it (the collective needs them all); timed like `value`: barrier on both sides, MAX over ranks.
-        try:
+        # (no try/except around it with several ranks: a rank that failed alone would leave its peers inside the next
+        # collective until the process-group timeout -- the exception propagates and torchrun tears the job down)
+        def cfg4_object():
             ts = TrainStep(CFG4, dev, seed=rank)
             steps = max(5, min(args.steps, 20))
             wall, per_step = time_train_step(ts, steps, max(2, min(args.warmup, 5)), barrier)
             wall = max_over_ranks(wall)
+            allreduce_us = collective_us(steps)
             out["full_step_cfg4"] = {
                 "workload": (f"configs[3] per-GPU workload: msgat72 TRAINING step through engine.Trainer -- forward of "
                              f"R={CFG4['R']} components, Huber loss + metrics, backward, one flat all-reduce of "
@@ -594,13 +671,19 @@ def main():
                 "ms_per_step_median_hip_events": round(statistics.median(per_step), 4),
                 "value": round(CFG4["B"] * world / (wall / steps), 2), "unit": "samples/s",
                 "global_batch": CFG4["B"] * world, "trainable_parameters": ts.n_params,
-                "allreduce_bytes_per_step": ts.allreduce_bytes if world > 1 else 0,
+                "allreduce_bytes_per_step": ts.allreduce_bytes if world > 1 else 0, "allreduce_us": allreduce_us,
                 "allreduce_bytes_per_step_when_sharded": ts.allreduce_bytes,
             }
             del ts
             torch.cuda.empty_cache()
-        except RuntimeError as e:
-            out["full_step_cfg4"] = {"error": str(e).splitlines()[0][:160]}
+
+        if multi:
+            cfg4_object()
+        else:
+            try:
+                cfg4_object()
+            except RuntimeError as e:
+                out["full_step_cfg4"] = {"error": str(e).splitlines()[0][:160]}
 
     if rank == 0:
         out["roofline"] = roofline_object(hp)
@@ -644,7 +727,7 @@ def main():
 
         if args.workload == "pemsd7":
             try:
-                out["pemsd4"] = pemsd4_object(dev)
+                out["pemsd4"] = small_graph_object("pemsd4", dev)
             except RuntimeError as e:
                 out["pemsd4"] = {"error": str(e).splitlines()[0][:160]}
             try:

@@ -380,27 +380,21 @@ static int launch_aggregate_t(const int* ptr, const int* idx, int nnz, const msg
   const int CH = slab_channels(N, T, Cu, kLdsBudget);
   if (sell != nullptr) {  // E is in the position order of this layout (the caller permuted it by sell->src)
     const size_t lds = (size_t)N * sizeof(float4);
-    if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_sell<T4>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
-    }
+    static LdsGrant granted;
+    if (int st = grant_dynamic_lds(&k_agg_sell<T4>, lds, granted)) return st;
     hipLaunchKernelGGL((k_agg_sell<T4>), dim3((unsigned)cdiv(G, 8) * 8 * Cu * T4), dim3(kAggBlock), lds, s,
                        sell->slice_off, sell->lane_row, sell->idx, (const float4*)u, E, addvec, (const float4*)extra,
                        (float4*)v, G, Bg, Cu, N, sell->n_pos, sell->n_slices);
   } else if (addvec == nullptr && xdot == nullptr && nnz >= 8 && N * T4 <= 3 * kAggBlock && G * Cu >= 512) {
     // plain aggregate on a small graph: the persistent LDS-DMA ring, one block per CU
-    int dev = 0, ncu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
-      ncu = 256;  // MI355X
+    const int ncu = device_cu_count();
     const int nslab = G * Cu, per = cdiv(nslab, ncu), nb = cdiv(nslab, per);
     const int KI = cdiv(N * T4, kAggBlock);
     const size_t lds = (size_t)3 * KI * kAggBlock * sizeof(float4);
 #define MSGAT_RING(ki)                                                                                            \
     {                                                                                                               \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_ring<T4, ki>),                        \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
-      if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;                                                      \
+      static LdsGrant granted;                                                                                      \
+      if (int st = grant_dynamic_lds(&k_agg_ring<T4, ki>, lds, granted)) return st;                                 \
       hipLaunchKernelGGL((k_agg_ring<T4, ki>), dim3(nb), dim3(kAggBlock), lds, s, ptr, idx, (const float4*)u, E,    \
                          (float4*)v, Cu, N, nnz, nslab, per);                                                       \
     }
@@ -408,14 +402,9 @@ static int launch_aggregate_t(const int* ptr, const int* idx, int nnz, const msg
 #undef MSGAT_RING
   } else if (CH >= 1) {
     const size_t lds = (size_t)CH * N * T * sizeof(float);
-    if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_lds<T4, false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_lds<T4, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
-    }
+    static LdsGrant granted_plain, granted_dot;
+    if (int st = grant_dynamic_lds(&k_agg_lds<T4, false>, lds, granted_plain)) return st;
+    if (int st = grant_dynamic_lds(&k_agg_lds<T4, true>, lds, granted_dot)) return st;
     dim3 grid(cdiv(Cu, CH), G);
     if (xdot != nullptr && dap != nullptr && addvec != nullptr && Cu <= kAggDotMaxC) {
       hipLaunchKernelGGL((k_agg_lds<T4, true>), grid, dim3(kAggBlock), lds, s, ptr, idx, (const float4*)u, E, addvec,
@@ -427,11 +416,8 @@ static int launch_aggregate_t(const int* ptr, const int* idx, int nnz, const msg
     }
   } else if ((size_t)N * sizeof(float4) <= (size_t)kLdsMax - 1024 && nnz >= 8) {
     const size_t lds = (size_t)N * sizeof(float4);
-    if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_cols<T4>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
-    }
+    static LdsGrant granted;
+    if (int st = grant_dynamic_lds(&k_agg_cols<T4>, lds, granted)) return st;
     hipLaunchKernelGGL(k_agg_cols<T4>, dim3(Cu, G), dim3(kAggBlock), lds, s, ptr, idx, (const float4*)u, E,
                        addvec, (const float4*)extra, (float4*)v, Bg, Cu, N, nnz);
   } else {
@@ -710,10 +696,9 @@ static int launch_agg_sddmm_t(const msgat_graph_t& gr, const float* dv, const fl
   const int T = 4 * T4;
   const int CH = slab_channels(N, T, Cu, kLdsBudget);
   const size_t lds = agg_sddmm_lds(N, T, Cu, gr.nnz);
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_sddmm<T4>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
+  {
+    static LdsGrant granted;
+    if (int st = grant_dynamic_lds(&k_agg_sddmm<T4>, lds, granted)) return st;
   }
   const int nchunks = cdiv(Cu, CH);
   hipLaunchKernelGGL(k_agg_sddmm<T4>, dim3(nchunks, G), dim3(kAgsBlock), lds, s, gr.colptr, gr.crow, (const float4*)dv,
@@ -899,10 +884,9 @@ static int launch_sddmm_t(const msgat_graph_t& gr, const float* u, const float* 
     const int chj = cdiv(Cu, nch);
     const size_t lds = (size_t)N * sizeof(float4);
     if (sddmm_in_registers(sl)) {
-      if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm_sellreg<T4>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
+      {
+        static LdsGrant granted;
+        if (int st = grant_dynamic_lds(&k_sddmm_sellreg<T4>, lds, granted)) return st;
       }
       const int Q = cdiv(sl.n_slices, 2 * (kAggBlock / 64));
       hipLaunchKernelGGL(k_sddmm_sellreg<T4>, dim3((unsigned)cdiv(G, 8) * 8 * Q), dim3(kAggBlock), lds, s, sl.slice_off,
@@ -910,19 +894,17 @@ static int launch_sddmm_t(const msgat_graph_t& gr, const float* u, const float* 
       MSGAT_CHECK_LAUNCH();
       return MSGAT_OK;
     }
-    if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm_sell<T4>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
+    {
+      static LdsGrant granted;
+      if (int st = grant_dynamic_lds(&k_sddmm_sell<T4>, lds, granted)) return st;
     }
     hipLaunchKernelGGL(k_sddmm_sell<T4>, dim3(nch, G), dim3(kAggBlock), lds, s, sl.slice_off, sl.lane_row, sl.idx,
                        (const float4*)u, (const float4*)dv, dEp, Cu, N, sl.n_pos, sl.n_slices, chj, nch);
   } else if (CH >= 1) {
     const size_t lds = (size_t)CH * N * T * sizeof(float);
-    if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sddmm<T4, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
+    {
+      static LdsGrant granted;
+      if (int st = grant_dynamic_lds(&k_sddmm<T4, true>, lds, granted)) return st;
     }
     const int nchunks = cdiv(Cu, CH);
     dim3 grid(1, nchunks, G);

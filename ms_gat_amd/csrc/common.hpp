@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "msgat_hip.h"
 
 #define MSGAT_CHECK_LAUNCH()                                   \
@@ -43,6 +45,43 @@ __device__ __forceinline__ float f4dot(const float4& a, const float4& b, float a
 // softmax needs; exp2f() from the device library adds range scaling we do not want.
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+
+// Host-side queries a launcher would otherwise repeat on every call (`hipGetDevice` + `hipDeviceGetAttribute` +
+// `hipFuncSetAttribute` per launch are part of what makes a PEMSD4-sized step host-bound).  Both caches are per
+// device and lock-free; a lost race only repeats an idempotent driver call.
+constexpr int kMaxDevices = 32;
+inline int current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+  return dev;
+}
+// compute units of the current device (256 on MI355X, also the fallback when the query fails)
+inline int device_cu_count() {
+  static std::atomic<int> cached[kMaxDevices];
+  const int dev = current_device();
+  int ncu = cached[dev].load(std::memory_order_relaxed);
+  if (ncu <= 0) {
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    cached[dev].store(ncu, std::memory_order_relaxed);
+  }
+  return ncu;
+}
+// A kernel's dynamic-LDS ceiling (hipFuncAttributeMaxDynamicSharedMemorySize) has to be raised above 64 KiB once per
+// device, not once per launch: `granted` is the call site's own (static, zero-initialised) record of what it has
+// asked for so far.  Returns a status code.
+struct LdsGrant {
+  std::atomic<int> bytes[kMaxDevices];
+};
+template <typename K>
+inline int grant_dynamic_lds(K kernel, size_t lds, LdsGrant& granted) {
+  if (lds <= 64 * 1024) return MSGAT_OK;
+  std::atomic<int>& g = granted.bytes[current_device()];
+  if ((int)lds <= g.load(std::memory_order_acquire)) return MSGAT_OK;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
+  g.store((int)lds, std::memory_order_release);
+  return MSGAT_OK;
+}
 
 inline bool t_supported(int T) { return T == 4 || T == 8 || T == 12 || T == 16; }
 

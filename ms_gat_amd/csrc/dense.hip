@@ -58,10 +58,7 @@ constexpr float kDefer = 8.f;          // re-base the running max only when a sc
 // 8 blocks, others 3, and the kernel ran 1.7x longer than its median block).  Asking for unused
 // dynamic LDS caps the blocks per CU at ceil(blocks / CUs), which forces an even spread.
 static size_t balance_pad_bytes(int nblocks, size_t static_lds) {
-  int dev = 0, ncu = 0;
-  if (hipGetDevice(&dev) != hipSuccess ||
-      hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
-    ncu = 256;  // MI355X
+  const int ncu = device_cu_count();
 #ifdef MSGAT_DCAP
   const int per_cu = MSGAT_DCAP;        // lab: resident blocks per CU capped, the rest dispatched as slots free up
 #else
@@ -504,17 +501,17 @@ __global__ __launch_bounds__(kDBlock) void k_scores7(
 
 // Column split of the 7 + 1 form: the helper takes Th = 2 round(Tn / 18) of the Tn = ceil(N / 16) column tiles (an even
 // count: trips are two tiles; a helper tile costs about what an owner tile costs, and 7 Th ~ Tn - Th).  Returns the owners'
-// column count Ca (a multiple of 32), or 0 when the form does not apply: helper columns must fit one staged chunk, and
-// it only pays where the 128-row blocks leave the CUs unevenly loaded while the 112-row blocks do not.
+// column count Ca (a multiple of 16; an odd multiple when Tn is odd -- the kernels mask the empty half of the owners' last
+// two-tile trip, and the balance estimate below charges the owners for it), or 0 when the form does not apply: helper
+// columns must fit one staged chunk, and it only pays where the 128-row blocks leave the CUs unevenly loaded while the
+// 112-row blocks do not.
 static int scores7_owner_columns(int N, int G) {
-  int dev = 0, ncu = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
-    ncu = 256;
+  const int ncu = device_cu_count();
   const int Tn = cdiv(N, 16);
   const int Th = 2 * ((Tn + 9) / 18);
   if (Th < 2 || Th * 16 > kDMC || Tn - Th < 2) return 0;
   const double b8 = (double)cdiv(N, kDRows) * G / ncu, b7 = (double)cdiv(N, kHRows) * G / ncu;
-  const double eff8 = b8 / ceil(b8), eff7 = b7 / ceil(b7) * (7.0 * Tn / (8.0 * (Tn - Th)));   // useful share of the busiest CU's time
+  const double eff8 = b8 / ceil(b8), eff7 = b7 / ceil(b7) * (7.0 * Tn / (8.0 * (Tn - Th + ((Tn - Th) & 1))));   // useful share of the busiest CU's time
   if (b7 > 6.0 || eff7 <= eff8 + 0.03) return 0;
   return (Tn - Th) * 16;
 }

@@ -721,8 +721,12 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_glds(
   static_assert(!MIX || kPPW == 16, "one 16-position tile per wave");
   float mfrag[KS][NB];
   // B2 word of k-step s: row 4 s + kq of the tile = group (4 s + kq) / kRPI -- linear in s, so one register and an
-  // immediate offset per read.  Rows a >= Ca of the last k-step are other channels' finite data times a zero fragment.
+  // immediate offset per read.  Rows a >= Ca of the last k-steps hold other operands' data (B = x): those lanes read the
+  // tile's zero row instead, so a non-finite x cannot reach the mix output as 0 * Inf (the two-pass fallback never reads
+  // x for it either).  The launchers only pick a block shape for Ca > kCaMin, so the earlier k-steps need no select.
   constexpr int kMStep = (4 / kRPI) * (kGGroupF4 * 4);
+  constexpr int kCaMin = MA <= 2 ? (MA - 1) * 16 : (MA - 2) * 16;
+  const int zword = ngroups * (kGGroupF4 * 4) + j;
   const int mbase = (kq / kRPI) * (kGGroupF4 * 4) + (kq % kRPI) * TILE + 4 * (((kPPW / 4) * rwave + (j >> 2)) ^ swz(kq)) + (j & 3);
   auto load_mfrag = [&]() {
 #pragma unroll
@@ -754,7 +758,9 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_glds(
     for (int nb = 0; nb < NB; ++nb) d[nb] = zero4();
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const float bv = w[mbase + s * kMStep];
+      int word = mbase + s * kMStep;
+      if (4 * s + 3 >= kCaMin) word = (4 * s + kq < Ca) ? word : zword;
+      const float bv = w[word];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) d[nb] = mfma16(bv, mfrag[s][nb], d[nb]);
     }
@@ -878,9 +884,7 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_glds(
 
 // blocks per relation: one block per CU in total (the kernel is built for one resident block per CU)
 int chanpair_mfma_blocks(int R) {
-  int dev = 0, ncu = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
-    ncu = 256;  // MI355X
+  const int ncu = device_cu_count();
   return max(1, ncu / R);
 }
 
@@ -895,10 +899,9 @@ static int launch_chanpair_t(const SegList& A, const float* B, float* part, int 
   *nblk_used = nblk;
   // tile rows + the zero row + the ones row; the reduction re-uses the buffer a few tiles at a time
   const size_t lds = sizeof(float4) * (size_t)(((MA + NB) * 16 + 2) * (TILE / 4 + 1));
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chanpair_mfma<MA, NB, TWO, TILE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
+  {
+    static LdsGrant granted;
+    if (int st = grant_dynamic_lds(&k_chanpair_mfma<MA, NB, TWO, TILE>, lds, granted)) return st;
   }
   const dim3 grid = nz > 1 ? dim3((unsigned)cdiv(nblk * R, 8) * 8 * nz) : dim3(nblk, R, 1);
   hipLaunchKernelGGL((k_chanpair_mfma<MA, NB, TWO, TILE>), grid, dim3(kCpBlock), lds, s, A, B, part, Cb, P, Bg, nzb, b_ones,
@@ -925,10 +928,9 @@ static int launch_chanpair_glds_t(const SegList& A, const float* B, float* part,
   *nblk_used = nblk;
   const size_t lds = chanpair_glds_lds<MA, NB, TILE, NBUF>(Ca, Cb);
   if (lds > (size_t)kLdsMax || lds < (size_t)(MA * NB < 8 ? MA * NB : 8) * kCpWaves * 1024) return MSGAT_ERR_UNSUPPORTED;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chanpair_glds<MA, NB, TILE, NBUF, MODE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
+  {
+    static LdsGrant granted;
+    if (int st = grant_dynamic_lds(&k_chanpair_glds<MA, NB, TILE, NBUF, MODE>, lds, granted)) return st;
   }
   const dim3 grid = nz > 1 ? dim3((unsigned)cdiv(nblk * R, 8) * 8 * nz) : dim3(nblk, R, 1);
   hipLaunchKernelGGL((k_chanpair_glds<MA, NB, TILE, NBUF, MODE>), grid, dim3(kCpBlock), lds, s, A, B, part, Cb, P, Bg,

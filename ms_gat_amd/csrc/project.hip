@@ -45,6 +45,20 @@ int launch_qonly(const float* x, const float* alpha, float* q, int G, int Bg, in
 // partial per block, fixed order everywhere.
 constexpr int kAfChunk = 8;
 
+// Sum over the 64 lanes of a wave, result in lane 63: six v_add_f32 with DPP operands (quad_perm xor 1 / xor 2,
+// row_half_mirror, row_mirror, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) -- no LDS crossbar.
+// The kernel reduces Co * C sums per wave this way; as __shfl_xor butterflies (ds_bpermute_b32 + address arithmetic per
+// step) the reduction was most of its instructions: 24.5 us at PEMSD4 (C = 3) for 28 MB.  Fixed order.
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));
+  return v;
+}
+
 template <int C>
 __global__ __launch_bounds__(kBlock) void k_aggfirst_bwd(const float4* __restrict__ dz4, const float* __restrict__ W,
                                                          const float4* __restrict__ y4, float4* __restrict__ dy4,
@@ -78,10 +92,8 @@ __global__ __launch_bounds__(kBlock) void k_aggfirst_bwd(const float4* __restric
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         if (o0 + k < Co) f4fma(Wl[o * C + c], d[k], acc[c]);  // wave-uniform, no load inside
-        float w = f4dot(d[k], yv[c], 0.f);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off);
-        if (lane == 0 && o0 + k < Co) red[wave * Co * C + o * C + c] = w;
+        const float w = wave_sum_to_lane63(f4dot(d[k], yv[c], 0.f));
+        if (lane == 63 && o0 + k < Co) red[wave * Co * C + o * C + c] = w;
       }
     }
   }

@@ -157,14 +157,11 @@ static size_t chanatt_bwd_lds(int C, int cb, int T) {
 
 size_t chanatt_partial_floats(int G, int C, int cb, int T) { return (size_t)G * ((size_t)T * T + (size_t)cb * C); }
 
-template <typename K>
-static int raise_lds(K kernel, size_t lds) {
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
-  }
-  return MSGAT_OK;
+// one grant record per kernel instantiation (the template argument makes the static distinct)
+template <typename K, K kernel>
+static int raise_lds(size_t lds) {
+  static LdsGrant granted;
+  return grant_dynamic_lds(kernel, lds, granted);
 }
 
 int launch_chanatt_fwd(const float* pooled, const float* Wc, const float* conv, float* att, float* Mc, int G, int R,
@@ -173,7 +170,7 @@ int launch_chanatt_fwd(const float* pooled, const float* Wc, const float* conv, 
   if (lds > (size_t)kLdsMax - 1024) return MSGAT_ERR_UNSUPPORTED;
 #define MSGAT_CA_FWD(TT)                                                                                      \
   {                                                                                                           \
-    int st = raise_lds(&k_chanatt_fwd<TT>, lds);                                                              \
+    int st = raise_lds<decltype(&k_chanatt_fwd<TT>), &k_chanatt_fwd<TT>>(lds);                                                              \
     if (st) return st;                                                                                        \
     hipLaunchKernelGGL(k_chanatt_fwd<TT>, dim3(G), dim3(kSaBlock), lds, s, pooled, Wc, conv, att, Mc, G / R, C, cb); \
   }
@@ -198,7 +195,7 @@ int launch_chanatt_bwd(const float* dMc, const float* att, const float* pooled, 
   float* pconv = part + (size_t)G * T * T;   // [G,cb,C]
 #define MSGAT_CA_BWD(TT)                                                                                       \
   {                                                                                                            \
-    int st = raise_lds(&k_chanatt_bwd<TT>, lds);                                                               \
+    int st = raise_lds<decltype(&k_chanatt_bwd<TT>), &k_chanatt_bwd<TT>>(lds);                                                               \
     if (st) return st;                                                                                         \
     hipLaunchKernelGGL(k_chanatt_bwd<TT>, dim3(G), dim3(kSaBlock), lds, s, dMc, att, pooled, Wc, conv, dpooled, pWc, \
                        pconv, G / R, C, cb);                                                                   \

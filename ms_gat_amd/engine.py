@@ -24,7 +24,6 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 from time import localtime, strftime
-from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -147,7 +146,7 @@ class FlatAdam(optim.Optimizer):
         self._host_steps: List[int] = []             # host mirror of the per-parameter step counts
         self._captured_active: Optional[tuple] = None
         self._tables: Dict[tuple, tuple] = {}
-        self._gather_tables: "OrderedDict[tuple, tuple]" = OrderedDict()
+        self._gather_tables: dict = {}
         self._lr_on_device = None
         self._last_active: Optional[tuple] = None
         self.flat_grad = None
@@ -271,7 +270,7 @@ class FlatAdam(optim.Optimizer):
                 self._gather(grads, active, float(rank_weight))
             else:
                 self.flat_grad[self.numel:].fill_(float(rank_weight))
-            dist.all_reduce(self.flat_grad)
+            parallel.all_reduce_flat(self.flat_grad)
             divisor = self.flat_grad.data_ptr() + 4 * self.numel
         elif grads:
             torch._foreach_copy_([v for v, on in zip(self._grad_views, active) if on], grads)

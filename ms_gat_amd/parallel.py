@@ -12,7 +12,6 @@ size, so per-tensor buckets or overlap would only add launches).
 from __future__ import annotations
 
 import os
-from collections import OrderedDict
 from typing import Iterable, List, Sequence
 
 import torch
@@ -70,34 +69,77 @@ def sync_parameters(module: torch.nn.Module, src: int = 0) -> None:
                 off += t.numel()
 
 
+# HIP events around each flat all-reduce (on the launch stream), for the benchmark's `allreduce_us`: set to a list to
+# collect (start, end) pairs, None (default) to record nothing.
+collective_events = None
+
+
+def all_reduce_flat(flat: torch.Tensor) -> None:
+    """The step's ONE collective: sum of the flat fp32 buffer over all ranks (RCCL over xGMI for device tensors)."""
+    rec = collective_events
+    if rec is None or not flat.is_cuda:
+        dist.all_reduce(flat)
+        return
+    stream = torch.cuda.current_stream(flat.device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    dist.all_reduce(flat)
+    e1.record(stream)
+    rec.append((e0, e1))
+
+
+class _GatherTable:
+    """Device chunk table of one gradient layout (sizes + offsets): the offset and length columns never change; the
+    pointer column is refreshed from a pinned host buffer with a stream-ordered copy when an allocator hands the
+    gradients out at new addresses (eager steps with ragged batches do) -- no synchronising pageable upload on the
+    path in front of the collective."""
+
+    def __init__(self, sizes, offsets, dev):
+        from . import _lib
+        chunk = int(_lib.lib().msgat_adam_chunk_elems())
+        self.rel, offs, lens = [], [], []       # rel: (gradient index, byte offset) of every chunk
+        for i, (n, o) in enumerate(zip(sizes, offsets)):
+            for s in range(0, n, chunk):
+                self.rel.append((i, 4 * s))
+                offs.append(o + s)
+                lens.append(min(chunk, n - s))
+        self.n = len(self.rel)
+        self.offs = torch.tensor(offs, dtype=torch.int64).to(dev)
+        self.lens = torch.tensor(lens, dtype=torch.int32).to(dev)
+        self.ptrs = torch.zeros(max(self.n, 1), dtype=torch.int64, device=dev)
+        self.host = torch.zeros(max(self.n, 1), dtype=torch.int64).pin_memory()
+        self.copied = None           # event behind the last host -> device copy of the pointer column
+        self.current = None
+
+    def point_at(self, bases: tuple) -> None:
+        if bases == self.current:
+            return
+        if self.copied is not None:
+            self.copied.synchronize()            # the pinned buffer is free again (long done in practice)
+        h = self.host.numpy()
+        for k, (i, b) in enumerate(self.rel):
+            h[k] = bases[i] + b
+        self.ptrs.copy_(self.host, non_blocking=True)
+        self.copied = torch.cuda.Event()
+        self.copied.record(torch.cuda.current_stream(self.ptrs.device))
+        self.current = bases
+
+
 def gather_scaled(flat: torch.Tensor, grads: Sequence[torch.Tensor], offsets: Sequence[int], weight: float,
-                  weight_index: int, cache: "OrderedDict") -> None:
+                  weight_index: int, cache: dict) -> None:
     """flat[offsets[i] : ...] = weight * grads[i] for every gradient and flat[weight_index] = weight, in ONE launch
-    (`msgat_gather_scaled`, csrc/tail.hip).  The device table of gradient pointers is cached in `cache` by those
-    pointers: a replayed HIP graph or a warm caching allocator hands out the same ones step after step."""
+    (`msgat_gather_scaled`, csrc/tail.hip).  `cache` keeps one persistent device table per gradient layout
+    (`_GatherTable`): a replayed HIP graph or a warm caching allocator hands out the same pointers step after step and
+    nothing is uploaded; new pointers cost one asynchronous copy from pinned memory."""
     from . import _lib
     keep = [g if g.is_contiguous() else g.contiguous() for g in grads]
-    key = (tuple(g.data_ptr() for g in keep), tuple(offsets))
-    hit = cache.get(key)
-    if hit is None:
-        chunk = int(_lib.lib().msgat_adam_chunk_elems())
-        ptrs, offs, lens = [], [], []
-        for g, o in zip(keep, offsets):
-            for s in range(0, g.numel(), chunk):
-                ptrs.append(g.data_ptr() + 4 * s)
-                offs.append(o + s)
-                lens.append(min(chunk, g.numel() - s))
-        dev = flat.device
-        hit = (torch.tensor(ptrs, dtype=torch.int64).to(dev), torch.tensor(offs, dtype=torch.int64).to(dev),
-               torch.tensor(lens, dtype=torch.int32).to(dev), len(ptrs))
-        cache[key] = hit
-        while len(cache) > 8:            # eager launches only (never captured): old tables may go
-            cache.popitem(last=False)
-    else:
-        cache.move_to_end(key)
-    src, offs, lens, n = hit
-    st = _lib.lib().msgat_gather_scaled(src.data_ptr(), offs.data_ptr(), lens.data_ptr(), n, float(weight),
-                                        flat.data_ptr(), int(weight_index),
+    key = (tuple(g.numel() for g in keep), tuple(offsets))
+    table = cache.get(key)
+    if table is None:
+        table = cache[key] = _GatherTable(key[0], key[1], flat.device)
+    table.point_at(tuple(g.data_ptr() for g in keep))
+    st = _lib.lib().msgat_gather_scaled(table.ptrs.data_ptr(), table.offs.data_ptr(), table.lens.data_ptr(), table.n,
+                                        float(weight), flat.data_ptr(), int(weight_index),
                                         torch.cuda.current_stream(flat.device).cuda_stream)
     _lib.check(st, "msgat_gather_scaled")
 
@@ -121,7 +163,7 @@ class FlatGradAllReduce:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             self.offsets.append(off)
             off += p.numel()
-        self._tables: "OrderedDict" = OrderedDict()
+        self._tables: dict = {}
 
     @property
     def nbytes(self) -> int:
@@ -137,7 +179,7 @@ class FlatGradAllReduce:
             # device tensors: one launch in front of the collective, one behind it; the averaged gradients are
             # handed back as views of the flat buffer (no copy back)
             gather_scaled(self.flat, [p.grad for p in self.params], self.offsets, weight, self.numel, self._tables)
-            dist.all_reduce(self.flat)
+            all_reduce_flat(self.flat)
             self.flat[: self.numel].div_(self.flat[self.numel])
             for p, v in zip(self.params, self.views):
                 p.grad = v

@@ -80,6 +80,17 @@ def pytest_sessionfinish(session, exitstatus):
             f.write(f"{what}\t{key}\t{err:.3e}\t{bar:.0e}\t{bar / max(err, 1e-30):.1f}\t{v}\n")
 
 
+def assert_parity(got, want, what, key, tol=1e-4, floor_eps=1e-5):
+    """The parity bar in both forms: max-norm `rel_err < tol` AND, per entry, |a-b| <= 1e-4 |b| + floor_eps max|b| (an
+    entry far below the tensor's maximum may not be wrong by more than ~its own 1e-4 plus a tenth of the bar).  The
+    violating fraction at the tighter floor 1e-6 max|b| goes on record (MSGAT_PARITY_LOG)."""
+    e = rel_err(got, want)
+    viol = (elementwise_violations(got, want, 1e-4, 1e-6), elementwise_violations(got, want, 1e-4, floor_eps))
+    record_err(what, key, e, tol, viol)
+    assert e < tol, f"{what} {key}: rel err {e:.3e} >= {tol}"
+    assert viol[1] == 0.0, f"{what} {key}: {viol[1]:.2e} of the entries outside 1e-4|b| + {floor_eps:g} max|b|"
+
+
 GATT_CASES = ["b2c3n16", "b2c1n64", "b2c72n64", "b2c3n307"]
 
 

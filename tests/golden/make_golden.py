@@ -22,7 +22,12 @@ Fixtures:
                            sample: the size bench.py reports on is pinned by the reference itself, not only by the oracle.
                            Inputs are stored as int8 multiples of 1/32 (exact in fp32), the adjacency as its non-zeros.
 
+  meam_72to72_n64.npz      MEAM(72 -> 72) fwd+bwd at N = 64: N*T = 768 positions per channel slab, past the 512 below which
+                           the library's one-pass convolution backward and segmented mixing forms are not selected -- the
+                           reference's own MEAM gradients reach those kernels.  x and dout are fp16-exact (stored as fp16).
+
     python tests/golden/make_golden.py --only headline     # just that one
+    python tests/golden/make_golden.py --only meam64
 """
 import os
 import sys
@@ -138,7 +143,7 @@ def headline_case(seed):
     print(f"gacn_headline_n883.npz: {os.path.getsize(path) / 1024:.0f} KiB")
 
 
-def meam_case(tag, cin, cout, N, B, seed):
+def meam_case(tag, cin, cout, N, B, seed, half_inputs=False):
     torch.manual_seed(seed)
     T = 12
     m = MEAM(cin, cout, n_nodes=N, n_timesteps=T, dilations=[1, 2])
@@ -149,13 +154,19 @@ def meam_case(tag, cin, cout, N, B, seed):
             else:
                 torch.nn.init.uniform_(p, -p.size(0) ** -0.5, p.size(0) ** -0.5)
     adj = synthetic_adjacency(N, N, seed + 1)
-    x = torch.randn(B, cin, N, T, requires_grad=True)
+    x = torch.randn(B, cin, N, T)
     dout = torch.randn(B, cout, N, T)
+    if half_inputs:   # exactly representable in fp16: stored at half the size
+        x, dout = x.half().float(), dout.half().float()
+    x.requires_grad_(True)
     out = m(x, t(adj))
     out.backward(dout)
     arrays = {f"p.{k}": v for k, v in m.state_dict().items()}
     arrays.update({f"g.{k}": p.grad for k, p in m.named_parameters()})
-    save(f"meam_{tag}.npz", x=x, adj=adj, dout=dout, out=out, dx=x.grad, **arrays)
+    if half_inputs:
+        save(f"meam_{tag}.npz", x=x.detach().half(), adj=adj, dout=dout.half(), out=out, dx=x.grad, **arrays)
+    else:
+        save(f"meam_{tag}.npz", x=x, adj=adj, dout=dout, out=out, dx=x.grad, **arrays)
 
 
 def msgat_case(seed):
@@ -294,6 +305,9 @@ if __name__ == "__main__":
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "headline":
         headline_case(1100)
         sys.exit(0)
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "meam64":
+        meam_case("72to72_n64", 72, 72, 64, 2, 1200, half_inputs=True)
+        sys.exit(0)
     headline_case(1100)
     gatt_case("b2c3n16", 2, 3, 16, 12, 20, 100)
     gatt_case("b2c1n64", 2, 1, 64, 12, 70, 200)
@@ -306,3 +320,4 @@ if __name__ == "__main__":
     slices_case(800)
     cfg1_case(900)
     loader_case(1000)
+    meam_case("72to72_n64", 72, 72, 64, 2, 1200, half_inputs=True)

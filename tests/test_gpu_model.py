@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, record_err, rel_err
+from conftest import assert_parity, load_golden, record_err, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -19,20 +19,24 @@ def _state(g):
     return {k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("p.")}
 
 
-@pytest.mark.parametrize("tag,cin", [("3to72_n32", 3), ("72to72_n32", 72)])
-def test_meam_block_matches_reference_forward_and_backward(tag, cin):
+@pytest.mark.parametrize("tag,cin,n", [("3to72_n32", 3, 32), ("72to72_n32", 72, 32), ("72to72_n64", 72, 64)])
+def test_meam_block_matches_reference_forward_and_backward(tag, cin, n):
+    """The reference's own MEAM outputs and gradients (tests/golden/make_golden.py).  N = 64 gives 768 positions per
+    channel slab: the one-pass convolution backward (`k_chanpair_glds<5|7,5,64,3,2>`) and the segmented mixing forms are
+    only selected from 512 positions up, so that case is what pins them to the reference (msgat.py:121-131)."""
     from ms_gat_amd import model
     g = load_golden(f"meam_{tag}.npz")
-    m = model.MEAM(cin, 72, n_nodes=32, n_timesteps=12, dilations=[1, 2])
+    m = model.MEAM(cin, 72, n_nodes=n, n_timesteps=12, dilations=[1, 2])
     m.load_state_dict(_state(g))
     m.to(_dev())
-    x = torch.from_numpy(g["x"]).to(_dev()).requires_grad_(True)
+    x = torch.from_numpy(g["x"]).float().to(_dev()).requires_grad_(True)
     out = m(x, torch.from_numpy(g["adj"]).to(_dev()))
-    out.backward(torch.from_numpy(g["dout"]).to(_dev()))
-    assert rel_err(out.detach().cpu(), g["out"]) < TOL
-    assert rel_err(x.grad.cpu(), g["dx"]) < TOL
+    out.backward(torch.from_numpy(g["dout"]).float().to(_dev()))
+    what = f"meam_{tag}"
+    assert_parity(out.detach().cpu(), g["out"], what, "out")
+    assert_parity(x.grad.cpu(), g["dx"], what, "dx")
     for name, p in m.named_parameters():
-        assert rel_err(p.grad.cpu(), g[f"g.{name}"]) < TOL, name
+        assert_parity(p.grad.cpu(), g[f"g.{name}"], what, name)
 
 
 def test_msgat72_forward_loss_and_all_gradients_match_reference():
@@ -46,13 +50,13 @@ def test_msgat72_forward_loss_and_all_gradients_match_reference():
     pred = net(X, H, D)
     loss = engine.HuberLoss(50.0)(pred, Y)
     loss.backward()
-    assert rel_err(pred.detach().cpu(), g["pred"]) < TOL
+    assert_parity(pred.detach().cpu(), g["pred"], "msgat72_n32", "pred")
     assert abs(float(loss) - float(g["loss"])) < TOL * abs(float(g["loss"]))
     checked = 0
     for name, p in net.named_parameters():
         if p.grad is None:
             continue
-        assert rel_err(p.grad.cpu(), g[f"g.{name}"]) < TOL, name
+        assert_parity(p.grad.cpu(), g[f"g.{name}"], "msgat72_n32", name)
         checked += 1
     assert checked == sum(1 for k in g if k.startswith("g."))
     # the graph branch really ran in the HIP library: its parameters received gradients

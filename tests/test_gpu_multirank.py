@@ -16,7 +16,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import rel_err
+from conftest import record_err, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -138,6 +138,44 @@ def test_flat_adam_collective_branch_equals_the_step_spelled_out_in_torch(tmp_pa
     assert got["worst_grad"] < 1e-5, got
     assert got["ok_weight"]                     # the last element of the buffer carries sum_r(w_r) after the collective
     assert set(got["steps"]) == {len(sizes)}
+
+
+def _first_step_gradient_worker(rank, world, port, size, out_dir):
+    """ONE training step from identical parameters; rank 0 stores the gradient the update consumed, per parameter: with
+    two ranks flat[:numel] / flat[numel] after the collective (sum_r n_r g_r / sum_r n_r), in one process the gradient
+    of the whole batch as backward left it."""
+    from ms_gat_amd import engine
+    net, batches = _model_and_batches((size,))
+    _join(rank, world, port)
+    tr = engine.Trainer(net, 50.0, os.path.join(out_dir, f"grad_w{world}"))
+    tr.run_epoch(batches, gpu_id=0, epoch=1, mode="train")
+    opt = tr.optimizer
+    flat = opt.flat_grad[: opt.numel] / opt.flat_grad[opt.numel] if world > 1 else opt.flat_grad[: opt.numel]
+    names = {id(p): n for n, p in net.named_parameters()}
+    if rank == 0:
+        torch.save({names[id(p)]: flat[o:o + p.numel()].view_as(p).detach().cpu() for p, o in zip(opt._params, opt._offsets)},
+                   os.path.join(out_dir, f"grad_w{world}.pt"))
+    _leave(world)
+
+
+@pytest.mark.parametrize("size", [8, 7])   # shards 4 + 4 and 4 + 3
+def test_whole_step_gradient_of_two_ranks_equals_the_single_process_gradient(tmp_path, size):
+    """The gradient of a whole training step BEFORE Adam: two ranks on their shards (gather scaled by the shard size,
+    one all-reduce, divided by the summed size) against one process on the whole batch, every parameter tensor to 1e-5
+    (max-norm; only the summation order over the batch differs).  The parameter comparison below is a smoke check --
+    Adam's first steps are sign-like -- this one bounds what the collective step feeds the optimizer."""
+    for world in (1, 2):
+        mp.spawn(_first_step_gradient_worker, args=(world, _free_port(), size, str(tmp_path)), nprocs=world, join=True)
+    one = torch.load(str(tmp_path / "grad_w1.pt"), weights_only=False)
+    two = torch.load(str(tmp_path / "grad_w2.pt"), weights_only=False)
+    assert one.keys() == two.keys() and len(one) > 20
+    worst = max(rel_err(two[k], one[k]) for k in one if float(one[k].abs().max()) > 0)
+    record_err(f"two_ranks_vs_one_gradient_b{size}", "worst tensor", worst, 1e-5)
+    for k in one:
+        if float(one[k].abs().max()) > 0:
+            assert rel_err(two[k], one[k]) < 1e-5, (k, rel_err(two[k], one[k]))
+        else:
+            assert float(two[k].abs().max()) == 0.0, k
 
 
 @pytest.mark.parametrize("sizes", [(8, 8, 8), (8, 7, 3, 1)])   # even shards; ragged ones incl. a batch smaller than the world

@@ -59,11 +59,11 @@ def test_branch_oracle_with_our_state_dict_matches_reference_meam():
     pins the oracle the GPU branch kernels are checked against, and the parameter layout."""
     from ms_gat_amd import model
     from oracle import dense_torch
-    for tag, cin in (("3to72_n32", 3), ("72to72_n32", 72)):
+    for tag, cin, n in (("3to72_n32", 3, 32), ("72to72_n32", 72, 32), ("72to72_n64", 72, 64)):
         g, ref = _ref_state(f"meam_{tag}.npz")
-        m = model.MEAM(cin, 72, n_nodes=32, n_timesteps=12, dilations=[1, 2])
+        m = model.MEAM(cin, 72, n_nodes=n, n_timesteps=12, dilations=[1, 2])
         m.load_state_dict(ref)
-        x, adj = torch.from_numpy(g["x"]), torch.from_numpy(g["adj"])
+        x, adj = torch.from_numpy(g["x"]).float(), torch.from_numpy(g["adj"])
         out = dense_torch.meam_dense(x, adj, dict(m.state_dict()), [1, 2])
         assert rel_err(out.detach(), g["out"]) < 1e-5, tag
 

@@ -9,7 +9,8 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 dev = torch.device("cuda:0")
-hp = bench.HotPath(bench.WORKLOADS["pemsd7"], dev, 0)
+WL = sys.argv[1] if len(sys.argv) > 1 else "pemsd7"
+hp = bench.HotPath(bench.WORKLOADS[WL], dev, 0)
 sync = lambda: torch.cuda.synchronize(dev)  # noqa: E731
 bench.settle(hp.step, dev)
 for k, w in ((20, 5), (50, 10)):

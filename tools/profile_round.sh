@@ -1,7 +1,9 @@
 #!/bin/bash
 # Collects the profiles a round commits under profiles/rNN/.  Runs ON THE GPU BOX:
 #     gpurun --timeout 1200 -- 'bash tools/profile_round.sh r03 [parts]'
-# parts (default "hot full stress pmc"):
+# parts (default "hot full stress pmc"; "pemsd4" on request):
+#   pemsd4  kernel trace of `bench.py --workload pemsd4 --no-baselines` (configs[1]): per-kernel totals per step and one
+#           step in launch order with the gaps between launches (the eager step is host-bound there)
 #   hot     rocprofv3 kernel trace of `bench.py --no-baselines` (the hot-path step): per-kernel totals per step,
 #           one step in launch order, the attention-aggregate kernel by phase (cold loop / in step / cached loop)
 #   full    kernel traces of whole training steps (tools/full_model_profile.py, R = 3 and R = 5) + unprofiled wall times
@@ -21,6 +23,14 @@ if has hot; then
   python3 $R/tools/roofline_trace_table.py $KT > $O/aggregate_by_phase.txt
   cp $(ls $O/bench_kt/*/*kernel_stats.csv | head -1) $O/hot_path_kernel_stats.csv 2>/dev/null
   rm -rf $O/bench_kt
+fi
+if has pemsd4; then
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p4_kt -- python3 $R/bench.py --workload pemsd4 --no-baselines --steps 50 --warmup 10 > $O/pemsd4_bench_under_rocprof.json 2>/dev/null
+  KT=$(ls $O/p4_kt/*/*kernel_trace.csv | head -1)
+  python3 $R/tools/trace_summary.py $KT k_qonly 1 30 40 > $O/pemsd4_per_step.txt
+  python3 $R/tools/trace_one_step.py $O/p4_kt --anchor k_qonly > $O/pemsd4_launches.txt 2>&1
+  cp $(ls $O/p4_kt/*/*kernel_stats.csv | head -1) $O/pemsd4_kernel_stats.csv 2>/dev/null
+  rm -rf $O/p4_kt
 fi
 if has full; then
   for r in 3 5; do
