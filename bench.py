@@ -522,6 +522,58 @@ def gpu_busy_us(fn, dev, steps=20):
     return sum(e.device_time_total for e in ev) / steps, sum(e.count for e in ev) / steps
 
 
+def hbm_kernel_table(hp, dev, steps=10):
+    """Per-kernel GPU time of one hot-path step (torch's profiler) and, for the four HBM-bound slab / channel-mixing
+    passes of the second depth, the fraction of the 8 TB/s roofline their algorithmic bytes reach:
+      k_project_mfma   u = W x, q = alpha . x         4 G P (C + Co + 1)
+      k_agg_ring/lds   v = E u                        2 . 4 G Co P
+      k_agg_sddmm      du = E^T dz and the SDDMM      3 . 4 G Co P
+      k_chanpair_*     dW | dalpha AND dx, one pass   4 G P (Co + 1 + 2 C)
+    (in-step durations: the operands of one kernel are partly cache-resident from its producer)."""
+    import re
+    from torch.profiler import ProfilerActivity, profile
+    wl = hp.wl
+    G, P, C, Co = wl["R"] * wl["B"], wl["N"] * wl["T"], wl["hidden"], wl["Co"]
+    algo = {"k_project_mfma": 4 * G * P * (C + Co + 1), "k_agg_ring": 8 * G * Co * P, "k_agg_sddmm": 12 * G * Co * P,
+            "k_chanpair_glds": 4 * G * P * (Co + 1 + 2 * C), "k_chanpair_mfma": 4 * G * P * (Co + 1 + C)}
+    torch.cuda.synchronize(dev)
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(steps):
+            hp.step()
+        torch.cuda.synchronize(dev)
+    rows = {}
+    for e in prof.key_averages():
+        if e.device_time_total <= 0:
+            continue
+        name = re.sub(r"\(.*", "", e.key).replace("void ", "").replace("msgat::", "")
+        us = e.device_time_total / max(e.count, 1)
+        row = {"us": round(us, 1), "per_step": round(e.count / steps, 1)}
+        for key, nbytes in algo.items():
+            # the second depth's launch is the large one; the contraction forms appear once per step at these widths
+            if name.startswith(key) and e.count / steps <= 1.0:
+                row["algorithmic_bytes"] = nbytes
+                row["frac_of_hbm_peak"] = round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 3)
+        rows[name] = row
+    return dict(sorted(rows.items(), key=lambda kv: -kv[1]["us"] * kv[1]["per_step"]))
+
+
+def widths_object(hidden, dev, steps=20):
+    """The hot-path step at the widths of the other two models of the reference's registry (main.py:17,
+    msgat.py:220-229): msgat48 (48 -> 16) and msgat96 (96 -> 32) on the headline graph (PEMSD7-like, R = 3, B = 32)."""
+    wl = dict(WORKLOADS["pemsd7"], hidden=hidden, Co=hidden // 3)
+    hp = HotPath(wl, dev, seed=0)
+    sync = lambda: torch.cuda.synchronize(dev)  # noqa: E731
+    settle(hp.step, dev, 30.0)
+    wall, per = timed_steps(hp.step, steps, 5, dev, sync)
+    obj = {"workload": (f"pemsd7 graph, msgat{hidden} widths: GACN {wl['Cin']}->{wl['Co']} and {hidden}->{wl['Co']}, "
+                        f"R={wl['R']}, B={wl['B']}, forward+backward of the hot path"),
+           "ms_per_step": round(wall / steps * 1e3, 4), "ms_per_step_median_hip_events": round(statistics.median(per), 4),
+           "samples_per_s": round(wl["B"] / (wall / steps), 2), "kernels": hbm_kernel_table(hp, dev)}
+    del hp
+    torch.cuda.empty_cache()
+    return obj
+
+
 def small_graph_object(name, dev, steps=100):
     """A workload whose step is ~0.2 ms of GPU work in 17 launches (configs[1], PEMSD4: N = 307, 3 features, B = 64, ONE
     relation): launched kernel by kernel the host cannot keep the GPU busy, so the step is also captured once and
@@ -730,6 +782,12 @@ def main():
                 out["pemsd4"] = small_graph_object("pemsd4", dev)
             except RuntimeError as e:
                 out["pemsd4"] = {"error": str(e).splitlines()[0][:160]}
+            for hidden in (48, 96):
+                try:
+                    out[f"widths{hidden}"] = widths_object(hidden, dev)
+                except RuntimeError as e:
+                    out[f"widths{hidden}"] = {"error": str(e).splitlines()[0][:160]}
+            out["widths72_kernels"] = hbm_kernel_table(hp, dev)
             try:
                 out["stress"] = stress_object(dev)
             except RuntimeError as e:

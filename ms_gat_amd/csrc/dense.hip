@@ -558,6 +558,44 @@ int launch_scores(const msgat_graph_t& gr, const float* q, const float* Wg, floa
   return MSGAT_ERR_UNSUPPORTED;
 }
 
+// The sparse part of the column pass: sum over the in-edges of column m of g_e kW[row_e], this lane's four timesteps.
+// Four edges per trip with clamped, unconditional loads (the surplus masked by a zero coefficient): a trip is two
+// dependent round trips (edge ids, then coefficient and kW row) behind the column extent, whatever the degree.  As one
+// edge per iteration the loop was 2 x degree dependent round trips at the END of a kernel whose blocks are all resident
+// -- pure tail.  Same order of the sum, same bits.
+template <int T>
+__device__ __forceinline__ float4 in_edge_term(const int* __restrict__ colptr, const int* __restrict__ crow,
+                                               const int* __restrict__ cperm, const float* __restrict__ gEg,
+                                               const float* __restrict__ kWg, int mcol, int quad) {
+  const int c0 = colptr[mcol], c1 = colptr[mcol + 1];
+  float4 sp = f4zero();
+  for (int k = c0; k < c1; k += 4) {
+    int ep[4], er[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kk = min(k + i, c1 - 1);
+      ep[i] = cperm[kk];
+      er[i] = crow[kk];
+    }
+    float ge[4];
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float raw = gEg[ep[i]];
+      ge[i] = (k + i < c1) ? raw : 0.f;
+      v[i] = reinterpret_cast<const float4*>(kWg + (size_t)er[i] * T)[quad];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sp.x = fmaf(ge[i], v[i].x, sp.x);
+      sp.y = fmaf(ge[i], v[i].y, sp.y);
+      sp.z = fmaf(ge[i], v[i].z, sp.z);
+      sp.w = fmaf(ge[i], v[i].w, sp.w);
+    }
+  }
+  return sp;
+}
+
 // ---- backward: dense column pass ------------------------------------------------------------------------
 // Wave w owns columns m0 + 16w .. +15 (B operand of the score product: their q) and streams all rows
 // through LDS: kW2 rows (A operand), delta*kW rows (payload) and lse2.  Score tile D[i = row][j = column]:
@@ -658,15 +696,7 @@ __global__ __launch_bounds__(kDBlock) void k_bwd_dense_col(
   if (!valid || quad >= T4) return;
 
   // D2[s = 4*quad + rr][column]: this lane owns dq[mcol][4*quad .. +3]; add the sparse in-edge term
-  float4 sp = f4zero();
-  for (int k = colptr[mcol]; k < colptr[mcol + 1]; ++k) {
-    const float ge = gE[(size_t)g * nnz + cperm[k]];
-    const float4 v = reinterpret_cast<const float4*>(kWg + (size_t)crow[k] * T)[quad];
-    sp.x = fmaf(ge, v.x, sp.x);
-    sp.y = fmaf(ge, v.y, sp.y);
-    sp.z = fmaf(ge, v.z, sp.z);
-    sp.w = fmaf(ge, v.w, sp.w);
-  }
+  const float4 sp = in_edge_term<T>(colptr, crow, cperm, gE + (size_t)g * nnz, kWg, mcol, quad);
   float4* dst = reinterpret_cast<float4*>(dq + ((size_t)g * N + mcol) * T) + quad;
   float4 v = *dst;
   v.x += sp.x - ((da[0] + db[0]) + (dc[0] + dd[0]));
@@ -827,15 +857,7 @@ __global__ __launch_bounds__(kDBlock) void k_bwd_dense_col7(
   if (!valid || quad >= T4) return;
 
   const int cl = 16 * wave + j;
-  float4 sp = f4zero();
-  for (int k = colptr[mcol]; k < colptr[mcol + 1]; ++k) {
-    const float ge = gE[(size_t)g * nnz + cperm[k]];
-    const float4 v = reinterpret_cast<const float4*>(kWg + (size_t)crow[k] * T)[quad];
-    sp.x = fmaf(ge, v.x, sp.x);
-    sp.y = fmaf(ge, v.y, sp.y);
-    sp.z = fmaf(ge, v.z, sp.z);
-    sp.w = fmaf(ge, v.w, sp.w);
-  }
+  const float4 sp = in_edge_term<T>(colptr, crow, cperm, gE + (size_t)g * nnz, kWg, mcol, quad);
   float4* dst = reinterpret_cast<float4*>(dq + ((size_t)g * N + mcol) * T) + quad;
   float4 v = *dst;
   v.x += sp.x - (((da[0] + db[0]) + (dc[0] + dd[0])) + hpay[cl][4 * quad + 0]);

@@ -234,7 +234,9 @@ static int proj_passes_mg(int Co, int* mg_out) {
   // all output tiles in one pass when they fit the accumulator registers: up to 7 x 16 channels (188 registers, two
   // waves per SIMD -- forced by the kernel's launch bounds, left alone the allocator took more than 256 and one wave).
   // A 72 -> 98 channel mixing in ONE pass over its input: 288 -> 252 us against two passes of 4 and 3 tiles.
-  const int passes = cdiv(Mt, kProjMaxMG);
+  // Several passes: at most 6 tiles each -- the ring is re-loaded per pass there, and with 7 tiles that form needs
+  // 2-4 registers more than the 256 a wave has (it spilled).
+  const int passes = Mt <= kProjMaxMG ? 1 : cdiv(Mt, kProjMaxMG - 1);
   *mg_out = cdiv(Mt, passes);
   return passes;
 }
@@ -266,8 +268,13 @@ static int launch_project_mg(const SegList& in, const float* M, int m_in_major, 
     if (segs) { if (has_add) MSGAT_PROJ(Q, ONE, true, true); else MSGAT_PROJ(Q, ONE, true, false); }   \
     else { if (has_add) MSGAT_PROJ(Q, ONE, false, true); else MSGAT_PROJ(Q, ONE, false, false); }      \
   } while (0)
-  if (qvec != nullptr) { if (one) MSGAT_PROJ2(true, true); else MSGAT_PROJ2(true, false); }
-  else { if (one) MSGAT_PROJ2(false, true); else MSGAT_PROJ2(false, false); }
+  if constexpr (MG == kProjMaxMG) {   // proj_passes_mg() hands out 7 tiles only when one pass covers the output
+    if (!one) return MSGAT_ERR_UNSUPPORTED;
+    if (qvec != nullptr) MSGAT_PROJ2(true, true); else MSGAT_PROJ2(false, true);
+  } else {
+    if (qvec != nullptr) { if (one) MSGAT_PROJ2(true, true); else MSGAT_PROJ2(true, false); }
+    else { if (one) MSGAT_PROJ2(false, true); else MSGAT_PROJ2(false, false); }
+  }
 #undef MSGAT_PROJ2
 #undef MSGAT_PROJ
   MSGAT_CHECK_LAUNCH();
@@ -580,6 +587,8 @@ struct ChanMix {
   float* dump = nullptr;         // >= 256 floats (16-B aligned) nobody reads
 };
 
+// With several z-blocks over B (nzb > 1; the mix forms never cut A: all its rows must be in LDS) each block writes the
+// mix output of ITS columns c0 .. c0 + cb.
 // MODE 0: the contraction.  MODE 1 (MIX): every wave also computes the mix output of its 16 positions.  MODE 2 (SPLIT, for
 // the wide channel blocks whose accumulators leave no registers for the matrix fragments): waves 0-3 contract (16
 // positions of a 64-position tile each), waves 4-7 compute the mix output from the same LDS tiles -- two roles with
@@ -618,13 +627,14 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_glds(
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int j = lane & 15, kq = lane >> 4;
   const int a_per = cdiv(Ca, nza);
+  const int c_per = cdiv(Cb, nzb);      // even split (<= 16 NB: the host picked nzb = ceil(Cb / 16 NB))
   const int a0 = (zb / nzb) * a_per;
-  const int c0 = (zb % nzb) * (NB * 16);
-  const int ca = min(a_per, Ca - a0), cb = min(NB * 16, Cb - c0);
+  const int c0 = (zb % nzb) * c_per;
+  const int ca = min(a_per, Ca - a0), cb = min(c_per, Cb - c0);
   const int rows = ca + cb;
   // buffer = the groups of the block's largest z-block (the host sized LDS for that), a constant group (zero row,
   // ones row), a dump group
-  const int ngroups = cdiv(min(a_per, Ca) + min(NB * 16, Cb), kRPI);
+  const int ngroups = cdiv(min(a_per, Ca) + min(c_per, Cb), kRPI);
   const int bufF4 = (ngroups + 2) * kGGroupF4;
   const int zero_row = ngroups * kRPI, ones_row = zero_row + 1;
   const int tpg = cdiv(P, TILE);
@@ -734,7 +744,7 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_glds(
       const int a = 4 * s + kq;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const int c = nb * 16 + j;
+        const int c = c0 + nb * 16 + j;     // this z-block's columns of the matrix
         const int cc = min(c, Cbr - 1);
         float v;
         if (mix.Mlast != nullptr) {   // kernel-uniform: the matrix's last row lives in another array
@@ -744,7 +754,7 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_glds(
         } else {
           v = mix.Mw[((size_t)r * Ca + min(a, Ca - 1)) * Cbr + cc];
         }
-        mfrag[s][nb] = (c < Cbr && a < Ca) ? v : 0.f;
+        mfrag[s][nb] = (nb * 16 + j < cb && c < Cbr && a < Ca) ? v : 0.f;
       }
     }
   };
@@ -769,8 +779,8 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_glds(
     float* og = mix.out + ((size_t)r * Bg + b) * Cbr * P + pos;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      const int c = nb * 16 + j;
-      float* dst = (c < Cbr && pos < P) ? og + (size_t)c * P : mix.dump + 4 * lane;   // a select on the address: no branch
+      const int c = c0 + nb * 16 + j;
+      float* dst = (nb * 16 + j < cb && c < Cbr && pos < P) ? og + (size_t)c * P : mix.dump + 4 * lane;   // a select on the address: no branch
       *reinterpret_cast<f32x4*>(dst) = d[nb];
     }
   };
@@ -913,8 +923,8 @@ static int launch_chanpair_t(const SegList& A, const float* B, float* part, int 
 // LDS bytes of the LDS-DMA form for a channel matrix cut into nza x nzb z-blocks
 template <int MA, int NB, int TILE, int NBUF>
 static size_t chanpair_glds_lds(int Ca, int Cb) {
-  const int nza = cdiv(Ca, MA * 16);
-  const int rows = min(cdiv(Ca, nza), Ca) + min(NB * 16, Cb);
+  const int nza = cdiv(Ca, MA * 16), nzb = cdiv(Cb, NB * 16);
+  const int rows = min(cdiv(Ca, nza), Ca) + min(cdiv(Cb, nzb), Cb);
   return sizeof(float4) * (size_t)NBUF * (cdiv(rows, 256 / TILE) + 2) * kGGroupF4;
 }
 
@@ -939,59 +949,121 @@ static int launch_chanpair_glds_t(const SegList& A, const float* B, float* part,
   return MSGAT_OK;
 }
 
-// The contraction of [A | Alast] against B AND mixout = [Mw | Mlast]^T [A | Alast] in one pass (k_chanpair_glds<MIX>).
-// *done = 0 (nothing launched) when the shape is not one the fused form covers: the caller runs the two passes.
-int launch_chanpair_mix(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
-                        const float* Mw, const float* Mlast, float* mixout, hipStream_t s, int* nblk_used, int* done) {
+// ---- which LDS-DMA form for which channel block -----------------------------------------------------------------
+// X(MA, NB, TILE, MIXMODE): a [16 MA x 16 NB] channel block staged in three buffers of TILE positions; MIXMODE says how
+// the one-pass form (contraction AND mix output) runs: 1 = every wave does both (128-position tiles), 2 = waves 0-3
+// contract and waves 4-7 mix (64-position tiles: what three buffers of that many rows leave room for), 0 = there is
+// none.  The list covers the channel counts of the three models of the reference's registry (main.py:17,
+// msgat.py:220-229: 48 / 72 / 96 hidden channels, 16 / 24 / 32 per branch):
+//                       GACN projection backward     merged channel mixing          residual convolution
+//                       [Co + 1 x C]                 [4 Co + 2 x C + 1]             [C x C + 1]
+//   msgat48             17 x 48   <2,3,128> mix 1    66 x 49   <5,4,64> mix 2       48 x 49   <3,4,128> mix 1
+//   msgat72             25 x 72   <2,5,128> mix 1    98 x 73   <7,5,64> mix 2       72 x 73   <5,5,64>  mix 2
+//   msgat96             33 x 96   <3,6,64>  mix 2    130 x 97  <9,4,64> mix 2       96 x 97   <6,4,64>  mix 2
+//                                                    two z-blocks over B, 49 + 48 columns each with ALL rows of A
+//                                                    (a [96 x 112] accumulator block spills; A is read twice, B once)
+#define MSGAT_GLDS_FORMS(X) \
+  X(2, 3, 128, 1) X(2, 4, 128, 1) X(2, 5, 128, 1) X(3, 4, 128, 1) X(3, 6, 64, 2) X(5, 4, 64, 2) X(5, 5, 64, 2) \
+  X(7, 5, 64, 2) X(6, 4, 64, 2) X(9, 4, 64, 2)
+
+// Launches the form [MA x NB] if the list has it (and its buffers fit LDS); *handled = 0 and nothing launched otherwise.
+static int launch_glds_form(int MA, int NB, bool with_mix, const SegList& A, const float* B, float* part, int R, int Bg,
+                            int Cb, int P, int nblk, int b_ones, hipStream_t s, int* nblk_used, const ChanMix& mix,
+                            int* handled) {
+  const int Ca = A.total();
+  *handled = 0;
+#define MSGAT_GLDS_TRY(ma, nb, tile, mode)                                                                            \
+  if (MA == ma && NB == nb) {                                                                                         \
+    if ((with_mix && mode == 0) || chanpair_glds_lds<ma, nb, tile, 3>(Ca, Cb) > (size_t)kLdsMax) return MSGAT_OK;      \
+    *handled = 1;                                                                                                     \
+    if (with_mix) return launch_chanpair_glds_t<ma, nb, tile, 3, mode>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used, mix); \
+    return launch_chanpair_glds_t<ma, nb, tile, 3, 0>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used);          \
+  }
+  MSGAT_GLDS_FORMS(MSGAT_GLDS_TRY)
+#undef MSGAT_GLDS_TRY
+  return MSGAT_OK;
+}
+
+static bool glds_form_exists(int MA, int NB, bool with_mix) {
+#define MSGAT_GLDS_HAS(ma, nb, tile, mode) \
+  if (MA == ma && NB == nb) return !with_mix || mode != 0;
+  MSGAT_GLDS_FORMS(MSGAT_GLDS_HAS)
+#undef MSGAT_GLDS_HAS
+  return false;
+}
+
+// rows of >= 512 positions in whole float4s: every group spans several tiles (shorter rows: the register-staged kernel)
+static bool glds_rows_ok(int P) { return P % 4 == 0 && P >= 512; }
+
+// The contraction AND mixout = M^T A in one pass (k_chanpair_glds, MODE 1 / 2): part[a, c] (c < Cb; with b_ones a virtual
+// last channel of ones in B) and mixout[g, c, p] = sum_a M[r, a, c] A[g, a, p] over B's Cb - b_ones real channels, with
+// M = [R, Ca, Cb - b_ones] -- or, Mlast given, [Mw | Mlast] with Mw = [R, Ca - 1, .] and Mlast = [R, .] its last row
+// ([W | alpha] of the GACN projection).  All Ca rows must be in LDS at once (one z-block); a block one tile taller than
+// the operand is fine (the kernels mask rows >= Ca and read the zero row for them).  *done = 0 (nothing launched) when
+// no form covers the shape: the caller runs the two passes.
+static int launch_glds_mix(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
+                           int b_ones, const float* Mw, const float* Mlast, float* mixout, hipStream_t s, int* nblk_used,
+                           int* done) {
   const int Ca = A.total();
   *done = 0;
-  if (!(P % 4 == 0 && P >= 512 && Cb > 64 && Cb <= 80 && Ca > 16 && Ca <= 32)) return MSGAT_OK;
-  if (chanpair_glds_lds<2, 5, 128, 3>(Ca, Cb) > (size_t)kLdsMax) return MSGAT_OK;
+  if (!glds_rows_ok(P) || Ca <= 16) return MSGAT_OK;
   ChanMix mix;
   mix.Mw = Mw; mix.Mlast = Mlast; mix.out = mixout;
   mix.dump = part + (((size_t)R * nblk * Ca * Cb + 3) & ~(size_t)3);   // chanpair_partial_floats() leaves 260 floats behind the partials
-  *done = 1;
-  return launch_chanpair_glds_t<2, 5, 128, 3, 1>(A, B, part, R, Bg, Cb, P, nblk, 0, s, nblk_used, mix);
+  for (int nzb = 1; nzb <= 2; ++nzb) {           // z-blocks over B: each stages all of A
+    const int NB = cdiv(cdiv(Cb, nzb), 16);
+    if (cdiv(Cb, NB * 16) != nzb) continue;      // the kernel derives nzb from the block width
+    for (int MA = cdiv(Ca, 16); MA <= cdiv(Ca, 16) + 1; ++MA) {
+      if (!glds_form_exists(MA, NB, true)) continue;
+      const int st = launch_glds_form(MA, NB, true, A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used, mix, done);
+      if (st || *done) return st;
+    }
+  }
+  return MSGAT_OK;
 }
 
-// The same for the wide channel blocks: part[a, c] (c < Cb; with b_ones a virtual last channel of ones in B) and
-// mixout[g, c, p] = sum_a M[r, a, c] A[g, a, p] over B's Cb - b_ones real channels, M = [R, Ca, Cb - b_ones].
+int launch_chanpair_mix(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
+                        const float* Mw, const float* Mlast, float* mixout, hipStream_t s, int* nblk_used, int* done) {
+  return launch_glds_mix(A, B, part, R, Bg, Cb, P, nblk, 0, Mw, Mlast, mixout, s, nblk_used, done);
+}
+
 int launch_chanpair_mix_wide(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
                              int b_ones, const float* M, float* mixout, hipStream_t s, int* nblk_used, int* done) {
-  const int Ca = A.total();
-  *done = 0;
-  if (!(P % 4 == 0 && P >= 512 && Cb > 64 && Cb <= 80 && Ca > 48 && Ca <= 112)) return MSGAT_OK;
-  ChanMix mix;
-  mix.Mw = M; mix.out = mixout;
-  mix.dump = part + (((size_t)R * nblk * Ca * Cb + 3) & ~(size_t)3);
-  if (Ca <= 80) {
-    if (chanpair_glds_lds<5, 5, 64, 3>(Ca, Cb) > (size_t)kLdsMax) return MSGAT_OK;
-    *done = 1;
-    return launch_chanpair_glds_t<5, 5, 64, 3, 2>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used, mix);
-  }
-  if (chanpair_glds_lds<7, 5, 64, 3>(Ca, Cb) > (size_t)kLdsMax) return MSGAT_OK;
-  *done = 1;
-  return launch_chanpair_glds_t<7, 5, 64, 3, 2>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used, mix);
+  return launch_glds_mix(A, B, part, R, Bg, Cb, P, nblk, b_ones, M, nullptr, mixout, s, nblk_used, done);
 }
 
 int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
                          int b_ones, hipStream_t s, int* nblk_used) {
   const int Ca = A.total();
-  const int MA = min(cdiv(Ca, 16), 3), NB = min(cdiv(Cb, 16), 6);
 #ifndef MSGAT_NO_GLDS
-  // LDS-DMA staging where two half-length tiles of all rows fit LDS (MA + NB <= 9) and every group spans several tiles
-  if (P % 4 == 0 && P >= 512 && Cb > 64 && Cb <= 80) {
-    // 17..32 against 65..80 channels (dW, dalpha of the GACN projection): three 128-position buffers
-    if (Ca > 16 && Ca <= 32 && chanpair_glds_lds<2, 5, 128, 3>(Ca, Cb) <= (size_t)kLdsMax)
-      return launch_chanpair_glds_t<2, 5, 128, 3>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used);
-    // 49..80 against 65..80 (the residual convolution's weight gradient, 72 x 73): one [80 x 80] block
-    if (Ca > 48 && Ca <= 80 && chanpair_glds_lds<5, 5, 64, 3>(Ca, Cb) <= (size_t)kLdsMax)
-      return launch_chanpair_glds_t<5, 5, 64, 3>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used);
-    // 81..112 against 65..80 (the merged channel mixing of a MEAM block): ONE [112 x 80] block, three 64-position buffers
-    if (Ca > 80 && Ca <= 112 && chanpair_glds_lds<7, 5, 64, 3>(Ca, Cb) <= (size_t)kLdsMax)
-      return launch_chanpair_glds_t<7, 5, 64, 3>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used);
+  // LDS-DMA staging where the list above has a block for the shape: the fewest z-blocks over A (each re-reads B) whose
+  // row count some form of this width covers, the smallest such form
+  if (glds_rows_ok(P) && Ca > 16) {
+    // fewest rows staged in total: nzb z-blocks over B each stage A, nza z-blocks over A each stage B
+    int best_ma = 0, best_nb = 0;
+    long best_cost = -1;
+    for (int nzb = 1; nzb <= 2; ++nzb)
+      for (int nza = 1; nza <= 3; ++nza) {
+        const int NBg = cdiv(cdiv(Cb, nzb), 16);
+        if (cdiv(Cb, NBg * 16) != nzb) continue;
+        for (int ma = max(cdiv(cdiv(Ca, nza), 16), 2); ma <= 9; ++ma) {
+          if (!glds_form_exists(ma, NBg, false) || cdiv(Ca, ma * 16) != nza) continue;
+          const long cost = (long)nzb * Ca + (long)nza * Cb;
+          if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_ma = ma; best_nb = NBg; }
+          break;   // the smallest block of this width that covers the rows
+        }
+      }
+    if (best_cost >= 0) {
+      int handled = 0;
+      const int st = launch_glds_form(best_ma, best_nb, false, A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used, ChanMix(), &handled);
+      if (st || handled) return st;
+    }
   }
 #endif
+  // the register-staged kernel.  Block shapes whose accumulators + two register sets in flight exceed the 256
+  // registers of a 2-waves-per-SIMD block are not offered ([48 x 80], [48 x 96] and [32 x 96] spilled 18 / 93 / 14
+  // registers): a wider B is cut into z-blocks, which re-read A
+  const int MA = min(cdiv(Ca, 16), 3), NB = min(cdiv(Cb, 16), MA == 3 ? 4 : (MA == 2 ? 5 : 6));
   // 49..80 A channels against 17..80 B channels: half-length tiles hold all of A and B in LDS at once -- ONE pass over
   // both operands where the [48 x 96] blocks take two z-blocks that each re-read B (72 x 73, the residual tail's weight
   // gradient: 286 -> 174 us).  Not for wider A (a [112 x 80] block spills and ran at 372 us against 344 for the two
@@ -1017,8 +1089,8 @@ int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, i
 #define MSGAT_CP(ma, nb) \
   if (MA == ma && NB == nb) return launch_chanpair_t<ma, nb>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used);
   MSGAT_CP(1, 1) MSGAT_CP(1, 2) MSGAT_CP(1, 3) MSGAT_CP(1, 4) MSGAT_CP(1, 5) MSGAT_CP(1, 6)
-  MSGAT_CP(2, 1) MSGAT_CP(2, 2) MSGAT_CP(2, 3) MSGAT_CP(2, 4) MSGAT_CP(2, 5) MSGAT_CP(2, 6)
-  MSGAT_CP(3, 1) MSGAT_CP(3, 2) MSGAT_CP(3, 3) MSGAT_CP(3, 4) MSGAT_CP(3, 5) MSGAT_CP(3, 6)
+  MSGAT_CP(2, 1) MSGAT_CP(2, 2) MSGAT_CP(2, 3) MSGAT_CP(2, 4) MSGAT_CP(2, 5)
+  MSGAT_CP(3, 1) MSGAT_CP(3, 2) MSGAT_CP(3, 3) MSGAT_CP(3, 4)
 #undef MSGAT_CP
   return MSGAT_ERR_UNSUPPORTED;
 }

@@ -114,33 +114,45 @@ __global__ __launch_bounds__(kRowBlock) void k_bwd_rows(
   };
   // dkW[n] = sum_e g_e q[col_e] - delta_n pq[n] = sum_e g_e (q[col_e] - pq[n]): subtracting
   // first keeps a saturated (one-hot) row exact -- pq[n] then equals q[col_e] bit for bit.
-  // Two edges per trip: their index / weight loads are independent and issue together.
+  // Four edges per trip, every load unconditional (indices clamped to the row's last edge, the surplus masked by a
+  // zero coefficient): a trip is two dependent round trips -- column indices, then coefficients and q / u rows -- and a
+  // wave takes ceil(max degree / 4) of them.  With one or two edges per trip the PEMS rows (1 + ~Poisson(2) edges, some
+  // row of every wave has 6-8) cost 3-4 trips; the sums run in edge order either way, so the bits do not change.
+  const int e0 = valid ? rowptr[n] : 0;
   const int e1 = valid ? rowptr[n + 1] : 0;
-  for (int e = valid ? rowptr[n] : 0; e < e1; e += 2) {
-    const bool two = e + 1 < e1;
-    const int eb = two ? e + 1 : e;
-    const int ca = col[e], cb = col[eb];
-    const float ga = edge_grad(e, ca);
-    const float gb = two ? edge_grad(eb, cb) : 0.f;
-    if (DC > 0) {
-      gE[(size_t)g * nnz + e] = ga;
-      if (two) gE[(size_t)g * nnz + eb] = gb;
-    }
-    const float4* qa = reinterpret_cast<const float4*>(qg + (size_t)ca * T);
-    const float4* qb = reinterpret_cast<const float4*>(qg + (size_t)cb * T);
-    d += ga;
-    d += gb;
+  for (int e = e0; e < e1; e += 4) {
+    int ee[4], cc[4];
 #pragma unroll
-    for (int t4 = 0; t4 < T4; ++t4) {
-      const float4 va = qa[t4], vb = qb[t4];
-      dk[4 * t4 + 0] = fmaf(ga, va.x - pr[4 * t4 + 0], dk[4 * t4 + 0]);
-      dk[4 * t4 + 1] = fmaf(ga, va.y - pr[4 * t4 + 1], dk[4 * t4 + 1]);
-      dk[4 * t4 + 2] = fmaf(ga, va.z - pr[4 * t4 + 2], dk[4 * t4 + 2]);
-      dk[4 * t4 + 3] = fmaf(ga, va.w - pr[4 * t4 + 3], dk[4 * t4 + 3]);
-      dk[4 * t4 + 0] = fmaf(gb, vb.x - pr[4 * t4 + 0], dk[4 * t4 + 0]);
-      dk[4 * t4 + 1] = fmaf(gb, vb.y - pr[4 * t4 + 1], dk[4 * t4 + 1]);
-      dk[4 * t4 + 2] = fmaf(gb, vb.z - pr[4 * t4 + 2], dk[4 * t4 + 2]);
-      dk[4 * t4 + 3] = fmaf(gb, vb.w - pr[4 * t4 + 3], dk[4 * t4 + 3]);
+    for (int i = 0; i < 4; ++i) {
+      ee[i] = min(e + i, e1 - 1);
+      cc[i] = col[ee[i]];
+    }
+    float gg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float raw = edge_grad(ee[i], cc[i]);
+      gg[i] = (e + i < e1) ? raw : 0.f;
+    }
+    if (DC > 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (e + i < e1) gE[(size_t)g * nnz + ee[i]] = gg[i];
+    }
+    float4 qv[4][T4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t4 = 0; t4 < T4; ++t4) qv[i][t4] = reinterpret_cast<const float4*>(qg + (size_t)cc[i] * T)[t4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      d += gg[i];
+#pragma unroll
+      for (int t4 = 0; t4 < T4; ++t4) {
+        dk[4 * t4 + 0] = fmaf(gg[i], qv[i][t4].x - pr[4 * t4 + 0], dk[4 * t4 + 0]);
+        dk[4 * t4 + 1] = fmaf(gg[i], qv[i][t4].y - pr[4 * t4 + 1], dk[4 * t4 + 1]);
+        dk[4 * t4 + 2] = fmaf(gg[i], qv[i][t4].z - pr[4 * t4 + 2], dk[4 * t4 + 2]);
+        dk[4 * t4 + 3] = fmaf(gg[i], qv[i][t4].w - pr[4 * t4 + 3], dk[4 * t4 + 3]);
+      }
     }
   }
   if (valid) {

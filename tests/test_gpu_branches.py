@@ -401,6 +401,14 @@ def test_temporal_attention_taps_are_one_launch_each_way(R, Bg, N, K, T, dil):
     ((81,), 79, 1, 64, 2),                # P = 768: six tiles per group; 81 rows = five full fragments + 1
     ((24, 1), 72, 0, 13, 2),              # P = 156 < 512: register-staged kernel
     ((48,), 24, 1, 883, 2),               # narrow B: register-staged kernel
+    ((16, 1), 48, 0, 883, 2),             # msgat48: <2,3,128,3>
+    ((16, 32, 16, 1, 1), 48, 1, 883, 2),  # msgat48 merged mixing (66 x 49): <5,4,64,3>
+    ((48,), 48, 1, 307, 2),               # msgat48 residual convolution (48 x 49): <3,4,128,3>
+    ((32, 1), 96, 0, 883, 2),             # msgat96: <3,6,64,3>
+    ((32, 64, 32, 1, 1), 96, 1, 307, 2),  # msgat96 merged mixing (130 x 97): <9,4,64,3>, two z-blocks of 49 + 48 columns
+    ((96,), 96, 1, 883, 1),               # msgat96 residual convolution (96 x 97): <6,4,64,3>, two z-blocks over B
+    ((24, 1), 96, 0, 13, 2),              # P = 156, 96 columns: register-staged [32 x 80] blocks, two z-blocks over B
+    ((40,), 90, 1, 20, 3),                # P = 240: register-staged [48 x 64] blocks
 ])
 def test_contract_segments_matches_float64_and_repeats_bit_for_bit(segs, Cb, ones, N, Bg):
     import ctypes as C
@@ -443,8 +451,15 @@ def test_contract_segments_matches_float64_and_repeats_bit_for_bit(segs, Cb, one
     ((72,), 72, 1, 883, 1),               # residual convolution: SPLIT form <5,5>
     ((49,), 65, 0, 307, 3),               # lower edges of the <5,5> form, no bias column
     ((81,), 79, 1, 64, 2),                # lower edge of <7,5>; P = 768
-    ((24,), 72, 0, 883, 2),               # no fused form for 24 x 72 behind this entry point: the two passes
+    ((24,), 72, 0, 883, 2),               # <2,5,128,3,1> (every wave contracts and mixes), plain matrix
     ((72,), 72, 1, 13, 2),                # P = 156: the two passes
+    ((16, 32, 16, 1, 1), 48, 1, 883, 2),  # msgat48 merged mixing (66 x 49): <5,4,64,3,2>
+    ((48,), 48, 1, 883, 1),               # msgat48 residual convolution (48 x 49): <3,4,128,3,1>
+    ((33,), 40, 0, 307, 2),               # lower edge of <3,4>, B of 40 channels
+    ((32, 64, 32, 1, 1), 96, 1, 883, 1),  # msgat96 merged mixing (130 x 97): <9,4,64,3,2>, z-blocks over B with all of A
+    ((96,), 96, 1, 883, 1),               # msgat96 residual convolution (96 x 97): <6,4,64,3,2>, two z-blocks
+    ((96,), 96, 1, 64, 3),                # the same at P = 768
+    ((33,), 96, 0, 307, 2),               # <3,6,64,3,2>, no bias column
 ])
 def test_contract_mix_segments_gives_matrix_bias_and_input_gradients_in_one_pass(segs, Cb, ones, N, Bg):
     """msgat_contract_mix_segments = the backward of y = M x (+ bias): dM (| dbias) AND dx from one pass over dy and x,
@@ -488,7 +503,8 @@ def test_contract_mix_segments_gives_matrix_bias_and_input_gradients_in_one_pass
         assert err < 1e-5, key
 
 
-@pytest.mark.parametrize("R,Bg,C,Co,N", [(3, 2, 72, 24, 883), (2, 2, 72, 24, 13), (1, 3, 48, 16, 307), (2, 1, 80, 31, 64)])
+@pytest.mark.parametrize("R,Bg,C,Co,N", [(3, 2, 72, 24, 883), (2, 2, 72, 24, 13), (1, 3, 48, 16, 307), (2, 1, 80, 31, 64),
+                                         (3, 2, 48, 16, 883), (3, 2, 96, 32, 883), (1, 2, 64, 20, 64), (2, 1, 90, 40, 307)])
 def test_stage_project_backward_matches_float64(R, Bg, C, Co, N):
     """msgat_stage_project_backward: dW = du x^T, dalpha = dq . x, dx = W^T du + alpha (x) dq -- the fused one-pass
     form (C in 65..80, Co + 1 in 17..32, rows of >= 512 positions) and the two-pass form behind the same entry point."""

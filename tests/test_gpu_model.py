@@ -115,18 +115,21 @@ def test_hip_graph_training_matches_eager_training(tmp_path):
     assert set(graphed.optimizer._host_steps) == set(eager.optimizer._host_steps) == {18}
 
 
-@pytest.mark.parametrize("factory,cin,R", [("msgat48", 1, 2), ("msgat96", 3, 1), ("msgat72", 3, 2)])
-def test_whole_model_matches_the_dense_op_sequence(factory, cin, R):
+@pytest.mark.parametrize("factory,cin,R,N", [("msgat48", 1, 2, 23), ("msgat96", 3, 1, 23), ("msgat72", 3, 2, 23),
+                                             ("msgat48", 3, 2, 64), ("msgat96", 1, 2, 64), ("msgat72", 1, 2, 64)])
+def test_whole_model_matches_the_dense_op_sequence(factory, cin, R, N):
     """Every width / dilation recipe of the reference's factories (msgat.py:220-229; msgat96 stacks four
     convolutions in its first TACN) through the library, against the same parameters evaluated with the
-    reference's dense op sequence (oracle/dense_torch.py) in float64: prediction and every gradient."""
+    reference's dense op sequence (oracle/dense_torch.py) in float64: prediction and every gradient.  N = 64 gives
+    768 positions per channel slab: every width then runs its LDS-DMA one-pass backward forms (mfma.hip
+    MSGAT_GLDS_FORMS; below 512 positions the register-staged kernels run)."""
     from ms_gat_amd import model
     from oracle import dense_torch
     torch.manual_seed(7)
-    N, T, B = 23, 12, 3
+    T, B = 12, 3
     gen = torch.Generator().manual_seed(11)
     import ms_gat_amd
-    adj = ms_gat_amd.synthetic_adjacency(N, 30, seed=5)
+    adj = ms_gat_amd.synthetic_adjacency(N, N + 7, seed=5)
     net = getattr(model, factory)(n_components=R, in_channels=cin, in_timesteps=T, out_timesteps=T, use_te=True,
                                   adj=adj).to(_dev())
     X = torch.randn(B, R, cin, N, T, generator=gen).to(_dev())

@@ -313,6 +313,16 @@ def _dense_oracle_gpu(x, adj, Wg, alpha, W, dz):
                 dalpha=np.stack(outs["dalpha"]), dW=np.stack(outs["dW"]))
 
 
+@pytest.mark.parametrize("C,Co,Bg", [(48, 16, 8), (96, 32, 8)])
+def test_other_registry_widths_at_the_headline_graph_size(C, Co, Bg):
+    """msgat48 and msgat96 (the other two models of the reference's registry, main.py:17, msgat.py:220-229) at N = 883:
+    their second-depth GACN takes the one-pass LDS-DMA backward forms <2,3,128,3,1> resp. <3,6,64,3,2> (mfma.hip)."""
+    prob = random_problem(3, Bg, C, Co, 883, 12, 866, seed=170 + C)
+    got = run_ours(*prob)
+    want = _dense_oracle_gpu(*prob)
+    assert_close(got, want, what=f"PEMSD7 widths {C}->{Co}")
+
+
 @pytest.mark.parametrize("C,Bg", [(1, 32), (72, 32)])
 def test_pemsd7_full_size_against_dense_eager(C, Bg):
     """configs[2]: PEMSD7-like N=883, B=32, R=3, C in {1, 72} -> Co=24."""
