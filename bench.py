@@ -108,8 +108,10 @@ class HotPath:
                 p.grad = None
         # (each depth's forward and backward back to back measures the same: 0.737 vs 0.730-0.740 ms)
         zs = [m(x, self.graph) for m, x in zip(self.layers, self.xs)]
-        for z, dz in zip(reversed(zs), reversed(self.dzs)):
-            z.backward(dz)
+        # ONE backward call, as a training step makes one: the engine runs the second depth's node first (it was
+        # created last).  Two calls cost a second start of the autograd engine (~150 us of host time each at this
+        # size, tools/host_overhead.py), which a launch-bound step (PEMSD4) would be charged for.
+        torch.autograd.backward(zs, self.dzs)
         if allreduce:  # one flat bucket: the payload is KBs, the collective is latency-bound
             self.sync(weight=float(self.wl["B"]))
 

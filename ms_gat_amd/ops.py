@@ -60,45 +60,47 @@ class _GACNFunction(torch.autograd.Function):
         gstruct, _keep = graph.on(dev)
         nnz = max(graph.nnz, 1)
 
-        def new(*s):
-            return torch.empty(s, device=dev, dtype=torch.float32)
-
-        z = new(G, Co if Co else Cin, N, T)
-        q, kW, lse, E = new(G, N, T), new(G, N, T), new(G, N), new(G, nnz)
-        pq = new(G, N, T) if need_bwd else None
-        Ec = new(G, nnz) if need_bwd else None          # E in CSC order, for the transposed passes of backward
+        # Everything backward needs besides the inputs (q, kW, lse, pq, E, E in CSC order, the projected / aggregated
+        # features u) and the SELL scratch lives in ONE allocation, addressed by offset: seven `torch.empty` calls
+        # per forward were a quarter of its host time, which is what a PEMSD4-sized step is bound by.
+        z = torch.empty((G, Co if Co else Cin, N, T), device=dev, dtype=torch.float32)
         if mode == _lib.MODE_PROJ_FIRST:
-            u = new(G, Co, N, T)
+            n_u = G * Co * N * T
         elif mode == _lib.MODE_AGG_FIRST and need_bwd:
-            u = new(G, Cin, N, T)
+            n_u = G * Cin * N * T
         else:
-            u = None
-        nscratch = int(L.msgat_edge_scratch_floats(C.byref(shape), C.byref(gstruct)))
-        scratch = new(nscratch) if nscratch else None   # E in the order of the SELL layout (large graphs)
-        io = _lib.Fwd(_ptr(x), _ptr(alpha), _ptr(Wg), _ptr(W), _ptr(z), _ptr(q), _ptr(kW), _ptr(lse), _ptr(pq),
-                      _ptr(E), _ptr(u), int(need_bwd), _ptr(scratch), _ptr(Ec))
+            n_u = 0
+        nscratch = int(L.msgat_edge_scratch_floats(C.byref(shape), C.byref(gstruct)))  # E in the SELL layout's order
+        sizes = (G * N * T, G * N * T, G * N, G * N * T if need_bwd else 0, G * nnz, G * nnz if need_bwd else 0, n_u, nscratch)
+        offs, total = [], 0
+        for n in sizes:                      # 256-byte aligned pieces
+            offs.append(total)
+            total += (n + 63) & ~63
+        buf = torch.empty(max(total, 64), device=dev, dtype=torch.float32)
+        base = buf.data_ptr()
+        ptr = [base + 4 * o if n else None for o, n in zip(offs, sizes)]
+        q, kW, lse, pq, E, Ec, u, scratch = ptr
+        io = _lib.Fwd(_ptr(x), _ptr(alpha), _ptr(Wg), _ptr(W), _ptr(z), q, kW, lse, pq, E, u, int(need_bwd), scratch, Ec)
         st = L.msgat_gacn_forward(C.byref(shape), C.byref(gstruct), C.byref(io), _stream_handle(dev))
         _lib.check(st, "msgat_gacn_forward")
 
         if need_bwd:
             ctx.graph, ctx.dims, ctx.has_W = graph, (R, G // R, Cin, Co, N, T), W is not None
-            saved = [x, alpha, Wg, q, kW, lse, pq, E, Ec]
+            ctx.offs = tuple(o if n else -1 for o, n in zip(offs, sizes))
             if W is not None:
-                saved.append(W)
-            if u is not None:
-                saved.append(u)
-            ctx.has_u = u is not None
-            ctx.save_for_backward(*saved)
+                ctx.save_for_backward(x, alpha, Wg, buf, W)
+            else:
+                ctx.save_for_backward(x, alpha, Wg, buf)
         return z
 
     @staticmethod
     def backward(ctx, dz):
         L = _lib.lib()
-        saved = list(ctx.saved_tensors)
-        x, alpha, Wg, q, kW, lse, pq, E, Ec = saved[:9]
-        rest = saved[9:]
-        W = rest.pop(0) if ctx.has_W else None
-        u = rest.pop(0) if ctx.has_u else None
+        saved = ctx.saved_tensors
+        x, alpha, Wg, buf = saved[:4]
+        W = saved[4] if ctx.has_W else None
+        base = buf.data_ptr()
+        q, kW, lse, pq, E, Ec, u, _scratch = (None if o < 0 else base + 4 * o for o in ctx.offs)
         dev = x.device
         R, Bg, Cin, Co, N, T = ctx.dims
         shape = _lib.Shape(R, Bg, Cin, Co, N, T)
@@ -113,9 +115,8 @@ class _GACNFunction(torch.autograd.Function):
         dW = None if W is None else torch.empty_like(W)
         nbytes = L.msgat_bwd_workspace_bytes(C.byref(shape), C.byref(gstruct))
         ws = torch.empty(max(int(nbytes), 256), device=dev, dtype=torch.uint8)
-        io = _lib.Bwd(_ptr(x), _ptr(alpha), _ptr(Wg), _ptr(W), _ptr(q), _ptr(kW), _ptr(lse), _ptr(pq), _ptr(E),
-                      _ptr(u), _ptr(dz), _ptr(dx), _ptr(dalpha), _ptr(dWg), _ptr(dW), _ptr(ws), ws.numel(), dz_gs,
-                      _ptr(Ec))
+        io = _lib.Bwd(_ptr(x), _ptr(alpha), _ptr(Wg), _ptr(W), q, kW, lse, pq, E, u, _ptr(dz), _ptr(dx), _ptr(dalpha),
+                      _ptr(dWg), _ptr(dW), _ptr(ws), ws.numel(), dz_gs, Ec)
         st = L.msgat_gacn_backward(C.byref(shape), C.byref(gstruct), C.byref(io), _stream_handle(dev))
         _lib.check(st, "msgat_gacn_backward")
         return dx, dalpha, dWg, dW, None

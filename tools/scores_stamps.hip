@@ -2,11 +2,13 @@
 #define MSGAT_STAMPS 1
 #include "../ms_gat_amd/csrc/dense.hip"
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include <algorithm>
 #include <random>
-int main() {
-  const int G = 96, N = 883, T = 12, nnz = 2615, Bg = 32;
+int main(int argc, char** argv) {   // scores_stamps [G N nnz]  (default: the PEMSD7 workload; PEMSD4: 64 307 987)
+  const int G = argc > 1 ? atoi(argv[1]) : 96, N = argc > 2 ? atoi(argv[2]) : 883, T = 12;
+  const int nnz = argc > 3 ? atoi(argv[3]) : 2615, Bg = G / (argc > 1 ? 1 : 3);
   float *q, *Wg, *kW, *lse, *pq, *E, *val; int *rowptr, *col, *erow;
   hipMalloc(&q, (size_t)G * N * T * 4); hipMalloc(&kW, (size_t)G * N * T * 4); hipMalloc(&pq, (size_t)G * N * T * 4);
   hipMalloc(&Wg, 3 * T * T * 4); hipMalloc(&lse, G * N * 4); hipMalloc(&E, (size_t)G * nnz * 4); hipMalloc(&val, nnz * 4);
