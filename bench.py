@@ -480,6 +480,26 @@ def collective_us(last):
     return round(statistics.median(us), 1)
 
 
+class _StdoutToStderr:
+    """OS-level redirection of fd 1 to fd 2 (C libraries write there directly), undone on exit."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        try:
+            C.CDLL(None).fflush(None)      # what the libraries still hold in C stdio buffers goes to stderr too
+        except OSError:
+            pass
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def respawn_under_torchrun(args):
     """`python bench.py --gpus N` with N > 1 and no process-group environment: become the launcher -- start one rank per
     GPU with torch.distributed.run as a CHILD process (nothing here has touched the GPU yet) and exit with its code.
@@ -649,10 +669,16 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        # RCCL prints a version banner (and gloo its connection report) on fd 1 when a communicator comes up: stdout must
+        # carry the ONE JSON line and nothing else, so fd 1 points at stderr until the first collective has run
+        with _StdoutToStderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            first = torch.ones(1, device=dev)
+            dist.all_reduce(first)
+            torch.cuda.synchronize(dev)
 
     def barrier():
         if multi:
