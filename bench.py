@@ -618,7 +618,18 @@ def small_graph_object(name, dev, steps=100):
     _, eager_fwd = timed_steps(lambda: dense_reference_step(hp, dev, wl["B"], backward=False), 10, 2, dev, sync)
     _, eager_all = timed_steps(lambda: dense_reference_step(hp, dev, wl["B"], backward=True), 10, 2, dev, sync)
     fwd = statistics.median(fwd_g)
+    # the whole msgat72 TRAINING step at this size (engine.Trainer: forward, loss, backward, Adam; ~150 launches for a
+    # few ms of GPU work): launched eagerly and as the HIP graph `Trainer(hip_graph=True)` captures
+    cfg = dict(N=wl["N"], E=wl["E"], B=wl["B"], R=wl["R"], Cin=wl["Cin"], T=wl["T"])
+    train = {}
+    for key, graph in (("train_step_eager_launch_ms", False), ("train_step_hip_graph_ms", True)):
+        ts = TrainStep(cfg, dev, hip_graph=graph)
+        w, per = time_train_step(ts, 20, 5, sync)
+        train[key] = round(statistics.median(per), 4)
+        del ts
+    torch.cuda.empty_cache()
     return {
+        **train,
         "workload": (f"{name}: N={wl['N']} nodes, {wl['E']} undirected edges (+self loops), T={wl['T']}, B={wl['B']}, "
                      f"R={wl['R']} relation{'s' if wl['R'] > 1 else ''}, GACN {wl['Cin']}->{wl['Co']} and "
                      f"{wl['hidden']}->{wl['Co']}, forward+backward"),

@@ -591,13 +591,20 @@ extern "C" int msgat_gacn_forward(const msgat_shape_t* sh, const msgat_graph_t* 
   const int G = sh->R * sh->Bg, P = sh->N * sh->T;
   float* pq = io->need_bwd ? io->pq : nullptr;
 
+  // q = alpha . x: out of the projection pass (PROJ_FIRST), inside the score kernel (one input channel: a component's
+  // first MEAM on PEMSD7 / PEMSD8), or from its own small pass
+  const bool q_in_scores = mode != MSGAT_MODE_PROJ_FIRST && scores_take_x(sh->C);
   if (mode == MSGAT_MODE_PROJ_FIRST)
     st = launch_project(io->x, io->W, 0, io->alpha, nullptr, nullptr, io->u, io->q, G, sh->Bg, sh->C, sh->Co, P, s);
-  else
+  else if (!q_in_scores)
     st = launch_qonly(io->x, io->alpha, io->q, G, sh->Bg, sh->C, P, s);
   if (st) return st;
 
-  st = launch_scores(*gr, io->q, io->Wg, io->kW, io->lse, pq, io->E, io->Ec, G, sh->Bg, sh->N, sh->T, s);
+  if (q_in_scores)
+    st = launch_scores(*gr, nullptr, io->Wg, io->kW, io->lse, pq, io->E, io->Ec, G, sh->Bg, sh->N, sh->T, s, io->x, io->alpha,
+                       sh->C, io->q);
+  else
+    st = launch_scores(*gr, io->q, io->Wg, io->kW, io->lse, pq, io->E, io->Ec, G, sh->Bg, sh->N, sh->T, s);
   if (st) return st;
 
   switch (mode) {

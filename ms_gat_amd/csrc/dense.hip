@@ -39,6 +39,36 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // the nested fmaxf into v_max3_f32 by itself.
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
+// Where a node's q row comes from: the q array (XC = 0), or -- the first MEAM of a component on a one-feature dataset --
+// q = sum_c alpha[c] x[c] computed on the fly from the XC channel slabs of x[g] (attention.py:33).  The
+// fma order is k_qonly's (c ascending from zero), so the bits are the ones that kernel wrote; the block stores the rows it
+// owns for the backward.  That removes the k_qonly launch (4.9 us at PEMSD7 size) from the forward.
+template <int T, int XC>
+struct QRows {
+  const float* base;      // XC == 0: q[g] ([N,T]);  XC > 0: x[g] ([XC,N,T])
+  float a[XC > 0 ? XC : 1];
+  size_t cs;              // channel stride of x in floats (N * T)
+  __device__ __forceinline__ float4 row4(size_t node, int t4) const {
+    if (XC == 0) return reinterpret_cast<const float4*>(base + node * T)[t4];
+    float4 v[XC > 0 ? XC : 1];
+#pragma unroll
+    for (int c = 0; c < XC; ++c) v[c] = reinterpret_cast<const float4*>(base + c * cs + node * T)[t4];
+    float4 acc = f4zero();
+#pragma unroll
+    for (int c = 0; c < XC; ++c) f4fma(a[c], v[c], acc);
+    return acc;
+  }
+};
+template <int T, int XC>
+__device__ __forceinline__ QRows<T, XC> make_qrows(const float* qsrc, const float* alpha, int g, int r, int N) {
+  QRows<T, XC> qr;
+  qr.cs = (size_t)N * T;
+  qr.base = qsrc + (size_t)g * (XC > 0 ? XC : 1) * N * T;
+#pragma unroll
+  for (int c = 0; c < (XC > 0 ? XC : 1); ++c) qr.a[c] = XC > 0 ? alpha[r * XC + c] : 0.f;
+  return qr;
+}
+
 // 8 waves = 2 per SIMD.  Tried (round 2): 7 waves per block, which makes the PEMSD7 grid (N = 883, G = 96) exactly
 // 3.0 blocks per CU instead of 2.6 (3 rounds of 112 rows instead of 3 of 128): k_scores 60.7 -> 63.7 us,
 // k_bwd_dense_col 60.2 -> 61.0 us -- 7 waves spread 2,2,2,1 over the SIMDs, and the matrix pipe is per SIMD.
@@ -82,12 +112,13 @@ static size_t balance_pad_bytes(int nblocks, size_t static_lds) {
 // Wave w owns rows n0 + 16w .. +15 (B operand of the score product: their kW2) and streams all
 // columns.  Score tile D[i = column][j = row]: lane (row j, quad) holds its row against columns
 // m0 + 4*quad + r.  Payload tile D2[i = timestep s][j = row] += q[m][s] P[row][m].
-template <int T, bool WITH_PQ>
+template <int T, bool WITH_PQ, int XC = 0>
 __global__ __launch_bounds__(kDBlock) void k_scores(
     const float* __restrict__ q, const float* __restrict__ Wg, const int* __restrict__ rowptr,
     const int* __restrict__ col, const float* __restrict__ val, const int* __restrict__ erow,
     float* __restrict__ kW, float* __restrict__ lse, float* __restrict__ pq, float* __restrict__ E,
-    const int* __restrict__ cpos, float* __restrict__ Ec, int Bg, int N, int nnz) {
+    const int* __restrict__ cpos, float* __restrict__ Ec, int Bg, int N, int nnz,
+    const float* __restrict__ alpha, float* __restrict__ qout) {   // XC > 0: `q` is x[G,XC,N,T], the q rows go to qout
   constexpr int T4 = T / 4;
   __shared__ float4 qs4[kDMC * kPS / 4];  // staged columns: [column][q(T) | zeros]
   __shared__ float kw2s[kDRows][T];       // the block's rows, log2-scaled, for the edge pass
@@ -101,7 +132,7 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
   const int n0 = blockIdx.x * kDRows;
   const int n = n0 + 16 * wave + j;  // this lane's row (shared by its 4 quads)
   const bool valid = n < N;
-  const float* qg = q + (size_t)g * N * T;
+  const QRows<T, XC> qrows = make_qrows<T, XC>(q, alpha, g, r, N);
   const float* wg = Wg + (size_t)r * T * T;
 
   MSGAT_STAMP(0);
@@ -112,8 +143,9 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
 #pragma unroll
     for (int t4 = 0; t4 < T4; ++t4) {
       float4 v = f4zero();
-      if (valid) v = reinterpret_cast<const float4*>(qg + (size_t)n * T)[t4];
+      if (valid) v = qrows.row4((size_t)n, t4);
       qr[4 * t4 + 0] = v.x; qr[4 * t4 + 1] = v.y; qr[4 * t4 + 2] = v.z; qr[4 * t4 + 3] = v.w;
+      if (XC > 0 && valid && quad == 0) reinterpret_cast<float4*>(qout + ((size_t)g * N + n) * T)[t4] = v;   // kept for backward
     }
 #pragma unroll
     for (int kk = 0; kk < T4; ++kk) {
@@ -150,7 +182,7 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
       const int i = threadIdx.x + k * kDBlock;
       const int c = i / kF4, f = i - c * kF4;
       const bool live = (c < cols) && (f < T4);
-      const float4 v = reinterpret_cast<const float4*>(qg + (size_t)(c0 + (live ? c : 0)) * T)[live ? f : 0];
+      const float4 v = qrows.row4((size_t)(c0 + (live ? c : 0)), live ? f : 0);
       const float keep = live ? 1.f : 0.f;  // multiply, not select: keeps the load out of a branch
       const float one = (ONES && c < cols && f == T4) ? 1.f : 0.f;  // the ones column, at index T of the staged row
       pre[k] = make_float4(fmaf(v.x, keep, one), v.y * keep, v.z * keep, v.w * keep);
@@ -248,11 +280,11 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
   const int e1 = rowptr[min(n0 + kDRows, N)];
   for (int e = e0 + threadIdx.x; e < e1; e += kDBlock) {
     const int nl = erow[e] - n0;
-    const float4* qm = reinterpret_cast<const float4*>(qg + (size_t)col[e] * T);
+    const size_t ce = (size_t)col[e];
     float a = 0.f;
 #pragma unroll
     for (int t4 = 0; t4 < T4; ++t4) {
-      const float4 v = qm[t4];
+      const float4 v = qrows.row4(ce, t4);
       a = fmaf(v.x, kw2s[nl][4 * t4 + 0], a);
       a = fmaf(v.y, kw2s[nl][4 * t4 + 1], a);
       a = fmaf(v.z, kw2s[nl][4 * t4 + 2], a);
@@ -278,12 +310,13 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
 constexpr int kHOwners = 7;
 constexpr int kHRows = 16 * kHOwners;
 
-template <int T, bool WITH_PQ>
+template <int T, bool WITH_PQ, int XC = 0>
 __global__ __launch_bounds__(kDBlock) void k_scores7(
     const float* __restrict__ q, const float* __restrict__ Wg, const int* __restrict__ rowptr,
     const int* __restrict__ col, const float* __restrict__ val, const int* __restrict__ erow,
     float* __restrict__ kW, float* __restrict__ lse, float* __restrict__ pq, float* __restrict__ E,
-    const int* __restrict__ cpos, float* __restrict__ Ec, int Bg, int N, int nnz, int Ca) {
+    const int* __restrict__ cpos, float* __restrict__ Ec, int Bg, int N, int nnz, int Ca,
+    const float* __restrict__ alpha, float* __restrict__ qout) {
   constexpr int T4 = T / 4;
   constexpr bool ONES = WITH_PQ && T < 16;
   constexpr int kOThreads = 64 * kHOwners;                      // lanes that stage the owners' chunks
@@ -305,7 +338,7 @@ __global__ __launch_bounds__(kDBlock) void k_scores7(
   const int n0 = blockIdx.x * kHRows;
   const int n = n0 + 16 * wave + j;
   const bool valid = owner && n < N;
-  const float* qg = q + (size_t)g * N * T;
+  const QRows<T, XC> qrows = make_qrows<T, XC>(q, alpha, g, r, N);
   const float* wg = Wg + (size_t)r * T * T;
   const int colsh = N - Ca;             // 1 .. kDMC (host-checked)
   const int nchunk = cdiv(Ca, kDMC);
@@ -315,7 +348,7 @@ __global__ __launch_bounds__(kDBlock) void k_scores7(
   for (int i = threadIdx.x; i < kDMC * kF4; i += kDBlock) {
     const int c = i / kF4, f = i - c * kF4;
     const bool live = (c < colsh) && (f < T4);
-    const float4 v = reinterpret_cast<const float4*>(qg + (size_t)(Ca + (live ? c : 0)) * T)[live ? f : 0];
+    const float4 v = qrows.row4((size_t)(Ca + (live ? c : 0)), live ? f : 0);
     const float keep = live ? 1.f : 0.f;
     const float one = (ONES && c < colsh && f == T4) ? 1.f : 0.f;
     qh4[i] = make_float4(fmaf(v.x, keep, one), v.y * keep, v.z * keep, v.w * keep);
@@ -386,7 +419,7 @@ __global__ __launch_bounds__(kDBlock) void k_scores7(
         const int i = threadIdx.x + k * kOThreads;
         const int c = i / kF4, f = i - c * kF4;
         const bool live = (c < cols) && (f < T4);
-        const float4 v = reinterpret_cast<const float4*>(qg + (size_t)(c0 + (live ? c : 0)) * T)[live ? f : 0];
+        const float4 v = qrows.row4((size_t)(c0 + (live ? c : 0)), live ? f : 0);
         const float keep = live ? 1.f : 0.f;
         const float one = (ONES && c < cols && f == T4) ? 1.f : 0.f;
         pre[k] = make_float4(fmaf(v.x, keep, one), v.y * keep, v.z * keep, v.w * keep);
@@ -398,8 +431,9 @@ __global__ __launch_bounds__(kDBlock) void k_scores7(
 #pragma unroll
       for (int t4 = 0; t4 < T4; ++t4) {
         float4 v = f4zero();
-        if (valid) v = reinterpret_cast<const float4*>(qg + (size_t)n * T)[t4];
+        if (valid) v = qrows.row4((size_t)n, t4);
         qr[4 * t4 + 0] = v.x; qr[4 * t4 + 1] = v.y; qr[4 * t4 + 2] = v.z; qr[4 * t4 + 3] = v.w;
+        if (XC > 0 && valid && quad == 0) reinterpret_cast<float4*>(qout + ((size_t)g * N + n) * T)[t4] = v;   // kept for backward
       }
 #pragma unroll
       for (int kk = 0; kk < T4; ++kk) {
@@ -483,11 +517,11 @@ __global__ __launch_bounds__(kDBlock) void k_scores7(
   const int e1 = rowptr[min(n0 + kHRows, N)];
   for (int e = e0 + threadIdx.x; e < e1; e += kDBlock) {
     const int nl = erow[e] - n0;
-    const float4* qm = reinterpret_cast<const float4*>(qg + (size_t)col[e] * T);
+    const size_t ce = (size_t)col[e];
     float a = 0.f;
 #pragma unroll
     for (int t4 = 0; t4 < T4; ++t4) {
-      const float4 v = qm[t4];
+      const float4 v = qrows.row4(ce, t4);
       a = fmaf(v.x, kw2s[nl][4 * t4 + 0], a);
       a = fmaf(v.y, kw2s[nl][4 * t4 + 1], a);
       a = fmaf(v.z, kw2s[nl][4 * t4 + 2], a);
@@ -516,20 +550,21 @@ static int scores7_owner_columns(int N, int G) {
   return (Tn - Th) * 16;
 }
 
-template <int T>
-static int launch_scores_t(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW,
-                           float* lse, float* pq, float* E, float* Ec, int G, int Bg, int N, hipStream_t s) {
+// XC > 0: `q` is read-only x[G,XC,N,T] and the q rows are WRITTEN to qout (see QRows); XC = 0: `q` is the q array
+template <int T, int XC>
+static int launch_scores_x(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW, float* lse, float* pq,
+                           float* E, float* Ec, int G, int Bg, int N, hipStream_t s, const float* alpha, float* qout) {
 #ifndef MSGAT_NO_SCORES7
   if (const int Ca = scores7_owner_columns(N, G)) {
     dim3 grid7(cdiv(N, kHRows), G);
     const size_t lds7 = sizeof(float) * (2 * kDMC * kPS + kHRows * T + 3 * kHRows + kHRows * 17);
     const size_t pad7 = balance_pad_bytes((int)(grid7.x * grid7.y), lds7);
     if (pq != nullptr)
-      hipLaunchKernelGGL((k_scores7<T, true>), grid7, dim3(kDBlock), pad7, s, q, Wg, gr.rowptr, gr.col, gr.val,
-                         gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, Ca);
+      hipLaunchKernelGGL((k_scores7<T, true, XC>), grid7, dim3(kDBlock), pad7, s, q, Wg, gr.rowptr, gr.col, gr.val,
+                         gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, Ca, alpha, qout);
     else
-      hipLaunchKernelGGL((k_scores7<T, false>), grid7, dim3(kDBlock), pad7, s, q, Wg, gr.rowptr, gr.col, gr.val,
-                         gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, Ca);
+      hipLaunchKernelGGL((k_scores7<T, false, XC>), grid7, dim3(kDBlock), pad7, s, q, Wg, gr.rowptr, gr.col, gr.val,
+                         gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, Ca, alpha, qout);
     MSGAT_CHECK_LAUNCH();
     return MSGAT_OK;
   }
@@ -538,22 +573,36 @@ static int launch_scores_t(const msgat_graph_t& gr, const float* q, const float*
   const size_t static_lds = sizeof(float) * (kDMC * kPS + kDRows * T + kDRows);
   const size_t pad = balance_pad_bytes((int)(grid.x * grid.y), static_lds);
   if (pq != nullptr)
-    hipLaunchKernelGGL((k_scores<T, true>), grid, dim3(kDBlock), pad, s, q, Wg, gr.rowptr, gr.col, gr.val,
-                       gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz);
+    hipLaunchKernelGGL((k_scores<T, true, XC>), grid, dim3(kDBlock), pad, s, q, Wg, gr.rowptr, gr.col, gr.val,
+                       gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, alpha, qout);
   else
-    hipLaunchKernelGGL((k_scores<T, false>), grid, dim3(kDBlock), pad, s, q, Wg, gr.rowptr, gr.col, gr.val,
-                       gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz);
+    hipLaunchKernelGGL((k_scores<T, false, XC>), grid, dim3(kDBlock), pad, s, q, Wg, gr.rowptr, gr.col, gr.val,
+                       gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, alpha, qout);
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
 
+template <int T>
+static int launch_scores_t(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW, float* lse, float* pq,
+                           float* E, float* Ec, int G, int Bg, int N, hipStream_t s, const float* x, const float* alpha,
+                           int C, float* qout) {
+  if (x != nullptr && C == 1) return launch_scores_x<T, 1>(gr, x, Wg, kW, lse, pq, E, Ec, G, Bg, N, s, alpha, qout);
+  return launch_scores_x<T, 0>(gr, q, Wg, kW, lse, pq, E, Ec, G, Bg, N, s, nullptr, nullptr);
+}
+
+// One input channel only (PEMSD7 / PEMSD8): -4.9 us per hot-path step.  With three (PEMSD3 / PEMSD4) the three loads per
+// staged float4 cost the kernel what the k_qonly launch costs (17.1 us against 12.1 + 4.7 at N = 307): not instantiated.
+bool scores_take_x(int C) { return C == 1; }
+
 int launch_scores(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW, float* lse,
-                  float* pq, float* E, float* Ec, int G, int Bg, int N, int T, hipStream_t s) {
+                  float* pq, float* E, float* Ec, int G, int Bg, int N, int T, hipStream_t s, const float* x,
+                  const float* alpha, int C, float* qout) {
+  if (x != nullptr && (!scores_take_x(C) || alpha == nullptr || qout == nullptr)) return MSGAT_ERR_UNSUPPORTED;
   switch (T) {
-    case 4: return launch_scores_t<4>(gr, q, Wg, kW, lse, pq, E, Ec, G, Bg, N, s);
-    case 8: return launch_scores_t<8>(gr, q, Wg, kW, lse, pq, E, Ec, G, Bg, N, s);
-    case 12: return launch_scores_t<12>(gr, q, Wg, kW, lse, pq, E, Ec, G, Bg, N, s);
-    case 16: return launch_scores_t<16>(gr, q, Wg, kW, lse, pq, E, Ec, G, Bg, N, s);
+    case 4: return launch_scores_t<4>(gr, q, Wg, kW, lse, pq, E, Ec, G, Bg, N, s, x, alpha, C, qout);
+    case 8: return launch_scores_t<8>(gr, q, Wg, kW, lse, pq, E, Ec, G, Bg, N, s, x, alpha, C, qout);
+    case 12: return launch_scores_t<12>(gr, q, Wg, kW, lse, pq, E, Ec, G, Bg, N, s, x, alpha, C, qout);
+    case 16: return launch_scores_t<16>(gr, q, Wg, kW, lse, pq, E, Ec, G, Bg, N, s, x, alpha, C, qout);
   }
   return MSGAT_ERR_UNSUPPORTED;
 }
