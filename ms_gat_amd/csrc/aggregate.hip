@@ -11,8 +11,6 @@
 // the result out coalesced.  Slabs that do not fit (N > ~3400) fall back to a
 // gather-from-L2 kernel.  Either way the kernel is HBM-bound: algorithmic bytes =
 // read u once + write v once.
-#include <stdlib.h>
-
 #include "common.hpp"
 #include "sell.hpp"
 
@@ -354,119 +352,9 @@ __global__ __launch_bounds__(kAggBlock) void k_agg_sell(
   }
 }
 
-// ---- the same on HALF columns: two resident blocks per CU -------------------------------------------------------
-// k_agg_sell's phases -- stage the column, gather, results back through LDS, store -- run one after the other, and the
-// 128 KB column leaves room for ONE block per CU, so nothing overlaps (0.24 of 8 TB/s; removing any one phase in a lab
-// build saved more than its share: profiles/r02/stress_agg_sell_lab.txt).  A persistent block that prefetched the next
-// column into registers lost (one vmcnt for loads and stores, 128 VGPRs + scratch), and so did slice pairs.  Here the
-// overlap comes from the hardware scheduler instead: a block takes a 2-timestep HALF column (N x 8 B = 64 KB at
-// N = 8192), two blocks are resident per CU (launch bounds: 8 waves per SIMD = 64 VGPRs -- the accumulators are float2 now), and one
-// block's staging round trip and stores run under the other's gathers.  Price: the edge stream of a group is read once
-// per half column instead of once per column (from L2: the XCD pinning keeps it there), and a gather instruction
-// moves 8 instead of 16 bytes per lane.
-// MEASURED (round 4, profiles/r04/stress_agg_sell_lab.txt): 2.77 -> 4.00 ms per launch at the stress graph.  Twice the
-// gather instructions and twice the edge loads cost 1.2 ms more than the overlap of two resident blocks gives back: the
-// gather phase is bound by LDS / L1 issue, not by latency the scheduler could hide.  Not selected; kept behind
-// MSGAT_AGG_SELL=half for the lab record only.
-__device__ __forceinline__ void f2fma(float a, const float2& x, float2& acc) {
-  acc.x = fmaf(a, x.x, acc.x);
-  acc.y = fmaf(a, x.y, acc.y);
-}
-__device__ __forceinline__ void sell_gather2(const SellTrip& x, const float2* slab, float2& acc) {
-  const int4 id = sell_unpack(x.id);
-  f2fma(x.e.x, slab[id.x], acc);
-  f2fma(x.e.y, slab[id.y], acc);
-  f2fma(x.e.z, slab[id.z], acc);
-  f2fma(x.e.w, slab[id.w], acc);
-}
-
-template <int T2>
-__global__ __launch_bounds__(kAggBlock, 8) void k_agg_sell_half(
-    const int* __restrict__ slice_off, const int* __restrict__ lane_row, const uint16_t* __restrict__ sidx,
-    const float2* __restrict__ u2, const float* __restrict__ Es, const float* __restrict__ addvec,
-    const float2* __restrict__ extra2, float2* __restrict__ v2, int G, int Bg, int Cu, int N, int n_pos,
-    int n_slices) {
-  extern __shared__ float2 slab2[];  // [N]: half column j of the [N][T2] slab
-  // block -> (group, channel, half column) as in k_agg_sell: group g on XCD g % 8, the T/2 half-column blocks of a slab
-  // in consecutive slots of that XCD
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int j = slot % T2;
-  const int c = (slot / T2) % Cu;
-  const int g = (slot / (T2 * Cu)) * 8 + xcd;
-  if (g >= G) return;
-  const int r = g / Bg;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const size_t base = ((size_t)g * Cu + c) * N * T2;
-  const float* Eg = Es + (size_t)g * n_pos;
-  const float av = (addvec != nullptr) ? addvec[r * Cu + c] : 0.f;
-  {
-    constexpr int NBS = 8;
-    const float2* src = u2 + base;
-    for (int n0 = 0; n0 < N; n0 += NBS * kAggBlock) {
-      float2 t[NBS];
-#pragma unroll
-      for (int i = 0; i < NBS; ++i) t[i] = src[(size_t)min(n0 + i * kAggBlock + (int)threadIdx.x, N - 1) * T2 + j];
-#pragma unroll
-      for (int i = 0; i < NBS; ++i) slab2[min(n0 + i * kAggBlock + (int)threadIdx.x, N - 1)] = t[i];
-    }
-  }
-  __syncthreads();
-  float2 accs[kSellMaxSlices];
-#pragma unroll
-  for (int i = 0; i < kSellMaxSlices; ++i) {
-    accs[i] = make_float2(0.f, 0.f);
-    const int s = wave + i * (kAggBlock / 64);
-    if (s < n_slices) {  // wave-uniform
-      const int off = slice_off[s];
-      const int ntrip = (slice_off[s + 1] - off) >> 8;
-      const uint2* pi4 = reinterpret_cast<const uint2*>(sidx + off) + lane;
-      const float4* pe4 = reinterpret_cast<const float4*>(Eg + off) + lane;
-      float2 acc = make_float2(0.f, 0.f);
-      if (ntrip > 0) {
-        SellTrip a, b, c4, d;
-        sell_issue(pi4, pe4, 0, ntrip, a);
-        sell_issue(pi4, pe4, 1, ntrip, b);
-        sell_issue(pi4, pe4, 2, ntrip, c4);
-        sell_issue(pi4, pe4, 3, ntrip, d);
-        for (int t = 0; t < ntrip; t += kSD) {
-          sell_gather2(a, slab2, acc);
-          sell_issue(pi4, pe4, t + 4, ntrip, a);
-          if (t + 1 < ntrip) sell_gather2(b, slab2, acc);
-          sell_issue(pi4, pe4, t + 5, ntrip, b);
-          if (t + 2 < ntrip) sell_gather2(c4, slab2, acc);
-          sell_issue(pi4, pe4, t + 6, ntrip, c4);
-          if (t + 3 < ntrip) sell_gather2(d, slab2, acc);
-          sell_issue(pi4, pe4, t + 7, ntrip, d);
-        }
-      }
-      accs[i] = acc;
-    }
-  }
-  __syncthreads();  // every wave is done reading the staged half column
-#pragma unroll
-  for (int i = 0; i < kSellMaxSlices; ++i) {
-    const int s = wave + i * (kAggBlock / 64);
-    if (s < n_slices) {
-      const int row = lane_row[64 * s + lane];
-      if (row >= 0) slab2[row] = accs[i];
-    }
-  }
-  __syncthreads();
-  for (int n = threadIdx.x; n < N; n += kAggBlock) {
-    float2 acc = slab2[n];
-    if (addvec != nullptr) f2fma(av, extra2[((size_t)g * N + n) * T2 + j], acc);
-    v2[base + (size_t)n * T2 + j] = acc;
-  }
-}
-
-// MSGAT_AGG_SELL=full|half overrides the choice (A/B runs: tools/stress_kernels.py)
-static int agg_sell_half_preference() {
-  static const int pref = [] {
-    const char* e = getenv("MSGAT_AGG_SELL");
-    return e == nullptr ? -1 : (e[0] == 'h' ? 1 : 0);
-  }();
-  return pref;
-}
+// (A half-column form -- 2-timestep columns of 64 KB, two resident blocks per CU, so that one block's staging and stores run
+// under the other's gathers -- was measured in round 4 and lost, 2.77 -> 4.00 ms: profiles/r04/stress_agg_sell_lab.txt has
+// the numbers and the reading; the kernel is in the history at commit 2d1af2e.)
 
 // ---- gather-from-L2 aggregate (not even one column fits LDS) ------------------------------------------
 template <int T4>
@@ -496,19 +384,6 @@ static int launch_aggregate_t(const int* ptr, const int* idx, int nnz, const msg
   const int CH = slab_channels(N, T, Cu, kLdsBudget);
   if (sell != nullptr) {  // E is in the position order of this layout (the caller permuted it by sell->src)
     const size_t lds = (size_t)N * sizeof(float4);
-    // half columns (two resident blocks per CU) when two of them fit LDS and a whole column fits only once
-    const size_t lds_half = (size_t)N * sizeof(float2);
-    const int pref = agg_sell_half_preference();
-    const bool half = pref == 1 && 2 * lds_half <= (size_t)kLdsMax - 2048;   // measured slower (see above): on request only
-    if (half) {
-      static LdsGrant granted_half;
-      if (int st = grant_dynamic_lds(&k_agg_sell_half<2 * T4>, lds_half, granted_half)) return st;
-      hipLaunchKernelGGL((k_agg_sell_half<2 * T4>), dim3((unsigned)cdiv(G, 8) * 8 * Cu * 2 * T4), dim3(kAggBlock), lds_half, s,
-                         sell->slice_off, sell->lane_row, sell->idx, (const float2*)u, E, addvec, (const float2*)extra,
-                         (float2*)v, G, Bg, Cu, N, sell->n_pos, sell->n_slices);
-      MSGAT_CHECK_LAUNCH();
-      return MSGAT_OK;
-    }
     static LdsGrant granted;
     if (int st = grant_dynamic_lds(&k_agg_sell<T4>, lds, granted)) return st;
     hipLaunchKernelGGL((k_agg_sell<T4>), dim3((unsigned)cdiv(G, 8) * 8 * Cu * T4), dim3(kAggBlock), lds, s,
