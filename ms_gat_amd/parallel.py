@@ -107,21 +107,27 @@ class _GatherTable:
         self.offs = torch.tensor(offs, dtype=torch.int64).to(dev)
         self.lens = torch.tensor(lens, dtype=torch.int32).to(dev)
         self.ptrs = torch.zeros(max(self.n, 1), dtype=torch.int64, device=dev)
-        self.host = torch.zeros(max(self.n, 1), dtype=torch.int64).pin_memory()
-        self.copied = None           # event behind the last host -> device copy of the pointer column
+        # a ring of pinned staging buffers, each with the event behind its last copy: re-using one waits for THAT copy
+        # only -- four steps back, i.e. never in practice -- so a step whose gradients moved does not stall the host
+        # behind the device (waiting for the newest copy would: it sits at the end of the previous step)
+        self.host = [torch.zeros(max(self.n, 1), dtype=torch.int64).pin_memory() for _ in range(4)]
+        self.copied = [None] * len(self.host)
+        self.turn = 0
         self.current = None
 
     def point_at(self, bases: tuple) -> None:
         if bases == self.current:
             return
-        if self.copied is not None:
-            self.copied.synchronize()            # the pinned buffer is free again (long done in practice)
-        h = self.host.numpy()
-        for k, (i, b) in enumerate(self.rel):
-            h[k] = bases[i] + b
-        self.ptrs.copy_(self.host, non_blocking=True)
-        self.copied = torch.cuda.Event()
-        self.copied.record(torch.cuda.current_stream(self.ptrs.device))
+        k = self.turn
+        self.turn = (k + 1) % len(self.host)
+        if self.copied[k] is not None:
+            self.copied[k].synchronize()
+        h = self.host[k].numpy()
+        for j, (i, b) in enumerate(self.rel):
+            h[j] = bases[i] + b
+        self.ptrs.copy_(self.host[k], non_blocking=True)
+        self.copied[k] = torch.cuda.Event()
+        self.copied[k].record(torch.cuda.current_stream(self.ptrs.device))
         self.current = bases
 
 
