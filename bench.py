@@ -39,8 +39,12 @@ import subprocess
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+# dmabuf IPC only on this driver (RCCL / device-tensor sharing across processes): must be in the environment before HSA
+# comes up, i.e. before the first HIP call of this process -- not only before init_process_group
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
