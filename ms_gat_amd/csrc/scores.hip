@@ -181,14 +181,32 @@ __global__ __launch_bounds__(kRowBlock) void k_bwd_rows(
     reinterpret_cast<float4*>(ds + threadIdx.x * T)[t4] = make_float4(dk[4 * t4], dk[4 * t4 + 1], dk[4 * t4 + 2], dk[4 * t4 + 3]);
   }
   __syncthreads();
-  if (threadIdx.x < T * T) {
-    const int t = threadIdx.x / T, s = threadIdx.x - t * T;
-    float a0 = 0.f, a1 = 0.f;
-    for (int row = 0; row < kRowBlock; row += 2) {
-      a0 = fmaf(qs[row * T + t], ds[row * T + s], a0);
-      a1 = fmaf(qs[(row + 1) * T + t], ds[(row + 1) * T + s], a1);
+  // D[t][s] = sum_rows q[row][t] dkW[row][s] on the matrix core: each of the four waves contracts its 64 rows (16 k-steps of
+  // four rows: lane (i, kq) supplies q[row 4k + kq][i] and dkW[row 4k + kq][i]), the four tiles are summed in a fixed order.
+  // As 144 lanes walking all 256 rows (two LDS reads per fma, one dependent chain per lane) this tail cost 2.6-3 us of a
+  // 13-18 us launch (lab build without it, round 4).
+  {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = lane & 15, kq = lane >> 4;
+    const int ic = i < T ? i : 0;
+    const float keep = i < T ? 1.f : 0.f;
+    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int row = 64 * wave + 4 * k + kq;
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(qs[row * T + ic] * keep, ds[row * T + ic] * keep, d, 0, 0, 0);
     }
-    dwg_part[((size_t)g * nblk + blockIdx.x) * (T * T) + threadIdx.x] = a0 + a1;
+    __syncthreads();          // everyone is done reading qs: it now carries the four tiles
+    static_assert(kRowBlock == 256 && kRowBlock * 4 >= 4 * 256, "four waves, one 16x16 tile each");
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) qs[wave * 256 + reg * 64 + lane] = d[reg];
+    __syncthreads();
+    const int e = threadIdx.x;                       // element (reg = e >> 6, lane = e & 63) of the tile
+    const int t = 4 * ((e & 63) >> 4) + (e >> 6);    // D row 4 quad + reg
+    const int sc = e & 15;                           // D column
+    const float v = (qs[e] + qs[256 + e]) + (qs[512 + e] + qs[768 + e]);
+    if (t < T && sc < T) dwg_part[((size_t)g * nblk + blockIdx.x) * (T * T) + t * T + sc] = v;
   }
 }
 
