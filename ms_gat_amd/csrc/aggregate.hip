@@ -88,9 +88,13 @@ __global__ __launch_bounds__(kAggBlock) void k_agg_lds(
   for (int i = threadIdx.x; i < total; i += kAggBlock) slab[i] = u4[base + i];
   __syncthreads();
 
+  // gridDim.z blocks share a slab's output rows (each stages the whole slab: the re-reads come from L2) -- with one block
+  // per (group, chunk) the first MEAM's backward aggregate (C = 1 or 3: G blocks) ran on a third of the CUs
+  const int seg = cdiv(NT4, (int)gridDim.z);
+  const int s_end = min((int)(blockIdx.z + 1) * seg, NT4);
   float da[kAggDotMaxC] = {0.f, 0.f, 0.f, 0.f};
   const float* Eg = E + (size_t)g * nnz;
-  for (int s = threadIdx.x; s < NT4; s += kAggBlock) {
+  for (int s = blockIdx.z * seg + threadIdx.x; s < s_end; s += kAggBlock) {
     const int n = s / T4;
     const int j = s - n * T4;
     const int e0 = ptr[n], e1 = ptr[n + 1];
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(kAggBlock) void k_agg_lds(
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < kAggBlock / 64; ++w) t += dred[w][threadIdx.x];
-      dap[(size_t)g * Cu + c0 + threadIdx.x] = t;
+      dap[((size_t)g * gridDim.z + blockIdx.z) * Cu + c0 + threadIdx.x] = t;   // one partial per (group, row split)
     }
   }
 }
@@ -409,11 +413,15 @@ static int launch_aggregate_t(const int* ptr, const int* idx, int nnz, const msg
     static LdsGrant granted_plain, granted_dot;
     if (int st = grant_dynamic_lds(&k_agg_lds<T4, false>, lds, granted_plain)) return st;
     if (int st = grant_dynamic_lds(&k_agg_lds<T4, true>, lds, granted_dot)) return st;
-    dim3 grid(cdiv(Cu, CH), G);
+    // few blocks (the first MEAM's backward: G of them): up to kAggMaxSplit blocks share a slab's rows
+    const int nblocks = cdiv(Cu, CH) * G;
+    int split = device_cu_count() / max(nblocks, 1);
+    split = max(1, min(min(split, kAggMaxSplit), (N * T4) / 256));
+    dim3 grid(cdiv(Cu, CH), G, split);
     if (xdot != nullptr && dap != nullptr && addvec != nullptr && Cu <= kAggDotMaxC) {
       hipLaunchKernelGGL((k_agg_lds<T4, true>), grid, dim3(kAggBlock), lds, s, ptr, idx, (const float4*)u, E, addvec,
                          (const float4*)extra, (float4*)v, Bg, Cu, N, nnz, CH, (const float4*)xdot, dap);
-      if (dot_done != nullptr) *dot_done = 1;
+      if (dot_done != nullptr) *dot_done = split;   // partials per group
     } else {
       hipLaunchKernelGGL((k_agg_lds<T4, false>), grid, dim3(kAggBlock), lds, s, ptr, idx, (const float4*)u, E, addvec,
                          (const float4*)extra, (float4*)v, Bg, Cu, N, nnz, CH, nullptr, nullptr);

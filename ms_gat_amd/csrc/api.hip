@@ -72,13 +72,13 @@ BwdPlan plan_bwd(const msgat_shape_t& sh, const msgat_graph_t& gr) {
   size_t cp = 0, cp2 = 0;
   if (p.mode == MSGAT_MODE_PLAIN) {
     cp = chanpair_partial_floats(p.G, sh.Bg, 1, sh.C);
-    if (G * (size_t)sh.C > cp) cp = G * (size_t)sh.C;
+    if (G * (size_t)sh.C * kAggMaxSplit > cp) cp = G * (size_t)sh.C * kAggMaxSplit;
   } else if (p.mode == MSGAT_MODE_AGG_FIRST) {
     cp = chanpair_partial_floats(p.G, sh.Bg, sh.Co, sh.C);
     const size_t fused = G * (size_t)aggfirst_blocks((int)P) * sh.Co * sh.C;
     if (sh.C <= kAggFirstMaxC && fused > cp) cp = fused;
     cp2 = chanpair_partial_floats(p.G, sh.Bg, 1, sh.C);
-    if (G * (size_t)sh.C > cp2) cp2 = G * (size_t)sh.C;
+    if (G * (size_t)sh.C * kAggMaxSplit > cp2) cp2 = G * (size_t)sh.C * kAggMaxSplit;
   } else {
     cp = chanpair_partial_floats(p.G, sh.Bg, sh.Co + 1, sh.C);
   }
@@ -746,7 +746,7 @@ extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t*
                       &dot_done, io->Ec);
   if (st) return st;
   if (dot_done)
-    st = launch_reduce_groups_defer(dap, sh->R, Bg, C, io->dalpha, s, &jobs);
+    st = launch_reduce_groups_defer(dap, sh->R, Bg * dot_done, C, io->dalpha, s, &jobs);
   else
     st = launch_chanpair(nullptr, dq, io->x, dap, nullptr, 0, io->dalpha, C, G, Bg, 1, C, P, s, &jobs);
   if (st) return st;

@@ -255,8 +255,10 @@ int launch_scores(const msgat_graph_t& gr, const float* q, const float* Wg, floa
 // MSGAT_SELL_SLACK readable floats behind the last row) and the SELL kernel runs
 // xdot/dap (both or neither; Cu <= kAggDotMaxC, addvec given): the slab kernel also leaves dap[g,c] =
 // sum_p extra[g,p] xdot[g,c,p] -- dalpha = dq . x of the AGG_FIRST / PLAIN backward -- when it runs (returns
-// MSGAT_OK and sets *dot_done); other kernel forms leave *dot_done = 0 and the caller contracts separately
+// MSGAT_OK and sets *dot_done to the number of partials per group it left: dap[(g * dot_done + i) * Cu + c]); other
+// kernel forms leave *dot_done = 0 and the caller contracts separately
 constexpr int kAggDotMaxC = 4;
+constexpr int kAggMaxSplit = 3;   // blocks that may share one slab's output rows (k_agg_lds)
 int launch_aggregate(const int* ptr, const int* idx, int nnz, const msgat_sell_t* sell, const float* u,
                      const float* E, const float* addvec, const float* extra, float* v, int G, int Bg, int Cu,
                      int N, int T, hipStream_t s, const float* xdot = nullptr, float* dap = nullptr,
