@@ -50,16 +50,18 @@ __global__ __launch_bounds__(kBlock) void k_edge_grad_csc(const float* __restric
   const int k = blockIdx.x * kBlock + threadIdx.x;
   if (k >= nnz) return;
   const float* p = dEp + (size_t)g * nchunks * nnz + k;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  // eight independent loads in flight per trip (the fused pass leaves one partial per channel: 24 at msgat72's widths, so
+  // four per trip were six dependent round trips); fixed summation order
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float ec = Ec[(size_t)g * nnz + k];
+  const int dst = cperm[k];
   int c = 0;
-  for (; c + 4 <= nchunks; c += 4) {
-    a0 += p[(size_t)(c + 0) * nnz];
-    a1 += p[(size_t)(c + 1) * nnz];
-    a2 += p[(size_t)(c + 2) * nnz];
-    a3 += p[(size_t)(c + 3) * nnz];
+  for (; c + 8 <= nchunks; c += 8) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] += p[(size_t)(c + i) * nnz];
   }
-  for (; c < nchunks; ++c) a0 += p[(size_t)c * nnz];
-  gE[(size_t)g * nnz + cperm[k]] = Ec[(size_t)g * nnz + k] * ((a0 + a1) + (a2 + a3));
+  for (; c < nchunks; ++c) a[0] += p[(size_t)c * nnz];
+  gE[(size_t)g * nnz + dst] = ec * (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7])));
 }
 
 
