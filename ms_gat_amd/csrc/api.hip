@@ -591,9 +591,11 @@ extern "C" int msgat_gacn_forward(const msgat_shape_t* sh, const msgat_graph_t* 
   const int G = sh->R * sh->Bg, P = sh->N * sh->T;
   float* pq = io->need_bwd ? io->pq : nullptr;
 
-  // q = alpha . x: out of the projection pass (PROJ_FIRST), inside the score kernel (one input channel: a component's
-  // first MEAM on PEMSD7 / PEMSD8), or from its own small pass
-  const bool q_in_scores = mode != MSGAT_MODE_PROJ_FIRST && scores_take_x(sh->C);
+  // q = alpha . x: out of the projection pass (PROJ_FIRST), inside the score kernel (one input channel; three when the
+  // kernel also finishes an AGG_FIRST layer), or from its own small pass
+  const bool tail = mode == MSGAT_MODE_AGG_FIRST && sh->Co <= 64 && scores_take_x(sh->C, true) &&
+                    !sell_usable(gr->sell_rows, gr->nnz, sh->N, sh->T);
+  const bool q_in_scores = mode != MSGAT_MODE_PROJ_FIRST && scores_take_x(sh->C, tail);
   if (mode == MSGAT_MODE_PROJ_FIRST)
     st = launch_project(io->x, io->W, 0, io->alpha, nullptr, nullptr, io->u, io->q, G, sh->Bg, sh->C, sh->Co, P, s);
   else if (!q_in_scores)
@@ -602,10 +604,12 @@ extern "C" int msgat_gacn_forward(const msgat_shape_t* sh, const msgat_graph_t* 
 
   if (q_in_scores)
     st = launch_scores(*gr, nullptr, io->Wg, io->kW, io->lse, pq, io->E, io->Ec, G, sh->Bg, sh->N, sh->T, s, io->x, io->alpha,
-                       sh->C, io->q);
+                       sh->C, io->q, tail ? io->W : nullptr, tail ? sh->Co : 0, (tail && io->need_bwd) ? io->u : nullptr,
+                       tail ? io->z : nullptr);
   else
     st = launch_scores(*gr, io->q, io->Wg, io->kW, io->lse, pq, io->E, io->Ec, G, sh->Bg, sh->N, sh->T, s);
   if (st) return st;
+  if (tail) return MSGAT_OK;   // z (and y) came out of the score kernel
 
   switch (mode) {
     case MSGAT_MODE_PLAIN:

@@ -244,12 +244,15 @@ int launch_chanpair_mix_wide(const SegList& A, const float* B, float* part, int 
                              int b_ones, const float* M, float* mixout, hipStream_t s, int* nblk_used, int* done);
 int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
                          int b_ones, hipStream_t s, int* nblk_used);
-// x / alpha / C / qout given (scores_take_x(C): the single input channel of a component's first MEAM): q = alpha . x is
-// computed inside the kernel from x[G,C,N,T] and written to qout -- no k_qonly launch; `q` is ignored then
-bool scores_take_x(int C);
+// x / alpha / C / qout given (scores_take_x): q = alpha . x is computed inside the kernel from x[G,C,N,T] and written to
+// qout -- no k_qonly launch; `q` is ignored then.  apW / apCo / apZ given as well (AGG_FIRST, W[R,apCo,C]): the kernel
+// also finishes the layer for its rows, y = E x (to apY[G,C,N,T] when not NULL) and z = W y (to apZ[G,apCo,N,T]) -- no
+// k_agg_proj launch.
+bool scores_take_x(int C, bool with_tail);
 int launch_scores(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW, float* lse,
                   float* pq, float* E, float* Ec, int G, int Bg, int N, int T, hipStream_t s,
-                  const float* x = nullptr, const float* alpha = nullptr, int C = 0, float* qout = nullptr);
+                  const float* x = nullptr, const float* alpha = nullptr, int C = 0, float* qout = nullptr,
+                  const float* apW = nullptr, int apCo = 0, float* apY = nullptr, float* apZ = nullptr);
 // v[g,c,n,:] = sum_{e in ptr[n]..ptr[n+1]} E[g,e] u[g,c,idx[e],:] (+ addvec[r,c]*extra[g,n,:])
 // sell != nullptr: E is in that layout's position order (permuted by sell->src, row stride sell->n_pos, with
 // MSGAT_SELL_SLACK readable floats behind the last row) and the SELL kernel runs

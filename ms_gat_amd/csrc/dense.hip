@@ -69,6 +69,70 @@ __device__ __forceinline__ QRows<T, XC> make_qrows(const float* qsrc, const floa
   return qr;
 }
 
+// AGG_FIRST forward with 1 or 3 input channels (the first MEAM of every component): the block has just written the edge
+// coefficients of its rows, so it can finish the layer itself -- y[c,n,:] = sum_e E_e x[c,col_e,:] (attention.py:36) and
+// z[o,n,:] = sum_c W[o,c] y[c,n,:] (msgat.py:27) for its rows -- instead of a separate k_agg_proj launch that re-reads E and the
+// row extents (9.3 us of a 73-us forward at PEMSD4 size).  Lane = (row, 4 timesteps); four edges per trip with clamped loads;
+// the output channels in chunks of eight so that the tail's registers stay below the score loop's.
+// The row extents, and -- when the block's rows have at most kTailEdges edges (CACHED) -- the column indices and the
+// coefficients the edge pass has just computed, wait in LDS: the tail's only global round trip is the gather of x rows.
+constexpr int kTailEdges = 1024;
+typedef const int __attribute__((address_space(3))) * lds_ci;
+typedef const float __attribute__((address_space(3))) * lds_cf;
+
+template <int T, int XC, bool CACHED>
+__device__ __forceinline__ void agg_proj_tail(const QRows<T, XC>& xr, lds_ci rp, lds_ci lcol, lds_cf lE,
+                                              const int* __restrict__ col, const float* __restrict__ Eg,
+                                              const float* __restrict__ Wr, int Co, float* __restrict__ yg,
+                                              float* __restrict__ zg, int n0, int rows, int N) {
+  constexpr int T4 = T / 4;
+  constexpr int C = XC > 0 ? XC : 1;
+  const size_t NT = (size_t)N * T;
+  const int eb = rp[0];
+  for (int s = threadIdx.x; s < rows * T4; s += blockDim.x) {
+    const int rl = s / T4, j = s - rl * T4;
+    const int n = n0 + rl;
+    const int e0 = rp[rl], e1 = rp[rl + 1];
+    float4 y[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) y[c] = f4zero();
+    for (int e = e0; e < e1; e += 4) {
+      int cc[4];
+      float w[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ee = min(e + i, e1 - 1);
+        cc[i] = CACHED ? lcol[ee - eb] : col[ee];
+        const float raw = CACHED ? lE[ee - eb] : Eg[ee];
+        w[i] = (e + i < e1) ? raw : 0.f;
+      }
+      float4 xv[4][C];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < C; ++c) xv[i][c] = reinterpret_cast<const float4*>(xr.base + c * xr.cs + (size_t)cc[i] * T)[j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < C; ++c) f4fma(w[i], xv[i][c], y[c]);
+    }
+    if (yg != nullptr) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) reinterpret_cast<float4*>(yg + c * NT + (size_t)n * T)[j] = y[c];
+    }
+    for (int o0 = 0; o0 < Co; o0 += 8) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int o = min(o0 + k, Co - 1);
+        float4 acc = f4zero();
+#pragma unroll
+        for (int c = 0; c < C; ++c) f4fma(Wr[o * C + c], y[c], acc);
+        if (o0 + k < Co) reinterpret_cast<float4*>(zg + o * NT + (size_t)n * T)[j] = acc;
+      }
+    }
+  }
+}
+
 // 8 waves = 2 per SIMD.  Tried (round 2): 7 waves per block, which makes the PEMSD7 grid (N = 883, G = 96) exactly
 // 3.0 blocks per CU instead of 2.6 (3 rounds of 112 rows instead of 3 of 128): k_scores 60.7 -> 63.7 us,
 // k_bwd_dense_col 60.2 -> 61.0 us -- 7 waves spread 2,2,2,1 over the SIMDs, and the matrix pipe is per SIMD.
@@ -118,7 +182,8 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
     const int* __restrict__ col, const float* __restrict__ val, const int* __restrict__ erow,
     float* __restrict__ kW, float* __restrict__ lse, float* __restrict__ pq, float* __restrict__ E,
     const int* __restrict__ cpos, float* __restrict__ Ec, int Bg, int N, int nnz,
-    const float* __restrict__ alpha, float* __restrict__ qout) {   // XC > 0: `q` is x[G,XC,N,T], the q rows go to qout
+    const float* __restrict__ alpha, float* __restrict__ qout,   // XC > 0: `q` is x[G,XC,N,T], the q rows go to qout
+    const float* __restrict__ apW, int apCo, float* __restrict__ apY, float* __restrict__ apZ) {   // XC > 0 and apZ: the aggregate + projection tail
   constexpr int T4 = T / 4;
   __shared__ float4 qs4[kDMC * kPS / 4];  // staged columns: [column][q(T) | zeros]
   __shared__ float kw2s[kDRows][T];       // the block's rows, log2-scaled, for the edge pass
@@ -278,6 +343,12 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
   // chain below is the MFMA's k order starting from 0, exactly what k_bwd_dense_col re-creates.
   const int e0 = rowptr[n0];
   const int e1 = rowptr[min(n0 + kDRows, N)];
+  __shared__ int tl_rp[XC > 0 ? kDRows + 1 : 1];
+  __shared__ int tl_col[XC > 0 ? kTailEdges : 1];
+  __shared__ float tl_E[XC > 0 ? kTailEdges : 1];
+  const bool with_tail = XC > 0 && apZ != nullptr;               // kernel-uniform
+  const bool tail_cached = with_tail && e1 - e0 <= kTailEdges;    // block-uniform
+  if (with_tail && (int)threadIdx.x <= min(kDRows, N - n0)) tl_rp[threadIdx.x] = rowptr[n0 + threadIdx.x];
   for (int e = e0 + threadIdx.x; e < e1; e += kDBlock) {
     const int nl = erow[e] - n0;
     const size_t ce = (size_t)col[e];
@@ -295,8 +366,22 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
     // the same coefficient at its CSC position: the transposed passes of backward (du = E^T dv on the CSC) then
     // start without a re-ordering launch
     if (Ec != nullptr) Ec[(size_t)g * nnz + cpos[e]] = ev;
+    if (tail_cached) { tl_col[e - e0] = (int)ce; tl_E[e - e0] = ev; }
   }
   MSGAT_STAMP(5);
+  if (with_tail) {
+    __syncthreads();                // the block's coefficients are in LDS (or, uncached, in memory)
+    const size_t NT = (size_t)N * T;
+    const float* Wr = apW + (size_t)r * apCo * XC;
+    float* yg = apY != nullptr ? apY + (size_t)g * XC * NT : nullptr;
+    float* zg = apZ + (size_t)g * apCo * NT;
+    if (tail_cached)
+      agg_proj_tail<T, XC, true>(qrows, (lds_ci)tl_rp, (lds_ci)tl_col, (lds_cf)tl_E, col, E + (size_t)g * nnz, Wr, apCo, yg, zg, n0,
+                                 min(kDRows, N - n0), N);
+    else
+      agg_proj_tail<T, XC, false>(qrows, (lds_ci)tl_rp, (lds_ci)tl_col, (lds_cf)tl_E, col, E + (size_t)g * nnz, Wr, apCo, yg, zg,
+                                  n0, min(kDRows, N - n0), N);
+  }
 }
 
 // ---- forward, 7 owner waves + 1 helper wave ---------------------------------------------------------------------
@@ -316,7 +401,8 @@ __global__ __launch_bounds__(kDBlock) void k_scores7(
     const int* __restrict__ col, const float* __restrict__ val, const int* __restrict__ erow,
     float* __restrict__ kW, float* __restrict__ lse, float* __restrict__ pq, float* __restrict__ E,
     const int* __restrict__ cpos, float* __restrict__ Ec, int Bg, int N, int nnz, int Ca,
-    const float* __restrict__ alpha, float* __restrict__ qout) {
+    const float* __restrict__ alpha, float* __restrict__ qout,
+    const float* __restrict__ apW, int apCo, float* __restrict__ apY, float* __restrict__ apZ) {
   constexpr int T4 = T / 4;
   constexpr bool ONES = WITH_PQ && T < 16;
   constexpr int kOThreads = 64 * kHOwners;                      // lanes that stage the owners' chunks
@@ -515,6 +601,12 @@ __global__ __launch_bounds__(kDBlock) void k_scores7(
   // edge coefficients of this block's rows (see k_scores)
   const int e0 = rowptr[min(n0, N)];
   const int e1 = rowptr[min(n0 + kHRows, N)];
+  __shared__ int tl_rp[XC > 0 ? kHRows + 1 : 1];
+  __shared__ int tl_col[XC > 0 ? kTailEdges : 1];
+  __shared__ float tl_E[XC > 0 ? kTailEdges : 1];
+  const bool with_tail = XC > 0 && apZ != nullptr;               // kernel-uniform
+  const bool tail_cached = with_tail && e1 - e0 <= kTailEdges;    // block-uniform
+  if (with_tail && (int)threadIdx.x <= min(kHRows, N - n0)) tl_rp[threadIdx.x] = rowptr[n0 + threadIdx.x];
   for (int e = e0 + threadIdx.x; e < e1; e += kDBlock) {
     const int nl = erow[e] - n0;
     const size_t ce = (size_t)col[e];
@@ -530,6 +622,20 @@ __global__ __launch_bounds__(kDBlock) void k_scores7(
     const float ev = fast_exp2(a - lse2s[nl]) * val[e];
     E[(size_t)g * nnz + e] = ev;
     if (Ec != nullptr) Ec[(size_t)g * nnz + cpos[e]] = ev;
+    if (tail_cached) { tl_col[e - e0] = (int)ce; tl_E[e - e0] = ev; }
+  }
+  if (with_tail) {   // see k_scores
+    __syncthreads();
+    const size_t NT = (size_t)N * T;
+    const float* Wr = apW + (size_t)r * apCo * XC;
+    float* yg = apY != nullptr ? apY + (size_t)g * XC * NT : nullptr;
+    float* zg = apZ + (size_t)g * apCo * NT;
+    if (tail_cached)
+      agg_proj_tail<T, XC, true>(qrows, (lds_ci)tl_rp, (lds_ci)tl_col, (lds_cf)tl_E, col, E + (size_t)g * nnz, Wr, apCo, yg, zg, n0,
+                                 min(kHRows, N - n0), N);
+    else
+      agg_proj_tail<T, XC, false>(qrows, (lds_ci)tl_rp, (lds_ci)tl_col, (lds_cf)tl_E, col, E + (size_t)g * nnz, Wr, apCo, yg, zg,
+                                  n0, min(kHRows, N - n0), N);
   }
 }
 
@@ -553,31 +659,34 @@ static int scores7_owner_columns(int N, int G) {
 // XC > 0: `q` is read-only x[G,XC,N,T] and the q rows are WRITTEN to qout (see QRows); XC = 0: `q` is the q array
 template <int T, int XC>
 static int launch_scores_x(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW, float* lse, float* pq,
-                           float* E, float* Ec, int G, int Bg, int N, hipStream_t s, const float* alpha, float* qout) {
+                           float* E, float* Ec, int G, int Bg, int N, hipStream_t s, const float* alpha, float* qout,
+                           const float* apW = nullptr, int apCo = 0, float* apY = nullptr, float* apZ = nullptr) {
 #ifndef MSGAT_NO_SCORES7
   if (const int Ca = scores7_owner_columns(N, G)) {
     dim3 grid7(cdiv(N, kHRows), G);
-    const size_t lds7 = sizeof(float) * (2 * kDMC * kPS + kHRows * T + 3 * kHRows + kHRows * 17);
+    const size_t lds7 = sizeof(float) * (2 * kDMC * kPS + kHRows * T + 3 * kHRows + kHRows * 17) +
+                        (XC > 0 ? sizeof(int) * (kHRows + 1 + 2 * kTailEdges) : 0);   // + the tail's row extents / edges
     const size_t pad7 = balance_pad_bytes((int)(grid7.x * grid7.y), lds7);
     if (pq != nullptr)
       hipLaunchKernelGGL((k_scores7<T, true, XC>), grid7, dim3(kDBlock), pad7, s, q, Wg, gr.rowptr, gr.col, gr.val,
-                         gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, Ca, alpha, qout);
+                         gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, Ca, alpha, qout, apW, apCo, apY, apZ);
     else
       hipLaunchKernelGGL((k_scores7<T, false, XC>), grid7, dim3(kDBlock), pad7, s, q, Wg, gr.rowptr, gr.col, gr.val,
-                         gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, Ca, alpha, qout);
+                         gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, Ca, alpha, qout, apW, apCo, apY, apZ);
     MSGAT_CHECK_LAUNCH();
     return MSGAT_OK;
   }
 #endif
   dim3 grid(cdiv(N, kDRows), G);
-  const size_t static_lds = sizeof(float) * (kDMC * kPS + kDRows * T + kDRows);
+  const size_t static_lds = sizeof(float) * (kDMC * kPS + kDRows * T + kDRows) +
+                            (XC > 0 ? sizeof(int) * (kDRows + 1 + 2 * kTailEdges) : 0);
   const size_t pad = balance_pad_bytes((int)(grid.x * grid.y), static_lds);
   if (pq != nullptr)
     hipLaunchKernelGGL((k_scores<T, true, XC>), grid, dim3(kDBlock), pad, s, q, Wg, gr.rowptr, gr.col, gr.val,
-                       gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, alpha, qout);
+                       gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, alpha, qout, apW, apCo, apY, apZ);
   else
     hipLaunchKernelGGL((k_scores<T, false, XC>), grid, dim3(kDBlock), pad, s, q, Wg, gr.rowptr, gr.col, gr.val,
-                       gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, alpha, qout);
+                       gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, alpha, qout, apW, apCo, apY, apZ);
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
@@ -585,24 +694,27 @@ static int launch_scores_x(const msgat_graph_t& gr, const float* q, const float*
 template <int T>
 static int launch_scores_t(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW, float* lse, float* pq,
                            float* E, float* Ec, int G, int Bg, int N, hipStream_t s, const float* x, const float* alpha,
-                           int C, float* qout) {
-  if (x != nullptr && C == 1) return launch_scores_x<T, 1>(gr, x, Wg, kW, lse, pq, E, Ec, G, Bg, N, s, alpha, qout);
+                           int C, float* qout, const float* apW, int apCo, float* apY, float* apZ) {
+  if (x != nullptr && C == 1) return launch_scores_x<T, 1>(gr, x, Wg, kW, lse, pq, E, Ec, G, Bg, N, s, alpha, qout, apW, apCo, apY, apZ);
+  if (x != nullptr && C == 3) return launch_scores_x<T, 3>(gr, x, Wg, kW, lse, pq, E, Ec, G, Bg, N, s, alpha, qout, apW, apCo, apY, apZ);
   return launch_scores_x<T, 0>(gr, q, Wg, kW, lse, pq, E, Ec, G, Bg, N, s, nullptr, nullptr);
 }
 
-// One input channel only (PEMSD7 / PEMSD8): -4.9 us per hot-path step.  With three (PEMSD3 / PEMSD4) the three loads per
-// staged float4 cost the kernel what the k_qonly launch costs (17.1 us against 12.1 + 4.7 at N = 307): not instantiated.
-bool scores_take_x(int C) { return C == 1; }
+// q inside the score kernel: with ONE input channel always (PEMSD7 / PEMSD8 / PEMSD3: -4.9 us per hot-path step); with three
+// (PEMSD4 / PEMSD8) only together with the aggregate + projection tail -- on their own the three loads per staged float4 cost
+// the kernel what the k_qonly launch costs (17.1 us against 12.1 + 4.7 at N = 307), with the tail a launch of 9.3 us goes too.
+bool scores_take_x(int C, bool with_tail) { return C == 1 || (C == 3 && with_tail); }
 
 int launch_scores(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW, float* lse,
                   float* pq, float* E, float* Ec, int G, int Bg, int N, int T, hipStream_t s, const float* x,
-                  const float* alpha, int C, float* qout) {
-  if (x != nullptr && (!scores_take_x(C) || alpha == nullptr || qout == nullptr)) return MSGAT_ERR_UNSUPPORTED;
+                  const float* alpha, int C, float* qout, const float* apW, int apCo, float* apY, float* apZ) {
+  if (x != nullptr && (!scores_take_x(C, apZ != nullptr) || alpha == nullptr || qout == nullptr)) return MSGAT_ERR_UNSUPPORTED;
+  if (apZ != nullptr && (x == nullptr || apW == nullptr || apCo <= 0)) return MSGAT_ERR_UNSUPPORTED;
   switch (T) {
-    case 4: return launch_scores_t<4>(gr, q, Wg, kW, lse, pq, E, Ec, G, Bg, N, s, x, alpha, C, qout);
-    case 8: return launch_scores_t<8>(gr, q, Wg, kW, lse, pq, E, Ec, G, Bg, N, s, x, alpha, C, qout);
-    case 12: return launch_scores_t<12>(gr, q, Wg, kW, lse, pq, E, Ec, G, Bg, N, s, x, alpha, C, qout);
-    case 16: return launch_scores_t<16>(gr, q, Wg, kW, lse, pq, E, Ec, G, Bg, N, s, x, alpha, C, qout);
+    case 4: return launch_scores_t<4>(gr, q, Wg, kW, lse, pq, E, Ec, G, Bg, N, s, x, alpha, C, qout, apW, apCo, apY, apZ);
+    case 8: return launch_scores_t<8>(gr, q, Wg, kW, lse, pq, E, Ec, G, Bg, N, s, x, alpha, C, qout, apW, apCo, apY, apZ);
+    case 12: return launch_scores_t<12>(gr, q, Wg, kW, lse, pq, E, Ec, G, Bg, N, s, x, alpha, C, qout, apW, apCo, apY, apZ);
+    case 16: return launch_scores_t<16>(gr, q, Wg, kW, lse, pq, E, Ec, G, Bg, N, s, x, alpha, C, qout, apW, apCo, apY, apZ);
   }
   return MSGAT_ERR_UNSUPPORTED;
 }
