@@ -34,15 +34,67 @@ def _require_device_tensor(name: str, t: torch.Tensor, device=None):
         raise ValueError(f"{name} is on {t.device}, expected {device}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream_handle(device) -> int:
+    """The current HIP stream of `device` as an integer handle.  (`torch.cuda.current_stream(...).cuda_stream` builds a
+    Stream object per call, ~5 us -- a tenth of the host time of a PEMSD4-sized forward.)"""
+    if _raw_stream is not None:
+        return _raw_stream(device.index if device.index is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class _GacnPlan:
+    """Everything of a GACN call that depends only on its dimensions, its graph and whether backward state is kept:
+    the shape / graph structures handed to the library, the layout of the one buffer that carries what a forward saves
+    (q, kW, lse, pq, E, E in CSC order, u, the SELL scratch) and the backward workspace size.  Built once per
+    (graph, device, dims, need_bwd): the library queries and the offset arithmetic were ~10 us of host time per call."""
+    __slots__ = ("graph", "shape", "gstruct", "keep", "mode", "sizes", "offs", "total", "bwd_bytes", "z_channels")
+
+    def __init__(self, graph, dev, R, Bg, Cin, Co, N, T, need_bwd):
+        L = _lib.lib()
+        G = R * Bg
+        self.graph = graph
+        self.shape = _lib.Shape(R, Bg, Cin, Co, N, T)
+        self.gstruct, self.keep = graph.on(dev)
+        self.mode = L.msgat_gacn_mode(Cin, Co)
+        nnz = max(graph.nnz, 1)
+        if self.mode == _lib.MODE_PROJ_FIRST:
+            n_u = G * Co * N * T
+        elif self.mode == _lib.MODE_AGG_FIRST and need_bwd:
+            n_u = G * Cin * N * T
+        else:
+            n_u = 0
+        nscratch = int(L.msgat_edge_scratch_floats(C.byref(self.shape), C.byref(self.gstruct)))  # E in the SELL layout's order
+        self.sizes = (G * N * T, G * N * T, G * N, G * N * T if need_bwd else 0, G * nnz, G * nnz if need_bwd else 0, n_u, nscratch)
+        offs, total = [], 0
+        for n in self.sizes:                 # 256-byte aligned pieces
+            offs.append(total if n else -1)
+            total += (n + 63) & ~63
+        self.offs, self.total = tuple(offs), max(total, 64)
+        self.bwd_bytes = None                # asked for by the first backward
+        self.z_channels = Co if Co else Cin
+
+
+_PLANS: dict = {}
+
+
+def _gacn_plan(graph, dev, R, Bg, Cin, Co, N, T, need_bwd) -> _GacnPlan:
+    key = (id(graph), dev.index, R, Bg, Cin, Co, N, T, need_bwd)
+    plan = _PLANS.get(key)
+    if plan is None or plan.graph is not graph:      # (an id can be re-used by another graph object)
+        if len(_PLANS) > 256:
+            _PLANS.clear()
+        plan = _PLANS[key] = _GacnPlan(graph, dev, R, Bg, Cin, Co, N, T, need_bwd)
+    return plan
 
 
 class _GACNFunction(torch.autograd.Function):
     """x[G,C,N,T], alpha[R,C], Wg[R,T,T], W[R,Co,C] or None -> z[G,Co|C,N,T];  G = R*Bg."""
 
     @staticmethod
-    def forward(ctx, x, alpha, Wg, W, graph: SparseGraph):
+    def forward(ctx, x, alpha, Wg, W, graph: SparseGraph, recording: bool = True):
         L = _lib.lib()
         dev = x.device
         G, Cin, N, T = x.shape
@@ -50,43 +102,29 @@ class _GACNFunction(torch.autograd.Function):
         if G % R != 0:
             raise ValueError(f"{G} groups cannot be split over {R} relations")
         Co = 0 if W is None else W.shape[1]
-        shape = _lib.Shape(R, G // R, Cin, Co, N, T)
-        mode = L.msgat_gacn_mode(Cin, Co)
-        need_bwd = any(ctx.needs_input_grad)
+        # `needs_input_grad` is True under torch.no_grad() as well (it mirrors requires_grad); whether a graph is being
+        # recorded is known only to the caller (inside forward grad mode is always off).  Inference then skips everything
+        # backward alone needs: pq (4 of the 7 matrix-core instructions per score tile), E in CSC order, the saved y.
+        need_bwd = bool(recording) and any(ctx.needs_input_grad)
+        plan = _gacn_plan(graph, dev, R, G // R, Cin, Co, N, T, need_bwd)
 
         x = x.contiguous()
         alpha, Wg = alpha.contiguous(), Wg.contiguous()
         W = None if W is None else W.contiguous()
-        gstruct, _keep = graph.on(dev)
-        nnz = max(graph.nnz, 1)
 
         # Everything backward needs besides the inputs (q, kW, lse, pq, E, E in CSC order, the projected / aggregated
         # features u) and the SELL scratch lives in ONE allocation, addressed by offset: seven `torch.empty` calls
         # per forward were a quarter of its host time, which is what a PEMSD4-sized step is bound by.
-        z = torch.empty((G, Co if Co else Cin, N, T), device=dev, dtype=torch.float32)
-        if mode == _lib.MODE_PROJ_FIRST:
-            n_u = G * Co * N * T
-        elif mode == _lib.MODE_AGG_FIRST and need_bwd:
-            n_u = G * Cin * N * T
-        else:
-            n_u = 0
-        nscratch = int(L.msgat_edge_scratch_floats(C.byref(shape), C.byref(gstruct)))  # E in the SELL layout's order
-        sizes = (G * N * T, G * N * T, G * N, G * N * T if need_bwd else 0, G * nnz, G * nnz if need_bwd else 0, n_u, nscratch)
-        offs, total = [], 0
-        for n in sizes:                      # 256-byte aligned pieces
-            offs.append(total)
-            total += (n + 63) & ~63
-        buf = torch.empty(max(total, 64), device=dev, dtype=torch.float32)
+        z = torch.empty((G, plan.z_channels, N, T), device=dev, dtype=torch.float32)
+        buf = torch.empty(plan.total, device=dev, dtype=torch.float32)
         base = buf.data_ptr()
-        ptr = [base + 4 * o if n else None for o, n in zip(offs, sizes)]
-        q, kW, lse, pq, E, Ec, u, scratch = ptr
+        q, kW, lse, pq, E, Ec, u, scratch = (None if o < 0 else base + 4 * o for o in plan.offs)
         io = _lib.Fwd(_ptr(x), _ptr(alpha), _ptr(Wg), _ptr(W), _ptr(z), q, kW, lse, pq, E, u, int(need_bwd), scratch, Ec)
-        st = L.msgat_gacn_forward(C.byref(shape), C.byref(gstruct), C.byref(io), _stream_handle(dev))
+        st = L.msgat_gacn_forward(C.byref(plan.shape), C.byref(plan.gstruct), C.byref(io), _stream_handle(dev))
         _lib.check(st, "msgat_gacn_forward")
 
         if need_bwd:
-            ctx.graph, ctx.dims, ctx.has_W = graph, (R, G // R, Cin, Co, N, T), W is not None
-            ctx.offs = tuple(o if n else -1 for o, n in zip(offs, sizes))
+            ctx.plan, ctx.has_W = plan, W is not None
             if W is not None:
                 ctx.save_for_backward(x, alpha, Wg, buf, W)
             else:
@@ -100,11 +138,10 @@ class _GACNFunction(torch.autograd.Function):
         x, alpha, Wg, buf = saved[:4]
         W = saved[4] if ctx.has_W else None
         base = buf.data_ptr()
-        q, kW, lse, pq, E, Ec, u, _scratch = (None if o < 0 else base + 4 * o for o in ctx.offs)
+        plan = ctx.plan
+        q, kW, lse, pq, E, Ec, u, _scratch = (None if o < 0 else base + 4 * o for o in plan.offs)
         dev = x.device
-        R, Bg, Cin, Co, N, T = ctx.dims
-        shape = _lib.Shape(R, Bg, Cin, Co, N, T)
-        gstruct, _keep = ctx.graph.on(dev)
+        shape, gstruct = plan.shape, plan.gstruct
         # a gradient that arrives as a channel slice dout[:, a:b] of a wider tensor is read in place where the library
         # can (one 98 MB copy less per GACN at PEMSD7 size), copied otherwise
         dz, dz_gs = _sliced_grad(dz, lambda: L.msgat_bwd_accepts_strided_dz(C.byref(shape), C.byref(gstruct)))
@@ -113,13 +150,14 @@ class _GACNFunction(torch.autograd.Function):
         dalpha = torch.empty_like(alpha)
         dWg = torch.empty_like(Wg)
         dW = None if W is None else torch.empty_like(W)
-        nbytes = L.msgat_bwd_workspace_bytes(C.byref(shape), C.byref(gstruct))
-        ws = torch.empty(max(int(nbytes), 256), device=dev, dtype=torch.uint8)
+        if plan.bwd_bytes is None:
+            plan.bwd_bytes = max(int(L.msgat_bwd_workspace_bytes(C.byref(shape), C.byref(gstruct))), 256)
+        ws = torch.empty(plan.bwd_bytes, device=dev, dtype=torch.uint8)
         io = _lib.Bwd(_ptr(x), _ptr(alpha), _ptr(Wg), _ptr(W), q, kW, lse, pq, E, u, _ptr(dz), _ptr(dx), _ptr(dalpha),
                       _ptr(dWg), _ptr(dW), _ptr(ws), ws.numel(), dz_gs, Ec)
         st = L.msgat_gacn_backward(C.byref(shape), C.byref(gstruct), C.byref(io), _stream_handle(dev))
         _lib.check(st, "msgat_gacn_backward")
-        return dx, dalpha, dWg, dW, None
+        return dx, dalpha, dWg, dW, None, None
 
 
 def gacn(x: torch.Tensor, alpha: torch.Tensor, Wg: torch.Tensor, W: Optional[torch.Tensor],
@@ -145,7 +183,7 @@ def gacn(x: torch.Tensor, alpha: torch.Tensor, Wg: torch.Tensor, W: Optional[tor
     graph = adjacency if isinstance(adjacency, SparseGraph) else graph_of(adjacency)
     if graph.n_nodes != N:
         raise ValueError(f"adjacency has {graph.n_nodes} nodes, signals have {N}")
-    return _GACNFunction.apply(x, alpha, Wg, W, graph)
+    return _GACNFunction.apply(x, alpha, Wg, W, graph, torch.is_grad_enabled())
 
 
 def graph_attention(x, alpha, Wg, adjacency):
@@ -804,7 +842,7 @@ class _AttentionCoreFunction(torch.autograd.Function):
     msgat_attention_backward)."""
 
     @staticmethod
-    def forward(ctx, u, q, Wg, graph: SparseGraph):
+    def forward(ctx, u, q, Wg, graph: SparseGraph, recording: bool = True):
         L = _lib.lib()
         u, q, Wg = u.contiguous(), q.contiguous(), Wg.contiguous()
         G, Cu, N, T = u.shape
@@ -812,7 +850,7 @@ class _AttentionCoreFunction(torch.autograd.Function):
         dev = u.device
         shape = _lib.Shape(R, G // R, Cu, 0, N, T)
         gstruct, _keep = graph.on(dev)
-        need_bwd = any(ctx.needs_input_grad)
+        need_bwd = bool(recording) and any(ctx.needs_input_grad)   # see _GACNFunction.forward
         kW, lse, E = _new(u, G, N, T), _new(u, G, N), _new(u, G, max(graph.nnz, 1))
         pq = _new(u, G, N, T) if need_bwd else None
         Ec = _new(u, G, max(graph.nnz, 1)) if need_bwd else None     # E in CSC order, for backward's transposed pass
@@ -845,7 +883,7 @@ class _AttentionCoreFunction(torch.autograd.Function):
                                         _ptr(pq), _ptr(E), _ptr(Ec), _ptr(Wg), _ptr(du), _ptr(dq), _ptr(dWg), _ptr(ws),
                                         ws.numel(), _stream_handle(dev))
         _lib.check(st, "msgat_attention_backward")
-        return du, dq, dWg, None
+        return du, dq, dWg, None, None
 
 
 def attention_core(u: torch.Tensor, q: torch.Tensor, Wg: torch.Tensor, adjacency) -> torch.Tensor:
@@ -859,7 +897,7 @@ def attention_core(u: torch.Tensor, q: torch.Tensor, Wg: torch.Tensor, adjacency
     graph = adjacency if isinstance(adjacency, SparseGraph) else graph_of(adjacency)
     if graph.n_nodes != N:
         raise ValueError(f"adjacency has {graph.n_nodes} nodes, signals have {N}")
-    return _AttentionCoreFunction.apply(u, q, Wg, graph)
+    return _AttentionCoreFunction.apply(u, q, Wg, graph, torch.is_grad_enabled())
 
 
 # ---- the tiny attention matrices of a MEAM block, one launch each way ----------------------------------------------
