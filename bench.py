@@ -822,6 +822,8 @@ def main():
             torch.cuda.empty_cache()
         except RuntimeError as e:
             out["full_model_error"] = str(e).splitlines()[0][:160]
+            import traceback
+            traceback.print_exc()       # (stderr: stdout carries the JSON line only)
 
         if args.workload == "pemsd7":
             try:

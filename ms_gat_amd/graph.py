@@ -186,7 +186,15 @@ def graph_of(adjacency: torch.Tensor) -> SparseGraph:
     hit = _CACHE.get(key)
     if hit is not None:
         g, ref, snapshot = hit
-        if ref() is adjacency or torch.equal(snapshot, adjacency.detach()):
+        if ref() is adjacency:
+            _CACHE.move_to_end(key)
+            return g
+        # another tensor object at a cached address: compare contents ONCE (a device read-back, which a HIP-graph capture
+        # cannot contain) and remember the new object, so that its later calls -- the captured one included -- hit by
+        # identity.  (A model built where a freed model's adjacency lived used to compare on every call, and its first
+        # capture failed with "operation not permitted when stream is capturing".)
+        if not (adjacency.is_cuda and torch.cuda.is_current_stream_capturing()) and torch.equal(snapshot, adjacency.detach()):
+            _CACHE[key] = (g, weakref.ref(adjacency), snapshot)
             _CACHE.move_to_end(key)
             return g
     if adjacency.is_cuda and torch.cuda.is_current_stream_capturing():

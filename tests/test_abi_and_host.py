@@ -324,6 +324,25 @@ def test_graph_cache_hits_same_tensor_and_detects_recycled_storage():
     assert graph.graph_of(b.data.view(30, 30)) is not g2
 
 
+def test_graph_cache_compares_a_new_object_at_a_cached_address_once(monkeypatch):
+    """A tensor OBJECT the cache has not seen at an address it has (a new model built where a freed model's adjacency
+    lived) is confirmed by a content comparison ONCE and then hit by identity: the comparison reads the device back, so
+    a per-call comparison cost a host sync per GACN call and made the first HIP-graph capture of such a model fail
+    ("operation not permitted when stream is capturing", found by bench.py's full_step_cfg3 in round 4)."""
+    import ms_gat_amd
+    from ms_gat_amd import graph
+    a = ms_gat_amd.synthetic_adjacency(20, 22, 5)
+    g1 = graph.graph_of(a)
+    v = a.view(20, 20)                                   # another object, same storage address and version
+    calls = []
+    real = torch.equal
+    monkeypatch.setattr(torch, "equal", lambda x, y: calls.append(1) or real(x, y))
+    assert graph.graph_of(v) is g1 and len(calls) == 1
+    assert graph.graph_of(v) is g1 and len(calls) == 1   # by identity now
+    assert graph.graph_of(a) is g1 and len(calls) == 2   # the first object is the stranger now: compared once, remembered
+    assert graph.graph_of(a) is g1 and len(calls) == 2
+
+
 def test_cpu_tensors_are_refused_not_silently_computed():
     import ms_gat_amd
     from ms_gat_amd._lib import MsgatError

@@ -18,10 +18,10 @@ has() { [[ " $PARTS " == *" $1 "* ]]; }
 if has hot; then
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_kt -- python3 $R/bench.py --no-baselines --steps 20 --warmup 5 > $O/bench_hot_under_rocprof.json 2>/dev/null
   KT=$(ls $O/bench_kt/*/*kernel_trace.csv | head -1)
-  # (anchor: a kernel launched once per step -- k_agg_proj, the first depth's aggregate; k_qonly is gone from this
-  # workload since round 4, its work happens inside the score kernel)
-  python3 $R/tools/trace_summary.py $KT k_agg_proj 1 15 40 > $O/hot_path_per_step.txt
-  python3 $R/tools/trace_one_step.py $O/bench_kt --anchor k_agg_proj > $O/hot_path_launches.txt 2>&1
+  # (anchor: a kernel launched once per step -- k_project_mfma, the second depth's projection; k_qonly and k_agg_proj are
+  # gone from this workload since round 4: the first depth's forward is one launch)
+  python3 $R/tools/trace_summary.py $KT k_project_mfma 1 15 40 > $O/hot_path_per_step.txt
+  python3 $R/tools/trace_one_step.py $O/bench_kt --anchor k_project_mfma > $O/hot_path_launches.txt 2>&1
   python3 $R/tools/roofline_trace_table.py $KT > $O/aggregate_by_phase.txt
   cp $(ls $O/bench_kt/*/*kernel_stats.csv | head -1) $O/hot_path_kernel_stats.csv 2>/dev/null
   rm -rf $O/bench_kt
@@ -29,8 +29,8 @@ fi
 if has pemsd4; then
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p4_kt -- python3 $R/bench.py --workload pemsd4 --no-baselines --steps 50 --warmup 10 > $O/pemsd4_bench_under_rocprof.json 2>/dev/null
   KT=$(ls $O/p4_kt/*/*kernel_trace.csv | head -1)
-  python3 $R/tools/trace_summary.py $KT k_qonly 1 30 40 > $O/pemsd4_per_step.txt
-  python3 $R/tools/trace_one_step.py $O/p4_kt --anchor k_qonly > $O/pemsd4_launches.txt 2>&1
+  python3 $R/tools/trace_summary.py $KT k_project_mfma 1 30 40 > $O/pemsd4_per_step.txt
+  python3 $R/tools/trace_one_step.py $O/p4_kt --anchor k_project_mfma > $O/pemsd4_launches.txt 2>&1
   cp $(ls $O/p4_kt/*/*kernel_stats.csv | head -1) $O/pemsd4_kernel_stats.csv 2>/dev/null
   rm -rf $O/p4_kt
 fi
