@@ -161,6 +161,8 @@ def test_modules_are_drop_in_for_the_reference_golden():
     (2, 2, 1, 24, 300, 4, 350),    # one input channel: q = alpha x is computed inside the score kernel (QRows<T,1>), T = 4
     (1, 2, 1, 0, 883, 8, 866),     # ... PLAIN, T = 8, and a size that takes the helper-wave form k_scores7<8,*,1>
     (1, 2, 1, 24, 257, 16, 300),   # ... T = 16
+    (1, 2, 3, 24, 150, 12, 4000),  # AGG_FIRST tail with more than 1024 edges per row block: the uncached (global) operand path
+    (2, 1, 1, 8, 150, 12, 4000),   # ... one channel
     (1, 1, 2, 0, 1, 12, 0),        # a single node: only the self loop
     (1, 1, 200, 180, 20, 12, 25),  # matrix too large for the MFMA kernel's LDS: VALU projection, blocked dW
     (1, 2, 33, 40, 21, 12, 25),    # AGG_FIRST with > 32 channels on both sides
