@@ -57,15 +57,19 @@ def _compile(hipcc: str, src: str, obj: str, extra) -> None:
         sys.stderr.write(r.stderr)
 
 
-def build(force: bool = False, verbose: bool = True, extra_flags=(), lab: bool = False, out: str = LIB) -> str:
+def build(force: bool = False, verbose: bool = True, extra_flags=(), lab: bool = False, out: str = LIB,
+          objdir: str = OBJDIR) -> str:
     """Compile every HIP source for gfx950 and link libmsgat_hip.so; returns its path.
-    lab=True: a diagnostic build (give it another `out`) that also carries the tools/*_lab.hip units."""
+    lab=True: a diagnostic build (give it another `out` and `objdir`) that also carries the tools/*_lab.hip units
+    and is compiled with -DMSGAT_LAB (environment switches for A/B runs of kernel forms)."""
     hipcc = _hipcc()
-    os.makedirs(OBJDIR, exist_ok=True)
+    os.makedirs(objdir, exist_ok=True)
+    if lab:
+        extra_flags = [*extra_flags, "-DMSGAT_LAB"]
     jobs, objs = [], []
     for name in SOURCES + (LAB_SOURCES if lab else []):
         src = name if os.path.isabs(name) else os.path.join(CSRC, name)
-        obj = os.path.join(OBJDIR, os.path.basename(name).rsplit(".", 1)[0] + ".o")
+        obj = os.path.join(objdir, os.path.basename(name).rsplit(".", 1)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src, *HEADERS, os.path.abspath(__file__)]):
             jobs.append((src, obj))
@@ -89,6 +93,7 @@ def build(force: bool = False, verbose: bool = True, extra_flags=(), lab: bool =
 if __name__ == "__main__":
     if "--lab" in sys.argv:   # python -m ms_gat_amd.build --lab  ->  build/lab/libmsgat_lab.so
         os.makedirs(os.path.join(ROOT, "build", "lab"), exist_ok=True)
-        build(force="--force" in sys.argv, lab=True, out=os.path.join(ROOT, "build", "lab", "libmsgat_lab.so"))
+        build(force="--force" in sys.argv, lab=True, out=os.path.join(ROOT, "build", "lab", "libmsgat_lab.so"),
+              objdir=os.path.join(ROOT, "build", "lab", "obj"))
     else:
         build(force="--force" in sys.argv)

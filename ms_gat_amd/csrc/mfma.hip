@@ -18,6 +18,9 @@
 //     loads, so 256-position tiles of all rows are staged through LDS in 1-KiB row pieces by a
 //     persistent split-K kernel (see k_chanpair_mfma).
 #include "common.hpp"
+#ifdef MSGAT_LAB
+#include <cstdlib>
+#endif
 
 namespace msgat {
 
@@ -928,13 +931,23 @@ static size_t chanpair_glds_lds(int Ca, int Cb) {
   return sizeof(float4) * (size_t)NBUF * (cdiv(rows, 256 / TILE) + 2) * kGGroupF4;
 }
 
+#ifdef MSGAT_LAB
+static int lab_env(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+#endif
+
 template <int MA, int NB, int TILE, int NBUF, int MODE = 0>
 static int launch_chanpair_glds_t(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P,
                                   int nblk_max, int b_ones, hipStream_t s, int* nblk_used, ChanMix mix = ChanMix()) {
   const int Ca = A.total();
   const int nza = cdiv(Ca, MA * 16), nzb = cdiv(Cb, NB * 16);
   const int nz = nza * nzb;
-  const int nblk = nz > 1 ? max(1, nblk_max / nz) : nblk_max;
+  int nblk = nz > 1 ? max(1, nblk_max / nz) : nblk_max;
+#ifdef MSGAT_LAB
+  nblk = min(nblk_max, max(1, lab_env("MSGAT_LAB_BPC", 1) * nblk_max / nz));   // resident blocks per CU
+#endif
   *nblk_used = nblk;
   const size_t lds = chanpair_glds_lds<MA, NB, TILE, NBUF>(Ca, Cb);
   if (lds > (size_t)kLdsMax || lds < (size_t)(MA * NB < 8 ? MA * NB : 8) * kCpWaves * 1024) return MSGAT_ERR_UNSUPPORTED;
@@ -964,7 +977,15 @@ static int launch_chanpair_glds_t(const SegList& A, const float* B, float* part,
 //                                                    (a [96 x 112] accumulator block spills; A is read twice, B once)
 #define MSGAT_GLDS_FORMS(X) \
   X(2, 3, 128, 1) X(2, 4, 128, 1) X(2, 5, 128, 1) X(3, 4, 128, 1) X(3, 6, 64, 2) X(5, 4, 64, 2) X(5, 5, 64, 2) \
-  X(7, 5, 64, 2) X(6, 4, 64, 2) X(9, 4, 64, 2)
+  X(7, 5, 64, 2) X(6, 4, 64, 2) X(9, 4, 64, 2) MSGAT_GLDS_LAB_FORMS(X)
+// lab builds (-DMSGAT_LAB): narrow blocks over B -- several z-blocks per run that each stage all of A (re-read from the
+// XCD's L2) and write FEW mix channels over the run's whole position range
+#ifdef MSGAT_LAB
+#define MSGAT_GLDS_LAB_FORMS(X) \
+  X(2, 1, 128, 1) X(2, 2, 128, 1) X(7, 1, 64, 2) X(7, 2, 64, 2) X(7, 3, 64, 2) X(5, 1, 64, 2) X(5, 2, 64, 2) X(5, 3, 64, 2)
+#else
+#define MSGAT_GLDS_LAB_FORMS(X)
+#endif
 
 // Launches the form [MA x NB] if the list has it (and its buffers fit LDS); *handled = 0 and nothing launched otherwise.
 static int launch_glds_form(int MA, int NB, bool with_mix, const SegList& A, const float* B, float* part, int R, int Bg,
@@ -1010,7 +1031,11 @@ static int launch_glds_mix(const SegList& A, const float* B, float* part, int R,
   ChanMix mix;
   mix.Mw = Mw; mix.Mlast = Mlast; mix.out = mixout;
   mix.dump = part + (((size_t)R * nblk * Ca * Cb + 3) & ~(size_t)3);   // chanpair_partial_floats() leaves 260 floats behind the partials
-  for (int nzb = 1; nzb <= 2; ++nzb) {           // z-blocks over B: each stages all of A
+  int nzb_lo = 1, nzb_hi = 2;
+#ifdef MSGAT_LAB
+  if (lab_env("MSGAT_LAB_NZB", 0) > 0) nzb_lo = nzb_hi = lab_env("MSGAT_LAB_NZB", 0);
+#endif
+  for (int nzb = nzb_lo; nzb <= nzb_hi; ++nzb) {           // z-blocks over B: each stages all of A
     const int NB = cdiv(cdiv(Cb, nzb), 16);
     if (cdiv(Cb, NB * 16) != nzb) continue;      // the kernel derives nzb from the block width
     for (int MA = cdiv(Ca, 16); MA <= cdiv(Ca, 16) + 1; ++MA) {

@@ -13,6 +13,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    # A/B runs of a diagnostic build (python -m ms_gat_amd.build --lab): MSGAT_TEST_LIB=build/lab/libmsgat_lab.so
+    if os.environ.get("MSGAT_TEST_LIB"):
+        from ms_gat_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(os.environ["MSGAT_TEST_LIB"])
 
 
 def load_golden(name):
