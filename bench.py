@@ -327,7 +327,7 @@ class TrainStep:
     backward, (with several ranks) ONE flat all-reduce of all gradients, Adam.  `dense=True` swaps every block for
     the reference's eager op sequence (the PyTorch-ROCm baseline of the same step)."""
 
-    def __init__(self, cfg, dev, seed=0, dense=False, hip_graph=False):
+    def __init__(self, cfg, dev, seed=0, dense=False, hip_graph=False, stacked=True):
         import tempfile
         import ms_gat_amd
         from ms_gat_amd import engine, model
@@ -336,6 +336,8 @@ class TrainStep:
         adj = ms_gat_amd.synthetic_adjacency(cfg["N"], cfg["E"], seed=0)
         net = model.msgat72(n_components=cfg["R"], in_channels=cfg["Cin"], in_timesteps=cfg["T"],
                             out_timesteps=cfg["T"], use_te=True, adj=adj).to(dev)
+        if not stacked:
+            net.stack_components = False   # the reference's loop over components (msgat.py:204), this package's blocks
         if dense:
             net.stack_components = False   # the reference's loop over components (msgat.py:204)
             for tpc in net.tpcs:
@@ -517,6 +519,91 @@ def respawn_under_torchrun(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
     return subprocess.call(cmd, env=env)
+
+
+class DropInLoop:
+    """The hot path as INTEGRATION.md's Option A issues it: the reference's un-stacked loop over components
+    (msgat.py:204) with `ms_gat_amd.GACN` swapped in for its `GACN` (msgat.py:127) -- R separate module calls per depth,
+    B groups each, the same parameters / inputs / upstream gradients as `HotPath` (relation r of the stacked tensors)."""
+
+    def __init__(self, hp):
+        import ms_gat_amd
+        wl = hp.wl
+        self.wl, self.graph, self.adj = wl, hp.graph, hp.adj.to(hp.device)
+        self.mods, self.xs, self.dzs = [], [], []
+        for depth, (stacked_layer, x, dz) in enumerate(zip(hp.layers, hp.xs, hp.dzs)):
+            cin = x.shape[2]
+            for r in range(wl["R"]):
+                m = ms_gat_amd.GACN(cin, wl["Co"], wl["T"]).to(hp.device)
+                with torch.no_grad():
+                    m.gatt.Wg.copy_(stacked_layer.Wg[r]); m.gatt.alpha.copy_(stacked_layer.alpha[r]); m.W.copy_(stacked_layer.W[r])
+                self.mods.append(m)
+                self.xs.append(x[r].detach().clone().requires_grad_(True))
+                self.dzs.append(dz[r].contiguous())
+        self.calls_per_step = 2 * len(self.mods)    # one library call forward, one backward per module
+
+    def step(self, adjacency=None):
+        adjacency = self.adj if adjacency is None else adjacency     # the dense [N,N] tensor, as the reference passes it
+        for m, x in zip(self.mods, self.xs):
+            x.grad = None
+            for p in m.parameters():
+                p.grad = None
+        zs = [m(x, adjacency) for m, x in zip(self.mods, self.xs)]
+        torch.autograd.backward(zs, self.dzs)
+        return zs
+
+
+def host_enqueue_us(fn, dev, steps=100):
+    """Host time to ENQUEUE one call of `fn` (the GPU may lag behind), and the wall time per call."""
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    host = time.perf_counter() - t0
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    return host / steps * 1e6, wall / steps * 1e6
+
+
+def dropin_object(hp, dev, steps=50):
+    """What a maintainer gets who follows INTEGRATION.md section 3, Option A, and nothing else: (a) the hot path as R
+    separate GACN module calls per depth, launched eagerly; (b) the msgat72 training step with the components evaluated
+    one by one (`stack_components = False`), eager and replayed as a HIP graph -- next to the stacked schedule's figures."""
+    wl = hp.wl
+    sync = lambda: torch.cuda.synchronize(dev)  # noqa: E731
+    loop = DropInLoop(hp)
+    settle(loop.step, dev, 20.0)
+    wall, per = timed_steps(loop.step, steps, 10, dev, sync)
+    busy, launches = gpu_busy_us(loop.step, dev)
+    host, _ = host_enqueue_us(loop.step, dev)
+    host_stacked, _ = host_enqueue_us(hp.step, dev)
+    busy_stacked, launches_stacked = gpu_busy_us(hp.step, dev)
+    obj = {
+        "workload": (f"hot path as R={wl['R']} separate ms_gat_amd.GACN module calls per depth (reference loop msgat.py:204, "
+                     f"module swap msgat.py:127), B={wl['B']} groups per call, dense [N,N] adjacency argument, eager launches"),
+        "ms_per_step": round(wall / steps * 1e3, 4), "ms_per_step_median_hip_events": round(statistics.median(per), 4),
+        "gpu_busy_ms_per_step": round(busy * 1e-3, 4), "launches_per_step": round(launches, 1),
+        "library_calls_per_step": loop.calls_per_step,
+        "host_enqueue_us_per_step": round(host, 1), "host_enqueue_us_per_library_call": round(host / loop.calls_per_step, 1),
+        "stacked": {"gpu_busy_ms_per_step": round(busy_stacked * 1e-3, 4), "launches_per_step": round(launches_stacked, 1),
+                    "host_enqueue_us_per_step": round(host_stacked, 1), "library_calls_per_step": 4,
+                    "host_enqueue_us_per_library_call": round(host_stacked / 4, 1)},
+    }
+    del loop
+    cfg3 = dict(CFG4, R=wl["R"])
+    for key, kw in (("train_step_unstacked_eager_ms", dict(stacked=False)),
+                    ("train_step_unstacked_hip_graph_ms", dict(stacked=False, hip_graph=True)),
+                    ("train_step_stacked_eager_ms", dict())):
+        ts = TrainStep(cfg3, dev, **kw)
+        w, per = time_train_step(ts, 20, 5, sync)
+        obj[key] = round(statistics.median(per), 3)
+        obj[key.replace("_ms", "_wall_ms")] = round(w / 20 * 1e3, 3)
+        del ts
+        torch.cuda.empty_cache()
+    obj["train_step_unstacked_over_stacked"] = round(obj["train_step_unstacked_eager_wall_ms"] / obj["train_step_stacked_eager_wall_ms"], 3)
+    return obj
 
 
 def capture(fn, dev, warm=3):
@@ -836,6 +923,10 @@ def main():
                 except RuntimeError as e:
                     out[f"widths{hidden}"] = {"error": str(e).splitlines()[0][:160]}
             out["widths72_kernels"] = hbm_kernel_table(hp, dev)
+            try:
+                out["dropin_loop"] = dropin_object(hp, dev)
+            except RuntimeError as e:
+                out["dropin_loop"] = {"error": str(e).splitlines()[0][:160]}
             try:
                 out["stress"] = stress_object(dev)
             except RuntimeError as e:

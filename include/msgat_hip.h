@@ -10,9 +10,15 @@
  * Conventions
  *   - plain C, PODs only: raw device pointers, ints, a hipStream_t passed as void*.
  *   - every device entry point only ENQUEUES kernels on `stream` and returns; it never
- *     allocates, frees, synchronises or touches global mutable state (re-entrant; safe
- *     under hipGraph capture).  All buffers, including the tensors saved for backward
- *     and the workspace, are owned by the caller.
+ *     allocates, frees or synchronises (re-entrant; safe under hipGraph capture).  All
+ *     buffers, including the tensors saved for backward and the workspace, are owned by
+ *     the caller.  The only process-wide state is a set of per-device, write-once caches
+ *     inside the launchers (csrc/common.hpp: the device's compute-unit count, and per
+ *     kernel the dynamic-LDS ceiling already granted by hipFuncSetAttribute): lock-free,
+ *     idempotent -- a lost race repeats a driver call -- and indexed by the CURRENT HIP
+ *     device, which the caller makes the device of `stream` before the call.  Device
+ *     ordinals >= 32 (or a failed hipGetDevice) are never aliased to another device's
+ *     entry: for them the driver calls are simply repeated on every launch.
  *   - return value: 0 (MSGAT_OK) or a negative MSGAT_ERR_* code; hipError_t e from a
  *     launch is reported as MSGAT_ERR_HIP_BASE - e.  No exceptions cross the ABI.
  *   - all floating point is IEEE fp32; tensors are dense, contiguous, row-major.

@@ -28,7 +28,7 @@ class GraphAttention(nn.Module):
         self.alpha = nn.Parameter(torch.empty(n_channels))
 
     def forward(self, signals: torch.Tensor, adjacency: torch.Tensor) -> torch.Tensor:
-        return ops.gacn(signals, self.alpha.unsqueeze(0), self.Wg.unsqueeze(0), None, adjacency)
+        return ops.gacn(signals, self.alpha, self.Wg, None, adjacency)
 
     def extra_repr(self) -> str:
         return f"n_channels={self.n_channels}, n_timesteps={self.n_timesteps}"
@@ -49,8 +49,7 @@ class GACN(nn.Module):
         self.W = nn.Parameter(torch.empty(out_channels, in_channels))
 
     def forward(self, signals: torch.Tensor, adjacency: torch.Tensor) -> torch.Tensor:
-        return ops.gacn(signals, self.gatt.alpha.unsqueeze(0), self.gatt.Wg.unsqueeze(0), self.W.unsqueeze(0),
-                        adjacency)
+        return ops.gacn(signals, self.gatt.alpha, self.gatt.Wg, self.W, adjacency)
 
     def extra_repr(self) -> str:
         return (f"in_channels={self.in_channels}, out_channels={self.out_channels}, "

@@ -50,19 +50,24 @@ __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_lo
 // `hipFuncSetAttribute` per launch are part of what makes a PEMSD4-sized step host-bound).  Both caches are per
 // device and lock-free; a lost race only repeats an idempotent driver call.
 constexpr int kMaxDevices = 32;
-inline int current_device() {
+// the current device's slot of the per-device caches, or -1 when it has none (query failed, or an ordinal >= 32):
+// such a device is never aliased to another one's slot -- its launches repeat the driver calls every time
+inline int current_device_slot() {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return -1;
   return dev;
 }
 // compute units of the current device (256 on MI355X, also the fallback when the query fails)
 inline int device_cu_count() {
   static std::atomic<int> cached[kMaxDevices];
-  const int dev = current_device();
-  int ncu = cached[dev].load(std::memory_order_relaxed);
+  const int slot = current_device_slot();
+  int ncu = slot >= 0 ? cached[slot].load(std::memory_order_relaxed) : 0;
   if (ncu <= 0) {
-    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-    cached[dev].store(ncu, std::memory_order_relaxed);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+      ncu = 256;
+    if (slot >= 0) cached[slot].store(ncu, std::memory_order_relaxed);
   }
   return ncu;
 }
@@ -75,11 +80,11 @@ struct LdsGrant {
 template <typename K>
 inline int grant_dynamic_lds(K kernel, size_t lds, LdsGrant& granted) {
   if (lds <= 64 * 1024) return MSGAT_OK;
-  std::atomic<int>& g = granted.bytes[current_device()];
-  if ((int)lds <= g.load(std::memory_order_acquire)) return MSGAT_OK;
+  const int slot = current_device_slot();
+  if (slot >= 0 && (int)lds <= granted.bytes[slot].load(std::memory_order_acquire)) return MSGAT_OK;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return MSGAT_ERR_HIP_BASE - (int)e;
-  g.store((int)lds, std::memory_order_release);
+  if (slot >= 0) granted.bytes[slot].store((int)lds, std::memory_order_release);
   return MSGAT_OK;
 }
 

@@ -73,6 +73,14 @@ class SparseGraph:
     SELL kernels (tests exercise them on small graphs this way); "never" omits them."""
 
     def __init__(self, adjacency: torch.Tensor, sell: str = "auto"):
+        if adjacency.dim() > 2:
+            # the reference documents `adjacency: [..., n_nodes, n_nodes]` (attention.py:22: `att * adjacency`
+            # broadcasts, attention.py:36); its only caller passes ONE [N,N] matrix (msgat.py:127, :190), and so does
+            # everything here: the CSR / CSC / SELL structures are built per graph, not per sample
+            raise ValueError(
+                f"adjacency must be one [n_nodes, n_nodes] matrix, got {tuple(adjacency.shape)}: the batched form "
+                "`[..., n_nodes, n_nodes]` that the reference's attention.py:22 documents is not supported -- call the "
+                "op once per adjacency (one SparseGraph each)")
         if adjacency.dim() != 2 or adjacency.size(0) != adjacency.size(1):
             raise ValueError(f"adjacency must be [N,N], got {tuple(adjacency.shape)}")
         a = adjacency.detach().to(device="cpu", dtype=torch.float32).contiguous()

@@ -50,12 +50,11 @@ class _GacnPlan:
     the shape / graph structures handed to the library, the layout of the one buffer that carries what a forward saves
     (q, kW, lse, pq, E, E in CSC order, u, the SELL scratch) and the backward workspace size.  Built once per
     (graph, device, dims, need_bwd): the library queries and the offset arithmetic were ~10 us of host time per call."""
-    __slots__ = ("graph", "shape", "gstruct", "keep", "mode", "sizes", "offs", "total", "bwd_bytes", "z_channels")
+    __slots__ = ("shape", "gstruct", "keep", "mode", "sizes", "offs", "total", "bwd_bytes", "z_channels", "nscratch")
 
     def __init__(self, graph, dev, R, Bg, Cin, Co, N, T, need_bwd):
         L = _lib.lib()
         G = R * Bg
-        self.graph = graph
         self.shape = _lib.Shape(R, Bg, Cin, Co, N, T)
         self.gstruct, self.keep = graph.on(dev)
         self.mode = L.msgat_gacn_mode(Cin, Co)
@@ -67,7 +66,10 @@ class _GacnPlan:
         else:
             n_u = 0
         nscratch = int(L.msgat_edge_scratch_floats(C.byref(self.shape), C.byref(self.gstruct)))  # E in the SELL layout's order
-        self.sizes = (G * N * T, G * N * T, G * N, G * N * T if need_bwd else 0, G * nnz, G * nnz if need_bwd else 0, n_u, nscratch)
+        # (the SELL scratch is the forward's own workspace: allocated per call and dropped at its end, not carved from the
+        # saved buffer -- it is at least the size of E and would stay resident until backward for every GACN layer)
+        self.nscratch = nscratch
+        self.sizes = (G * N * T, G * N * T, G * N, G * N * T if need_bwd else 0, G * nnz, G * nnz if need_bwd else 0, n_u)
         offs, total = [], 0
         for n in self.sizes:                 # 256-byte aligned pieces
             offs.append(total if n else -1)
@@ -77,16 +79,18 @@ class _GacnPlan:
         self.z_channels = Co if Co else Cin
 
 
-_PLANS: dict = {}
-
-
 def _gacn_plan(graph, dev, R, Bg, Cin, Co, N, T, need_bwd) -> _GacnPlan:
-    key = (id(graph), dev.index, R, Bg, Cin, Co, N, T, need_bwd)
-    plan = _PLANS.get(key)
-    if plan is None or plan.graph is not graph:      # (an id can be re-used by another graph object)
-        if len(_PLANS) > 256:
-            _PLANS.clear()
-        plan = _PLANS[key] = _GacnPlan(graph, dev, R, Bg, Cin, Co, N, T, need_bwd)
+    # the plans live ON the graph object and die with it (a module-level table keyed by id(graph) kept every graph a
+    # process had ever used, and its device tensors, alive)
+    plans = graph.__dict__.get("_gacn_plans")
+    if plans is None:
+        plans = graph.__dict__["_gacn_plans"] = {}
+    key = (dev.index, R, Bg, Cin, Co, N, T, need_bwd)
+    plan = plans.get(key)
+    if plan is None:
+        if len(plans) > 256:
+            plans.clear()
+        plan = plans[key] = _GacnPlan(graph, dev, R, Bg, Cin, Co, N, T, need_bwd)
     return plan
 
 
@@ -98,17 +102,18 @@ class _GACNFunction(torch.autograd.Function):
         L = _lib.lib()
         dev = x.device
         G, Cin, N, T = x.shape
-        R = alpha.shape[0]
+        R = alpha.shape[0] if alpha.dim() == 2 else 1     # alpha [C], Wg [T,T], W [Co,C]: ONE relation, no leading axis
         if G % R != 0:
             raise ValueError(f"{G} groups cannot be split over {R} relations")
-        Co = 0 if W is None else W.shape[1]
+        Co = 0 if W is None else W.shape[-2]
         # `needs_input_grad` is True under torch.no_grad() as well (it mirrors requires_grad); whether a graph is being
         # recorded is known only to the caller (inside forward grad mode is always off).  Inference then skips everything
         # backward alone needs: pq (4 of the 7 matrix-core instructions per score tile), E in CSC order, the saved y.
         need_bwd = bool(recording) and any(ctx.needs_input_grad)
         plan = _gacn_plan(graph, dev, R, G // R, Cin, Co, N, T, need_bwd)
 
-        x = x.contiguous()
+        if not x.is_contiguous():
+            x = x.contiguous()
         alpha, Wg = alpha.contiguous(), Wg.contiguous()
         W = None if W is None else W.contiguous()
 
@@ -118,7 +123,9 @@ class _GACNFunction(torch.autograd.Function):
         z = torch.empty((G, plan.z_channels, N, T), device=dev, dtype=torch.float32)
         buf = torch.empty(plan.total, device=dev, dtype=torch.float32)
         base = buf.data_ptr()
-        q, kW, lse, pq, E, Ec, u, scratch = (None if o < 0 else base + 4 * o for o in plan.offs)
+        q, kW, lse, pq, E, Ec, u = (None if o < 0 else base + 4 * o for o in plan.offs)
+        scratch_t = torch.empty(plan.nscratch, device=dev, dtype=torch.float32) if plan.nscratch else None
+        scratch = _ptr(scratch_t)
         io = _lib.Fwd(_ptr(x), _ptr(alpha), _ptr(Wg), _ptr(W), _ptr(z), q, kW, lse, pq, E, u, int(need_bwd), scratch, Ec)
         st = L.msgat_gacn_forward(C.byref(plan.shape), C.byref(plan.gstruct), C.byref(io), _stream_handle(dev))
         _lib.check(st, "msgat_gacn_forward")
@@ -139,7 +146,7 @@ class _GACNFunction(torch.autograd.Function):
         W = saved[4] if ctx.has_W else None
         base = buf.data_ptr()
         plan = ctx.plan
-        q, kW, lse, pq, E, Ec, u, _scratch = (None if o < 0 else base + 4 * o for o in plan.offs)
+        q, kW, lse, pq, E, Ec, u = (None if o < 0 else base + 4 * o for o in plan.offs)
         dev = x.device
         shape, gstruct = plan.shape, plan.gstruct
         # a gradient that arrives as a channel slice dout[:, a:b] of a wider tensor is read in place where the library
@@ -166,6 +173,9 @@ def gacn(x: torch.Tensor, alpha: torch.Tensor, Wg: torch.Tensor, W: Optional[tor
 
     x [R*Bg, C, N, T] (relation-major), alpha [R,C], Wg [R,T,T], W [R,Co,C] or None,
     adjacency: dense [N,N] tensor or a prebuilt `SparseGraph`.  Returns [R*Bg, Co|C, N, T].
+    One relation may come without the leading axis -- alpha [C], Wg [T,T], W [Co,C], the reference's own parameter
+    shapes (attention.py:29-30, msgat.py:23): the module classes call it that way, so that no view nodes sit between
+    the parameters and the op (three `unsqueeze` forward and three more nodes backward were a sixth of a call's host time).
     """
     if x.dim() != 4:
         raise ValueError(f"signals must be [batch, channels, nodes, timesteps], got {tuple(x.shape)}")
@@ -173,13 +183,21 @@ def gacn(x: torch.Tensor, alpha: torch.Tensor, Wg: torch.Tensor, W: Optional[tor
     for name, t in (("alpha", alpha), ("Wg", Wg)) + ((("W", W),) if W is not None else ()):
         _require_device_tensor(name, t, x.device)
     G, Cin, N, T = x.shape
-    if alpha.dim() != 2 or alpha.shape[1] != Cin:
-        raise ValueError(f"alpha must be [R,{Cin}], got {tuple(alpha.shape)}")
-    R = alpha.shape[0]
-    if tuple(Wg.shape) != (R, T, T):
-        raise ValueError(f"Wg must be [{R},{T},{T}], got {tuple(Wg.shape)}")
-    if W is not None and (W.dim() != 3 or W.shape[0] != R or W.shape[2] != Cin):
-        raise ValueError(f"W must be [{R},Co,{Cin}], got {tuple(W.shape)}")
+    if alpha.dim() == 1:                                  # one relation, the reference's parameter shapes
+        if alpha.shape[0] != Cin:
+            raise ValueError(f"alpha must be [{Cin}], got {tuple(alpha.shape)}")
+        if tuple(Wg.shape) != (T, T):
+            raise ValueError(f"Wg must be [{T},{T}], got {tuple(Wg.shape)}")
+        if W is not None and (W.dim() != 2 or W.shape[1] != Cin):
+            raise ValueError(f"W must be [Co,{Cin}], got {tuple(W.shape)}")
+    else:
+        if alpha.dim() != 2 or alpha.shape[1] != Cin:
+            raise ValueError(f"alpha must be [R,{Cin}], got {tuple(alpha.shape)}")
+        R = alpha.shape[0]
+        if tuple(Wg.shape) != (R, T, T):
+            raise ValueError(f"Wg must be [{R},{T},{T}], got {tuple(Wg.shape)}")
+        if W is not None and (W.dim() != 3 or W.shape[0] != R or W.shape[2] != Cin):
+            raise ValueError(f"W must be [{R},Co,{Cin}], got {tuple(W.shape)}")
     graph = adjacency if isinstance(adjacency, SparseGraph) else graph_of(adjacency)
     if graph.n_nodes != N:
         raise ValueError(f"adjacency has {graph.n_nodes} nodes, signals have {N}")
@@ -1126,9 +1144,27 @@ def _guard(fn, is_forward: bool):
         with torch.cuda.device(dev):
             return fn(ctx, *args)
 
+    # Outside an autocast region -- every call of this package's own engine, and the autograd thread unless the caller
+    # ran backward inside one -- torch.amp.custom_fwd is a no-op and custom_bwd an `autocast(enabled=False)` context
+    # around a region that has autocast off already: ~5 us of host time per backward call for nothing (a sixth of a
+    # GACN module call's host time, tools/host_overhead.py --dropin).  Both keep their exact semantics inside a region.
     if is_forward:
-        return torch.amp.custom_fwd(wrapped, device_type="cuda", cast_inputs=torch.float32)
-    return torch.amp.custom_bwd(wrapped, device_type="cuda")
+        in_region = torch.amp.custom_fwd(wrapped, device_type="cuda", cast_inputs=torch.float32)
+
+        @functools.wraps(fn)
+        def forward(ctx, *args):
+            if torch.is_autocast_enabled("cuda"):
+                return in_region(ctx, *args)
+            return wrapped(ctx, *args)
+        return forward
+
+    @functools.wraps(fn)
+    def backward(ctx, *args):
+        if torch.is_autocast_enabled("cuda"):
+            with torch.autocast(device_type="cuda", enabled=False):
+                return wrapped(ctx, *args)
+        return wrapped(ctx, *args)
+    return backward
 
 
 for _name, _cls in list(globals().items()):

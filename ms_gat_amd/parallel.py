@@ -118,6 +118,13 @@ class _GatherTable:
     def point_at(self, bases: tuple) -> None:
         if bases == self.current:
             return
+        if torch.cuda.is_current_stream_capturing():
+            # a captured upload would read a pinned ring buffer that later eager re-pointings overwrite, and after a
+            # replay `current` would no longer describe the device table: the gather would read stale addresses
+            raise RuntimeError(
+                "gather_scaled: the gradient addresses changed inside a HIP-graph capture; the pointer table cannot be "
+                "re-pointed there.  Keep the gather (and the collective behind it) outside the captured region, as "
+                "engine.Trainer does with several ranks, or run one eager step with these gradients first.")
         k = self.turn
         self.turn = (k + 1) % len(self.host)
         if self.copied[k] is not None:

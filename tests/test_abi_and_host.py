@@ -309,6 +309,35 @@ def test_sym_norm_adjacency_matches_reference_and_oracle():
     assert np.allclose(ms_gat_amd.sym_norm_adjacency(50, e).numpy(), gat_oracle.sym_norm_adjacency(50, e), atol=1e-7)
 
 
+def test_batched_adjacency_is_refused_with_a_pointer_to_the_reference():
+    """attention.py:22 documents `adjacency: [..., n_nodes, n_nodes]`; the sole caller passes [N,N] (msgat.py:127) and so
+    does everything here -- a batched adjacency must not be mistaken for a malformed one."""
+    import ms_gat_amd
+    from ms_gat_amd import graph
+    with pytest.raises(ValueError, match=r"attention\.py:22"):
+        ms_gat_amd.SparseGraph(torch.zeros(2, 5, 5))
+    with pytest.raises(ValueError, match=r"attention\.py:22"):
+        graph.graph_of(torch.eye(4).expand(3, 4, 4))
+    with pytest.raises(ValueError, match=r"\[N,N\]"):
+        ms_gat_amd.SparseGraph(torch.zeros(5, 4))
+
+
+def test_gacn_plans_live_on_their_graph_and_die_with_it():
+    """The per-shape plans of ops.gacn are stored on the SparseGraph (round-4 advisor finding: a module-level table keyed
+    by id(graph) kept every graph a process had used alive)."""
+    import gc
+    import weakref
+    import ms_gat_amd
+    from ms_gat_amd import ops
+    assert not hasattr(ops, "_PLANS")
+    g = ms_gat_amd.SparseGraph(ms_gat_amd.synthetic_adjacency(20, 20, 0))
+    g.__dict__["_gacn_plans"] = {"probe": object()}      # what _gacn_plan() creates on first use
+    ref = weakref.ref(g)
+    del g
+    gc.collect()
+    assert ref() is None
+
+
 def test_graph_cache_hits_same_tensor_and_detects_recycled_storage():
     import ms_gat_amd
     from ms_gat_amd import graph

@@ -144,6 +144,35 @@ def test_modules_are_drop_in_for_the_reference_golden():
     assert rel_err(y.cpu(), g["y"]) < TOL
 
 
+def test_one_relation_without_the_leading_axis_equals_the_stacked_call_bit_for_bit():
+    """ops.gacn takes the reference's own parameter shapes (alpha [C], Wg [T,T], W [Co,C]: attention.py:29-30,
+    msgat.py:23) for one relation -- what the module classes pass, so that no view nodes sit between parameter and op --
+    and computes exactly what the [1, ...] form computes; the gradients come back in the parameters' shapes."""
+    from ms_gat_amd import ops
+    import ms_gat_amd
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    adj = ms_gat_amd.synthetic_adjacency(41, 50, 2).to(dev)
+    for C, Co in ((3, 24), (72, 24), (5, 0)):
+        x = torch.randn(2, C, 41, 12, generator=g).to(dev)
+        alpha, Wg = (torch.randn(C, generator=g) * 0.3).to(dev), (torch.randn(12, 12, generator=g) * 0.3).to(dev)
+        W = (torch.randn(Co, C, generator=g) * 0.2).to(dev) if Co else None
+        dz = torch.randn(2, Co or C, 41, 12, generator=g).to(dev)
+        outs = []
+        for lead in (False, True):
+            ps = [t.clone().requires_grad_(True) for t in (alpha, Wg) + ((W,) if Co else ())]
+            xs = x.clone().requires_grad_(True)
+            args = [p.unsqueeze(0) if lead else p for p in ps]
+            z = ops.gacn(xs, args[0], args[1], args[2] if Co else None, adj)
+            z.backward(dz)
+            assert all(p.grad.shape == p.shape for p in ps)
+            outs.append([z.detach(), xs.grad] + [p.grad for p in ps])
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+    with pytest.raises(ValueError, match="Wg must be"):
+        ops.gacn(x, alpha, Wg.unsqueeze(0), None, adj)
+
+
 # ---------------------------------------------------------------------------------------
 # oracle comparisons on seeded inputs: modes, stacked relations, odd sizes
 # ---------------------------------------------------------------------------------------

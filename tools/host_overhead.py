@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where the HOST time of an eager hot-path step goes (cProfile over bench.HotPath.step at a launch-bound size):
-    python tools/host_overhead.py [--workload pemsd4] [--steps 300]"""
+    python tools/host_overhead.py [--workload pemsd4] [--steps 300] [--dropin]"""
 import argparse
 import cProfile
 import os
@@ -16,9 +16,12 @@ import bench  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="pemsd4")
 ap.add_argument("--steps", type=int, default=300)
+ap.add_argument("--dropin", action="store_true", help="the un-stacked loop of GACN module calls (bench.DropInLoop)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 hp = bench.HotPath(bench.WORKLOADS[a.workload], dev, 0)
+if a.dropin:
+    hp = bench.DropInLoop(hp)
 for _ in range(50):
     hp.step()
 torch.cuda.synchronize()
@@ -36,4 +39,4 @@ for _ in range(a.steps):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(22)
+st.sort_stats("tottime").print_stats(30)
