@@ -553,18 +553,23 @@ class DropInLoop:
         return zs
 
 
-def host_enqueue_us(fn, dev, steps=100):
-    """Host time to ENQUEUE one call of `fn` (the GPU may lag behind), and the wall time per call."""
-    for _ in range(10):
-        fn()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        fn()
-    host = time.perf_counter() - t0
-    torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0
-    return host / steps * 1e6, wall / steps * 1e6
+def host_enqueue_us(fn, dev, steps=100, repeats=3):
+    """Host time to ENQUEUE one call of `fn` (the GPU may lag behind), and the wall time per call: the best of
+    `repeats` rounds (the host of a shared box is noisy; the GPU side is what the other figures are for)."""
+    best = None
+    for _ in range(repeats):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        host = time.perf_counter() - t0
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t0
+        if best is None or host < best[0]:
+            best = (host, wall)
+    return best[0] / steps * 1e6, best[1] / steps * 1e6
 
 
 def dropin_object(hp, dev, steps=50):
@@ -576,9 +581,9 @@ def dropin_object(hp, dev, steps=50):
     loop = DropInLoop(hp)
     settle(loop.step, dev, 20.0)
     wall, per = timed_steps(loop.step, steps, 10, dev, sync)
-    busy, launches = gpu_busy_us(loop.step, dev)
-    host, _ = host_enqueue_us(loop.step, dev)
+    host, _ = host_enqueue_us(loop.step, dev)            # (before the profiler runs: its hooks linger on some builds)
     host_stacked, _ = host_enqueue_us(hp.step, dev)
+    busy, launches = gpu_busy_us(loop.step, dev)
     busy_stacked, launches_stacked = gpu_busy_us(hp.step, dev)
     obj = {
         "workload": (f"hot path as R={wl['R']} separate ms_gat_amd.GACN module calls per depth (reference loop msgat.py:204, "

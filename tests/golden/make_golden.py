@@ -26,8 +26,17 @@ Fixtures:
                            the library's one-pass convolution backward and segmented mixing forms are not selected -- the
                            reference's own MEAM gradients reach those kernels.  x and dout are fp16-exact (stored as fp16).
 
+  gacn_w48_n64.npz, gacn_w96_n64.npz   GACN(48 -> 16) / GACN(96 -> 32) fwd+bwd at N = 64 (768 positions per slab): the
+                           widths of the other two models of the registry (msgat.py:220-229) reach the library's LDS-DMA
+                           one-pass backward forms <2,3,128,3,1> / <3,6,64,3,2> with the reference's own gradients.
+                           Self-contained (x, adj, parameters, dz); x and dz fp16-exact.
+  meam_96to96_n64.npz      MEAM(96 -> 96), dilations [4,4] (the second block of msgat96), fwd+bwd at N = 64: the forms
+                           <9,4,64,3,2> (130 x 97 merged mixing) and <6,4,64,3,2> (96 x 97 residual convolution).
+  meam_48to48_n64.npz      MEAM(48 -> 48), dilations [2,4] (second block of msgat48): <5,4,64,3,2> and <3,4,128,3,1>.
+
     python tests/golden/make_golden.py --only headline     # just that one
     python tests/golden/make_golden.py --only meam64
+    python tests/golden/make_golden.py --only widths       # gacn_w48/w96 and meam_48to48 / meam_96to96
 """
 import os
 import sys
@@ -143,10 +152,33 @@ def headline_case(seed):
     print(f"gacn_headline_n883.npz: {os.path.getsize(path) / 1024:.0f} KiB")
 
 
-def meam_case(tag, cin, cout, N, B, seed, half_inputs=False):
+def gacn_width_case(tag, C, O, N, B, seed):
+    """GACN(C -> O) on its own inputs (LayerNorm output, as msgat.py:122 feeds it), fp16-exact x and dz."""
+    T = 12
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, C, N, T))
+    x = (x - x.mean(-1, keepdims=True)) / np.sqrt(x.var(-1, keepdims=True) + 1e-5)
+    x16, dz16 = x.astype(np.float16), rng.standard_normal((B, O, N, T)).astype(np.float16)
+    adj = synthetic_adjacency(N, N + 6, seed + 1)
+    Wg = (rng.standard_normal((T, T)) * (2.0 / (T + T)) ** 0.5).astype(np.float32)
+    alpha = rng.uniform(-C ** -0.5, C ** -0.5, size=C).astype(np.float32)
+    W = (rng.standard_normal((O, C)) * (2.0 / (O + C)) ** 0.5).astype(np.float32)
+    g = GACN(C, O, T)
+    with torch.no_grad():
+        g.gatt.Wg.copy_(t(Wg))
+        g.gatt.alpha.copy_(t(alpha))
+        g.W.copy_(t(W))
+    xt = t(x16.astype(np.float32)).requires_grad_(True)
+    z = g(xt, t(adj))
+    z.backward(t(dz16.astype(np.float32)))
+    save(f"gacn_{tag}.npz", x=x16, adj=adj, Wg=Wg, alpha=alpha, W=W, dz=dz16, z=z, dx=xt.grad, dWg=g.gatt.Wg.grad,
+         dalpha=g.gatt.alpha.grad, dW=g.W.grad)
+
+
+def meam_case(tag, cin, cout, N, B, seed, half_inputs=False, dilations=(1, 2)):
     torch.manual_seed(seed)
     T = 12
-    m = MEAM(cin, cout, n_nodes=N, n_timesteps=T, dilations=[1, 2])
+    m = MEAM(cin, cout, n_nodes=N, n_timesteps=T, dilations=list(dilations))
     with torch.no_grad():
         for p in m.parameters():
             if p.ndim >= 2:
@@ -308,6 +340,12 @@ if __name__ == "__main__":
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "meam64":
         meam_case("72to72_n64", 72, 72, 64, 2, 1200, half_inputs=True)
         sys.exit(0)
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "widths":
+        gacn_width_case("w48_n64", 48, 16, 64, 2, 1300)
+        gacn_width_case("w96_n64", 96, 32, 64, 2, 1400)
+        meam_case("48to48_n64", 48, 48, 64, 2, 1500, half_inputs=True, dilations=(2, 4))
+        meam_case("96to96_n64", 96, 96, 64, 2, 1600, half_inputs=True, dilations=(4, 4))
+        sys.exit(0)
     headline_case(1100)
     gatt_case("b2c3n16", 2, 3, 16, 12, 20, 100)
     gatt_case("b2c1n64", 2, 1, 64, 12, 70, 200)
@@ -321,3 +359,7 @@ if __name__ == "__main__":
     cfg1_case(900)
     loader_case(1000)
     meam_case("72to72_n64", 72, 72, 64, 2, 1200, half_inputs=True)
+    gacn_width_case("w48_n64", 48, 16, 64, 2, 1300)
+    gacn_width_case("w96_n64", 96, 32, 64, 2, 1400)
+    meam_case("48to48_n64", 48, 48, 64, 2, 1500, half_inputs=True, dilations=(2, 4))
+    meam_case("96to96_n64", 96, 96, 64, 2, 1600, half_inputs=True, dilations=(4, 4))

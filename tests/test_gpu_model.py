@@ -19,14 +19,19 @@ def _state(g):
     return {k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("p.")}
 
 
-@pytest.mark.parametrize("tag,cin,n", [("3to72_n32", 3, 32), ("72to72_n32", 72, 32), ("72to72_n64", 72, 64)])
-def test_meam_block_matches_reference_forward_and_backward(tag, cin, n):
+@pytest.mark.parametrize("tag,cin,n,cout,dilations", [
+    ("3to72_n32", 3, 32, 72, [1, 2]), ("72to72_n32", 72, 32, 72, [1, 2]), ("72to72_n64", 72, 64, 72, [1, 2]),
+    ("48to48_n64", 48, 64, 48, [2, 4]),     # msgat48's second block: <5,4,64,3,2> (66 x 49), <3,4,128,3,1> (48 x 49)
+    ("96to96_n64", 96, 64, 96, [4, 4]),     # msgat96's second block: <9,4,64,3,2> (130 x 97), <6,4,64,3,2> (96 x 97)
+])
+def test_meam_block_matches_reference_forward_and_backward(tag, cin, n, cout, dilations):
     """The reference's own MEAM outputs and gradients (tests/golden/make_golden.py).  N = 64 gives 768 positions per
     channel slab: the one-pass convolution backward (`k_chanpair_glds<5|7,5,64,3,2>`) and the segmented mixing forms are
-    only selected from 512 positions up, so that case is what pins them to the reference (msgat.py:121-131)."""
+    only selected from 512 positions up, so those cases are what pins them to the reference (msgat.py:121-131) -- at the
+    second-block widths of all three models of the registry (msgat.py:220-229)."""
     from ms_gat_amd import model
     g = load_golden(f"meam_{tag}.npz")
-    m = model.MEAM(cin, 72, n_nodes=n, n_timesteps=12, dilations=[1, 2])
+    m = model.MEAM(cin, cout, n_nodes=n, n_timesteps=12, dilations=dilations)
     m.load_state_dict(_state(g))
     m.to(_dev())
     x = torch.from_numpy(g["x"]).float().to(_dev()).requires_grad_(True)
@@ -283,9 +288,10 @@ def test_cfg4_per_rank_workload_full_training_step(tmp_path):
       * both against the reference's dense op sequence on the same GPU, in float64 AND in float32.  At this size the
         gradients of a ReLU network are not smooth functions of rounding: a handful of the 2.4e8 pre-activations sit
         within an ulp of zero, and any two fp32 implementations mask them differently.  The reference's own fp32
-        arithmetic is up to 2e-2 (max-norm, per tensor) away from float64 here, so the bar for the gradients is
-        "no further from float64 than the reference's fp32 run", recorded per run in the parity log; the prediction
-        and the loss -- smooth -- keep the 1e-4 bar;
+        arithmetic is up to 2e-2 (max-norm, per tensor) away from float64 here.  So the free-mask gradient figures (the
+        library's and the reference fp32 op sequence's distance from float64) are RECORDED in the parity log, and the
+        assertion is the forced-mask run: float64 with the library's own ReLU masks, every gradient tensor at the fixed
+        1e-4 bar; the prediction and the loss -- smooth -- keep the 1e-4 bar in both runs;
       * one step through engine.Trainer with the 7.8 MB flat gradient buffer Adam and the all-reduce share."""
     import copy
     import bench
@@ -339,11 +345,14 @@ def test_cfg4_per_rank_workload_full_training_step(tmp_path):
     assert set(g64) == set(g_s)
     lib = {k: rel_err(g_s[k].double(), g64[k]) for k in g64}
     ref = {k: rel_err(g32[k].double(), g64[k]) for k in g64}
-    record_err(what, "gradients, worst tensor (library)", max(lib.values()), max(2e-3, max(ref.values())))
-    record_err(what, "gradients, worst tensor (dense fp32 eager ops)", max(ref.values()), max(2e-3, max(ref.values())))
+    # Free ReLU masks: RECORDED, not asserted (round-4 review: "no worse than the reference's fp32" had a margin of 1.0x and
+    # could never fail usefully).  A handful of the 2.4e8 pre-activations sit within an ulp of zero and any two fp32
+    # implementations mask them differently; the assertion on the gradients is the forced-mask run below, at the fixed
+    # 1e-4 bar.  What IS asserted here is the smooth part: the median tensor.
+    record_err(what, "gradients, worst tensor, free masks (library; recorded only)", max(lib.values()), float("inf"))
+    record_err(what, "gradients, worst tensor, free masks (dense fp32 eager ops; recorded only)", max(ref.values()), float("inf"))
     record_err(what, "gradients, median tensor (library)", float(np.median(list(lib.values()))), TOL)
     record_err(what, "gradients, median tensor (dense fp32 eager ops)", float(np.median(list(ref.values()))), TOL)
-    assert max(lib.values()) <= max(2e-3, max(ref.values()))
     assert float(np.median(list(lib.values()))) < TOL
 
     # The mask-flip explanation as a test: the float64 op sequence again, but with every ReLU applying the set of active

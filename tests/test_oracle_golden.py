@@ -5,6 +5,7 @@ CPU only.  Tolerances: the fp32 dense torch restatement must match the reference
 reference's fp32 results to 2e-5 relative (the reference's own rounding).
 """
 import numpy as np
+import pytest
 import torch
 
 from conftest import load_golden, load_headline_golden, rel_err
@@ -81,6 +82,44 @@ def test_oracles_match_the_reference_at_the_headline_size():
     assert rel_err(zt.detach(), g["z"]) < 2e-6
     assert rel_err(x.grad, g["dx"]) < 2e-6
     assert rel_err(W.grad, g["dW"]) < 5e-6
+
+
+@pytest.mark.parametrize("tag", ["w48_n64", "w96_n64"])
+def test_oracles_match_the_reference_at_the_other_registry_widths(tag):
+    """GACN(48 -> 16) / GACN(96 -> 32) (msgat48 / msgat96, msgat.py:220-229) at N = 64: both oracles against the
+    reference's own forward and autograd, so the GPU tests of those widths stand on a pinned checker."""
+    g = load_golden(f"gacn_{tag}.npz")
+    f64 = lambda k: g[k].astype(np.float64)  # noqa: E731
+    z = gat_oracle.gacn_forward(f64("x"), f64("adj"), f64("Wg"), f64("alpha"), f64("W"))
+    assert rel_err(z, g["z"]) < 2e-5
+    dx, dWg, dalpha, dW = gat_oracle.gacn_backward(f64("x"), f64("adj"), f64("Wg"), f64("alpha"), f64("W"), f64("dz"))
+    for name, got in (("dx", dx), ("dWg", dWg), ("dalpha", dalpha), ("dW", dW)):
+        assert rel_err(got, g[name]) < 2e-5, name
+    t = lambda a: torch.from_numpy(a).float()  # noqa: E731
+    x = t(g["x"]).requires_grad_(True)
+    W = t(g["W"]).requires_grad_(True)
+    zt = dense_torch.gacn_dense(x, t(g["adj"]), t(g["Wg"]), t(g["alpha"]), W)
+    zt.backward(t(g["dz"]))
+    assert rel_err(zt.detach(), g["z"]) < 2e-6
+    assert rel_err(x.grad, g["dx"]) < 2e-6
+    assert rel_err(W.grad, g["dW"]) < 5e-6
+
+
+@pytest.mark.parametrize("tag,dilations", [("48to48_n64", [2, 4]), ("96to96_n64", [4, 4]), ("72to72_n64", [1, 2])])
+def test_dense_meam_restatement_matches_the_reference_block(tag, dilations):
+    """oracle/dense_torch.meam_dense (the eager baseline of bench.py and the checker of the model tests) against the
+    reference's MEAM output and input gradient at the second-block widths of all three registry models."""
+    g = load_golden(f"meam_{tag}.npz")
+    state = {k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("p.")}
+    for v in state.values():
+        v.requires_grad_(True)
+    x = torch.from_numpy(g["x"]).float().requires_grad_(True)
+    out = dense_torch.meam_dense(x, torch.from_numpy(g["adj"]), state, dilations)
+    out.backward(torch.from_numpy(g["dout"]).float())
+    assert rel_err(out.detach(), g["out"]) < 5e-6
+    assert rel_err(x.grad, g["dx"]) < 5e-6
+    for k, v in state.items():
+        assert rel_err(v.grad, g[f"g.{k}"]) < 2e-5, k
 
 
 def test_lse_matches_dense_softmax_denominator():

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Per-kernel GPU time of the msgat72 TRAINING step (bench.TrainStep, engine.Trainer) from torch's profiler:
+    python tools/train_kernels.py [--R 3] [--unstacked] [--width 72] [--lib build/lab/x.so] [--top 40]
+--unstacked evaluates the components one by one (the reference's loop, msgat.py:204) instead of the stacked schedule."""
+import argparse
+import os
+import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ap = argparse.ArgumentParser()
+ap.add_argument("--R", type=int, default=3)
+ap.add_argument("--steps", type=int, default=6)
+ap.add_argument("--top", type=int, default=40)
+ap.add_argument("--unstacked", action="store_true")
+ap.add_argument("--lib", default="")
+a = ap.parse_args()
+from ms_gat_amd import _lib  # noqa: E402
+if a.lib:
+    _lib.LIB_PATH = os.path.abspath(a.lib)
+import torch  # noqa: E402
+import bench  # noqa: E402
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
+
+dev = torch.device("cuda:0")
+ts = bench.TrainStep(dict(bench.CFG4, R=a.R), dev, stacked=not a.unstacked)
+ts.run(4)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CUDA]) as prof:
+    ts.run(a.steps)
+    torch.cuda.synchronize()
+rows = [e for e in prof.key_averages() if e.device_time_total > 0]
+tot = sum(e.device_time_total for e in rows) / a.steps
+n = sum(e.count for e in rows) / a.steps
+print(f"R={a.R} {'un-stacked loop' if a.unstacked else 'stacked'}: busy {tot / 1e3:.3f} ms/step, {n:.0f} launches/step")
+for e in sorted(rows, key=lambda e: -e.device_time_total)[: a.top]:
+    name = re.sub(r"\(.*", "", e.key).replace("void ", "").replace("msgat::", "")
+    print(f"{e.device_time_total / a.steps:9.1f} us/step  n={e.count / a.steps:5.1f}  avg {e.device_time_total / max(e.count, 1):8.1f} us  {name[:70]}")
