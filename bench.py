@@ -334,8 +334,8 @@ class TrainStep:
         torch.manual_seed(0)
         self.cfg, self.dev = cfg, dev
         adj = ms_gat_amd.synthetic_adjacency(cfg["N"], cfg["E"], seed=0)
-        net = model.msgat72(n_components=cfg["R"], in_channels=cfg["Cin"], in_timesteps=cfg["T"],
-                            out_timesteps=cfg["T"], use_te=True, adj=adj).to(dev)
+        net = model.build_msgat(f"ms-gat{cfg.get('hidden', 72)}", n_components=cfg["R"], in_channels=cfg["Cin"],
+                                in_timesteps=cfg["T"], out_timesteps=cfg["T"], use_te=True, adj=adj).to(dev)
         if not stacked:
             net.stack_components = False   # the reference's loop over components (msgat.py:204), this package's blocks
         if dense:
@@ -689,6 +689,22 @@ def widths_object(hidden, dev, steps=20):
            "samples_per_s": round(wl["B"] / (wall / steps), 2), "kernels": hbm_kernel_table(hp, dev)}
     del hp
     torch.cuda.empty_cache()
+    # the whole training step of that model (engine.Trainer, R = 3, B = 32): its wide one-pass backward forms (two
+    # z-blocks over B at 96 channels, each staging all of A) are timed here, with their names as the library reports them
+    from ms_gat_amd import _lib
+    co, P = hidden // 3, wl["N"] * wl["T"]
+    ts = TrainStep(dict(CFG4, R=wl["R"], hidden=hidden), dev)
+    w, per = time_train_step(ts, 20, 5, sync)
+    obj["train_step"] = {
+        "workload": f"msgat{hidden} training step (engine.Trainer), N={wl['N']}, R={wl['R']}, B={wl['B']}, T={wl['T']}",
+        "ms_per_step": round(w / 20 * 1e3, 3), "ms_per_step_median_hip_events": round(statistics.median(per), 3),
+        "samples_per_s": round(wl["B"] / (w / 20), 2), "trainable_parameters": ts.n_params,
+        "convolution_backward_forms": {
+            "gacn_projection": _lib.contract_form_name(co + 1, hidden, False, P, True),
+            "merged_channel_mixing": _lib.contract_form_name(4 * co + 2, hidden, True, P, True),
+            "residual_convolution": _lib.contract_form_name(hidden, hidden, True, P, True)}}
+    del ts
+    torch.cuda.empty_cache()
     return obj
 
 
@@ -743,9 +759,12 @@ def small_graph_object(name, dev, steps=100):
         "forward_gpu_busy_ms": round(busy_f * 1e-3, 4), "forward_launches": round(launches_f, 1),
         "eager_rocm_forward_ms": round(statistics.median(eager_fwd), 3),
         "eager_rocm_fwd_bwd_ms": round(statistics.median(eager_all), 3),
-        "speedup_vs_eager_rocm_forward": round(statistics.median(eager_fwd) / fwd, 2),
-        "speedup_vs_eager_rocm_forward_eager_launch": round(statistics.median(eager_fwd) / statistics.median(fwd_e), 2),
-        "speedup_vs_eager_rocm_fwd_bwd": round(statistics.median(eager_all) / statistics.median(per_g), 2),
+        # like for like: both sides launched eagerly from Python (round-4 advisor finding: the replayed step against an
+        # eager baseline mixed launch modes); the replayed figures carry their launch mode in the key
+        "speedup_vs_eager_rocm_forward": round(statistics.median(eager_fwd) / statistics.median(fwd_e), 2),
+        "speedup_vs_eager_rocm_forward_hip_graph": round(statistics.median(eager_fwd) / statistics.median(fwd_g), 2),
+        "speedup_vs_eager_rocm_fwd_bwd": round(statistics.median(eager_all) / statistics.median(per_e), 2),
+        "speedup_vs_eager_rocm_fwd_bwd_hip_graph": round(statistics.median(eager_all) / statistics.median(per_g), 2),
     }
 
 

@@ -374,6 +374,16 @@ int msgat_contract_segments(int32_t R, int32_t Bg, int32_t N, int32_t T, const m
 int msgat_contract_mix_segments(int32_t R, int32_t Bg, int32_t N, int32_t T, const msgat_seg_t* A, int32_t n_a,
                                 const float* B, int32_t Cb, int32_t with_ones, const float* M, float* partials,
                                 float* dst, float* mixout, void* stream);
+/* Host only, touches no device: the name of the kernel form a [Ca x Cb (+1 with_ones)] contraction over rows of
+ * n_positions = N*T takes -- with_mix = 1: as msgat_contract_mix_segments / msgat_stage_project_backward would run it,
+ * " + projection pass" appended when no one-pass form covers the shape; with_mix = 0: msgat_contract_segments.
+ * E.g. "k_chanpair_glds<7,5,64,3,2>" (LDS-DMA ring, [112 x 80] block, 64-position tiles, wave roles split),
+ * "k_chanpair_glds<9,4,64,3,2> nzb=2" (two z-blocks over B), "k_chanpair_mfma<3,2,true,256>" (register-staged).
+ * The string comes from the launchers' own selection code (csrc/mfma.hip), so it cannot drift from what runs; the forms
+ * exist for the channel counts of the reference's three models (main.py:17, msgat.py:220-229), other shapes fall back
+ * to the register-staged kernels.  buf: at least 128 bytes. */
+int msgat_contract_form_name(int32_t Ca, int32_t Cb, int32_t with_ones, int32_t n_positions, int32_t with_mix,
+                             char* buf, int32_t buflen);
 
 /* ---- device: the attention core on already projected features ----
  * Forward = msgat_stage_scores(q) + msgat_stage_aggregate(u) (above).  Backward of exactly that pair, for

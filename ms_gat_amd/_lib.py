@@ -102,6 +102,7 @@ _PROTOTYPES = {
     "msgat_stage_project_backward": (C.c_int, [C.POINTER(Shape)] + [C.c_void_p] * 10),
     "msgat_contract_mix_segments": (C.c_int, [C.c_int32] * 4 + [C.POINTER(Seg), C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "msgat_contract_form_name": (C.c_int, [C.c_int32] * 5 + [C.c_char_p, C.c_int32]),
     "msgat_attention_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Shape), C.POINTER(Graph)]),
     "msgat_attention_backward": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_int32] +
                                  [C.c_void_p] * 11 + [C.c_size_t, C.c_void_p]),
@@ -163,6 +164,14 @@ def check(status: int, what: str) -> None:
     if status != MSGAT_OK:
         msg = lib().msgat_status_string(status)
         raise MsgatError(f"{what} failed: {msg.decode() if msg else status} (status {status})")
+
+
+def contract_form_name(Ca: int, Cb: int, with_ones: bool, n_positions: int, with_mix: bool) -> str:
+    """Which kernel form the backward of a 1x1 convolution (with_mix) or a plain channel-pair contraction takes for this
+    shape: `msgat_contract_form_name` (host only, no device needed)."""
+    buf = C.create_string_buffer(160)
+    check(lib().msgat_contract_form_name(Ca, Cb, int(with_ones), n_positions, int(with_mix), buf, 160), "msgat_contract_form_name")
+    return buf.value.decode()
 
 
 def exported_symbols():

@@ -2,6 +2,7 @@
 // Argument checks happen on the host before anything is enqueued: a bad shape must come
 // back as a status code, never as a faulting kernel.
 #include "common.hpp"
+#include <cstdio>
 
 using namespace msgat;
 
@@ -399,6 +400,22 @@ extern "C" int msgat_contract_segments(int32_t R, int32_t Bg, int32_t N, int32_t
   const int Cbx = Cb + with_ones;
   return launch_chanpair_seg(sa, B, partials, dst, sa.total() * Cbx, nullptr, 0, R * Bg, Bg, Cbx, N * T,
                              (hipStream_t)stream, with_ones);
+}
+
+extern "C" int msgat_contract_form_name(int32_t Ca, int32_t Cb, int32_t with_ones, int32_t n_positions, int32_t with_mix,
+                                        char* buf, int32_t buflen) {
+  if (!buf || buflen <= 0) return MSGAT_ERR_NULL;
+  if (Ca <= 0 || Cb <= 0 || Ca > kMaxC + 2 || Cb > kMaxC || n_positions <= 0 || (with_ones != 0 && with_ones != 1))
+    return MSGAT_ERR_SHAPE;
+  char name[96];
+  int one = 0, nza = 1, nzb = 1;
+  const int st = contract_form_name(Ca, Cb + with_ones, with_ones, n_positions, with_mix, name, (int)sizeof name, &one, &nza, &nzb);
+  if (st) return st;
+  char za[24] = "", zb[24] = "";
+  if (nza > 1) snprintf(za, sizeof za, " nza=%d", nza);
+  if (nzb > 1) snprintf(zb, sizeof zb, " nzb=%d", nzb);
+  snprintf(buf, (size_t)buflen, "%s%s%s%s", name, za, zb, (with_mix && !one) ? " + projection pass" : "");
+  return MSGAT_OK;
 }
 
 extern "C" int msgat_contract_mix_segments(int32_t R, int32_t Bg, int32_t N, int32_t T, const msgat_seg_t* A, int32_t n_a,

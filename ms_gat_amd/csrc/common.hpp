@@ -249,6 +249,8 @@ int launch_chanpair_mix_wide(const SegList& A, const float* B, float* part, int 
                              int b_ones, const float* M, float* mixout, hipStream_t s, int* nblk_used, int* done);
 int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
                          int b_ones, hipStream_t s, int* nblk_used);
+int contract_form_name(int Ca, int Cb, int b_ones, int P, int with_mix, char* buf, int buflen, int* one_pass, int* nza,
+                       int* nzb);
 // x / alpha / C / qout given (scores_take_x): q = alpha . x is computed inside the kernel from x[G,C,N,T] and written to
 // qout -- no k_qonly launch; `q` is ignored then.  apW / apCo / apZ given as well (AGG_FIRST, W[R,apCo,C]): the kernel
 // also finishes the layer for its rows, y = E x (to apY[G,C,N,T] when not NULL) and z = W y (to apZ[G,apCo,N,T]) -- no

@@ -18,11 +18,20 @@
 //     loads, so 256-position tiles of all rows are staged through LDS in 1-KiB row pieces by a
 //     persistent split-K kernel (see k_chanpair_mfma).
 #include "common.hpp"
+#include <cstdio>
 #ifdef MSGAT_LAB
 #include <cstdlib>
 #endif
 
 namespace msgat {
+
+// msgat_contract_form_name(): the launchers below run as usual up to the point where they would touch the device, and
+// the leaf that would launch writes its kernel's name here instead.  Thread-private, set only by that query.
+struct FormProbe {
+  char name[96];
+  int nza, nzb;
+};
+static thread_local FormProbe* g_form_probe = nullptr;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -912,6 +921,11 @@ static int launch_chanpair_t(const SegList& A, const float* B, float* part, int 
   *nblk_used = nblk;
   // tile rows + the zero row + the ones row; the reduction re-uses the buffer a few tiles at a time
   const size_t lds = sizeof(float4) * (size_t)(((MA + NB) * 16 + 2) * (TILE / 4 + 1));
+  if (g_form_probe) {
+    snprintf(g_form_probe->name, sizeof g_form_probe->name, "k_chanpair_mfma<%d,%d,%s,%d>", MA, NB, TWO ? "true" : "false", TILE);
+    g_form_probe->nza = nza; g_form_probe->nzb = nzb;
+    return MSGAT_OK;
+  }
   {
     static LdsGrant granted;
     if (int st = grant_dynamic_lds(&k_chanpair_mfma<MA, NB, TWO, TILE>, lds, granted)) return st;
@@ -951,6 +965,11 @@ static int launch_chanpair_glds_t(const SegList& A, const float* B, float* part,
   *nblk_used = nblk;
   const size_t lds = chanpair_glds_lds<MA, NB, TILE, NBUF>(Ca, Cb);
   if (lds > (size_t)kLdsMax || lds < (size_t)(MA * NB < 8 ? MA * NB : 8) * kCpWaves * 1024) return MSGAT_ERR_UNSUPPORTED;
+  if (g_form_probe) {
+    snprintf(g_form_probe->name, sizeof g_form_probe->name, "k_chanpair_glds<%d,%d,%d,%d,%d>", MA, NB, TILE, NBUF, MODE);
+    g_form_probe->nza = nza; g_form_probe->nzb = nzb;
+    return MSGAT_OK;
+  }
   {
     static LdsGrant granted;
     if (int st = grant_dynamic_lds(&k_chanpair_glds<MA, NB, TILE, NBUF, MODE>, lds, granted)) return st;
@@ -1118,6 +1137,27 @@ int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, i
   MSGAT_CP(3, 1) MSGAT_CP(3, 2) MSGAT_CP(3, 3) MSGAT_CP(3, 4)
 #undef MSGAT_CP
   return MSGAT_ERR_UNSUPPORTED;
+}
+
+// Which kernel a [Ca x Cb] channel-pair contraction over rows of P positions takes (with_mix: the one-pass form that also
+// writes the mix output; *one_pass = 0 there means "no fused form: the contraction below plus a projection pass").
+// Runs the launchers' own selection code with the probe set: nothing is launched, no device is touched.
+int contract_form_name(int Ca, int Cb, int b_ones, int P, int with_mix, char* buf, int buflen, int* one_pass, int* nza,
+                       int* nzb) {
+  FormProbe probe{};
+  SegList A = seg_single(reinterpret_cast<const float*>(16), Ca);   // never dereferenced
+  float* fake = reinterpret_cast<float*>(16);
+  int nblk = 0, done = 0, st = MSGAT_OK;
+  g_form_probe = &probe;
+  if (with_mix) st = launch_glds_mix(A, fake, fake, 1, 1, Cb, P, 256, b_ones, fake, nullptr, fake, nullptr, &nblk, &done);
+  if (!st && !done) st = launch_chanpair_mfma(A, fake, fake, 1, 1, Cb, P, 256, b_ones, nullptr, &nblk);
+  g_form_probe = nullptr;
+  if (st) return st;
+  if (one_pass) *one_pass = done;
+  if (nza) *nza = probe.nza;
+  if (nzb) *nzb = probe.nzb;
+  if (buf && buflen > 0) snprintf(buf, (size_t)buflen, "%s", probe.name);
+  return MSGAT_OK;
 }
 
 }  // namespace msgat

@@ -309,6 +309,32 @@ def test_sym_norm_adjacency_matches_reference_and_oracle():
     assert np.allclose(ms_gat_amd.sym_norm_adjacency(50, e).numpy(), gat_oracle.sym_norm_adjacency(50, e), atol=1e-7)
 
 
+@pytest.mark.parametrize("hidden", [48, 72, 96])
+def test_every_convolution_backward_of_the_registry_models_takes_a_one_pass_lds_dma_form(hidden):
+    """The three models of the reference's registry (main.py:17, msgat.py:220-229: 48 / 72 / 96 hidden channels, a third
+    per branch) produce three 1x1-convolution backward shapes per second-level block; at rows of >= 512 positions each
+    must take a one-pass LDS-DMA form (contraction AND input gradient from one read of the operands) -- a silent
+    fall-back to the register-staged kernels plus a projection pass is what `msgat_contract_form_name` makes visible."""
+    from ms_gat_amd import _lib
+    co = hidden // 3
+    sites = {"GACN projection [Co+1 x C]": (co + 1, hidden, False),
+             "merged channel mixing [4Co+2 x C+1]": (4 * co + 2, hidden, True),
+             "residual convolution [C x C+1]": (hidden, hidden, True)}
+    for P in (512, 64 * 12, 307 * 12, 883 * 12):
+        for what, (Ca, Cb, ones) in sites.items():
+            name = _lib.contract_form_name(Ca, Cb, ones, P, True)
+            assert name.startswith("k_chanpair_glds<") and "projection pass" not in name, (hidden, what, P, name)
+            mode = int(name.split(">")[0].split(",")[-1])
+            assert mode in (1, 2), name                                   # a MIX form, not the plain contraction
+    # below 512 positions per row, and for channel counts outside the registry, the two-pass form is reported as such
+    assert _lib.contract_form_name(25, 72, False, 156, True) == "k_chanpair_mfma<2,5,true,256> + projection pass"
+    assert "projection pass" in _lib.contract_form_name(150, 120, True, 883 * 12, True)
+    # plain contractions report their kernel too
+    assert _lib.contract_form_name(98, 72, True, 883 * 12, False).startswith("k_chanpair_glds<7,5,64,3,0>")
+    with pytest.raises(_lib.MsgatError):
+        _lib.contract_form_name(0, 72, False, 100, True)
+
+
 def test_batched_adjacency_is_refused_with_a_pointer_to_the_reference():
     """attention.py:22 documents `adjacency: [..., n_nodes, n_nodes]`; the sole caller passes [N,N] (msgat.py:127) and so
     does everything here -- a batched adjacency must not be mistaken for a malformed one."""
