@@ -329,6 +329,22 @@ int msgat_time_mix(const float* src, const float* A, int32_t a_per_group, const 
                    int32_t G, int32_t Co, int32_t K, int32_t N, int32_t T, int32_t backward, int32_t R,
                    int32_t src_group_stride, void* stream);
 size_t msgat_time_mix_partial_floats(int32_t G, int32_t K, int32_t T);
+/* msgat_causal_conv: a causal dilated [1,2] convolution -- nn.Conv2d(Ci, Co, [1,2], padding=[0,d], dilation=[1,d])
+ * followed by Chomp(d), msgat.py:69-74: every TACN layer after the first -- in ONE pass over its input, with
+ * taps [R, 2*Co, Ci] = [W0; W1] (W0 acts on in[t-d], W1 on in[t]; model.TACN.stacked_taps):
+ *   backward = 0:  dst[g,co,n,t] = bias[co] + sum_ci W0[co,ci] src[g,ci,n,t-d] + W1[co,ci] src[g,ci,n,t]   src [G,Ci,N,T]
+ *   backward = 1:  dst[g,ci,n,t] = sum_co W0[co,ci] src[g,co,n,t+d] + W1[co,ci] src[g,co,n,t]              src [G,Co,N,T]
+ * (terms whose timestep falls outside [0,T) are zero).  It replaces msgat_mix_segments (Ci -> 2*Co), the [G,2*Co,N,T]
+ * intermediate and msgat_time_mix with constant shift matrices: the shifted operand is an unaligned 16-byte load of
+ * the same row of T plus a per-lane element mask.  bias [Co] or (bias_per_relation) [R,Co], forward only.
+ * src_group_stride: src is a channel slice of a [G, src_group_stride, N, T] tensor (0: contiguous by itself).
+ * msgat_causal_conv_fused(Ci, Co) = 1 when both directions have a one-pass form for these widths (else the entry point
+ * returns MSGAT_ERR_UNSUPPORTED and the caller runs the two passes). */
+int msgat_causal_conv_fused(int32_t Ci, int32_t Co);
+int msgat_causal_conv(const float* src, const float* taps, const float* bias, int32_t bias_per_relation, float* dst,
+                      int32_t R, int32_t Bg, int32_t Ci, int32_t Co, int32_t N, int32_t T, int32_t dilation,
+                      int32_t backward, int32_t src_group_stride, void* stream);
+
 int msgat_time_mix_grad_matrix(const float* dout, const float* y, float* dA, float* partials, int32_t G,
                                int32_t Co, int32_t K, int32_t N, int32_t T, int32_t dout_group_stride, void* stream);
 int msgat_node_pool(const float* x, const float* w, float* pooled, int64_t slabs, int32_t N, int32_t T,

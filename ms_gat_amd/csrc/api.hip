@@ -270,6 +270,7 @@ extern "C" int msgat_stage_mix_epilogue(const msgat_shape_t* sh, int32_t Ci, int
                             Co, sh->N * sh->T, epi, (hipStream_t)stream);
 }
 
+static int check_rgnt(int32_t R, int32_t Bg, int32_t N, int32_t T);
 static int check_rows(int32_t G, int32_t Co, int32_t K, int32_t N, int32_t T) {
   if (G <= 0 || Co <= 0 || N <= 0) return MSGAT_ERR_SHAPE;
   if (!t_supported(T) || K < 1 || K > 2) return MSGAT_ERR_UNSUPPORTED;
@@ -287,6 +288,27 @@ extern "C" int msgat_time_mix(const float* src, const float* A, int32_t a_per_gr
   if (src_group_stride != 0 && (!backward || src_group_stride < Co || src_group_stride > 4 * kMaxC)) return MSGAT_ERR_SHAPE;
   return launch_tmix(src, A, a_per_group, backward ? nullptr : bias, dst, G, Co, K, N, T, backward, R,
                      (hipStream_t)stream, src_group_stride);
+}
+
+extern "C" int msgat_causal_conv_fused(int32_t Ci, int32_t Co) {
+  return (Ci > 0 && Co > 0 && project_taps_supported(Ci, Co) && project_taps_supported(Co, Ci)) ? 1 : 0;
+}
+
+extern "C" int msgat_causal_conv(const float* src, const float* taps, const float* bias, int32_t bias_per_relation,
+                                 float* dst, int32_t R, int32_t Bg, int32_t Ci, int32_t Co, int32_t N, int32_t T,
+                                 int32_t dilation, int32_t backward, int32_t src_group_stride, void* stream) {
+  if (!src || !taps || !dst) return MSGAT_ERR_NULL;
+  int st = check_rgnt(R, Bg, N, T);
+  if (st) return st;
+  if (Ci <= 0 || Co <= 0 || Ci > kMaxC || Co > kMaxC || dilation <= 0) return MSGAT_ERR_SHAPE;
+  const int Cs = backward ? Co : Ci;                 // channels of src
+  if (src_group_stride != 0 && (src_group_stride < Cs || src_group_stride > 4 * kMaxC)) return MSGAT_ERR_SHAPE;
+  if (!msgat_causal_conv_fused(Ci, Co)) return MSGAT_ERR_UNSUPPORTED;
+  const int G = R * Bg, P = N * T, d = dilation < T ? dilation : T;   // a dilation of T or more: the shifted tap sees nothing
+  hipStream_t s = (hipStream_t)stream;
+  if (!backward)
+    return launch_project_taps(src, src_group_stride, taps, 0, bias, bias_per_relation ? Co : 0, dst, G, Bg, Ci, Co, P, T, -d, s);
+  return launch_project_taps(src, src_group_stride, taps, 1, nullptr, 0, dst, G, Bg, Co, Ci, P, T, d, s);
 }
 
 extern "C" size_t msgat_time_mix_partial_floats(int32_t G, int32_t K, int32_t T) {

@@ -249,6 +249,9 @@ int launch_chanpair_mix_wide(const SegList& A, const float* B, float* part, int 
                              int b_ones, const float* M, float* mixout, hipStream_t s, int* nblk_used, int* done);
 int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
                          int b_ones, hipStream_t s, int* nblk_used);
+bool project_taps_supported(int Cr, int Co);
+int launch_project_taps(const float* in, int in_gstride, const float* taps, int m_in_major, const float* bias,
+                        int bias_rstride, float* out, int G, int Bg, int Cr, int Co, int P, int T, int tshift, hipStream_t s);
 int contract_form_name(int Ca, int Cb, int b_ones, int P, int with_mix, char* buf, int buflen, int* one_pass, int* nza,
                        int* nzb);
 // x / alpha / C / qout given (scores_take_x): q = alpha . x is computed inside the kernel from x[G,C,N,T] and written to

@@ -81,14 +81,28 @@ __device__ __forceinline__ void store_global(const float* p, const float4& v) {
 #ifndef MSGAT_PROJ_LB
 #define MSGAT_PROJ_LB 2   // waves per SIMD the register allocation must leave room for (= blocks per CU)
 #endif
-template <int MG, bool DO_Q, bool ONEPASS, bool SEGS, bool HAS_ADD>
+// TAPS: a causal dilated [1,2] convolution (msgat.py:69-74 behind a Chomp; its autograd with tshift > 0) in ONE pass:
+//   out[co,n,t] = sum_ci W0[co,ci] in[ci,n,t + tshift] + W1[co,ci] in[ci,n,t]     (terms outside 0 <= t + tshift < T are zero)
+// The input's Cr rows appear as 2 Cr virtual channels -- the first Cr shifted along time, the second Cr plain -- under
+// the matrix [W0 | W1]; a lane's float4 is 4 consecutive timesteps of ONE row of T (T % 4 == 0), so the shifted
+// operand is one unaligned 16-B load of the same row plus a lane-constant element mask.  Replaces the channel mixing
+// Cr -> 2 Co, the [G,2Co,N,T] intermediate and the time-mixing pass of every TACN layer whose taps are constant shifts.
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef const f32x4_a4 __attribute__((address_space(1)))* gf4_in_a4;
+__device__ __forceinline__ float4 load_global_a4(const float* p) {   // dword-aligned 16-B load
+  const f32x4_a4 v = *(gf4_in_a4)(const f32x4_a4*)p;
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+
+template <int MG, bool DO_Q, bool ONEPASS, bool SEGS, bool HAS_ADD, bool TAPS = false>
 __global__ __launch_bounds__(kBlock, MSGAT_PROJ_LB) void k_project_mfma(
     SegList in, const float* __restrict__ M, int m_in_major,
     const float* __restrict__ qvec, const float* __restrict__ addvec,
     const float4* __restrict__ extra4, SegList out, float4* __restrict__ q4, int Bg,
-    int P4, MixEpilogue epi) {
+    int P4, MixEpilogue epi, int tshift = 0, int T = 4) {
   extern __shared__ float lds[];
-  const int Ci = in.total(), Co = out.total();
+  const int Cr = in.total();                  // rows the input really has
+  const int Ci = TAPS ? 2 * Cr : Cr, Co = out.total();
   const bool has_extra = addvec != nullptr;
   const int Kx = Ci + (has_extra ? 1 : 0);  // the extra "channel" carries addvec (x) extra
   const int K4 = (Kx + 3) >> 2;             // k-steps
@@ -123,11 +137,48 @@ __global__ __launch_bounds__(kBlock, MSGAT_PROJ_LB) void k_project_mfma(
 
   // channel 4*kk + kq of this lane's 4 positions; padding channels alias a real one (their matrix
   // column is zero) -- never a branch
+  // TAPS: lane constants of the shifted operand.  Element e of the lane's float4 is timestep t0 + e of its row; the
+  // shifted value in[t0 + e + tshift] exists iff 0 <= t0 + e + tshift < T.  At the two ends of a channel row the
+  // unaligned load would leave the row (and, for the first / last row of the tensor, the allocation): there the lane
+  // loads its own (aligned) float4 instead and moves the elements in registers.
+  const int t0 = TAPS ? (4 * p4c) % T : 0;
+  const int spos = 4 * p4c + tshift;                                  // first element of the shifted float4
+  const int sfix = TAPS ? (spos < 0 ? 1 : (spos > 4 * P4 - 4 ? 2 : 0)) : 0;
+  float4 km = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (TAPS) {
+    km.x = (t0 + 0 + tshift >= 0 && t0 + 0 + tshift < T) ? 1.f : 0.f;
+    km.y = (t0 + 1 + tshift >= 0 && t0 + 1 + tshift < T) ? 1.f : 0.f;
+    km.z = (t0 + 2 + tshift >= 0 && t0 + 2 + tshift < T) ? 1.f : 0.f;
+    km.w = (t0 + 3 + tshift >= 0 && t0 + 3 + tshift < T) ? 1.f : 0.f;
+  }
+  const int sabs = tshift < 0 ? -tshift : tshift;
   auto loadB = [&](int kk) -> float4 {
     const int ci = 4 * min(kk, K4 - 1) + kq;
+    if (TAPS) {   // raw load only: what the value still needs (tap_fix) happens when it is consumed, not in front of the ring
+      const int cv = min(ci, Ci - 1);                // virtual channel: < Cr shifted, >= Cr plain
+      const bool sh = cv < Cr;
+      const float* base = in.template row<false>(g, sh ? cv : cv - Cr, 4 * P4);
+      return load_global_a4(base + ((sh && sfix == 0) ? spos : 4 * p4c));
+    }
     const float* base = SEGS ? rowtab[min(ci, Ci - 1)] : in.template row<false>(g, min(ci, Ci - 1), 4 * P4);
     const float* p = (ci == Ci && has_extra) ? reinterpret_cast<const float*>(ex) : base + 4 * (size_t)p4c;
     return load_global(p);
+  };
+  // TAPS, at consume time (branch-free: every lane runs the selects): a shifted channel's float4 gets its row-end
+  // correction -- the own float4 moved by |tshift| elements where the unaligned load would have left the row -- and the
+  // lane's timestep mask
+  auto tap_fix = [&](int kk, float4 v) -> float4 {
+    const bool sh = min(4 * min(kk, K4 - 1) + kq, Ci - 1) < Cr;
+    const float4 right = make_float4(0.f, sabs == 1 ? v.x : 0.f, sabs == 1 ? v.y : (sabs == 2 ? v.x : 0.f),
+                                     sabs == 1 ? v.z : (sabs == 2 ? v.y : (sabs == 3 ? v.x : 0.f)));
+    const float4 left = make_float4(sabs == 1 ? v.y : (sabs == 2 ? v.z : (sabs == 3 ? v.w : 0.f)),
+                                    sabs == 1 ? v.z : (sabs == 2 ? v.w : 0.f), sabs == 1 ? v.w : 0.f, 0.f);
+    const bool r1 = sh && sfix == 1, r2 = sh && sfix == 2;
+    v.x = r1 ? right.x : (r2 ? left.x : v.x); v.y = r1 ? right.y : (r2 ? left.y : v.y);
+    v.z = r1 ? right.z : (r2 ? left.z : v.z); v.w = r1 ? right.w : (r2 ? left.w : v.w);
+    v.x = (sh && km.x == 0.f) ? 0.f : v.x; v.y = (sh && km.y == 0.f) ? 0.f : v.y;   // selects, not products: what is
+    v.z = (sh && km.z == 0.f) ? 0.f : v.z; v.w = (sh && km.w == 0.f) ? 0.f : v.w;   // masked belongs to another row
+    return v;
   };
 
   // ONEPASS (all output tiles fit the accumulators, the usual case): the first chunk of the stream is
@@ -149,7 +200,11 @@ __global__ __launch_bounds__(kBlock, MSGAT_PROJ_LB) void k_project_mfma(
       const int i = min(i0 + u * kBlock, total - 1);
       const int co = i / Kpad, k = i - co * Kpad;
       const int coc = min(co, Co - 1), kc = min(k, Ci - 1);
-      const float m = m_in_major ? M[((size_t)r * Ci + kc) * Co + coc] : M[((size_t)r * Co + coc) * Ci + kc];
+      // TAPS, row-major taps [R, 2 Co, Cr] = [W0; W1]: M'(co, k) = W_{k / Cr}[co, k % Cr]; in-major (the backward's
+      // transposed pass over [R, 2 Co', Cr'] with Co' = Cr here) is the plain in-major indexing of that same array
+      const float m = m_in_major ? M[((size_t)r * Ci + kc) * Co + coc]
+                      : (TAPS ? M[((size_t)r * 2 * Co + (size_t)(kc / Cr) * Co + coc) * Cr + kc % Cr]
+                              : M[((size_t)r * Co + coc) * Ci + kc]);
       const float a = has_extra ? addvec[r * Co + coc] : 0.f;
       w[u] = (co < Co) ? ((k < Ci) ? m : ((k == Ci) ? a : 0.f)) : 0.f;
     }
@@ -176,7 +231,8 @@ __global__ __launch_bounds__(kBlock, MSGAT_PROJ_LB) void k_project_mfma(
 #pragma unroll
       for (int i = 0; i < kKC; ++i) ring[i] = loadB(i);
     }
-    auto step = [&](int kk, const float4& b) {
+    auto step = [&](int kk, const float4& braw) {
+      const float4 b = TAPS ? tap_fix(kk, braw) : braw;
 #pragma unroll
       for (int mg = 0; mg < MG; ++mg) {
         const float a = wrow[mg * 16 * Kpad + 4 * kk];
@@ -309,6 +365,43 @@ int launch_project_mfma(const SegList& in, const float* M, int m_in_major, const
     default: return launch_project_mg<7>(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, P4, epi, s);
 
   }
+}
+
+// The causal dilated convolution in one pass (k_project_mfma<.., TAPS>): in [G,Cr,P] (a channel slice of a wider
+// tensor when in_gstride > Cr), taps [R, 2 Co', Cr'] row-major; m_in_major = 0: forward (Co' = Co, Cr' = Cr, tshift =
+// -dilation); m_in_major = 1: its input gradient (Co' = Cr, Cr' = Co: the same array read in-major, tshift = +dilation).
+bool project_taps_supported(int Cr, int Co) {
+  int MG;
+  return Cr > 0 && Co >= 8 && proj_passes_mg(Co, &MG) == 1 && project_mfma_lds_bytes(2 * Cr, Co, false) <= 64 * 1024;
+}
+
+int launch_project_taps(const float* in, int in_gstride, const float* taps, int m_in_major, const float* bias,
+                        int bias_rstride, float* out, int G, int Bg, int Cr, int Co, int P, int T, int tshift, hipStream_t s) {
+  if (!project_taps_supported(Cr, Co) || T % 4 != 0 || P % T != 0 || tshift < -T || tshift > T) return MSGAT_ERR_UNSUPPORTED;
+  SegList sin = seg_single(in, Cr);
+  if (in_gstride > Cr) sin.gstride[0] = in_gstride;
+  const SegList sout = seg_single(out, Co);
+  MixEpilogue epi;
+  epi.bias = bias;
+  epi.bias_rstride = bias_rstride;
+  const int P4 = P / 4;
+  int MG;
+  proj_passes_mg(Co, &MG);
+  const size_t lds = project_mfma_lds_bytes(2 * Cr, Co, false);
+  const dim3 grid(cdiv(P4, 64), G);
+#define MSGAT_TAPS(mg)                                                                                                   \
+  case mg:                                                                                                              \
+    hipLaunchKernelGGL((k_project_mfma<mg, false, true, false, false, true>), grid, dim3(kBlock), lds, s, sin, taps,     \
+                       m_in_major, (const float*)nullptr, (const float*)nullptr, (const float4*)nullptr, sout,           \
+                       (float4*)nullptr, Bg, P4, epi, tshift, T);                                                       \
+    break;
+  switch (MG) {
+    MSGAT_TAPS(1) MSGAT_TAPS(2) MSGAT_TAPS(3) MSGAT_TAPS(4) MSGAT_TAPS(5) MSGAT_TAPS(6) MSGAT_TAPS(7)
+    default: return MSGAT_ERR_UNSUPPORTED;
+  }
+#undef MSGAT_TAPS
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -162,6 +162,10 @@ class TACN(nn.Module):
             conv = self.seq[1 + 2 * i]
             if i == 0:
                 taps = self.first_taps(pooled)                                                # [B,2,T,T]
+            elif ops.causal_conv_fused(h.shape[1], conv.out_channels):
+                # constant shift taps: channel mixing, the [B,2Co,N,T] intermediate and the time mixing are one pass
+                h = ops.causal_conv(h, self.stacked_taps(i).unsqueeze(0), conv.bias, d)
+                continue
             else:
                 taps = ops.causal_shift_taps(T, d, mixed.device)                              # [1,2,T,T], cached constant
                 mixed = ops.mix(h, self.stacked_taps(i).unsqueeze(0))

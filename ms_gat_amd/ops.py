@@ -486,6 +486,83 @@ def time_mix(y: torch.Tensor, A: torch.Tensor, bias: Optional[torch.Tensor] = No
     return _TimeMixFunction.apply(y, A, bias)
 
 
+class _CausalConvFunction(torch.autograd.Function):
+    """h[G,Ci,N,T], taps[R,2Co,Ci] = [W0; W1], bias[Co] | [R,Co] | None -> bias + W0 h[t-d] + W1 h[t]: one pass each way
+    (msgat_causal_conv); the weight gradient contracts [dout[t+d]; dout] with h."""
+
+    @staticmethod
+    def forward(ctx, h, taps, bias, dilation: int):
+        L = _lib.lib()
+        h, taps = h.contiguous(), taps.contiguous()
+        G, Ci, N, T = h.shape
+        R, Co = taps.shape[0], taps.shape[1] // 2
+        out = _new(h, G, Co, N, T)
+        b = None if bias is None else bias.contiguous()
+        st = L.msgat_causal_conv(_ptr(h), _ptr(taps), _ptr(b), int(b is not None and b.dim() == 2), _ptr(out), R, G // R,
+                                 Ci, Co, N, T, int(dilation), 0, 0, _stream_handle(h.device))
+        _lib.check(st, "msgat_causal_conv")
+        ctx.dilation, ctx.bias_R = int(dilation), (None if b is None else (b.shape[0] if b.dim() == 2 else 0))
+        ctx.save_for_backward(h, taps)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        h, taps = ctx.saved_tensors
+        G, Ci, N, T = h.shape
+        R, Co = taps.shape[0], taps.shape[1] // 2
+        keep, seg = _as_segment(dout)             # a channel slice of the block's concatenated gradient is read in place
+        stream = _stream_handle(h.device)
+        need = ctx.needs_input_grad
+        dh = dtaps = dbias = None
+        if need[0]:
+            dh = torch.empty_like(h)
+            st = L.msgat_causal_conv(seg.ptr, _ptr(taps), None, 0, _ptr(dh), R, G // R, Ci, Co, N, T, ctx.dilation, 1,
+                                     seg.group_stride, stream)
+            _lib.check(st, "msgat_causal_conv (backward)")
+        want_bias = ctx.bias_R is not None and need[2]
+        if need[1] or want_bias:
+            # d[W0; W1] = [dout[t+d]; dout] h^T: the transposed shift taps applied to dout give the 2 Co gradient rows,
+            # one contraction with h (and a virtual channel of ones: the bias gradient is its tap-1 half)
+            dmixed = _new(h, G, 2 * Co, N, T)
+            st = L.msgat_time_mix(seg.ptr, _ptr(causal_shift_taps(T, ctx.dilation, h.device)), 0, None, _ptr(dmixed), G, Co, 2,
+                                  N, T, 1, 1, seg.group_stride, stream)
+            _lib.check(st, "msgat_time_mix (backward)")
+            ones = int(bool(want_bias))
+            dM = _new(h, R, 2 * Co, Ci + ones)
+            part = _new(h, max(int(L.msgat_contract_segments_partial_floats(R, 2 * Co, Ci + ones)), 1))
+            arr = (_lib.Seg * 1)(_lib.Seg(dmixed.data_ptr(), 2 * Co, 0))
+            st = L.msgat_contract_segments(R, G // R, N, T, arr, 1, _ptr(h), Ci, ones, _ptr(part), _ptr(dM), stream)
+            _lib.check(st, "msgat_contract_segments")
+            if ones:
+                colsum = dM[:, Co:, Ci].contiguous()                      # [R,Co]: sum of dout over the relation's groups and positions
+                dbias = colsum if ctx.bias_R else colsum.sum(dim=0)
+                dM = dM[:, :, :Ci].contiguous()
+            dtaps = dM if need[1] else None
+        return dh, dtaps, dbias, None
+
+
+def causal_conv_fused(Ci: int, Co: int) -> bool:
+    """Whether `causal_conv` has its one-pass kernels for these widths (else use mix_multi + time_mix)."""
+    return bool(_lib.lib().msgat_causal_conv_fused(int(Ci), int(Co)))
+
+
+def causal_conv(h: torch.Tensor, taps: torch.Tensor, bias: Optional[torch.Tensor], dilation: int) -> torch.Tensor:
+    """A causal dilated [1,2] convolution -- `Conv2d(Ci, Co, [1,2], padding=[0,d], dilation=[1,d])` + `Chomp(d)`,
+    msgat.py:69-74 -- with both taps stacked on the output axis, taps [R, 2*Co, Ci] = [W0; W1] (W0 acts on h[t-d]):
+    out = bias + W0 h[t-d] + W1 h[t], R parameter sets over R*Bg groups, in one pass over h."""
+    _require_device_tensor("signals", h)
+    _require_device_tensor("taps", taps, h.device)
+    if h.dim() != 4 or taps.dim() != 3 or taps.shape[2] != h.shape[1] or taps.shape[1] % 2 or h.shape[0] % taps.shape[0]:
+        raise ValueError(f"causal_conv: signals {tuple(h.shape)} and taps {tuple(taps.shape)} do not match")
+    Co = taps.shape[1] // 2
+    if bias is not None and tuple(bias.shape) not in ((Co,), (taps.shape[0], Co)):
+        raise ValueError(f"bias must be [{Co}] or [{taps.shape[0]},{Co}]")
+    if dilation <= 0:
+        raise ValueError("dilation must be positive")
+    return _CausalConvFunction.apply(h, taps, bias, int(dilation))
+
+
 class _NodePoolFunction(torch.autograd.Function):
     """x[B,C,N,T], w[N] -> pooled[B,C,T] = sum_n w[n] x[b,c,n,:]   (attention.py:89)."""
 

@@ -123,8 +123,13 @@ def _tacn_finish(P, prefix: str, dilations, mixed: torch.Tensor, taps0: torch.Te
         if i == 0:
             taps = taps0                                                               # [G,2,T,T]
         else:
+            w = _taps(P, prefix, i)                                                    # [R,2Co,Ci]
+            if ops.causal_conv_fused(w.shape[2], w.shape[1] // 2):
+                # constant shift taps: channel mixing, the [G,2Co,N,T] intermediate and the time mixing are one pass
+                h = ops.causal_conv(h, w, bias, d)
+                continue
             taps = ops.causal_shift_taps(T, d, mixed.device)                           # [1,2,T,T], cached constant
-            (mixed,) = ops.mix_multi([h], _taps(P, prefix, i))
+            (mixed,) = ops.mix_multi([h], w)
         h = ops.time_mix(mixed, taps, bias)
     return h
 

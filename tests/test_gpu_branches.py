@@ -140,6 +140,52 @@ def test_tacn_module(B, Ci, Co, N, T, dil):
     _check(g_mine, _grads(o64, r, dout.double()), ["dx"] + [n for n, _ in m.named_parameters()])
 
 
+@pytest.mark.parametrize("R,Bg,Ci,Co,N,T,d", [
+    (3, 2, 24, 24, 883, 12, 2), (1, 3, 16, 16, 307, 12, 4), (2, 1, 32, 32, 64, 12, 1), (1, 2, 24, 16, 13, 8, 2),
+    (1, 2, 16, 24, 50, 16, 4), (2, 2, 24, 24, 5, 4, 1), (1, 2, 16, 16, 20, 4, 4), (1, 1, 24, 24, 1, 12, 3),
+    (1, 2, 40, 72, 33, 12, 2),
+])
+def test_causal_conv_is_the_dilated_convolution_and_its_autograd_in_one_pass_each(R, Bg, Ci, Co, N, T, d):
+    """ops.causal_conv = Conv2d(Ci, Co, [1,2], padding=[0,d], dilation=[1,d]) + Chomp(d) (msgat.py:69-74) for R parameter
+    sets: forward and input gradient are ONE pass each (k_project_mfma<.., TAPS>: the shifted tap is an unaligned load of
+    the same row of T); against torch's own convolution in float64, and the gradient also when it arrives as a channel
+    slice of a wider tensor.  The two-pass form (channel mixing + time mixing) must agree to rounding."""
+    from ms_gat_amd import ops
+    dev, G = _dev(), R * Bg
+    gen = torch.Generator().manual_seed(Ci + 3 * Co + d)
+    assert ops.causal_conv_fused(Ci, Co)
+    h = _rand(gen, G, Ci, N, T).requires_grad_(True)
+    w = _rand(gen, R, Co, Ci, 1, 2, scale=(2 * Ci) ** -0.5)          # nn.Conv2d weight layout per relation
+    bias = _rand(gen, R, Co, scale=0.3)
+    taps = torch.cat([w[..., 0, 0], w[..., 0, 1]], dim=1).contiguous().requires_grad_(True)   # [R, 2Co, Ci] = [W0; W1]
+    bias_l = bias.clone().requires_grad_(True)
+    wide = _rand(gen, G, Co + 5, N, T)
+    dout = wide[:, 2:2 + Co]                                          # a channel slice: read in place
+    out = ops.causal_conv(h, taps, bias_l, d)
+    out.backward(dout)
+    # float64 reference: the reference's own module sequence, relation by relation
+    h64 = h.detach().double().requires_grad_(True)
+    w64, b64 = w.double().requires_grad_(True), bias.double().requires_grad_(True)
+    refs = []
+    for r in range(R):
+        y = torch.nn.functional.conv2d(h64[r * Bg:(r + 1) * Bg], w64[r], b64[r], padding=(0, d), dilation=(1, d))
+        refs.append(y[..., : y.size(-1) - d])
+    ref = torch.cat(refs)
+    ref.backward(dout.double())
+    what = f"causal_conv R={R} {Ci}->{Co} N={N} T={T} d={d}"
+    for key, got, want in (("out", out.detach(), ref.detach()), ("dh", h.grad, h64.grad), ("dbias", bias_l.grad, b64.grad),
+                           ("dtaps", taps.grad, torch.cat([w64.grad[..., 0, 0], w64.grad[..., 0, 1]], dim=1))):
+        err = rel_err(got, want)
+        record_err(what, key, err, 1e-5)
+        assert err < 1e-5, key
+    # the two passes it replaces
+    (mixed,) = ops.mix_multi([h.detach()], taps.detach())
+    two = ops.time_mix(mixed, ops.causal_shift_taps(T, d, dev), bias)
+    assert rel_err(out.detach(), two) < 2e-6
+    for _ in range(2):   # repeats are bit-identical
+        assert torch.equal(ops.causal_conv(h.detach(), taps.detach(), bias, d), out.detach())
+
+
 @pytest.mark.parametrize("B,Ci,Co,N,T", [(2, 3, 24, 21, 12), (3, 72, 24, 50, 12), (32, 72, 24, 883, 12)])
 def test_cacn_module(B, Ci, Co, N, T):
     from ms_gat_amd import model
