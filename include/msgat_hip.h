@@ -340,6 +340,14 @@ size_t msgat_time_mix_partial_floats(int32_t G, int32_t K, int32_t T);
  * src_group_stride: src is a channel slice of a [G, src_group_stride, N, T] tensor (0: contiguous by itself).
  * msgat_causal_conv_fused(Ci, Co) = 1 when both directions have a one-pass form for these widths (else the entry point
  * returns MSGAT_ERR_UNSUPPORTED and the caller runs the two passes). */
+/* msgat_causal_conv_grad_weight: dtaps[r, k*Co + co, ci] = sum_{g in r, n, t} dout[g,co,n,t + (k == 0 ? d : 0)] h[g,ci,n,t]
+ * ([R, 2*Co, Ci + with_ones]; with_ones: column Ci = the sums of the gradient rows, whose tap-1 half [Co, 2*Co) is the
+ * bias gradient) -- the gradient rows [dout[t+d]; dout] are virtual (time-shifted reads of dout inside the contraction's
+ * staging loads), nothing [G,2*Co,N,T] is written.  partials: msgat_contract_segments_partial_floats(R, 2*Co, Ci + with_ones).
+ * dout may be a channel slice of a [G, dout_group_stride, N, T] tensor (0: contiguous). */
+int msgat_causal_conv_grad_weight(const float* dout, int32_t dout_group_stride, const float* h, float* partials, float* dtaps,
+                                  int32_t R, int32_t Bg, int32_t Ci, int32_t Co, int32_t N, int32_t T, int32_t dilation,
+                                  int32_t with_ones, void* stream);
 int msgat_causal_conv_fused(int32_t Ci, int32_t Co);
 int msgat_causal_conv(const float* src, const float* taps, const float* bias, int32_t bias_per_relation, float* dst,
                       int32_t R, int32_t Bg, int32_t Ci, int32_t Co, int32_t N, int32_t T, int32_t dilation,

@@ -89,6 +89,8 @@ _PROTOTYPES = {
     "msgat_time_mix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 8
                        + [C.c_void_p]),
     "msgat_time_mix_partial_floats": (C.c_size_t, [C.c_int32] * 3),
+    "msgat_causal_conv_grad_weight": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 8
+                                      + [C.c_void_p]),
     "msgat_causal_conv_fused": (C.c_int, [C.c_int32, C.c_int32]),
     "msgat_causal_conv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p] + [C.c_int32] * 9 + [C.c_void_p]),
     "msgat_time_mix_grad_matrix": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 6 + [C.c_void_p]),

@@ -311,6 +311,25 @@ extern "C" int msgat_causal_conv(const float* src, const float* taps, const floa
   return launch_project_taps(src, src_group_stride, taps, 1, nullptr, 0, dst, G, Bg, Co, Ci, P, T, d, s);
 }
 
+extern "C" int msgat_causal_conv_grad_weight(const float* dout, int32_t dout_group_stride, const float* h, float* partials,
+                                             float* dtaps, int32_t R, int32_t Bg, int32_t Ci, int32_t Co, int32_t N,
+                                             int32_t T, int32_t dilation, int32_t with_ones, void* stream) {
+  if (!dout || !h || !partials || !dtaps) return MSGAT_ERR_NULL;
+  int st = check_rgnt(R, Bg, N, T);
+  if (st) return st;
+  if (Ci <= 0 || Co <= 0 || Ci > kMaxC || 2 * Co > kMaxC || dilation <= 0 || (with_ones != 0 && with_ones != 1))
+    return MSGAT_ERR_SHAPE;
+  if (dout_group_stride != 0 && (dout_group_stride < Co || dout_group_stride > 4 * kMaxC)) return MSGAT_ERR_SHAPE;
+  SegList A = seg_single(dout, Co);
+  if (dout_group_stride > Co) A.gstride[0] = dout_group_stride;
+  const int Cbx = Ci + with_ones;
+  hipStream_t s = (hipStream_t)stream;
+  int nblk = 0;
+  st = launch_chanpair_shifted(A, h, partials, R, Bg, Cbx, N * T, chanpair_mfma_blocks(R), with_ones, dilation, T, s, &nblk);
+  if (st) return st;
+  return launch_reduce_groups(partials, R, nblk, 2 * Co * Cbx, dtaps, s);
+}
+
 extern "C" size_t msgat_time_mix_partial_floats(int32_t G, int32_t K, int32_t T) {
   if (G <= 0 || K < 1 || K > 2 || !t_supported(T)) return 0;
   return tmix_partial_floats(G, K, T);

@@ -249,6 +249,8 @@ int launch_chanpair_mix_wide(const SegList& A, const float* B, float* part, int 
                              int b_ones, const float* M, float* mixout, hipStream_t s, int* nblk_used, int* done);
 int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
                          int b_ones, hipStream_t s, int* nblk_used);
+int launch_chanpair_shifted(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
+                            int b_ones, int dilation, int T, hipStream_t s, int* nblk_used);
 bool project_taps_supported(int Cr, int Co);
 int launch_project_taps(const float* in, int in_gstride, const float* taps, int m_in_major, const float* bias,
                         int bias_rstride, float* out, int G, int Bg, int Cr, int Co, int P, int T, int tshift, hipStream_t s);

@@ -437,14 +437,25 @@ constexpr int kTile = 32 * kCpWaves;   // positions per staged tile (default): 3
 // TILE = 128: half-length tiles (512-B row pieces, two rows per wave-instruction, 4 k-steps per wave).  Half the LDS
 // per row, so [80 x 80] and [112 x 80] channel blocks fit: a 72- or 98-channel gradient against 73 channels is ONE
 // pass over both operands instead of two z-blocks that each re-read B.
-template <int MA, int NB, bool TWO = true, int TILE = kTile>
+// SHIFT: the A operand's Cr real rows appear as 2 Cr virtual rows -- row a < Cr is row a read `ashift` timesteps LATER
+// (A[a, n, t + ashift], zero where t + ashift >= T), row a >= Cr is row a - Cr as it stands: [dout[t+d]; dout], the
+// gradient at the two taps of a causal dilated convolution (msgat.py:69-74), without a pass that writes it out.  The
+// shifted float4 is an unaligned load of the same row of T (a float4 never straddles rows: T % 4 == 0); the last
+// float4 of a slab, where that load would leave the tensor, is its own float4 moved in registers.
+struct TimeShift {
+  int d = 0;   // 0: no virtual rows
+  int T = 4;
+};
+
+template <int MA, int NB, bool TWO = true, int TILE = kTile, bool SHIFT = false>
 __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
     SegList A, const float* __restrict__ B, float* __restrict__ part, int Cb, int P, int Bg, int nzb, int b_ones,
-    int nza, int nblk, int R) {
+    int nza, int nblk, int R, TimeShift ts) {
   // b_ones: B's last channel (index Cb-1) is a virtual row of ones, so part[a, Cb-1] = sum_p A[a,p] -- the bias
   // gradient of a 1x1 convolution comes out of the contraction that computes its weight gradient
   const int Cbr = Cb - b_ones;  // channels B really has
-  const int Ca = A.total();
+  const int Cr = A.total();     // rows A really has
+  const int Ca = SHIFT ? 2 * Cr : Cr;
   extern __shared__ float4 lds4[];
   constexpr int kLPR = TILE / 4;        // lanes per row piece (64: one row per wave-instruction)
   constexpr int kRPI = 64 / kLPR;        // rows per wave-instruction
@@ -499,6 +510,8 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
   const int lrow = lane / kLPR, lcol = lane % kLPR;
   const float* src[RPW];  // row pointer for group 0 of the relation
   int gstride[RPW];       // elements between consecutive groups of that row
+  unsigned shifted = 0;   // SHIFT: bit k = instruction k of this lane stages a time-shifted row
+  static_assert(RPW <= 32, "one flag bit per staging instruction");
 #pragma unroll
   for (int k = 0; k < RPW; ++k) {
     const int rr = (wave + kCpWaves * k) * kRPI + lrow;
@@ -506,7 +519,9 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
     const size_t g0 = (size_t)r * Bg;
     const float* p;
     if (row < ca) {  // A channel a0 + row: its segment's tensor and group stride
-      const int a = a0 + row;
+      const int av = a0 + row;                       // virtual row
+      const int a = SHIFT ? (av < Cr ? av : av - Cr) : av;
+      if (SHIFT && av < Cr) shifted |= 1u << k;
       int sk = 0;
 #pragma unroll
       for (int i = 1; i < kMaxSeg; ++i) sk += (i < A.n && a >= A.begin[i]) ? 1 : 0;
@@ -522,26 +537,46 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
     src[k] = p + 4 * lcol;
   }
   const int plast = P - 4 - 4 * lcol;  // clamp so that the float4 stays inside the row (P % 4 == 0)
-  auto fetch = [&](int t, float4 (&regs)[RPW]) {  // t relative to t0, clamped to the run
+  auto fetch = [&](int t, float4 (&regs)[RPW], int& pos) {  // t relative to t0, clamped to the run
     const int tau = t0 + min(t, ntile - 1);
     const int b = tau / tpg;
     const int p0 = (tau - b * tpg) * TILE;
     const float keep = (p0 + 4 * lcol < P) ? 1.f : 0.f;
     const int poff = min(p0, plast);
+    pos = poff + 4 * lcol;                                   // SHIFT: the lane's first position in the slab, for stash()
+    const int soff = (SHIFT && pos + ts.d <= P - 4) ? ts.d : 0;   // the slab's last float4 stays put (moved in stash())
 #pragma unroll
     for (int k = 0; k < RPW; ++k) {
       // tail positions are zeroed by a multiply, not a select: hipcc sinks a load that only feeds a
       // select into a branch, and a load inside a branch costs the counted vmcnt waits (the
       // clamped address re-reads finite in-row data, so x * 0 is exact)
-      const float4 v = *reinterpret_cast<const float4*>(src[k] + (size_t)b * gstride[k] + poff);
+      const float* gp = src[k] + (size_t)b * gstride[k] + poff;
+      float4 v;
+      if (SHIFT) v = load_global_a4(gp + (((shifted >> k) & 1u) ? soff : 0));
+      else v = *reinterpret_cast<const float4*>(gp);
       regs[k] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
     }
   };
-  auto stash = [&](const float4 (&regs)[RPW]) {
+  auto stash = [&](const float4 (&regs)[RPW], int pos) {
+    // SHIFT (when the values are consumed, not in front of the loads): element e of a shifted row's float4 is timestep
+    // tq + e + d of its row of T and exists iff that is < T; at the slab's last float4 the own values move left by d
+    const int tq = SHIFT ? pos % ts.T : 0;
+    const bool atend = SHIFT && pos + ts.d > P - 4;
+    const int d = ts.d;
 #pragma unroll
     for (int k = 0; k < RPW; ++k) {
       const int rr = (wave + kCpWaves * k) * kRPI + lrow;
-      if (rr < kZeroRow) lds4[rr * kRowF4 + lcol] = regs[k];
+      float4 v = regs[k];
+      if (SHIFT) {
+        const bool sh = (shifted >> k) & 1u;
+        const float4 left = make_float4(d == 1 ? v.y : (d == 2 ? v.z : (d == 3 ? v.w : 0.f)),
+                                        d == 1 ? v.z : (d == 2 ? v.w : 0.f), d == 1 ? v.w : 0.f, 0.f);
+        const bool mv = sh && atend;
+        v.x = mv ? left.x : v.x; v.y = mv ? left.y : v.y; v.z = mv ? left.z : v.z; v.w = mv ? left.w : v.w;
+        v.x = (sh && tq + 0 + d >= ts.T) ? 0.f : v.x; v.y = (sh && tq + 1 + d >= ts.T) ? 0.f : v.y;
+        v.z = (sh && tq + 2 + d >= ts.T) ? 0.f : v.z; v.w = (sh && tq + 3 + d >= ts.T) ? 0.f : v.w;
+      }
+      if (rr < kZeroRow) lds4[rr * kRowF4 + lcol] = v;
     }
   };
 
@@ -586,32 +621,34 @@ __global__ __launch_bounds__(kCpBlock) void k_chanpair_mfma(
   if (TWO) {
     if (ntile > 0) {
       float4 ra[RPW], rb[RPW];
-      fetch(0, ra);
-      fetch(1, rb);
+      int pa, pb;
+      fetch(0, ra, pa);
+      fetch(1, rb, pb);
       MSGAT_STAMP(1);
       for (int t = 0; t < ntile; t += 2) {
         lds_barrier();  // every wave is done reading the previous tile
-        stash(ra);
+        stash(ra, pa);
         lds_barrier();
         if (t == 0) MSGAT_STAMP(2);
-        fetch(t + 2, ra);
+        fetch(t + 2, ra, pa);
         multiply();
         if (t == 0) MSGAT_STAMP(3);
         lds_barrier();
-        stash(rb);
+        stash(rb, pb);
         lds_barrier();
-        fetch(t + 3, rb);
+        fetch(t + 3, rb, pb);
         if (t + 1 < ntile) multiply();  // wave-uniform; LDS reads and MFMAs only
       }
     }
   } else if (ntile > 0) {
     float4 ra[RPW];
-    fetch(0, ra);
+    int pa;
+    fetch(0, ra, pa);
     for (int t = 0; t < ntile; ++t) {
       lds_barrier();
-      stash(ra);
+      stash(ra, pa);
       lds_barrier();
-      fetch(t + 1, ra);  // clamped to the run: the last trip re-reads its own tile
+      fetch(t + 1, ra, pa);  // clamped to the run: the last trip re-reads its own tile
       multiply();
     }
   }
@@ -1003,10 +1040,13 @@ int chanpair_mfma_blocks(int R) {
   return max(1, ncu / R);
 }
 
+static thread_local TimeShift g_time_shift;   // set by launch_chanpair_mfma for the duration of its dispatch cascade
+
 template <int MA, int NB, bool TWO = true, int TILE = kTile>
 static int launch_chanpair_t(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk_max,
                              int b_ones, hipStream_t s, int* nblk_used) {
-  const int Ca = A.total();
+  const TimeShift ts = g_time_shift;
+  const int Ca = ts.d ? 2 * A.total() : A.total();
   const int nza = cdiv(Ca, MA * 16), nzb = cdiv(Cb, NB * 16);
   const int nz = nza * nzb;
   // several z-blocks: all of them resident at once (one block per CU), so fewer, longer runs per relation
@@ -1015,17 +1055,23 @@ static int launch_chanpair_t(const SegList& A, const float* B, float* part, int 
   // tile rows + the zero row + the ones row; the reduction re-uses the buffer a few tiles at a time
   const size_t lds = sizeof(float4) * (size_t)(((MA + NB) * 16 + 2) * (TILE / 4 + 1));
   if (g_form_probe) {
-    snprintf(g_form_probe->name, sizeof g_form_probe->name, "k_chanpair_mfma<%d,%d,%s,%d>", MA, NB, TWO ? "true" : "false", TILE);
+    snprintf(g_form_probe->name, sizeof g_form_probe->name, "k_chanpair_mfma<%d,%d,%s,%d%s>", MA, NB, TWO ? "true" : "false", TILE,
+             ts.d ? ",shift" : "");
     g_form_probe->nza = nza; g_form_probe->nzb = nzb;
     return MSGAT_OK;
   }
-  {
-    static LdsGrant granted;
-    if (int st = grant_dynamic_lds(&k_chanpair_mfma<MA, NB, TWO, TILE>, lds, granted)) return st;
-  }
   const dim3 grid = nz > 1 ? dim3((unsigned)cdiv(nblk * R, 8) * 8 * nz) : dim3(nblk, R, 1);
-  hipLaunchKernelGGL((k_chanpair_mfma<MA, NB, TWO, TILE>), grid, dim3(kCpBlock), lds, s, A, B, part, Cb, P, Bg, nzb, b_ones,
-                     nza, nblk, R);
+  if (ts.d) {
+    static LdsGrant granted;
+    if (int st = grant_dynamic_lds(&k_chanpair_mfma<MA, NB, TWO, TILE, true>, lds, granted)) return st;
+    hipLaunchKernelGGL((k_chanpair_mfma<MA, NB, TWO, TILE, true>), grid, dim3(kCpBlock), lds, s, A, B, part, Cb, P, Bg, nzb,
+                       b_ones, nza, nblk, R, ts);
+  } else {
+    static LdsGrant granted;
+    if (int st = grant_dynamic_lds(&k_chanpair_mfma<MA, NB, TWO, TILE, false>, lds, granted)) return st;
+    hipLaunchKernelGGL((k_chanpair_mfma<MA, NB, TWO, TILE, false>), grid, dim3(kCpBlock), lds, s, A, B, part, Cb, P, Bg, nzb,
+                       b_ones, nza, nblk, R, ts);
+  }
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
@@ -1169,13 +1215,25 @@ int launch_chanpair_mix_wide(const SegList& A, const float* B, float* part, int 
   return launch_glds_mix(A, B, part, R, Bg, Cb, P, nblk, b_ones, M, nullptr, mixout, s, nblk_used, done);
 }
 
+// A with time-shifted virtual rows (k_chanpair_mfma<.., SHIFT>): part is [2 Cr x Cb] for A's Cr real rows
+int launch_chanpair_shifted(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
+                            int b_ones, int dilation, int T, hipStream_t s, int* nblk_used) {
+  if (dilation <= 0 || T % 4 != 0 || P % T != 0) return MSGAT_ERR_SHAPE;
+  g_time_shift.d = dilation < T ? dilation : T;
+  g_time_shift.T = T;
+  const int st = launch_chanpair_mfma(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used);
+  g_time_shift = TimeShift();
+  return st;
+}
+
 int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P, int nblk,
                          int b_ones, hipStream_t s, int* nblk_used) {
-  const int Ca = A.total();
+  const bool shift = g_time_shift.d != 0;     // the LDS-DMA forms cannot shift: register-staged kernel
+  const int Ca = shift ? 2 * A.total() : A.total();
 #ifndef MSGAT_NO_GLDS
   // LDS-DMA staging where the list above has a block for the shape: the fewest z-blocks over A (each re-reads B) whose
   // row count some form of this width covers, the smallest such form
-  if (glds_rows_ok(P) && Ca > 16) {
+  if (!shift && glds_rows_ok(P) && Ca > 16) {
     // fewest rows staged in total: nzb z-blocks over B each stage A, nza z-blocks over A each stage B
     int best_ma = 0, best_nb = 0;
     long best_cost = -1;

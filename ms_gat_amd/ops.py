@@ -522,18 +522,14 @@ class _CausalConvFunction(torch.autograd.Function):
             _lib.check(st, "msgat_causal_conv (backward)")
         want_bias = ctx.bias_R is not None and need[2]
         if need[1] or want_bias:
-            # d[W0; W1] = [dout[t+d]; dout] h^T: the transposed shift taps applied to dout give the 2 Co gradient rows,
-            # one contraction with h (and a virtual channel of ones: the bias gradient is its tap-1 half)
-            dmixed = _new(h, G, 2 * Co, N, T)
-            st = L.msgat_time_mix(seg.ptr, _ptr(causal_shift_taps(T, ctx.dilation, h.device)), 0, None, _ptr(dmixed), G, Co, 2,
-                                  N, T, 1, 1, seg.group_stride, stream)
-            _lib.check(st, "msgat_time_mix (backward)")
+            # d[W0; W1] = [dout[t+d]; dout] h^T with the 2 Co gradient rows read as time-shifted views of dout inside the
+            # contraction (and a virtual channel of ones: the bias gradient is its tap-1 half)
             ones = int(bool(want_bias))
             dM = _new(h, R, 2 * Co, Ci + ones)
             part = _new(h, max(int(L.msgat_contract_segments_partial_floats(R, 2 * Co, Ci + ones)), 1))
-            arr = (_lib.Seg * 1)(_lib.Seg(dmixed.data_ptr(), 2 * Co, 0))
-            st = L.msgat_contract_segments(R, G // R, N, T, arr, 1, _ptr(h), Ci, ones, _ptr(part), _ptr(dM), stream)
-            _lib.check(st, "msgat_contract_segments")
+            st = L.msgat_causal_conv_grad_weight(seg.ptr, seg.group_stride, _ptr(h), _ptr(part), _ptr(dM), R, G // R, Ci, Co,
+                                                 N, T, ctx.dilation, ones, stream)
+            _lib.check(st, "msgat_causal_conv_grad_weight")
             if ones:
                 colsum = dM[:, Co:, Ci].contiguous()                      # [R,Co]: sum of dout over the relation's groups and positions
                 dbias = colsum if ctx.bias_R else colsum.sum(dim=0)
