@@ -88,6 +88,9 @@ inline int grant_dynamic_lds(K kernel, size_t lds, LdsGrant& granted) {
   return MSGAT_OK;
 }
 
+// the MFMA projection's matrix (+ row-pointer table) may take this much LDS: two blocks per CU still fit 160 KiB
+constexpr int kProjLdsMax = 78 * 1024;
+
 inline bool t_supported(int T) { return T == 4 || T == 8 || T == 12 || T == 16; }
 
 // how many channels of an [N,T] fp32 slab fit the per-block LDS budget

@@ -328,9 +328,15 @@ static int launch_project_mg(const SegList& in, const float* M, int m_in_major, 
   const bool one = cdiv(Co, 16) <= MG;
   const bool segs = in.n > 1 || out.n > 1 || epi.add.n > 1;
   const bool has_add = epi.add.n > 0;
+  // (matrices beyond 64 KiB of LDS -- 96 -> 130 channels, the merged mixing of msgat96 -- need the kernel's dynamic-LDS
+  // ceiling raised once per device; up to kProjLdsMax two blocks still share a CU)
 #define MSGAT_PROJ(Q, ONE, SG, AD)                                                                                      \
-  hipLaunchKernelGGL((k_project_mfma<MG, Q, ONE, SG, AD>), grid, dim3(kBlock), lds, s, in, M, m_in_major, qvec, addvec, \
-                     (const float4*)extra, out, (float4*)q, Bg, P4, epi)
+  do {                                                                                                                  \
+    static LdsGrant granted;                                                                                            \
+    if (int st_ = grant_dynamic_lds(&k_project_mfma<MG, Q, ONE, SG, AD>, lds, granted)) return st_;                      \
+    hipLaunchKernelGGL((k_project_mfma<MG, Q, ONE, SG, AD>), grid, dim3(kBlock), lds, s, in, M, m_in_major, qvec,        \
+                       addvec, (const float4*)extra, out, (float4*)q, Bg, P4, epi);                                     \
+  } while (0)
 #define MSGAT_PROJ2(Q, ONE)                                                          \
   do {                                                                               \
     if (segs) { if (has_add) MSGAT_PROJ(Q, ONE, true, true); else MSGAT_PROJ(Q, ONE, true, false); }   \
@@ -372,7 +378,7 @@ int launch_project_mfma(const SegList& in, const float* M, int m_in_major, const
 // -dilation); m_in_major = 1: its input gradient (Co' = Cr, Cr' = Co: the same array read in-major, tshift = +dilation).
 bool project_taps_supported(int Cr, int Co) {
   int MG;
-  return Cr > 0 && Co >= 8 && proj_passes_mg(Co, &MG) == 1 && project_mfma_lds_bytes(2 * Cr, Co, false) <= 64 * 1024;
+  return Cr > 0 && Co >= 8 && proj_passes_mg(Co, &MG) == 1 && project_mfma_lds_bytes(2 * Cr, Co, false) <= (size_t)kProjLdsMax;
 }
 
 int launch_project_taps(const float* in, int in_gstride, const float* taps, int m_in_major, const float* bias,
@@ -390,7 +396,10 @@ int launch_project_taps(const float* in, int in_gstride, const float* taps, int 
   const size_t lds = project_mfma_lds_bytes(2 * Cr, Co, false);
   const dim3 grid(cdiv(P4, 64), G);
 #define MSGAT_TAPS(mg)                                                                                                   \
-  case mg:                                                                                                              \
+  case mg: {                                                                                                            \
+    static LdsGrant granted;                                                                                            \
+    if (int st_ = grant_dynamic_lds(&k_project_mfma<mg, false, true, false, false, true>, lds, granted)) return st_;     \
+  }                                                                                                                     \
     hipLaunchKernelGGL((k_project_mfma<mg, false, true, false, false, true>), grid, dim3(kBlock), lds, s, sin, taps,     \
                        m_in_major, (const float*)nullptr, (const float*)nullptr, (const float4*)nullptr, sout,           \
                        (float4*)nullptr, Bg, P4, epi, tshift, T);                                                       \
@@ -1194,12 +1203,16 @@ static int launch_glds_mix(const SegList& A, const float* B, float* part, int R,
   if (lab_env("MSGAT_LAB_NZB", 0) > 0) nzb_lo = nzb_hi = lab_env("MSGAT_LAB_NZB", 0);
 #endif
   for (int nzb = nzb_lo; nzb <= nzb_hi; ++nzb) {           // z-blocks over B: each stages all of A
-    const int NB = cdiv(cdiv(Cb, nzb), 16);
-    if (cdiv(Cb, NB * 16) != nzb) continue;      // the kernel derives nzb from the block width
-    for (int MA = cdiv(Ca, 16); MA <= cdiv(Ca, 16) + 1; ++MA) {
-      if (!glds_form_exists(MA, NB, true)) continue;
-      const int st = launch_glds_form(MA, NB, true, A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used, mix, done);
-      if (st || *done) return st;
+    // the narrowest block that covers the z-block's columns, or one tile wider (columns past the operand read the zero
+    // row): the list is written for the widths WITH a bias column (49 / 73 / 97), and the same mixing without one
+    // (48 / 72 / 96 columns: the merged channel mixing of the stacked schedule) must not fall back to two passes
+    for (int NB = cdiv(cdiv(Cb, nzb), 16); NB <= cdiv(cdiv(Cb, nzb), 16) + 1; ++NB) {
+      if (cdiv(Cb, NB * 16) != nzb) continue;      // the kernel derives nzb from the block width
+      for (int MA = cdiv(Ca, 16); MA <= cdiv(Ca, 16) + 1; ++MA) {
+        if (!glds_form_exists(MA, NB, true)) continue;
+        const int st = launch_glds_form(MA, NB, true, A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used, mix, done);
+        if (st || *done) return st;
+      }
     }
   }
   return MSGAT_OK;

@@ -229,7 +229,7 @@ int launch_project_seg(const SegList& in, const float* M, int m_in_major, const 
                        const MixEpilogue& epi, hipStream_t s) {
   const int Ci = in.total(), Co = out.total();
   // matrix cores whenever there are enough output channels to fill a tile and the matrix fits LDS
-  if (Co >= 8 && project_mfma_lds_bytes(Ci, Co, addvec != nullptr) <= 64 * 1024)
+  if (Co >= 8 && project_mfma_lds_bytes(Ci, Co, addvec != nullptr) <= (size_t)kProjLdsMax)
     return launch_project_mfma(in, M, m_in_major, qvec, addvec, extra, out, q, G, Bg, P, epi, s);
   const int P4 = P / 4;
   // VALU fallback (few outputs or a very large matrix): widest tile that divides the work evenly; 24 and 32 cover the reference's widths

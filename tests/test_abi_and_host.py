@@ -317,9 +317,13 @@ def test_every_convolution_backward_of_the_registry_models_takes_a_one_pass_lds_
     fall-back to the register-staged kernels plus a projection pass is what `msgat_contract_form_name` makes visible."""
     from ms_gat_amd import _lib
     co = hidden // 3
+    # (the merged mixing carries a bias column in the per-component schedule, model.MEAM._merged_branches, and none in the
+    # stacked one, stacked._meam -- round 5 found the bias-less 48- and 96-channel shapes falling back to two passes)
     sites = {"GACN projection [Co+1 x C]": (co + 1, hidden, False),
              "merged channel mixing [4Co+2 x C+1]": (4 * co + 2, hidden, True),
-             "residual convolution [C x C+1]": (hidden, hidden, True)}
+             "merged channel mixing, no bias column [4Co+2 x C]": (4 * co + 2, hidden, False),
+             "residual convolution [C x C+1]": (hidden, hidden, True),
+             "residual convolution, no bias column [C x C]": (hidden, hidden, False)}
     for P in (512, 64 * 12, 307 * 12, 883 * 12):
         for what, (Ca, Cb, ones) in sites.items():
             name = _lib.contract_form_name(Ca, Cb, ones, P, True)

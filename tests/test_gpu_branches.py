@@ -506,6 +506,10 @@ def test_contract_segments_matches_float64_and_repeats_bit_for_bit(segs, Cb, one
     ((96,), 96, 1, 883, 1),               # msgat96 residual convolution (96 x 97): <6,4,64,3,2>, two z-blocks
     ((96,), 96, 1, 64, 3),                # the same at P = 768
     ((33,), 96, 0, 307, 2),               # <3,6,64,3,2>, no bias column
+    ((16, 32, 16, 1, 1), 48, 0, 883, 2),  # msgat48 merged mixing WITHOUT a bias column (the stacked schedule): a block one
+    ((48,), 48, 0, 307, 2),               #   tile wider than its 48 columns, <5,4,64,3,2> / <3,4,128,3,1>
+    ((32, 64, 32, 1, 1), 96, 0, 883, 1),  # msgat96 likewise: <9,4,64,3,2>, two z-blocks of 48 columns in 64-wide blocks
+    ((96,), 96, 0, 64, 2),                #   <6,4,64,3,2>
 ])
 def test_contract_mix_segments_gives_matrix_bias_and_input_gradients_in_one_pass(segs, Cb, ones, N, Bg):
     """msgat_contract_mix_segments = the backward of y = M x (+ bias): dM (| dbias) AND dx from one pass over dy and x,

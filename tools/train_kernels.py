@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel GPU time of the msgat72 TRAINING step (bench.TrainStep, engine.Trainer) from torch's profiler:
-    python tools/train_kernels.py [--R 3] [--unstacked] [--width 72] [--lib build/lab/x.so] [--top 40]
+    python tools/train_kernels.py [--R 3] [--unstacked] [--hidden 72] [--lib build/lab/x.so] [--top 40]
 --unstacked evaluates the components one by one (the reference's loop, msgat.py:204) instead of the stacked schedule."""
 import argparse
 import os
@@ -13,6 +13,7 @@ ap.add_argument("--R", type=int, default=3)
 ap.add_argument("--steps", type=int, default=6)
 ap.add_argument("--top", type=int, default=40)
 ap.add_argument("--unstacked", action="store_true")
+ap.add_argument("--hidden", type=int, default=72, help="48 | 72 | 96: the model of the registry (msgat.py:220-229)")
 ap.add_argument("--lib", default="")
 a = ap.parse_args()
 from ms_gat_amd import _lib  # noqa: E402
@@ -23,7 +24,7 @@ import bench  # noqa: E402
 from torch.profiler import ProfilerActivity, profile  # noqa: E402
 
 dev = torch.device("cuda:0")
-ts = bench.TrainStep(dict(bench.CFG4, R=a.R), dev, stacked=not a.unstacked)
+ts = bench.TrainStep(dict(bench.CFG4, R=a.R, hidden=a.hidden), dev, stacked=not a.unstacked)
 ts.run(4)
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
