@@ -18,7 +18,7 @@ ALG = {  # algorithmic bytes per launch, the workloads of tools/k
     "msgat::k_agg_lds<3, false>": 2 * 4 * G * Co * N * T + 4 * G * nnz + 8 * nnz + 4 * (N + 1),
     "msgat::k_agg_sell<3>": 2 * 4 * sG * sCu * sN * T + 4 * sG * snnz + 8 * snnz + 4 * (sN + 1),
     "msgat::k_sddmm_sellreg<3>": 2 * 4 * sG * sCu * sN * T,
-    "msgat::k_project_mfma<2, true, true, false, false>": 4 * G * N * T * (C + Co + 1),
+    "msgat::k_project_mfma<2, true, true, false, false, false>": 4 * G * N * T * (C + Co + 1),
     "msgat::k_chanpair_glds<2, 5, 128, 3, 0>": 4 * G * N * T * (Co + 1 + C),          # dW, dalpha alone (kbench contract)
     "msgat::k_chanpair_glds<2, 5, 128, 3, 1>": 4 * G * N * T * (Co + 1 + 2 * C),      # dW, dalpha AND dx (the hot path's pass)
     "msgat::k_chanpair_glds<7, 5, 64, 3, 2>": 4 * G * N * T * (98 + 2 * C),           # 98 x 73 mixing backward, one pass
