@@ -439,6 +439,15 @@ int msgat_head_grad_signal(const float* dout, const float* W, float* dx, int32_t
 size_t msgat_head_grad_weight_partial_floats(int32_t C, int32_t T, int32_t T_out, int32_t R);
 int msgat_head_grad_weight(const float* dout, const float* x, float* dWc, float* partials, int32_t B, int32_t C,
                            int32_t N, int32_t T, int32_t T_out, int32_t R, void* stream);
+/* msgat_layernorm_head_backward: the head's input gradient (msgat_head_grad_signal) AND the backward of the LayerNorm in
+ * front of it (msgat.py:158-159: fc(ln(x).transpose(1, 3))) in ONE pass over x: the [B,C,N,T] gradient between the two is
+ * built row by row in registers and consumed on the spot.  x is the LayerNorm's INPUT; relu_mask as in
+ * msgat_layernorm_backward; dln_weight / dln_bias [R,T] (either may be NULL);
+ * partials: msgat_layernorm_head_backward_partial_floats(B, C, N, T) floats. */
+size_t msgat_layernorm_head_backward_partial_floats(int32_t B, int32_t C, int32_t N, int32_t T);
+int msgat_layernorm_head_backward(const float* dout, const float* W, const float* x, const float* ln_weight, float* dx,
+                                  float* dln_weight, float* dln_bias, float* partials, int32_t B, int32_t C, int32_t N,
+                                  int32_t T, int32_t To, int32_t R, float eps, int32_t relu_mask, void* stream);
 
 /* ---- device: the tiny attention matrices of a MEAM block, one launch each way ----
  * In the reference each is a chain of batched [T x T] / [C x C] matmuls, a softmax, transposes, pads and stacks

@@ -590,6 +590,23 @@ extern "C" int msgat_head_grad_signal(const float* dout, const float* W, float* 
   return launch_head_dx(dout, W, dx, B, C, N, T, To, R, (hipStream_t)stream);
 }
 
+extern "C" size_t msgat_layernorm_head_backward_partial_floats(int32_t B, int32_t C, int32_t N, int32_t T) {
+  if (B <= 0 || C <= 0 || N <= 0 || !t_supported(T)) return 0;
+  return lnhead_partial_floats(B, C, N, T);
+}
+
+extern "C" int msgat_layernorm_head_backward(const float* dout, const float* W, const float* x, const float* ln_weight,
+                                             float* dx, float* dln_weight, float* dln_bias, float* partials, int32_t B,
+                                             int32_t C, int32_t N, int32_t T, int32_t To, int32_t R, float eps,
+                                             int32_t relu_mask, void* stream) {
+  if (!dout || !W || !x || !dx || !partials) return MSGAT_ERR_NULL;
+  int st = check_head(B, C, N, T, To);
+  if (st) return st;
+  if (R <= 0 || B % R || !(eps >= 0.f)) return MSGAT_ERR_SHAPE;
+  return launch_lnhead_bwd(dout, W, x, ln_weight, dx, dln_weight, dln_bias, partials, B, C, N, T, To, R, eps,
+                           relu_mask != 0, (hipStream_t)stream);
+}
+
 extern "C" size_t msgat_head_grad_weight_partial_floats(int32_t C, int32_t T, int32_t To, int32_t R) {
   if (C <= 0 || To <= 0 || R <= 0 || !t_supported(T)) return 0;
   return head_dw_partial_floats(C, T, To, R);

@@ -468,6 +468,137 @@ __global__ __launch_bounds__(kBlock) void k_head_dx(const float* __restrict__ do
   }
 }
 
+// The head's input gradient AND the backward of the LayerNorm in front of it (msgat.py:158-159: fc(ln(x).transpose(1,3)))
+// in ONE pass: dy[b,c,n,:] = sum_o W[o,:,c] dout[b,n,o] is built in registers exactly as k_head_dx builds it and consumed
+// on the spot by the LayerNorm backward of row (b,c,n) (layernorm.hip: k_ln_bwd, same formulas, same order), whose x row
+// the lane reads itself.  The [B,C,N,T] gradient between the two never exists: k_head_dx's 293 MB write and k_ln_bwd's
+// read of it (and one launch) go.  part[block][2T]: the block's share of (dweight | dbias) of the LayerNorm.
+template <int T>
+__device__ __forceinline__ float lnh_centre_row(float (&x)[T], float eps) {   // = layernorm.hip's centre_row
+  const float x0 = x[0];
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < T; ++t) { x[t] -= x0; s += x[t]; }
+  const float md = s * (1.0f / T);
+  float v = 0.f;
+#pragma unroll
+  for (int t = 0; t < T; ++t) { x[t] -= md; v = fmaf(x[t], x[t], v); }
+  return rsqrtf(v * (1.0f / T) + eps);
+}
+
+template <int T>
+__global__ __launch_bounds__(kBlock) void k_lnhead_bwd(const float* __restrict__ dout, const float* __restrict__ W,
+                                                       const float* __restrict__ x, const float* __restrict__ lnw,
+                                                       float* __restrict__ dx, float* __restrict__ part, int C, int N,
+                                                       int To, int Bg, float eps, int relu_mask) {
+  __shared__ __attribute__((aligned(16))) float Wl[kHeadCC][T][kHeadTo];
+  __shared__ float4 tiles[kBlock / kWave][RowTile<T>::kFloat4s];
+  __shared__ float red[kBlock / kWave][2 * T];
+  const int b = blockIdx.z, ck = blockIdx.y, rel = b / Bg;
+  W += (size_t)rel * To * T * C;
+  const int c0 = ck * kHeadCC, cn = min(kHeadCC, C - c0);
+  constexpr int kWn = (kHeadCC * kHeadTo * T + kBlock - 1) / kBlock;
+  float wv[kWn];
+#pragma unroll
+  for (int k = 0; k < kWn; ++k) {   // unconditional, clamped: see k_head_dx
+    const int i = min((int)threadIdx.x + k * kBlock, kHeadCC * kHeadTo * T - 1);
+    const int c = i / (kHeadTo * T), t = (i / kHeadTo) % T, o = i % kHeadTo;
+    const float w = W[((size_t)min(o, To - 1) * T + t) * C + c0 + min(c, cn - 1)];
+    wv[k] = (c < cn && o < To) ? w : 0.f;
+  }
+  const int n = blockIdx.x * kBlock + threadIdx.x;
+  const int nc = min(n, N - 1);
+  const bool live = n < N;
+  const float* src = dout + ((size_t)b * N + nc) * To;
+  float d[kHeadTo];
+#pragma unroll
+  for (int o = 0; o < kHeadTo; ++o) {
+    const float v = src[min(o, To - 1)];
+    d[o] = (o < To && live) ? v : 0.f;     // lanes past N: a zero gradient row
+  }
+#pragma unroll
+  for (int k = 0; k < kWn; ++k) {
+    const int i = threadIdx.x + k * kBlock;
+    if (i < kHeadCC * kHeadTo * T) (&Wl[0][0][0])[i] = wv[k];
+  }
+  float gw[T], dwa[T], dba[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) { gw[t] = lnw ? lnw[rel * T + t] : 1.f; dwa[t] = 0.f; dba[t] = 0.f; }
+  __syncthreads();
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const int n0 = n - lane;
+  const int nf = max(min(kWave, N - n0), 0) * (T / 4);      // 0: the whole wave lies past N (stores nothing)
+  const RowTile<T> rt(tiles[wave], lane);
+  // the x row of channel c + 1 is requested before channel c is worked on (clamped channel: the last trip re-reads its own
+  // row): a load and its use per trip left one exposed round trip per channel, 8 in a row per block
+  float4 xnext[T / 4];
+  auto fetch_x = [&](int c) {
+    const float4* xr = reinterpret_cast<const float4*>(x + (((size_t)b * C + c0 + min(c, cn - 1)) * N + nc) * T);
+#pragma unroll
+    for (int t4 = 0; t4 < T / 4; ++t4) xnext[t4] = xr[t4];
+  };
+  fetch_x(0);
+  for (int c = 0; c < cn; ++c) {
+    float gv[T], xv[T];
+#pragma unroll
+    for (int t4 = 0; t4 < T / 4; ++t4) {
+      const float4 a = xnext[t4];
+      xv[4 * t4 + 0] = a.x; xv[4 * t4 + 1] = a.y; xv[4 * t4 + 2] = a.z; xv[4 * t4 + 3] = a.w;
+    }
+    fetch_x(c + 1);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {   // the weights four at a time (one ds_read_b128 per four FMAs; same order of the sum)
+      gv[t] = 0.f;
+#pragma unroll
+      for (int o4 = 0; o4 < kHeadTo / 4; ++o4) {
+        const float4 w4 = *reinterpret_cast<const float4*>(&Wl[c][t][4 * o4]);
+        gv[t] = fmaf(w4.x, d[4 * o4 + 0], gv[t]);
+        gv[t] = fmaf(w4.y, d[4 * o4 + 1], gv[t]);
+        gv[t] = fmaf(w4.z, d[4 * o4 + 2], gv[t]);
+        gv[t] = fmaf(w4.w, d[4 * o4 + 3], gv[t]);
+      }
+    }
+    if (!live) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) xv[t] = 0.f;
+    }
+    unsigned positive = 0;
+#pragma unroll
+    for (int t = 0; t < T; ++t) positive |= (xv[t] > 0.f ? 1u : 0u) << t;
+    const float rstd = lnh_centre_row<T>(xv, eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      xv[t] *= rstd;                  // xhat
+      dba[t] += gv[t];
+      dwa[t] = fmaf(gv[t], xv[t], dwa[t]);
+      gv[t] *= gw[t];
+      s1 += gv[t];
+      s2 = fmaf(gv[t], xv[t], s2);
+    }
+    s1 *= (1.0f / T);
+    s2 *= (1.0f / T);
+#pragma unroll
+    for (int t = 0; t < T; ++t) gv[t] = rstd * (gv[t] - s1 - xv[t] * s2);
+    if (relu_mask) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) gv[t] = ((positive >> t) & 1u) ? gv[t] : 0.f;
+    }
+    if (nf > 0) rt.store(dx + (((size_t)b * C + c0 + c) * N + n0) * T, nf, gv);   // wave-uniform
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    float a = dwa[t], cc = dba[t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); cc += __shfl_xor(cc, o); }
+    if (lane == 0) { red[wave][t] = a; red[wave][T + t] = cc; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * T)
+    part[(((size_t)b * gridDim.y + ck) * gridDim.x + blockIdx.x) * 2 * T + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // dW partial[c, j, o, t] = sum over the j-th share of samples, all nodes: dout[b,n,o] x[b,c,n,t] -- like k_tmix_dA a
 // [To x T] outer-product sum over rows (b, n), on the matrix cores: lane (m, kq) supplies dout[b][n = 4s + kq][o = m]
 // and x[b][c][n = 4s + kq][t = m] (the VALU form held To*T = 192 accumulators per lane: 193 us for 293 MB).
@@ -552,6 +683,23 @@ int launch_head_dx(const float* dout, const float* W, float* dx, int B, int C, i
   MSGAT_T_SWITCH(T, hipLaunchKernelGGL(k_head_dx<TT>, grid, dim3(kBlock), 0, s, dout, W, dx, C, N, To, Bg));
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
+}
+
+size_t lnhead_partial_floats(int B, int C, int N, int T) {
+  return (size_t)B * cdiv(C, kHeadCC) * cdiv(N, kBlock) * 2 * T;
+}
+
+// dx [B,C,N,T] = LayerNorm backward of (head input gradient); dlnw / dlnb [R,T]
+int launch_lnhead_bwd(const float* dout, const float* W, const float* x, const float* lnw, float* dx, float* dlnw,
+                      float* dlnb, float* part, int B, int C, int N, int T, int To, int R, float eps, int relu_mask,
+                      hipStream_t s) {
+  const int Bg = B / R;
+  dim3 grid(cdiv(N, kBlock), cdiv(C, kHeadCC), B);
+  MSGAT_T_SWITCH(T, hipLaunchKernelGGL(k_lnhead_bwd<TT>, grid, dim3(kBlock), 0, s, dout, W, x, lnw, dx, part, C, N, To, Bg,
+                                       eps, relu_mask));
+  MSGAT_CHECK_LAUNCH();
+  // a relation's blocks are contiguous (b-major): J = Bg * channel chunks * node blocks partials of 2T columns each
+  return launch_reduce_split(part, R, Bg * (int)grid.y * (int)grid.x, 2 * T, dlnw, T, dlnb, T, s);
 }
 
 // dWc[c][o][t] (the caller permutes to the convolution's [To][T][1][C] layout)

@@ -366,6 +366,10 @@ int launch_node_pool_dw(const float* x, const float* dp, float* dw, float* part,
                         hipStream_t s);
 size_t head_fwd_partial_floats(int B, int C, int N, int To);
 size_t head_dw_partial_floats(int C, int T, int To, int R);
+size_t lnhead_partial_floats(int B, int C, int N, int T);
+int launch_lnhead_bwd(const float* dout, const float* W, const float* x, const float* lnw, float* dx, float* dlnw,
+                      float* dlnb, float* part, int B, int C, int N, int T, int To, int R, float eps, int relu_mask,
+                      hipStream_t s);
 int launch_head_fwd(const float* x, const float* W, const float* bias, float* out, float* part, int B, int C, int N,
                     int T, int To, int R, hipStream_t s);
 int launch_head_dx(const float* dout, const float* W, float* dx, int B, int C, int N, int T, int To, int R,

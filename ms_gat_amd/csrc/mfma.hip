@@ -373,6 +373,109 @@ int launch_project_mfma(const SegList& in, const float* M, int m_in_major, const
   }
 }
 
+// ---- the same convolution with ONE load per input float4 (Cr % 4 == 0: the widths of the reference's models) ---------
+// k_project_mfma<.., TAPS> loads every input row twice (the plain and the shifted operand): 12 loads per lane for 24
+// channels, half of them unaligned -- it ran at 2.9 TB/s of its algorithmic bytes.  Here a wave covers GP4 = the largest
+// multiple of T/4 that fits 16 lanes (15 float4 = 5 whole rows at T = 12, the 16th lane idle), so every row of T lies
+// inside ONE 16-lane group and the shifted operand is a lane shuffle of the loaded values: float4 index f of a row holds
+// timesteps 4f .. 4f+3, and in[t + s] for s = 4a + b comes from the float4s a and a + 1 lanes away (zero where the row
+// ends).  No unaligned load, no second load, nothing that could leave the tensor.
+template <int MG, int kMaxK>   // kMaxK: k-steps the registers hold (8: Cr <= 32, 16: Cr <= 64)
+__global__ __launch_bounds__(kBlock, 2) void k_causal_conv(
+    const float* __restrict__ in, int in_gstride, const float* __restrict__ taps, int m_in_major,
+    const float* __restrict__ bias, int bias_rstride, float* __restrict__ out, int Bg, int P4, int Cr, int Co,
+    int tshift, int T) {
+  extern __shared__ float lds[];
+  const int Ci = 2 * Cr;                      // virtual channels [shifted | plain]
+  const int K4r = Cr >> 2;                    // k-steps over the REAL channels (Cr % 4 == 0, host-checked)
+  const int Kpad = proj_kpad(Ci);
+  constexpr int Mrows = MG * 16;
+  float* Wl = lds;                            // [Mrows][Kpad]
+  float* bl = lds + Mrows * Kpad;             // [Mrows]
+  const int g = blockIdx.y, r = g / Bg;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = lane & 15, kq = lane >> 4;
+  const int F = T >> 2;                       // float4s per row of T
+  const int GP4 = (16 / F) * F;               // float4s a wave covers: whole rows only
+  const int p4 = (blockIdx.x * 4 + wave) * GP4 + j;
+  const bool pvalid = j < GP4 && p4 < P4;
+  const int p4c = min(p4, P4 - 1);
+  const float* base = in + (size_t)g * in_gstride * (4 * (size_t)P4) + 4 * (size_t)p4c;
+
+  float4 own[kMaxK];
+#pragma unroll
+  for (int k = 0; k < kMaxK; ++k)             // the whole input of the tile, requested before the matrix is staged
+    if (k < K4r) own[k] = load_global(base + (size_t)(4 * k + kq) * (4 * (size_t)P4));   // kernel-uniform guard
+
+  for (int i = threadIdx.x; i < Mrows * Kpad; i += kBlock) {
+    const int co = i / Kpad, k = i - co * Kpad;
+    const int coc = min(co, Co - 1), kc = min(k, Ci - 1);
+    const float m = m_in_major ? taps[((size_t)r * Ci + kc) * Co + coc]
+                               : taps[((size_t)r * 2 * Co + (size_t)(kc / Cr) * Co + coc) * Cr + kc % Cr];
+    Wl[i] = (co < Co && k < Ci) ? m : 0.f;
+  }
+  for (int i = threadIdx.x; i < Mrows; i += kBlock)
+    bl[i] = (bias != nullptr && i < Co) ? bias[(size_t)r * bias_rstride + i] : 0.f;
+  __syncthreads();
+
+  // lane constants of the shift: s = +-(4 a + b); source float4s a and a + 1 lanes away in the direction of the shift
+  const int f = j % F;
+  const int sabs = tshift < 0 ? -tshift : tshift, dir = tshift < 0 ? -1 : 1;
+  const int a = sabs >> 2, b = sabs & 3;
+  const bool vA = dir < 0 ? (f - a >= 0) : (f + a < F);
+  const bool vB = dir < 0 ? (f - a - 1 >= 0) : (f + a + 1 < F);
+  const int laneA = lane + dir * a, laneB = lane + dir * (a + 1);     // same kq group whenever the source is valid
+  auto shifted = [&](const float4& v) -> float4 {
+    float4 A = make_float4(__shfl(v.x, laneA), __shfl(v.y, laneA), __shfl(v.z, laneA), __shfl(v.w, laneA));
+    float4 B = make_float4(__shfl(v.x, laneB), __shfl(v.y, laneB), __shfl(v.z, laneB), __shfl(v.w, laneB));
+    A = vA ? A : f4zero();
+    B = vB ? B : f4zero();
+    if (dir < 0) {   // element e <- in[t0 + e - (4a + b)]: e >= b from A[e - b], else B[e - b + 4]
+      return make_float4(b == 0 ? A.x : (b == 1 ? B.w : (b == 2 ? B.z : B.y)),
+                         b == 0 ? A.y : (b == 1 ? A.x : (b == 2 ? B.w : B.z)),
+                         b == 0 ? A.z : (b == 1 ? A.y : (b == 2 ? A.x : B.w)),
+                         b == 0 ? A.w : (b == 1 ? A.z : (b == 2 ? A.y : A.x)));
+    }
+    // element e <- in[t0 + e + 4a + b]: e + b < 4 from A[e + b], else B[e + b - 4]
+    return make_float4(b == 0 ? A.x : (b == 1 ? A.y : (b == 2 ? A.z : A.w)),
+                       b == 0 ? A.y : (b == 1 ? A.z : (b == 2 ? A.w : B.x)),
+                       b == 0 ? A.z : (b == 1 ? A.w : (b == 2 ? B.x : B.y)),
+                       b == 0 ? A.w : (b == 1 ? B.x : (b == 2 ? B.y : B.z)));
+  };
+
+  f32x4 acc[MG][4];
+#pragma unroll
+  for (int mg = 0; mg < MG; ++mg)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[mg][i] = zero4();
+  const float* wrow = Wl + j * Kpad + kq;     // row co = tile*16 + j; column 4k + kq (shifted half), Cr + 4k + kq (plain half)
+#pragma unroll
+  for (int k = 0; k < kMaxK; ++k) {
+    if (k < K4r) {                            // kernel-uniform; MFMAs, shuffles and LDS reads only
+      const float4 pl = own[k];
+      const float4 sh = shifted(pl);
+#pragma unroll
+      for (int mg = 0; mg < MG; ++mg) {
+        const float a0 = wrow[mg * 16 * Kpad + 4 * k];
+        const float a1 = wrow[mg * 16 * Kpad + Cr + 4 * k];
+        acc[mg][0] = mfma16(a0, sh.x, acc[mg][0]); acc[mg][1] = mfma16(a0, sh.y, acc[mg][1]);
+        acc[mg][2] = mfma16(a0, sh.z, acc[mg][2]); acc[mg][3] = mfma16(a0, sh.w, acc[mg][3]);
+        acc[mg][0] = mfma16(a1, pl.x, acc[mg][0]); acc[mg][1] = mfma16(a1, pl.y, acc[mg][1]);
+        acc[mg][2] = mfma16(a1, pl.z, acc[mg][2]); acc[mg][3] = mfma16(a1, pl.w, acc[mg][3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int mg = 0; mg < MG; ++mg)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int co = mg * 16 + 4 * kq + reg;
+      const float bb = bl[co];
+      const float4 v = make_float4(acc[mg][0][reg] + bb, acc[mg][1][reg] + bb, acc[mg][2][reg] + bb, acc[mg][3][reg] + bb);
+      if (co < Co && pvalid) store_global(out + ((size_t)g * Co + co) * (4 * (size_t)P4) + 4 * (size_t)p4, v);
+    }
+}
+
 // The causal dilated convolution in one pass (k_project_mfma<.., TAPS>): in [G,Cr,P] (a channel slice of a wider
 // tensor when in_gstride > Cr), taps [R, 2 Co', Cr'] row-major; m_in_major = 0: forward (Co' = Co, Cr' = Cr, tshift =
 // -dilation); m_in_major = 1: its input gradient (Co' = Cr, Cr' = Co: the same array read in-major, tshift = +dilation).
@@ -394,6 +497,26 @@ int launch_project_taps(const float* in, int in_gstride, const float* taps, int 
   int MG;
   proj_passes_mg(Co, &MG);
   const size_t lds = project_mfma_lds_bytes(2 * Cr, Co, false);
+#ifndef MSGAT_TAPS_TWO_LOADS
+  if (Cr % 4 == 0 && Cr <= 64 && MG <= 4) {   // one load per input float4, the shifted operand by lane shuffles
+    const int F = T / 4, GP4 = (16 / F) * F;
+    const dim3 grid1(cdiv(P4, 4 * GP4), G);
+    const int gs = in_gstride > Cr ? in_gstride : Cr;
+#define MSGAT_CC(mg, kk)                                                                                               \
+  {                                                                                                                   \
+    static LdsGrant granted;                                                                                          \
+    if (int st_ = grant_dynamic_lds(&k_causal_conv<mg, kk>, lds, granted)) return st_;                                 \
+    hipLaunchKernelGGL((k_causal_conv<mg, kk>), grid1, dim3(kBlock), lds, s, in, gs, taps, m_in_major, bias,           \
+                       bias_rstride, out, Bg, P4, Cr, Co, tshift, T);                                                 \
+  }
+#define MSGAT_CC2(mg) case mg: if (Cr <= 32) MSGAT_CC(mg, 8) else MSGAT_CC(mg, 16) break;
+    switch (MG) { MSGAT_CC2(1) MSGAT_CC2(2) MSGAT_CC2(3) MSGAT_CC2(4) }
+#undef MSGAT_CC2
+#undef MSGAT_CC
+    MSGAT_CHECK_LAUNCH();
+    return MSGAT_OK;
+  }
+#endif
   const dim3 grid(cdiv(P4, 64), G);
 #define MSGAT_TAPS(mg)                                                                                                   \
   case mg: {                                                                                                            \

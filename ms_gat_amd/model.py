@@ -274,10 +274,11 @@ class TPC(nn.Module):
         for i, block in enumerate(self.tgacns):
             signals = block(signals, adjacency, relu_input=i > 0, premasked=True) if own else block(signals, adjacency)
         if own:
-            normed = ops.layer_norm_t(signals, self.ln.weight, self.ln.bias, self.ln.eps, relu_input=len(self.tgacns) > 0)
-        else:
-            normed = self.ln(signals)
-        # fc over the transposed activation, squeezed and transposed back (msgat.py:159-160): one pass
+            # LayerNorm, then fc over the transposed activation, squeezed and transposed back (msgat.py:158-160); backward
+            # is one pass for the head's input gradient and the LayerNorm together
+            return ops.ln_head(signals, self.ln.weight, self.ln.bias, self.ln.eps, self.fc.weight, self.fc.bias,
+                               relu_input=len(self.tgacns) > 0)                    # [B,N,T_out]
+        normed = self.ln(signals)
         return ops.head(normed, self.fc.weight, self.fc.bias)                      # [B,N,T_out]
 
 

@@ -762,6 +762,99 @@ class _HeadFunction(torch.autograd.Function):
         return dx, dW, db
 
 
+class _LnHeadFunction(torch.autograd.Function):
+    """x[B,C,N,T] -> head(layer_norm_t(x)): a component's last two steps (msgat.py:158-160).  Forward is the two library
+    passes; backward builds the head's input gradient in registers inside the LayerNorm-backward pass
+    (msgat_layernorm_head_backward), so the [B,C,N,T] gradient between the two is never written."""
+
+    @staticmethod
+    def forward(ctx, x, lnw, lnb, eps: float, W, bias, relu_input: bool):
+        L = _lib.lib()
+        x, W = x.contiguous(), W.contiguous()
+        B, Cc, N, T = x.shape
+        To = W.shape[-4]
+        R = 1 if W.dim() == 4 else W.shape[0]
+        stream = _stream_handle(x.device)
+        w = None if lnw is None else lnw.contiguous()
+        lb = None if lnb is None else lnb.contiguous()
+        Rl = 1 if w is None else w.numel() // T
+        xn = torch.empty_like(x)
+        st = L.msgat_layernorm_forward(_ptr(x), _ptr(w), _ptr(lb), _ptr(xn), B * Cc * N, T, eps, Rl, stream)
+        _lib.check(st, "msgat_layernorm_forward")
+        out = _new(x, B, N, To)
+        part = _new(x, max(int(L.msgat_head_forward_partial_floats(B, Cc, N, To)), 1))
+        b = None if bias is None else bias.contiguous()
+        st = L.msgat_head_forward(_ptr(xn), _ptr(W), _ptr(b), _ptr(out), _ptr(part), B, Cc, N, T, To, R, stream)
+        _lib.check(st, "msgat_head_forward")
+        ctx.eps, ctx.relu_input, ctx.has_lnw, ctx.has_lnb, ctx.has_bias = eps, bool(relu_input), w is not None, lb is not None, bias is not None
+        ctx.save_for_backward(*([x, xn, W] + ([w] if w is not None else [])))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        saved = ctx.saved_tensors
+        x, xn, W = saved[:3]
+        w = saved[3] if ctx.has_lnw else None
+        B, Cc, N, T = x.shape
+        To = W.shape[-4]
+        R = 1 if W.dim() == 4 else W.shape[0]
+        dout = dout.contiguous()
+        stream = _stream_handle(x.device)
+        need = ctx.needs_input_grad
+        dx = dlnw = dlnb = dW = db = None
+        if need[0] or need[1] or need[2]:
+            dx = torch.empty_like(x)
+            dlnw = torch.empty_like(w) if (ctx.has_lnw and need[1]) else None
+            dlnb = torch.empty(w.shape if ctx.has_lnw else (T,), device=x.device, dtype=torch.float32) if (ctx.has_lnb and need[2]) else None
+            part = _new(x, max(int(L.msgat_layernorm_head_backward_partial_floats(B, Cc, N, T)), 1))
+            st = L.msgat_layernorm_head_backward(_ptr(dout), _ptr(W), _ptr(x), _ptr(w), _ptr(dx), _ptr(dlnw), _ptr(dlnb),
+                                                 _ptr(part), B, Cc, N, T, To, R, ctx.eps, int(ctx.relu_input), stream)
+            _lib.check(st, "msgat_layernorm_head_backward")
+        if need[4]:
+            dWc = _new(x, R, Cc, To, T)
+            part = _new(x, max(int(L.msgat_head_grad_weight_partial_floats(Cc, T, To, R)), 1))
+            _lib.check(L.msgat_head_grad_weight(_ptr(dout), _ptr(xn), _ptr(dWc), _ptr(part), B, Cc, N, T, To, R, stream),
+                       "msgat_head_grad_weight")
+            dW = dWc.permute(0, 2, 3, 1).contiguous().unsqueeze(3)     # [R,To,T,1,C], contiguous once (see _HeadFunction)
+            if W.dim() == 4:
+                dW = dW[0]
+        if ctx.has_bias and need[5]:
+            if To in (4, 8, 12, 16):
+                key = (dout.device, N)
+                ones = _ones_cache.get(key)
+                if ones is None:
+                    ones = _ones_cache[key] = torch.ones(N, device=dout.device, dtype=torch.float32)
+                pooled = _new(dout, B, To)
+                _lib.check(L.msgat_node_pool(_ptr(dout), _ptr(ones), _ptr(pooled), B, N, To, 1, 0, 0, stream), "msgat_node_pool")
+                db = pooled.view(R, B // R, To).sum(dim=1) if W.dim() == 5 else pooled.sum(dim=0)
+            else:
+                db = dout.view(R, B // R, N, To).sum(dim=(1, 2)) if W.dim() == 5 else dout.sum(dim=(0, 1))
+        return dx if need[0] else None, dlnw, dlnb, None, dW, db, None
+
+
+def ln_head(x: torch.Tensor, ln_weight: Optional[torch.Tensor], ln_bias: Optional[torch.Tensor], eps: float,
+            W: torch.Tensor, bias: Optional[torch.Tensor] = None, relu_input: bool = False) -> torch.Tensor:
+    """`head(layer_norm_t(x, ln_weight, ln_bias, eps, relu_input), W, bias)` -- TPC's last two steps, msgat.py:158-160 --
+    with ONE backward pass over x for the head's input gradient and the LayerNorm backward together."""
+    _require_device_tensor("signals", x)
+    _require_device_tensor("weight", W, x.device)
+    T = x.shape[-1]
+    if (x.dim() != 4 or W.dim() not in (4, 5) or W.shape[-3] != T or W.shape[-2] != 1 or W.shape[-1] != x.shape[1]
+            or (W.dim() == 5 and x.shape[0] % W.shape[0])):
+        raise ValueError(f"ln_head: signals {tuple(x.shape)} and weight {tuple(W.shape)} do not match")
+    for name, t in (("ln_weight", ln_weight), ("ln_bias", ln_bias)):
+        if t is not None:
+            _require_device_tensor(name, t, x.device)
+            if t.shape[-1] != T or t.dim() > 2 or (t.dim() == 2 and x.shape[0] % t.shape[0]):
+                raise ValueError(f"{name} must be [{T}] or [R,{T}] with R dividing the leading axis, got {tuple(t.shape)}")
+    if ln_weight is not None and W.dim() == 5 and ln_weight.dim() == 2 and ln_weight.shape[0] != W.shape[0]:
+        raise ValueError("ln_head: the LayerNorm and the head must have the same number of parameter sets")
+    if x.numel() == 0 or (ln_weight is not None and ln_weight.numel() // T != (1 if W.dim() == 4 else W.shape[0])):
+        return head(layer_norm_t(x, ln_weight, ln_bias, eps, relu_input), W, bias)   # mixed parameter-set counts: the two ops
+    return _LnHeadFunction.apply(x, ln_weight, ln_bias, float(eps), W, bias, bool(relu_input))
+
+
 def head(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The component's prediction head: `fc(x.transpose(1, 3))[..., 0].transpose(1, 2)` of msgat.py:159-160
     with `fc = Conv2d(T, T_out, [1, C])`, as one pass over x."""

@@ -187,8 +187,8 @@ def forward(model, X: torch.Tensor, H: torch.Tensor, D: torch.Tensor) -> torch.T
     x = X.transpose(0, 1).reshape(R * B, *X.shape[2:])                                 # relation-major groups
     for level, m0 in enumerate(tpcs[0].tgacns):
         x = _meam(P, f"tgacns.{level}.", m0, x, model.adj, R, B, relu_input=level > 0)
-    xn = ops.layer_norm_t(x, P("ln.weight"), P("ln.bias"), tpcs[0].ln.eps, relu_input=len(tpcs[0].tgacns) > 0)
-    pred = ops.head(xn, P("fc.weight"), P("fc.bias"))                                  # [R*B,N,T_out]
+    pred = ops.ln_head(x, P("ln.weight"), P("ln.bias"), tpcs[0].ln.eps, P("fc.weight"), P("fc.bias"),
+                       relu_input=len(tpcs[0].tgacns) > 0)                             # [R*B,N,T_out]
     pred = pred.view(R, B, *pred.shape[1:])
     gate = model.te(H, D).transpose(0, 1) if model.te is not None else model.W.unsqueeze(1)          # [R,B|1,N,T_out]
     return (pred * gate).sum(dim=0)

@@ -112,3 +112,52 @@ def test_module_is_drop_in_for_nn_layernorm():
     mine.load_state_dict(ref.state_dict())
     x = torch.randn(2, 72, 100, 12, device=dev)
     assert rel_err(mine(x), ref(x)) < 1e-6
+
+
+@pytest.mark.parametrize("B,R,C,N,T,To,relu", [(6, 3, 72, 883, 12, 12, True), (2, 1, 5, 30, 12, 7, False), (4, 2, 9, 257, 8, 8, True),
+                                               (2, 2, 17, 64, 16, 12, True), (3, 1, 8, 1, 4, 4, False), (2, 1, 24, 300, 12, 3, True)])
+def test_ln_head_is_the_two_ops_with_one_backward_pass(B, R, C, N, T, To, relu):
+    """ops.ln_head = head(layer_norm_t(x)) (msgat.py:158-160) whose backward builds the head's input gradient inside the
+    LayerNorm-backward pass (msgat_layernorm_head_backward): against the float64 op sequence and against the two separate
+    ops (same formulas in the same order: dx must agree to rounding of the partial sums only)."""
+    from ms_gat_amd import ops
+    dev = _dev()
+    gen = torch.Generator(device="cpu").manual_seed(B + 3 * C + N)
+    x = torch.randn(B, C, N, T, generator=gen).to(dev)
+    if relu:
+        x = torch.relu(x + 0.3)                          # a ReLU output, as the blocks hand it over
+    shp = (To, T, 1, C) if R == 1 else (R, To, T, 1, C)
+    W = (torch.randn(*shp, generator=gen) * (T * C) ** -0.5).to(dev)
+    hb = (torch.randn(*((To,) if R == 1 else (R, To)), generator=gen) * 0.1).to(dev)
+    lw = (1 + 0.3 * torch.randn(*((T,) if R == 1 else (R, T)), generator=gen)).to(dev)
+    lb = (0.2 * torch.randn(*((T,) if R == 1 else (R, T)), generator=gen)).to(dev)
+    dout = torch.randn(B, N, To, generator=gen).to(dev)
+
+    def run(fused):
+        leaves = [t.clone().requires_grad_(True) for t in (x, lw, lb, W, hb)]
+        xs, lws, lbs, Ws, hbs = leaves
+        out = (ops.ln_head(xs, lws, lbs, 1e-5, Ws, hbs, relu_input=relu) if fused
+               else ops.head(ops.layer_norm_t(xs, lws, lbs, 1e-5, relu_input=relu), Ws, hbs))
+        out.backward(dout)
+        return [out.detach()] + [t.grad for t in leaves]
+
+    got, two = run(True), run(False)
+    names = ("out", "dx", "dln_weight", "dln_bias", "dW", "dbias")
+    for name, a, b in zip(names, got, two):
+        assert rel_err(a, b) < 2e-6, name
+    assert torch.equal(got[0], two[0])
+    # float64: the reference's op sequence, relation by relation
+    Bg = B // R
+    x64 = x.double().requires_grad_(True)
+    p64 = [t.double().requires_grad_(True) for t in (lw, lb, W, hb)]
+    outs = []
+    for r in range(R):
+        sl = slice(r * Bg, (r + 1) * Bg)
+        pr = [p if R == 1 else p[r] for p in p64]
+        xn = F.layer_norm(x64[sl], [T], pr[0], pr[1], 1e-5)
+        outs.append(F.conv2d(xn.transpose(1, 3), pr[2], pr[3])[..., 0].transpose(1, 2))
+    ref = torch.cat(outs)
+    ref.backward(dout.double())
+    dx64 = x64.grad if not relu else x64.grad * (x > 0)       # the mask of the ReLU that produced x (relu_input)
+    for name, a, b in zip(names, got, [ref.detach(), dx64] + [p.grad for p in p64]):
+        assert rel_err(a.double(), b) < TOL, name
