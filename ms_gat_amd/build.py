@@ -25,7 +25,7 @@ SOURCES = ["api.hip", "project.hip", "mfma.hip", "dense.hip", "scores.hip", "agg
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "sell.hpp"), os.path.join(CSRC, "rowtile.hpp"), os.path.join(INCLUDE, "msgat_hip.h")]
 # diagnostic translation units (never part of the product library): `build(lab=True)` / `--lab` adds them and their
 # extra, undeclared entry points for tools/stress_kernels.py --lab
-LAB_SOURCES = [os.path.join(ROOT, "tools", "agg_sell_lab.hip")]
+LAB_SOURCES = [os.path.join(ROOT, "tools", "agg_sell_lab.hip"), os.path.join(ROOT, "tools", "bwd_sell_lab.hip")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize",
          f"--offload-arch={ARCH}",

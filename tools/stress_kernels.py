@@ -27,8 +27,10 @@ def main():
     ap.add_argument("--sell", default="auto")
     ap.add_argument("--lab", type=int, default=-1, help="time tools/agg_sell_lab.hip's k_agg_sell with one phase removed "
                     "(0..4; needs `python -m ms_gat_amd.build --lab`)")
+    ap.add_argument("--fused", type=int, default=0, help="time tools/bwd_sell_lab.hip's fused du + dE column pass with this "
+                    "many waves per block (16 | 12 | 8), variants 0..2 (needs `python -m ms_gat_amd.build --lab`)")
     a = ap.parse_args()
-    if a.lab >= 0:
+    if a.lab >= 0 or a.fused:
         _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "lab", "libmsgat_lab.so")
     N, T, R, B, Cc, Co = a.N, 12, a.R, a.B, 72, 24
     G = R * B
@@ -62,6 +64,19 @@ def main():
                                                           scr.data_ptr() if nscr else None, st), "agg"))
     print(f"aggregate (incl. edge permute)  {ms:8.3f} ms   {alg / ms / 1e6:8.1f} GB/s algorithmic  sell={graph.has_sell} nnz={nnz}",
           flush=True)
+
+    if a.fused:
+        fn = L.msgat_lab_bwd_sell_fused
+        fn.restype, fn.argtypes = C.c_int, [C.POINTER(_lib.Shape), C.POINTER(_lib.Graph), C.c_int32] + [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_void_p]
+        npos = gs.sell_cols.n_pos
+        Es = torch.rand(G * npos + _lib.SELL_SLACK, device=dev)      # coefficients in sell_cols position order
+        dz, du, dE = torch.randn(G, Co, N, T, device=dev), torch.empty(G, Co, N, T, device=dev), torch.empty(G * npos + _lib.SELL_SLACK, device=dev)
+        print(f"sell_cols: {gs.sell_cols.n_slices} slices, n_pos {npos}, pair_trips {gs.sell_cols.pair_trips}", flush=True)
+        for lab, what in ((0, "scattered du stores"), (1, "no du stores"), (2, "du through LDS, N/Q consecutive rows per block")):
+            ms = timed(lambda: _lib.check(fn(sp, gp, Co, dz.data_ptr(), u.data_ptr(), Es.data_ptr(), du.data_ptr(), dE.data_ptr(),
+                                             a.fused, lab, st), "fused lab"))
+            print(f"fused du + dE, {a.fused} waves/block, {what:48s} {ms:8.3f} ms", flush=True)
+        return
 
     if a.lab >= 0:
         fn = L.msgat_lab_aggregate_sell
