@@ -179,7 +179,7 @@ def test_whole_step_gradient_of_two_ranks_equals_the_single_process_gradient(tmp
     record_err(f"two_ranks_vs_one_gradient_b{size}", "worst tensor", worst, 1e-5)
     for k in one:
         assert err(k) < 1e-5, (k, err(k))
-        else:
+        if float(one[k].abs().max()) == 0.0:
             assert float(two[k].abs().max()) == 0.0, k
 
 
