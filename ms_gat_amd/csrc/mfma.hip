@@ -1395,11 +1395,13 @@ int launch_chanpair_mfma(const SegList& A, const float* B, float* part, int R, i
   // registers of a 2-waves-per-SIMD block are not offered ([48 x 80], [48 x 96] and [32 x 96] spilled 18 / 93 / 14
   // registers): a wider B is cut into z-blocks, which re-read A
   const int MA = min(cdiv(Ca, 16), 3), NB = min(cdiv(Cb, 16), MA == 3 ? 4 : (MA == 2 ? 5 : 6));
-  // 49..80 A channels against 17..80 B channels: half-length tiles hold all of A and B in LDS at once -- ONE pass over
+  // 65..80 A channels against 17..80 B channels: half-length tiles hold all of A and B in LDS at once -- ONE pass over
   // both operands where the [48 x 96] blocks take two z-blocks that each re-read B (72 x 73, the residual tail's weight
   // gradient: 286 -> 174 us).  Not for wider A (a [112 x 80] block spills and ran at 372 us against 344 for the two
   // [64 x 80] blocks below) nor for a B of one tile (re-reading it is cheap: 64 -> 84 us).
-  if (NB >= 2 && NB <= 5 && Ca > 48 && Ca <= 80) {
+  // (49..64 rows go to the [64 x 16 NB] block below instead: 256-position tiles, 1-KiB row pieces -- the shifted
+  // [64 x 33] weight gradient of msgat96's convolutions 125 -> 110 us)
+  if (NB >= 2 && NB <= 5 && Ca > 64 && Ca <= 80) {
     switch (NB) {
       case 2: return launch_chanpair_t<5, 2, false, 128>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used);
       case 3: return launch_chanpair_t<5, 3, false, 128>(A, B, part, R, Bg, Cb, P, nblk, b_ones, s, nblk_used);
