@@ -226,36 +226,72 @@ __global__ __launch_bounds__(kSaBlock) void k_tempatt_fwd(const float* __restric
                                                           int N, int K, int dil) {
   __shared__ float lrs[2 * T * kTaRankMax];  // left [T][K], right [T][K]
   __shared__ float S[T * (T + 1)];
-  __shared__ float qt[kTaTile * T];                        // tile of q: [node][T]
-  __shared__ float wt[2 * kTaRankMax * (kTaTile + 1)];     // tile of both projections: [which*K + k][node], padded rows
+  __shared__ float qt[2][kTaTile * T];                        // tiles of q: [node][T], double-buffered
+  __shared__ float wt[2][2 * kTaRankMax * (kTaTile + 1)];     // tiles of both projections: [which*K + k][node], padded rows
   const int g = blockIdx.x, r = g / Bg;
   const float* q = pooled + (size_t)g * N * T;
   // one lane per (which, t, k): q[:,t] . Wt[k,:], the node axis walked in LDS tiles (both operands are re-used by
-  // 2K resp. T lanes; read straight from global the loop is one dependent L1 round trip per node: 74-94 us per launch)
+  // 2K resp. T lanes; read straight from global the loop is one dependent L1 round trip per node: 74-94 us per launch).
+  // Round 5: the next tile's global loads are in flight while the current one is multiplied (two LDS buffers, one
+  // barrier per tile) -- with load, barrier, multiply, barrier in sequence the 14 tiles of N = 883 were 14 exposed round
+  // trips on one block per group (96 blocks for 256 CUs): 54 us per launch.
   const bool owner = (int)threadIdx.x < 2 * T * K;
   const int ow = owner ? threadIdx.x / (T * K) : 0, orem = owner ? threadIdx.x - ow * T * K : 0;
   const int ot = orem / K, ok = orem - ot * K;
-  float acc = 0.f;
-  for (int n0 = 0; n0 < N; n0 += kTaTile) {
+  constexpr int kQn = (kTaTile * T + kSaBlock - 1) / kSaBlock;              // q elements a thread stages per tile
+  constexpr int kWn = (2 * kTaRankMax * kTaTile + kSaBlock - 1) / kSaBlock;  // projection elements (at most)
+  float qreg[kQn], wreg[kWn];
+  auto fetch = [&](int n0) {   // every load unconditional (clamped), zero past the end of the node axis
     const int nn = min(kTaTile, N - n0);
-    __syncthreads();
-    for (int i = threadIdx.x; i < kTaTile * T; i += kSaBlock) qt[i] = (i < nn * T) ? q[(size_t)n0 * T + i] : 0.f;
-    for (int i = threadIdx.x; i < 2 * K * kTaTile; i += kSaBlock) {
+#pragma unroll
+    for (int u = 0; u < kQn; ++u) {
+      const int i = threadIdx.x + u * kSaBlock;
+      const float v = q[(size_t)n0 * T + min(i, max(nn * T - 1, 0))];
+      qreg[u] = (i < nn * T) ? v : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < kWn; ++u) {
+      const int i = min((int)threadIdx.x + u * kSaBlock, 2 * K * kTaTile - 1);
       const int row = i / kTaTile, n = i - row * kTaTile;
       const float* W = (row >= K ? Wt2 : Wt1) + ((size_t)r * K + (row >= K ? row - K : row)) * N;
-      wt[row * (kTaTile + 1) + n] = (n < nn) ? W[n0 + n] : 0.f;
+      const float v = W[n0 + min(n, max(nn - 1, 0))];
+      wreg[u] = (n < nn) ? v : 0.f;
     }
-    __syncthreads();
+  };
+  auto stash = [&](int b) {
+#pragma unroll
+    for (int u = 0; u < kQn; ++u) {
+      const int i = threadIdx.x + u * kSaBlock;
+      if (i < kTaTile * T) qt[b][i] = qreg[u];
+    }
+#pragma unroll
+    for (int u = 0; u < kWn; ++u) {
+      const int i = threadIdx.x + u * kSaBlock;
+      if (i < 2 * K * kTaTile) wt[b][(i / kTaTile) * (kTaTile + 1) + (i % kTaTile)] = wreg[u];
+    }
+  };
+  float acc = 0.f;
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  int buf = 0;
+  for (int n0 = 0; n0 < N; n0 += kTaTile) {
+    const int nnext = min(n0 + kTaTile, ((N - 1) / kTaTile) * kTaTile);   // clamped: the last trip re-reads its own tile
+    fetch(nnext);
     if (owner) {
-      const float* wr = wt + (ow * K + ok) * (kTaTile + 1);
+      const float* wr = wt[buf] + (ow * K + ok) * (kTaTile + 1);
+      const float* qb = qt[buf];
       float a0 = 0.f, a1 = 0.f;
 #pragma unroll 8
       for (int n = 0; n < kTaTile; n += 2) {
-        a0 = fmaf(qt[n * T + ot], wr[n], a0);
-        a1 = fmaf(qt[(n + 1) * T + ot], wr[n + 1], a1);
+        a0 = fmaf(qb[n * T + ot], wr[n], a0);
+        a1 = fmaf(qb[(n + 1) * T + ot], wr[n + 1], a1);
       }
       acc += a0 + a1;
     }
+    stash(buf ^ 1);      // the other buffer: nobody reads it during this trip
+    __syncthreads();
+    buf ^= 1;
   }
   if (owner) {
     lrs[threadIdx.x] = acc;
