@@ -36,6 +36,25 @@ class _StackedView(torch.autograd.Function):
         return (None, *grad.unbind(0))
 
 
+class _StackedViewAll(torch.autograd.Function):
+    """`_StackedView` for ALL parameters of the components in one autograd node: forward(n, storage_1..n, then the R
+    parameters of each) -> the n storages as differentiable tensors.  One Function call per forward pass instead of one per
+    parameter access (40 per training step: ~0.7 ms of host time forward + backward at R = 3)."""
+
+    @staticmethod
+    def forward(ctx, n, *args):
+        ctx.n = n
+        ctx.R = (len(args) - n) // n
+        return tuple(s.view(s.shape) for s in args[:n])
+
+    @staticmethod
+    def backward(ctx, *grads):
+        out = [None] * (1 + ctx.n)
+        for g in grads:
+            out.extend(g.unbind(0) if g is not None else [None] * ctx.R)
+        return tuple(out)
+
+
 class ParamBank:
     """Per-component parameters of identical shape stored back to back, so that "the same parameter of all R
     components" is one [R, ...] tensor without a stacking kernel.
@@ -75,6 +94,21 @@ class ParamBank:
         if any(p.requires_grad for p in ps):
             return _StackedView.apply(st, *ps)
         return st
+
+
+def _all_views(bank: ParamBank):
+    """name -> stacked [R, ...] tensor for every parameter of the components, through ONE autograd node."""
+    names = list(bank.params[0])
+    for name in names:              # builds / repairs the storage rows (no autograd work: the result is discarded)
+        hit = bank.rows.get(name)
+        if hit is None or not all(p.data_ptr() == a for p, a in zip(*hit)):
+            with torch.no_grad():
+                bank.get(name)
+    storages = [bank.storage[name] for name in names]
+    params = [p for name in names for p in bank.rows[name][0]]
+    if not any(p.requires_grad for p in params):
+        return dict(zip(names, storages))
+    return dict(zip(names, _StackedViewAll.apply(len(names), *storages, *params)))
 
 
 def _bank(model) -> ParamBank:
@@ -192,7 +226,7 @@ def forward(model, X: torch.Tensor, H: torch.Tensor, D: torch.Tensor) -> torch.T
     """X [B,R,C,N,T], H [B], D [B] -> [B,N,T_out]: `MSGAT.forward` with all R components in each kernel."""
     tpcs = list(model.tpcs)
     R, B = len(tpcs), X.shape[0]
-    P = _bank(model).get
+    P = _all_views(_bank(model)).__getitem__
     x = X.transpose(0, 1).reshape(R * B, *X.shape[2:])                                 # relation-major groups
     for level, m0 in enumerate(tpcs[0].tgacns):
         x = _meam(P, f"tgacns.{level}.", m0, x, model.adj, R, B, relu_input=level > 0)
