@@ -377,8 +377,19 @@ __global__ __launch_bounds__(kSaBlock) void k_tempatt_bwd(const float* __restric
     }
 #pragma unroll
     for (int t = 0; t < T; ++t) dq[t] = 0.f;
-    for (int k = 0; k < K; ++k) {
-      const float w1 = W1[(size_t)k * N + n], w2 = W2[(size_t)k * N + n];
+    // the node's column of both projections, requested together (a load and its use per trip of the k loop was 2 K
+    // dependent round trips per node)
+    float w1v[kTaRankMax], w2v[kTaRankMax];
+#pragma unroll
+    for (int k = 0; k < kTaRankMax; ++k) {
+      const int kc = min(k, K - 1);
+      w1v[k] = W1[(size_t)kc * N + n];
+      w2v[k] = W2[(size_t)kc * N + n];
+    }
+#pragma unroll
+    for (int k = 0; k < kTaRankMax; ++k) {
+      if (k >= K) break;                       // kernel-uniform
+      const float w1 = w1v[k], w2 = w2v[k];
       float g1 = 0.f, g2 = 0.f;
 #pragma unroll
       for (int t = 0; t < T; ++t) {
