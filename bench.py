@@ -885,6 +885,13 @@ def main():
             }
             del ts
             torch.cuda.empty_cache()
+            if not multi:   # the same step replayed as one HIP graph (Trainer(hip_graph=True)): independent of the host's speed
+                tg = TrainStep(CFG4, dev, seed=rank, hip_graph=True)
+                wg, perg = time_train_step(tg, steps, max(2, min(args.warmup, 5)), barrier)
+                out["full_step_cfg4"]["hip_graph_replay_ms_per_step"] = round(wg / steps * 1e3, 4)
+                out["full_step_cfg4"]["hip_graph_replay_ms_per_step_median_hip_events"] = round(statistics.median(perg), 4)
+                del tg
+                torch.cuda.empty_cache()
 
         if multi:
             cfg4_object()

@@ -1,3 +1,7 @@
+#!/bin/bash
+# End-of-round measurements (GPU box): kernel traces of the hot path and the training steps, per-kernel tables of the three
+# registry models, the bench line with the driver's arguments and with the defaults, the five-rank rehearsal on one GPU.
+#     gpurun --timeout 1200 -- 'bash tools/final_measurements.sh'   (results under gpurun_out/r05/)
 mkdir -p gpurun_out/r05
 bash tools/profile_round.sh r05 "hot full" > gpurun_out/profile_round_r05b.log 2>&1
 python3 tools/train_kernels.py --R 3 --top 60 > gpurun_out/r05/train_kernels_stacked_final.txt 2>/dev/null
