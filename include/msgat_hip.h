@@ -45,7 +45,9 @@
 extern "C" {
 #endif
 
-#define MSGAT_ABI_VERSION 5
+/* 6 (round 5): + msgat_contract_form_name, msgat_causal_conv{,_fused,_grad_weight}, msgat_layernorm_head_backward
+ * {,_partial_floats}; no existing signature or structure changed since 5. */
+#define MSGAT_ABI_VERSION 6
 
 enum {
   MSGAT_OK = 0,

@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libmsgat_hip.so")
 
 MSGAT_OK = 0
-ABI_VERSION = 5  # MSGAT_ABI_VERSION of include/msgat_hip.h
+ABI_VERSION = 6  # MSGAT_ABI_VERSION of include/msgat_hip.h
 MODE_PLAIN, MODE_AGG_FIRST, MODE_PROJ_FIRST = 0, 1, 2
 
 c_float_p = C.POINTER(C.c_float)
