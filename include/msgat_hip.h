@@ -46,7 +46,7 @@ extern "C" {
 #endif
 
 /* 6 (round 5): + msgat_contract_form_name, msgat_causal_conv{,_fused,_grad_weight}, msgat_layernorm_head_backward
- * {,_partial_floats}; no existing signature or structure changed since 5. */
+ * {,_partial_floats}, msgat_layernorm_backward_pooled; no existing signature or structure changed since 5. */
 #define MSGAT_ABI_VERSION 6
 
 enum {
@@ -297,6 +297,15 @@ size_t msgat_layernorm_partial_floats(int64_t rows, int32_t T, int32_t R);
 int msgat_layernorm_backward(const float* x, const float* weight, const float* dy, const float* dx_add,
                              float* dx, float* dweight, float* dbias, float* partials, int64_t rows,
                              int32_t T, float eps, int32_t R, int32_t relu_mask, void* stream);
+/* msgat_layernorm_backward_pooled: msgat_layernorm_backward for a LayerNorm whose output y [.., N, T] ALSO fed a node
+ * pooling p[s,t] = sum_n pool_w[n] y[s,n,t] over its [N,T] slabs (ChannelAttention's pooled signal, attention.py:89, taken
+ * of MEAM's normalised input, msgat.py:122-125): that consumer's gradient pool_w[n] dpooled[s,t] is rank one and is added
+ * to dy row by row inside this pass, instead of by msgat_node_pool_grad_signal in a pass of its own over the activation.
+ * pool_w [R,N] (one set per relation), dpooled [rows / N, T]; everything else as msgat_layernorm_backward. */
+int msgat_layernorm_backward_pooled(const float* x, const float* weight, const float* dy, const float* dx_add,
+                                    const float* pool_w, const float* dpooled, int32_t N, float* dx, float* dweight,
+                                    float* dbias, float* partials, int64_t rows, int32_t T, float eps, int32_t R,
+                                    int32_t relu_mask, void* stream);
 
 /* ---- device: the temporal and channel branches of MEAM ----
  * Building blocks for TACN (src/models/msgat.py:57-80, TemporalAttention attention.py:58-66) and CACN

@@ -383,7 +383,8 @@ int launch_reduce_split(const float* part, int R, int J, int Wd, float* dst0, in
 int launch_layernorm_fwd(const float* x, const float* w, const float* b, float* y, long long rows, int T,
                          float eps, int R, hipStream_t s);
 int launch_layernorm_bwd(const float* x, const float* w, const float* dy, const float* add, float* dx, float* dw,
-                         float* db, float* part, long long rows, int T, float eps, int R, int relu_mask, hipStream_t s);
+                         float* db, float* part, long long rows, int T, float eps, int R, int relu_mask, hipStream_t s,
+                         const float* pool_w = nullptr, const float* dpooled = nullptr, int N = 1);
 
 // the tiny attention matrices of a MEAM block (smallatt.hip)
 size_t chanatt_partial_floats(int G, int C, int cb, int T);

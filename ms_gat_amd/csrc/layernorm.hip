@@ -73,11 +73,16 @@ __global__ __launch_bounds__(kBlock) void k_ln_fwd(const float* __restrict__ x, 
   }
 }
 
+// pool_w / dpooled (optional): the LayerNorm output also fed a node pooling p[s,t] = sum_n pool_w[n] y[s,n,t] over its
+// [N,T] slabs (ChannelAttention's pooled signal, attention.py:89, on MEAM's normalised input) -- that consumer's gradient
+// pool_w[n] dpooled[s,t] is rank one, so it is added to dy here, per row, instead of in a pass of its own over the
+// activation (k_node_pool_dx: a 293 MB read and a 293 MB write per block at PEMSD7 size).
 template <int T>
 __global__ __launch_bounds__(kBlock) void k_ln_bwd(const float* __restrict__ x, const float* __restrict__ w,
                                                    const float* __restrict__ dy, const float* __restrict__ add,
                                                    float* __restrict__ dx, float* __restrict__ part, long long rows,
-                                                   float eps, int relu_mask) {
+                                                   float eps, int relu_mask, const float* __restrict__ pool_w = nullptr,
+                                                   const float* __restrict__ dpooled = nullptr, int N = 1) {
   __shared__ float red[kBlock / kWave][2 * T];
   x += (size_t)blockIdx.y * rows * T;
   dy += (size_t)blockIdx.y * rows * T;
@@ -99,6 +104,14 @@ __global__ __launch_bounds__(kBlock) void k_ln_bwd(const float* __restrict__ x, 
     float xv[T], gv[T];
     load_row<T>(x + r * T, xv);
     load_row<T>(dy + r * T, gv);
+    if (pool_w != nullptr) {   // kernel-uniform: + pool_w[n] dpooled[slab,:] (row r of this relation = slab r / N, node r % N)
+      const int ri = (int)r, slab = ri / N, n = ri - slab * N;
+      const float pw = pool_w[(size_t)blockIdx.y * N + n];
+      float pv[T];
+      load_row<T>(dpooled + ((size_t)blockIdx.y * (size_t)(rows / N) + slab) * T, pv);
+#pragma unroll
+      for (int t = 0; t < T; ++t) gv[t] = fmaf(pw, pv[t], gv[t]);
+    }
     if (!live) {
 #pragma unroll
       for (int t = 0; t < T; ++t) { xv[t] = 0.f; gv[t] = 0.f; }
@@ -171,14 +184,16 @@ int launch_layernorm_fwd(const float* x, const float* w, const float* b, float* 
 }
 
 int launch_layernorm_bwd(const float* x, const float* w, const float* dy, const float* add, float* dx, float* dw,
-                         float* db, float* part, long long rows, int T, float eps, int R, int relu_mask, hipStream_t s) {
+                         float* db, float* part, long long rows, int T, float eps, int R, int relu_mask, hipStream_t s,
+                         const float* pool_w, const float* dpooled, int N) {
   rows /= R;  // per relation
+  if (pool_w != nullptr && (dpooled == nullptr || N <= 0 || rows % N != 0 || rows > 0x7fffffffLL)) return MSGAT_ERR_SHAPE;
   const int nb = ln_blocks(rows);
   switch (T) {
-    case 4: hipLaunchKernelGGL(k_ln_bwd<4>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps, relu_mask); break;
-    case 8: hipLaunchKernelGGL(k_ln_bwd<8>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps, relu_mask); break;
-    case 12: hipLaunchKernelGGL(k_ln_bwd<12>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps, relu_mask); break;
-    case 16: hipLaunchKernelGGL(k_ln_bwd<16>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps, relu_mask); break;
+    case 4: hipLaunchKernelGGL(k_ln_bwd<4>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps, relu_mask, pool_w, dpooled, N); break;
+    case 8: hipLaunchKernelGGL(k_ln_bwd<8>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps, relu_mask, pool_w, dpooled, N); break;
+    case 12: hipLaunchKernelGGL(k_ln_bwd<12>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps, relu_mask, pool_w, dpooled, N); break;
+    case 16: hipLaunchKernelGGL(k_ln_bwd<16>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps, relu_mask, pool_w, dpooled, N); break;
     default: return MSGAT_ERR_UNSUPPORTED;
   }
   MSGAT_CHECK_LAUNCH();

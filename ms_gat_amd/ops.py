@@ -297,6 +297,94 @@ class _LayerNormTeeFunction(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+class _LnPoolTeeFunction(torch.autograd.Function):
+    """x -> (LayerNorm(x), x, node_pool(LayerNorm(x), pool_w)): MEAM's first three reads of its input (msgat.py:122-125 with
+    attention.py:89 inside CACN) as one autograd node, so that backward adds the pooling's rank-one gradient
+    pool_w[n] dpooled[s,t] inside the LayerNorm-backward kernel (msgat_layernorm_backward_pooled) instead of in a pass of
+    its own over the activation, next to the residual path's gradient (`_LayerNormTeeFunction`)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps: float, relu_input: bool, pool_w):
+        L = _lib.lib()
+        x = x.contiguous()
+        B, Cc, N, T = x.shape
+        rows = B * Cc * N
+        y = torch.empty_like(x)
+        w = None if weight is None else weight.contiguous()
+        b = None if bias is None else bias.contiguous()
+        pw = pool_w.contiguous()
+        R = 1 if w is None else w.numel() // T
+        stream = _stream_handle(x.device)
+        _lib.check(L.msgat_layernorm_forward(_ptr(x), _ptr(w), _ptr(b), _ptr(y), rows, T, eps, R, stream), "msgat_layernorm_forward")
+        pooled = _new(x, B, Cc, T)
+        Rp = pw.numel() // N
+        _lib.check(L.msgat_node_pool(_ptr(y), _ptr(pw), _ptr(pooled), B * Cc, N, T, Rp, 0, 0, stream), "msgat_node_pool")
+        ctx.eps, ctx.relu_input, ctx.has_w, ctx.has_b, ctx.R, ctx.Rp = eps, bool(relu_input), w is not None, b is not None, R, Rp
+        ctx.save_for_backward(*([x, y, pw] + ([w] if w is not None else [])))
+        return y, x.view_as(x), pooled
+
+    @staticmethod
+    def backward(ctx, dy, dx_other, dpooled):
+        L = _lib.lib()
+        saved = ctx.saved_tensors
+        x, y, pw = saved[:3]
+        w = saved[3] if ctx.has_w else None
+        B, Cc, N, T = x.shape
+        rows = B * Cc * N
+        stream = _stream_handle(x.device)
+        need = ctx.needs_input_grad
+        dpw = None
+        if dpooled is not None and need[5]:
+            dpw = torch.empty_like(pw)
+            part = _new(x, max(int(L.msgat_node_pool_partial_floats(B, Cc, N)), 1))
+            _lib.check(L.msgat_node_pool_grad_weight(_ptr(y), _ptr(dpooled.contiguous()), _ptr(dpw), _ptr(part), B, Cc, N, T, ctx.Rp,
+                                                     stream), "msgat_node_pool_grad_weight")
+        if dy is None and dpooled is None:
+            if dx_other is not None and ctx.relu_input:
+                dx_other = torch.ops.aten.threshold_backward(dx_other.contiguous(), x, 0.0)
+            return dx_other, None, None, None, None, dpw
+        dy = torch.zeros_like(x) if dy is None else dy.contiguous()
+        other = None if dx_other is None else dx_other.contiguous()
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w) if ctx.has_w else None
+        db = torch.empty(w.shape if ctx.has_w else (T,), device=x.device, dtype=torch.float32) if ctx.has_b else None
+        part = _new(x, max(int(L.msgat_layernorm_partial_floats(rows, T, ctx.R)), 1))
+        if dpooled is not None and ctx.Rp == ctx.R:
+            st = L.msgat_layernorm_backward_pooled(_ptr(x), _ptr(w), _ptr(dy), _ptr(other), _ptr(pw), _ptr(dpooled.contiguous()), N,
+                                                   _ptr(dx), _ptr(dw), _ptr(db), _ptr(part), rows, T, ctx.eps, ctx.R,
+                                                   int(ctx.relu_input), stream)
+            _lib.check(st, "msgat_layernorm_backward_pooled")
+        else:
+            if dpooled is not None:      # parameter-set counts differ: the pooling's gradient in its own pass, then the LayerNorm
+                dyp = torch.empty_like(x)
+                _lib.check(L.msgat_node_pool_grad_signal(_ptr(pw), _ptr(dpooled.contiguous()), _ptr(dy), _ptr(dyp), B * Cc, N, T,
+                                                         ctx.Rp, stream), "msgat_node_pool_grad_signal")
+                dy = dyp
+            st = L.msgat_layernorm_backward(_ptr(x), _ptr(w), _ptr(dy), _ptr(other), _ptr(dx), _ptr(dw), _ptr(db), _ptr(part),
+                                            rows, T, ctx.eps, ctx.R, int(ctx.relu_input), stream)
+            _lib.check(st, "msgat_layernorm_backward")
+        return dx, dw, db, None, None, dpw
+
+
+def layer_norm_pool_tee(x: torch.Tensor, weight, bias, eps: float, relu_input: bool, pool_w: torch.Tensor):
+    """(layer_norm_t(x), x, node_pool(layer_norm_t(x), pool_w)): `layer_norm_t_tee` followed by `node_pool_tee`, as one
+    node whose backward adds the pooling's gradient inside the LayerNorm-backward kernel.  pool_w [N] or [R,N]."""
+    _require_device_tensor("signals", x)
+    _require_device_tensor("weights", pool_w, x.device)
+    T = x.shape[-1]
+    if x.dim() != 4 or pool_w.shape[-1] != x.shape[2] or pool_w.dim() > 2 or (pool_w.dim() == 2 and x.shape[0] % pool_w.shape[0]):
+        raise ValueError(f"layer_norm_pool_tee: signals {tuple(x.shape)}, pooling weights {tuple(pool_w.shape)}")
+    if x.numel() == 0 or not x.requires_grad:
+        normed = layer_norm_t(x, weight, bias, eps, relu_input)
+        return normed, x, node_pool(normed, pool_w)
+    for name, t in (("weight", weight), ("bias", bias)):
+        if t is not None:
+            _require_device_tensor(name, t, x.device)
+            if t.shape[-1] != T or t.dim() > 2 or (t.dim() == 2 and x.shape[0] % t.shape[0]):
+                raise ValueError(f"{name} must be [{T}] or [R,{T}] with R dividing the leading axis, got {tuple(t.shape)}")
+    return _LnPoolTeeFunction.apply(x, weight, bias, float(eps), bool(relu_input), pool_w)
+
+
 def layer_norm_t_tee(x: torch.Tensor, weight: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
                      eps: float = 1e-5, relu_input: bool = False):
     """(layer_norm_t(x), x): use the second value wherever the block reads its un-normalised input again.

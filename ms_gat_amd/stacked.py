@@ -182,14 +182,14 @@ def _meam(P, prefix: str, m0, x: torch.Tensor, adjacency, R: int, B: int, relu_i
     (`relu_input` there; here for the level below): the caller chains levels and must end with such a LayerNorm."""
     C, cb = m0.in_channels, m0.out_channels // 3
     T = x.shape[-1]
-    # (normed, x): the residual tail below reads x again; its gradient joins the LayerNorm's in one kernel
-    normed, x = ops.layer_norm_t_tee(x, P(prefix + "ln.weight"), P(prefix + "ln.bias"), m0.ln.eps, relu_input)
+    # (normed, x, pooled_c): the residual tail below reads x again and CACN pools the normalised input over the nodes
+    # (attention.py:89); both gradients join the LayerNorm's inside ONE backward kernel
+    normed, x, pooled_c = ops.layer_norm_pool_tee(x, P(prefix + "ln.weight"), P(prefix + "ln.bias"), m0.ln.eps, relu_input,
+                                                  P(prefix + "cacn.seq.0.alpha"))
 
     # CACN's per-sample channel matrix conv @ softmax(p Wc p^T) (attention.py:90-92, msgat.py:93-94): one launch
     conv_w = P(prefix + "cacn.seq.1.weight").flatten(2)                                # [R,cb,C,1,1] -> [R,cb,C]: a view
     conv_b = P(prefix + "cacn.seq.1.bias")                                             # [R,cb]
-    # (pooled, normed): the mixing passes below read `normed` too; their gradient joins inside the pooling's backward
-    pooled_c, normed = ops.node_pool_tee(normed, P(prefix + "cacn.seq.0.alpha"))
     Mc = ops.channel_attention_mix(pooled_c, P(prefix + "cacn.seq.0.Wc"), conv_w)
     Wg, alpha_g, W_g = P(prefix + "gacn.gatt.Wg"), P(prefix + "gacn.gatt.alpha"), P(prefix + "gacn.W")
     alpha_t = P(prefix + "tacn.seq.0.alpha")

@@ -161,3 +161,51 @@ def test_ln_head_is_the_two_ops_with_one_backward_pass(B, R, C, N, T, To, relu):
     dx64 = x64.grad if not relu else x64.grad * (x > 0)       # the mask of the ReLU that produced x (relu_input)
     for name, a, b in zip(names, got, [ref.detach(), dx64] + [p.grad for p in p64]):
         assert rel_err(a.double(), b) < TOL, name
+
+
+@pytest.mark.parametrize("B,R,C,N,T,relu", [(6, 3, 72, 883, 12, True), (2, 1, 5, 30, 12, False), (4, 2, 9, 257, 8, True), (2, 2, 3, 1, 16, False)])
+def test_layer_norm_pool_tee_adds_the_pooling_gradient_inside_the_layernorm_backward(B, R, C, N, T, relu):
+    """ops.layer_norm_pool_tee = layer_norm_t_tee + node_pool_tee as one node (msgat.py:122-125, attention.py:89): the
+    pooling's rank-one gradient joins dy inside the LayerNorm-backward kernel.  Against the two separate ops (same
+    formulas; only the place of one addition differs) and against float64."""
+    from ms_gat_amd import ops
+    dev = _dev()
+    gen = torch.Generator(device="cpu").manual_seed(B + C + N)
+    x = torch.randn(B, C, N, T, generator=gen).to(dev)
+    if relu:
+        x = torch.relu(x + 0.3)
+    lw = (1 + 0.3 * torch.randn(*((T,) if R == 1 else (R, T)), generator=gen)).to(dev)
+    lb = (0.2 * torch.randn(*((T,) if R == 1 else (R, T)), generator=gen)).to(dev)
+    pw = torch.randn(*((N,) if R == 1 else (R, N)), generator=gen).to(dev)
+    d_y, d_x2, d_p = (torch.randn(*s, generator=gen).to(dev) for s in ((B, C, N, T), (B, C, N, T), (B, C, T)))
+
+    def run(fused):
+        leaves = [t.clone().requires_grad_(True) for t in (x, lw, lb, pw)]
+        xs, lws, lbs, pws = leaves
+        if fused:
+            y, x2, p = ops.layer_norm_pool_tee(xs, lws, lbs, 1e-5, relu, pws)
+        else:
+            y, x2 = ops.layer_norm_t_tee(xs, lws, lbs, 1e-5, relu)
+            p, y = ops.node_pool_tee(y, pws)
+        torch.autograd.backward([y, x2, p], [d_y, d_x2, d_p])
+        return [y.detach(), p.detach()] + [t.grad for t in leaves]
+
+    got, two = run(True), run(False)
+    names = ("y", "pooled", "dx", "dln_weight", "dln_bias", "dpool_w")
+    for name, a, b in zip(names, got, two):
+        assert rel_err(a, b) < 2e-6, name
+    Bg = B // R
+    x64 = x.double().requires_grad_(True)
+    p64 = [t.double().requires_grad_(True) for t in (lw, lb, pw)]
+    ys, ps = [], []
+    for r in range(R):
+        sl = slice(r * Bg, (r + 1) * Bg)
+        pr = [p if R == 1 else p[r] for p in p64]
+        yr = F.layer_norm(x64[sl], [T], pr[0], pr[1], 1e-5)
+        ys.append(yr)
+        ps.append(torch.einsum("bcnt,n->bct", yr, pr[2]))
+    y64, pp64 = torch.cat(ys), torch.cat(ps)
+    torch.autograd.backward([y64, x64 * 1.0, pp64], [d_y.double(), d_x2.double(), d_p.double()])
+    dx64 = x64.grad if not relu else x64.grad * (x > 0)
+    for name, a, b in zip(names, got, [y64.detach(), pp64.detach(), dx64] + [p.grad for p in p64]):
+        assert rel_err(a.double(), b) < TOL, name
