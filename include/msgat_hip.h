@@ -46,7 +46,7 @@ extern "C" {
 #endif
 
 /* 6 (round 5): + msgat_contract_form_name, msgat_causal_conv{,_fused,_grad_weight}, msgat_layernorm_head_backward
- * {,_partial_floats}, msgat_layernorm_backward_pooled; no existing signature or structure changed since 5. */
+ * {,_partial_floats}, msgat_layernorm_backward_pooled, msgat_contract_mix_partial_floats; no existing signature or structure changed since 5. */
 #define MSGAT_ABI_VERSION 6
 
 enum {
@@ -405,7 +405,12 @@ int msgat_contract_segments(int32_t R, int32_t Bg, int32_t N, int32_t T, const m
  *   dst[r,a,c]     = sum_{g in r, p} A[g,a,p] B[g,c,p]      (dM; with_ones: column Cb = sum A, the bias gradient)
  *   mixout[g,c,p]  = sum_a M[r,a,c] A[g,a,p]                (dx, [G,Cb,N,T] contiguous)
  * i.e. msgat_contract_segments + msgat_mix_segments(m_in_major = 1) with A streamed once; shapes without a fused
- * form run those two passes.  partials: msgat_contract_segments_partial_floats(R, Ca, Cb + with_ones). */
+ * form run those two passes.  partials: msgat_contract_mix_partial_floats(R, Bg, N, T, Ca, Cb + with_ones). */
+/* partials of msgat_contract_mix_segments for Cb = channels of B INCLUDING the virtual one (round 5: with Cb <= 4 and one
+ * A segment the call is ONE pass over A -- dM | dbias and dx together, the form of the AGG_FIRST backward -- whose
+ * per-block partials outnumber those of the general form; msgat_contract_segments_partial_floats stays valid for
+ * msgat_contract_segments) */
+size_t msgat_contract_mix_partial_floats(int32_t R, int32_t Bg, int32_t N, int32_t T, int32_t Ca, int32_t Cb);
 int msgat_contract_mix_segments(int32_t R, int32_t Bg, int32_t N, int32_t T, const msgat_seg_t* A, int32_t n_a,
                                 const float* B, int32_t Cb, int32_t with_ones, const float* M, float* partials,
                                 float* dst, float* mixout, void* stream);

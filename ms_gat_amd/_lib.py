@@ -106,6 +106,7 @@ _PROTOTYPES = {
     "msgat_stage_project_backward": (C.c_int, [C.POINTER(Shape)] + [C.c_void_p] * 10),
     "msgat_contract_mix_segments": (C.c_int, [C.c_int32] * 4 + [C.POINTER(Seg), C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "msgat_contract_mix_partial_floats": (C.c_size_t, [C.c_int32] * 6),
     "msgat_contract_form_name": (C.c_int, [C.c_int32] * 5 + [C.c_char_p, C.c_int32]),
     "msgat_attention_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Shape), C.POINTER(Graph)]),
     "msgat_attention_backward": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_int32] +

@@ -459,6 +459,13 @@ extern "C" int msgat_contract_form_name(int32_t Ca, int32_t Cb, int32_t with_one
   return MSGAT_OK;
 }
 
+extern "C" size_t msgat_contract_mix_partial_floats(int32_t R, int32_t Bg, int32_t N, int32_t T, int32_t Ca, int32_t Cb) {
+  if (R <= 0 || Bg <= 0 || N <= 0 || T <= 0 || Ca <= 0 || Cb <= 0) return 0;
+  const size_t general = chanpair_partial_floats(R, 1, Ca, Cb);
+  const size_t tiny = Cb <= kAggFirstMaxC ? (size_t)R * Bg * aggfirst_blocks(N * T) * Ca * Cb : 0;
+  return general > tiny ? general : tiny;
+}
+
 extern "C" int msgat_contract_mix_segments(int32_t R, int32_t Bg, int32_t N, int32_t T, const msgat_seg_t* A, int32_t n_a,
                                            const float* B, int32_t Cb, int32_t with_ones, const float* M, float* partials,
                                            float* dst, float* mixout, void* stream) {
@@ -471,6 +478,12 @@ extern "C" int msgat_contract_mix_segments(int32_t R, int32_t Bg, int32_t N, int
   if (sa.n == 0) return MSGAT_ERR_SHAPE;
   const int Cbx = Cb + with_ones, Ca = sa.total(), P = N * T;
   hipStream_t s = (hipStream_t)stream;
+  // a convolution with 1..3 input channels (the first block of every component: 1 or 3 features): ONE pass over the
+  // Ca-channel gradient gives dM (| dbias) and dx (k_aggfirst_bwd) -- the caller sized `partials` with
+  // msgat_contract_mix_partial_floats, which knows this form
+  if (Cbx <= kAggFirstMaxC && sa.n == 1 && P % 4 == 0)
+    return launch_aggfirst_bwd(sa.ptr[0], M, B, mixout, partials, dst, R * Bg, Bg, Cb, Ca, P, s, nullptr, sa.gstride[0],
+                               with_ones);
   int nblk = 0, both = 0;
   st = launch_chanpair_mix_wide(sa, B, partials, R, Bg, Cbx, P, chanpair_mfma_blocks(R), with_ones, M, mixout, s, &nblk, &both);
   if (st) return st;

@@ -344,7 +344,7 @@ int launch_chanpair_seg(const SegList& A, const float* B, float* part, float* ds
 constexpr int kAggFirstMaxC = 4;
 int aggfirst_blocks(int P);
 int launch_aggfirst_bwd(const float* dz, const float* W, const float* y, float* dy, float* part, float* dW, int G,
-                        int Bg, int C, int Co, int P, hipStream_t s, ReduceJobs* defer, int dz_group_channels = 0);
+                        int Bg, int C, int Co, int P, hipStream_t s, ReduceJobs* defer, int dz_group_channels = 0, int ones = 0);
 // out[i] = sum_j part[j,i], i < Wd, split over dst0 (first n0) and dst1 (next n1); fixed order
 int launch_reduce_rows(const float* part, int J, int Wd, float* dst0, int n0, float* dst1, int n1,
                        hipStream_t s);

@@ -59,26 +59,32 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
   return v;
 }
 
-template <int C>
+// ONES: a virtual channel of ones behind y's C real ones -- column C of the partial is sum_p dz[o,p], the bias gradient of a
+// 1x1 convolution with C <= 3 input channels (round 5: the first block's residual / tap / CACN convolutions take this
+// kernel for their whole backward through msgat_contract_mix_segments; as contraction + projection they read the
+// Co-channel gradient twice: 78 + 35 us for the 72-channel residual gradient at PEMSD7 size).
+template <int C, bool ONES>
 __global__ __launch_bounds__(kBlock) void k_aggfirst_bwd(const float4* __restrict__ dz4, const float* __restrict__ W,
                                                          const float4* __restrict__ y4, float4* __restrict__ dy4,
                                                          float* __restrict__ part, int Bg, int Co, int P4, int dzgs) {
+  constexpr int CT = C + (ONES ? 1 : 0);    // columns of the weight-gradient partial
   extern __shared__ float lds[];
   float* Wl = lds;                        // [Co][C]
-  float* red = lds + Co * C;              // [4 waves][Co*C]
+  float* red = lds + Co * C;              // [4 waves][Co*CT]
   const int g = blockIdx.y;
   const int r = g / Bg;
   for (int i = threadIdx.x; i < Co * C; i += kBlock) Wl[i] = W[(size_t)r * Co * C + i];
   const int p4 = blockIdx.x * kBlock + threadIdx.x;
   const float keep = p4 < P4 ? 1.f : 0.f;
   const int p4c = min(p4, P4 - 1);  // clamped, unconditional loads; lanes past the end contribute keep = 0
-  float4 yv[C], acc[C];
+  float4 yv[CT], acc[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     const float4 v = y4[((size_t)g * C + c) * P4 + p4c];
     yv[c] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
     acc[c] = f4zero();
   }
+  if (ONES) yv[CT - 1] = make_float4(keep, keep, keep, keep);
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float4* src = dz4 + (size_t)g * dzgs * P4 + p4c;  // dz may be a channel slice of a wider tensor
@@ -90,10 +96,10 @@ __global__ __launch_bounds__(kBlock) void k_aggfirst_bwd(const float4* __restric
     for (int k = 0; k < kAfChunk; ++k) {
       const int o = min(o0 + k, Co - 1);  // a chunk past Co repeats the last channel; its results are not stored
 #pragma unroll
-      for (int c = 0; c < C; ++c) {
-        if (o0 + k < Co) f4fma(Wl[o * C + c], d[k], acc[c]);  // wave-uniform, no load inside
+      for (int c = 0; c < CT; ++c) {
+        if (c < C && o0 + k < Co) f4fma(Wl[o * C + min(c, C - 1)], d[k], acc[min(c, C - 1)]);  // wave-uniform, no load inside
         const float w = wave_sum_to_lane63(f4dot(d[k], yv[c], 0.f));
-        if (lane == 63 && o0 + k < Co) red[wave * Co * C + o * C + c] = w;
+        if (lane == 63 && o0 + k < Co) red[wave * Co * CT + o * CT + c] = w;
       }
     }
   }
@@ -102,31 +108,36 @@ __global__ __launch_bounds__(kBlock) void k_aggfirst_bwd(const float4* __restric
     for (int c = 0; c < C; ++c) dy4[((size_t)g * C + c) * P4 + p4] = acc[c];
   }
   __syncthreads();
-  float* out = part + ((size_t)g * gridDim.x + blockIdx.x) * (Co * C);
-  for (int i = threadIdx.x; i < Co * C; i += kBlock)
-    out[i] = (red[i] + red[Co * C + i]) + (red[2 * Co * C + i] + red[3 * Co * C + i]);
+  float* out = part + ((size_t)g * gridDim.x + blockIdx.x) * (Co * CT);
+  for (int i = threadIdx.x; i < Co * CT; i += kBlock)
+    out[i] = (red[i] + red[Co * CT + i]) + (red[2 * Co * CT + i] + red[3 * Co * CT + i]);
 }
 
 int aggfirst_blocks(int P) { return cdiv(P / 4, kBlock); }
 
 int launch_aggfirst_bwd(const float* dz, const float* W, const float* y, float* dy, float* part, float* dW, int G,
-                        int Bg, int C, int Co, int P, hipStream_t s, ReduceJobs* defer, int dzgs) {
+                        int Bg, int C, int Co, int P, hipStream_t s, ReduceJobs* defer, int dzgs, int ones) {
   const int P4 = P / 4, nb = aggfirst_blocks(P);
-  const size_t lds = (size_t)5 * Co * C * sizeof(float);
+  const int CT = C + (ones ? 1 : 0);
+  if (CT > kAggFirstMaxC) return MSGAT_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)(Co * C + 4 * Co * CT) * sizeof(float);
   dim3 grid(nb, G);
-#define MSGAT_AF(CC)                                                                                              \
-  hipLaunchKernelGGL(k_aggfirst_bwd<CC>, grid, dim3(kBlock), lds, s, (const float4*)dz, W, (const float4*)y, \
+#define MSGAT_AF(CC, ON)                                                                                          \
+  hipLaunchKernelGGL((k_aggfirst_bwd<CC, ON>), grid, dim3(kBlock), lds, s, (const float4*)dz, W, (const float4*)y, \
                      (float4*)dy, part, Bg, Co, P4, dzgs > 0 ? dzgs : Co)
-  switch (C) {
-    case 1: MSGAT_AF(1); break;
-    case 2: MSGAT_AF(2); break;
-    case 3: MSGAT_AF(3); break;
-    case 4: MSGAT_AF(4); break;
+  switch (ones ? 10 + C : C) {
+    case 1: MSGAT_AF(1, false); break;
+    case 2: MSGAT_AF(2, false); break;
+    case 3: MSGAT_AF(3, false); break;
+    case 4: MSGAT_AF(4, false); break;
+    case 11: MSGAT_AF(1, true); break;
+    case 12: MSGAT_AF(2, true); break;
+    case 13: MSGAT_AF(3, true); break;
     default: return MSGAT_ERR_UNSUPPORTED;
   }
 #undef MSGAT_AF
   MSGAT_CHECK_LAUNCH();
-  return launch_reduce_groups_defer(part, G / Bg, Bg * nb, Co * C, dW, s, defer);
+  return launch_reduce_groups_defer(part, G / Bg, Bg * nb, Co * CT, dW, s, defer);
 }
 
 // ---- general channel projection --------------------------------------------------------

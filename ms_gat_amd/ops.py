@@ -1052,7 +1052,9 @@ class _MixMultiFunction(torch.autograd.Function):
                 x = x.contiguous()
                 ones = int(want_bias and i == 0)   # the bias gradient = contraction with a virtual channel of ones
                 dMi = _new(like, R, Co, c + ones)
-                part = _new(like, max(int(L.msgat_contract_segments_partial_floats(R, Co, c + ones)), 1))
+                nfl = (L.msgat_contract_mix_partial_floats(R, G // R, N, T, Co, c + ones) if both
+                       else L.msgat_contract_segments_partial_floats(R, Co, c + ones))
+                part = _new(like, max(int(nfl), 1))
                 if both:
                     st = L.msgat_contract_mix_segments(R, G // R, N, T, ad, nd, _ptr(x), c, ones, _ptr(M), _ptr(part),
                                                        _ptr(dMi), _ptr(d_ins[0]), stream)

@@ -510,6 +510,11 @@ def test_contract_segments_matches_float64_and_repeats_bit_for_bit(segs, Cb, one
     ((48,), 48, 0, 307, 2),               #   tile wider than its 48 columns, <5,4,64,3,2> / <3,4,128,3,1>
     ((32, 64, 32, 1, 1), 96, 0, 883, 1),  # msgat96 likewise: <9,4,64,3,2>, two z-blocks of 48 columns in 64-wide blocks
     ((96,), 96, 0, 64, 2),                #   <6,4,64,3,2>
+    ((72,), 1, 1, 883, 2),                # a convolution with ONE input channel (the first block of a PEMSD7 component) and a
+    ((48,), 3, 1, 307, 2),                #   bias, three channels (PEMSD4), no bias column, a short row: k_aggfirst_bwd<C, ONES>
+    ((24,), 1, 0, 64, 3),
+    ((72,), 3, 0, 13, 2),
+    ((40,), 2, 1, 50, 1),
 ])
 def test_contract_mix_segments_gives_matrix_bias_and_input_gradients_in_one_pass(segs, Cb, ones, N, Bg):
     """msgat_contract_mix_segments = the backward of y = M x (+ bias): dM (| dbias) AND dx from one pass over dy and x,
@@ -526,7 +531,7 @@ def test_contract_mix_segments_gives_matrix_bias_and_input_gradients_in_one_pass
     arr = (_lib.Seg * len(segs))()
     for i, (t, c) in enumerate(zip(wide, segs)):
         arr[i] = _lib.Seg(t[:, 2:].data_ptr(), c, c + 2)
-    part = torch.empty(max(int(L.msgat_contract_segments_partial_floats(R, Ca, Cb + ones)), 1), device=dev)
+    part = torch.empty(max(int(L.msgat_contract_mix_partial_floats(R, Bg, N, T, Ca, Cb + ones)), 1), device=dev)
     outs = []
     for rep in range(4):
         part.fill_(float("nan"))
