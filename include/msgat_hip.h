@@ -301,11 +301,14 @@ int msgat_layernorm_backward(const float* x, const float* weight, const float* d
  * pooling p[s,t] = sum_n pool_w[n] y[s,n,t] over its [N,T] slabs (ChannelAttention's pooled signal, attention.py:89, taken
  * of MEAM's normalised input, msgat.py:122-125): that consumer's gradient pool_w[n] dpooled[s,t] is rank one and is added
  * to dy row by row inside this pass, instead of by msgat_node_pool_grad_signal in a pass of its own over the activation.
- * pool_w [R,N] (one set per relation), dpooled [rows / N, T]; everything else as msgat_layernorm_backward. */
-int msgat_layernorm_backward_pooled(const float* x, const float* weight, const float* dy, const float* dx_add,
-                                    const float* pool_w, const float* dpooled, int32_t N, float* dx, float* dweight,
-                                    float* dbias, float* partials, int64_t rows, int32_t T, float eps, int32_t R,
-                                    int32_t relu_mask, void* stream);
+ * pool_w [R,N] (one set per relation), dpooled [rows / N, T]; everything else as msgat_layernorm_backward.
+ * dpool_w [R,N] (optional, with dpool_rows: `rows` floats of scratch): the pooling weights' gradient
+ * sum_s y[s,n,:] . dpooled[s,:] out of the same pass (y is rebuilt from x, weight and `bias`, the LayerNorm's own), instead
+ * of msgat_node_pool_grad_weight's pass over the stored y. */
+int msgat_layernorm_backward_pooled(const float* x, const float* weight, const float* bias, const float* dy,
+                                    const float* dx_add, const float* pool_w, const float* dpooled, int32_t N, float* dx,
+                                    float* dweight, float* dbias, float* dpool_w, float* dpool_rows, float* partials,
+                                    int64_t rows, int32_t T, float eps, int32_t R, int32_t relu_mask, void* stream);
 
 /* ---- device: the temporal and channel branches of MEAM ----
  * Building blocks for TACN (src/models/msgat.py:57-80, TemporalAttention attention.py:58-66) and CACN

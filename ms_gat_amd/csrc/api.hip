@@ -659,15 +659,17 @@ extern "C" int msgat_layernorm_backward(const float* x, const float* weight, con
                               (hipStream_t)stream);
 }
 
-extern "C" int msgat_layernorm_backward_pooled(const float* x, const float* weight, const float* dy, const float* dx_add,
-                                               const float* pool_w, const float* dpooled, int32_t N, float* dx,
-                                               float* dweight, float* dbias, float* partials, int64_t rows, int32_t T,
-                                               float eps, int32_t R, int32_t relu_mask, void* stream) {
+extern "C" int msgat_layernorm_backward_pooled(const float* x, const float* weight, const float* bias, const float* dy,
+                                               const float* dx_add, const float* pool_w, const float* dpooled, int32_t N,
+                                               float* dx, float* dweight, float* dbias, float* dpool_w, float* dpool_rows,
+                                               float* partials, int64_t rows, int32_t T, float eps, int32_t R,
+                                               int32_t relu_mask, void* stream) {
   if (!x || !dy || !dx || !partials || !pool_w || !dpooled) return MSGAT_ERR_NULL;
+  if ((dpool_w == nullptr) != (dpool_rows == nullptr)) return MSGAT_ERR_NULL;
   if (rows <= 0 || !(eps >= 0.f) || R <= 0 || R > 65535 || rows % R || N <= 0 || (rows / R) % N) return MSGAT_ERR_SHAPE;
   if (!t_supported(T)) return MSGAT_ERR_UNSUPPORTED;
   return launch_layernorm_bwd(x, weight, dy, dx_add, dx, dweight, dbias, partials, rows, T, eps, R, relu_mask != 0,
-                              (hipStream_t)stream, pool_w, dpooled, N);
+                              (hipStream_t)stream, pool_w, dpooled, N, bias, dpool_rows, dpool_w);
 }
 
 // ---- fused forward ---------------------------------------------------------------------------------

@@ -384,7 +384,8 @@ int launch_layernorm_fwd(const float* x, const float* w, const float* b, float* 
                          float eps, int R, hipStream_t s);
 int launch_layernorm_bwd(const float* x, const float* w, const float* dy, const float* add, float* dx, float* dw,
                          float* db, float* part, long long rows, int T, float eps, int R, int relu_mask, hipStream_t s,
-                         const float* pool_w = nullptr, const float* dpooled = nullptr, int N = 1);
+                         const float* pool_w = nullptr, const float* dpooled = nullptr, int N = 1, const float* lnb = nullptr,
+                         float* dpw_rows = nullptr, float* dpw = nullptr);
 
 // the tiny attention matrices of a MEAM block (smallatt.hip)
 size_t chanatt_partial_floats(int G, int C, int cb, int T);

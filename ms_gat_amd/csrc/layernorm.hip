@@ -82,7 +82,9 @@ __global__ __launch_bounds__(kBlock) void k_ln_bwd(const float* __restrict__ x, 
                                                    const float* __restrict__ dy, const float* __restrict__ add,
                                                    float* __restrict__ dx, float* __restrict__ part, long long rows,
                                                    float eps, int relu_mask, const float* __restrict__ pool_w = nullptr,
-                                                   const float* __restrict__ dpooled = nullptr, int N = 1) {
+                                                   const float* __restrict__ dpooled = nullptr, int N = 1,
+                                                   const float* __restrict__ lnb = nullptr,
+                                                   float* __restrict__ dpw_rows = nullptr) {
   __shared__ float red[kBlock / kWave][2 * T];
   x += (size_t)blockIdx.y * rows * T;
   dy += (size_t)blockIdx.y * rows * T;
@@ -111,6 +113,20 @@ __global__ __launch_bounds__(kBlock) void k_ln_bwd(const float* __restrict__ x, 
       load_row<T>(dpooled + ((size_t)blockIdx.y * (size_t)(rows / N) + slab) * T, pv);
 #pragma unroll
       for (int t = 0; t < T; ++t) gv[t] = fmaf(pw, pv[t], gv[t]);
+      if (dpw_rows != nullptr) {
+        // ... and the pooling weights' gradient dpool_w[n] = sum_slabs y[slab,n,:] . dpooled[slab,:]: this row's term, with
+        // y = xhat w + b rebuilt from x (one float per row; summed over the slabs by a reduction launch) instead of
+        // k_node_pool_dw's pass over the stored y
+        float xc[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) xc[t] = xv[t];
+        const float rs = centre_row<T>(xc, eps);
+        float dotp = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+          dotp = fmaf(fmaf(xc[t] * rs, wv[t], lnb ? lnb[blockIdx.y * T + t] : 0.f), pv[t], dotp);
+        if (live) dpw_rows[(size_t)blockIdx.y * rows + ri] = dotp;
+      }
     }
     if (!live) {
 #pragma unroll
@@ -185,19 +201,22 @@ int launch_layernorm_fwd(const float* x, const float* w, const float* b, float* 
 
 int launch_layernorm_bwd(const float* x, const float* w, const float* dy, const float* add, float* dx, float* dw,
                          float* db, float* part, long long rows, int T, float eps, int R, int relu_mask, hipStream_t s,
-                         const float* pool_w, const float* dpooled, int N) {
+                         const float* pool_w, const float* dpooled, int N, const float* lnb, float* dpw_rows, float* dpw) {
   rows /= R;  // per relation
   if (pool_w != nullptr && (dpooled == nullptr || N <= 0 || rows % N != 0 || rows > 0x7fffffffLL)) return MSGAT_ERR_SHAPE;
   const int nb = ln_blocks(rows);
   switch (T) {
-    case 4: hipLaunchKernelGGL(k_ln_bwd<4>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps, relu_mask, pool_w, dpooled, N); break;
-    case 8: hipLaunchKernelGGL(k_ln_bwd<8>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps, relu_mask, pool_w, dpooled, N); break;
-    case 12: hipLaunchKernelGGL(k_ln_bwd<12>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps, relu_mask, pool_w, dpooled, N); break;
-    case 16: hipLaunchKernelGGL(k_ln_bwd<16>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps, relu_mask, pool_w, dpooled, N); break;
+    case 4: hipLaunchKernelGGL(k_ln_bwd<4>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps, relu_mask, pool_w, dpooled, N, lnb, dpw_rows); break;
+    case 8: hipLaunchKernelGGL(k_ln_bwd<8>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps, relu_mask, pool_w, dpooled, N, lnb, dpw_rows); break;
+    case 12: hipLaunchKernelGGL(k_ln_bwd<12>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps, relu_mask, pool_w, dpooled, N, lnb, dpw_rows); break;
+    case 16: hipLaunchKernelGGL(k_ln_bwd<16>, dim3(nb, R), dim3(kBlock), 0, s, x, w, dy, add, dx, part, rows, eps, relu_mask, pool_w, dpooled, N, lnb, dpw_rows); break;
     default: return MSGAT_ERR_UNSUPPORTED;
   }
   MSGAT_CHECK_LAUNCH();
-  return launch_reduce_split(part, R, nb, 2 * T, dw, T, db, T, s);
+  if (int st = launch_reduce_split(part, R, nb, 2 * T, dw, T, db, T, s)) return st;
+  if (pool_w != nullptr && dpw_rows != nullptr && dpw != nullptr)   // dpool_w [R,N]: the column sums of a relation's [rows / N, N] terms
+    return launch_reduce_groups(dpw_rows, R, (int)(rows / N), N, dpw, s);
+  return MSGAT_OK;
 }
 
 }  // namespace msgat

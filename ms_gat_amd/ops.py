@@ -320,7 +320,7 @@ class _LnPoolTeeFunction(torch.autograd.Function):
         Rp = pw.numel() // N
         _lib.check(L.msgat_node_pool(_ptr(y), _ptr(pw), _ptr(pooled), B * Cc, N, T, Rp, 0, 0, stream), "msgat_node_pool")
         ctx.eps, ctx.relu_input, ctx.has_w, ctx.has_b, ctx.R, ctx.Rp = eps, bool(relu_input), w is not None, b is not None, R, Rp
-        ctx.save_for_backward(*([x, y, pw] + ([w] if w is not None else [])))
+        ctx.save_for_backward(*([x, y, pw] + ([w] if w is not None else []) + ([b] if b is not None else [])))
         return y, x.view_as(x), pooled
 
     @staticmethod
@@ -329,33 +329,43 @@ class _LnPoolTeeFunction(torch.autograd.Function):
         saved = ctx.saved_tensors
         x, y, pw = saved[:3]
         w = saved[3] if ctx.has_w else None
+        lnb = saved[3 + int(ctx.has_w)] if ctx.has_b else None      # the LayerNorm's bias: y is rebuilt from x for dpool_w
         B, Cc, N, T = x.shape
         rows = B * Cc * N
         stream = _stream_handle(x.device)
         need = ctx.needs_input_grad
         dpw = None
-        if dpooled is not None and need[5]:
-            dpw = torch.empty_like(pw)
+        fused = dpooled is not None and ctx.Rp == ctx.R           # the pooling's gradients inside the LayerNorm-backward kernel
+
+        def pool_weight_grad():     # its own pass over the stored y (msgat_node_pool_grad_weight)
+            g = torch.empty_like(pw)
             part = _new(x, max(int(L.msgat_node_pool_partial_floats(B, Cc, N)), 1))
-            _lib.check(L.msgat_node_pool_grad_weight(_ptr(y), _ptr(dpooled.contiguous()), _ptr(dpw), _ptr(part), B, Cc, N, T, ctx.Rp,
+            _lib.check(L.msgat_node_pool_grad_weight(_ptr(y), _ptr(dpooled.contiguous()), _ptr(g), _ptr(part), B, Cc, N, T, ctx.Rp,
                                                      stream), "msgat_node_pool_grad_weight")
+            return g
         if dy is None and dpooled is None:
             if dx_other is not None and ctx.relu_input:
                 dx_other = torch.ops.aten.threshold_backward(dx_other.contiguous(), x, 0.0)
-            return dx_other, None, None, None, None, dpw
+            return dx_other, None, None, None, None, None
         dy = torch.zeros_like(x) if dy is None else dy.contiguous()
         other = None if dx_other is None else dx_other.contiguous()
         dx = torch.empty_like(x)
         dw = torch.empty_like(w) if ctx.has_w else None
         db = torch.empty(w.shape if ctx.has_w else (T,), device=x.device, dtype=torch.float32) if ctx.has_b else None
         part = _new(x, max(int(L.msgat_layernorm_partial_floats(rows, T, ctx.R)), 1))
-        if dpooled is not None and ctx.Rp == ctx.R:
-            st = L.msgat_layernorm_backward_pooled(_ptr(x), _ptr(w), _ptr(dy), _ptr(other), _ptr(pw), _ptr(dpooled.contiguous()), N,
-                                                   _ptr(dx), _ptr(dw), _ptr(db), _ptr(part), rows, T, ctx.eps, ctx.R,
+        if fused:
+            want_pw = bool(need[5])
+            dpw = torch.empty_like(pw) if want_pw else None
+            rows_scratch = _new(x, rows) if want_pw else None
+            st = L.msgat_layernorm_backward_pooled(_ptr(x), _ptr(w), _ptr(lnb), _ptr(dy), _ptr(other), _ptr(pw),
+                                                   _ptr(dpooled.contiguous()), N, _ptr(dx), _ptr(dw), _ptr(db), _ptr(dpw),
+                                                   _ptr(rows_scratch), _ptr(part), rows, T, ctx.eps, ctx.R,
                                                    int(ctx.relu_input), stream)
             _lib.check(st, "msgat_layernorm_backward_pooled")
         else:
-            if dpooled is not None:      # parameter-set counts differ: the pooling's gradient in its own pass, then the LayerNorm
+            if dpooled is not None:      # parameter-set counts differ: the pooling's gradients in their own passes, then the LayerNorm
+                if need[5]:
+                    dpw = pool_weight_grad()
                 dyp = torch.empty_like(x)
                 _lib.check(L.msgat_node_pool_grad_signal(_ptr(pw), _ptr(dpooled.contiguous()), _ptr(dy), _ptr(dyp), B * Cc, N, T,
                                                          ctx.Rp, stream), "msgat_node_pool_grad_signal")
