@@ -46,7 +46,8 @@ extern "C" {
 #endif
 
 /* 6 (round 5): + msgat_contract_form_name, msgat_causal_conv{,_fused,_grad_weight}, msgat_layernorm_head_backward
- * {,_partial_floats}, msgat_layernorm_backward_pooled, msgat_contract_mix_partial_floats; no existing signature or structure changed since 5. */
+ * {,_partial_floats}, msgat_layernorm_{forward,backward}_pooled, msgat_layernorm_pool_partial_floats,
+ * msgat_contract_mix_partial_floats; no existing signature or structure changed since 5. */
 #define MSGAT_ABI_VERSION 6
 
 enum {
@@ -297,6 +298,16 @@ size_t msgat_layernorm_partial_floats(int64_t rows, int32_t T, int32_t R);
 int msgat_layernorm_backward(const float* x, const float* weight, const float* dy, const float* dx_add,
                              float* dx, float* dweight, float* dbias, float* partials, int64_t rows,
                              int32_t T, float eps, int32_t R, int32_t relu_mask, void* stream);
+/* msgat_layernorm_forward_pooled: msgat_layernorm_forward that also leaves the node pooling of its OUTPUT,
+ * pooled[s,t] = sum_n pool_w[n] y[s,n,t] over y's [N,T] slabs (ChannelAttention's pooled signal, attention.py:89, on MEAM's
+ * normalised input, msgat.py:122-125): a wave's 64 rows lie in at most two slabs (N >= 64, else MSGAT_ERR_UNSUPPORTED), every
+ * 64-row trip leaves its share of both and a small second launch adds a slab's shares in trip order -- instead of
+ * msgat_node_pool reading back the tensor that was just written.  pool_w [R,N], pooled [rows / N, T];
+ * partials: msgat_layernorm_pool_partial_floats(rows, T, R) floats. */
+size_t msgat_layernorm_pool_partial_floats(int64_t rows, int32_t T, int32_t R);
+int msgat_layernorm_forward_pooled(const float* x, const float* weight, const float* bias, float* y, const float* pool_w,
+                                   int32_t N, float* pooled, float* partials, int64_t rows, int32_t T, float eps, int32_t R,
+                                   void* stream);
 /* msgat_layernorm_backward_pooled: msgat_layernorm_backward for a LayerNorm whose output y [.., N, T] ALSO fed a node
  * pooling p[s,t] = sum_n pool_w[n] y[s,n,t] over its [N,T] slabs (ChannelAttention's pooled signal, attention.py:89, taken
  * of MEAM's normalised input, msgat.py:122-125): that consumer's gradient pool_w[n] dpooled[s,t] is rank one and is added

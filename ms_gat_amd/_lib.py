@@ -118,6 +118,9 @@ _PROTOTYPES = {
     "msgat_head_grad_signal": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 6 + [C.c_void_p]),
     "msgat_head_grad_weight_partial_floats": (C.c_size_t, [C.c_int32] * 4),
     "msgat_head_grad_weight": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 6 + [C.c_void_p]),
+    "msgat_layernorm_pool_partial_floats": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "msgat_layernorm_forward_pooled": (C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float,
+                                                C.c_int32, C.c_void_p]),
     "msgat_layernorm_backward_pooled": (C.c_int, [C.c_void_p] * 7 + [C.c_int32] + [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_float,
                                                  C.c_int32, C.c_int32, C.c_void_p]),
     "msgat_layernorm_head_backward_partial_floats": (C.c_size_t, [C.c_int32] * 4),

@@ -659,6 +659,20 @@ extern "C" int msgat_layernorm_backward(const float* x, const float* weight, con
                               (hipStream_t)stream);
 }
 
+extern "C" size_t msgat_layernorm_pool_partial_floats(int64_t rows, int32_t T, int32_t R) {
+  if (rows <= 0 || R <= 0 || rows % R || !t_supported(T)) return 0;
+  return layernorm_pool_partial_floats(rows, T, R);
+}
+
+extern "C" int msgat_layernorm_forward_pooled(const float* x, const float* weight, const float* bias, float* y,
+                                              const float* pool_w, int32_t N, float* pooled, float* partials, int64_t rows,
+                                              int32_t T, float eps, int32_t R, void* stream) {
+  if (!x || !y || !pool_w || !pooled || !partials) return MSGAT_ERR_NULL;
+  if (rows <= 0 || !(eps >= 0.f) || R <= 0 || R > 65535 || rows % R || N <= 0 || (rows / R) % N) return MSGAT_ERR_SHAPE;
+  if (!t_supported(T) || N < kWave) return MSGAT_ERR_UNSUPPORTED;
+  return launch_layernorm_fwd(x, weight, bias, y, rows, T, eps, R, (hipStream_t)stream, pool_w, partials, pooled, N);
+}
+
 extern "C" int msgat_layernorm_backward_pooled(const float* x, const float* weight, const float* bias, const float* dy,
                                                const float* dx_add, const float* pool_w, const float* dpooled, int32_t N,
                                                float* dx, float* dweight, float* dbias, float* dpool_w, float* dpool_rows,

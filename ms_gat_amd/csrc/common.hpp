@@ -381,7 +381,9 @@ size_t layernorm_partial_floats(long long rows, int T, int R);
 int launch_reduce_split(const float* part, int R, int J, int Wd, float* dst0, int n0, float* dst1, int n1,
                         hipStream_t s);
 int launch_layernorm_fwd(const float* x, const float* w, const float* b, float* y, long long rows, int T,
-                         float eps, int R, hipStream_t s);
+                         float eps, int R, hipStream_t s,
+                         const float* pool_w = nullptr, float* pool_part = nullptr, float* pooled = nullptr, int N = 1);
+size_t layernorm_pool_partial_floats(long long rows, int T, int R);
 int launch_layernorm_bwd(const float* x, const float* w, const float* dy, const float* add, float* dx, float* dw,
                          float* db, float* part, long long rows, int T, float eps, int R, int relu_mask, hipStream_t s,
                          const float* pool_w = nullptr, const float* dpooled = nullptr, int N = 1, const float* lnb = nullptr,

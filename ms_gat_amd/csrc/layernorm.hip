@@ -45,10 +45,27 @@ __device__ __forceinline__ float centre_row(float (&x)[T], float eps) {
   return rsqrtf(v * (1.0f / T) + eps);
 }
 
+// Sum over the 64 lanes of a wave, result in lane 63 (six DPP adds, fixed order: project.hip's wave_sum_to_lane63)
+__device__ __forceinline__ float ln_wave_sum63(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));
+  return v;
+}
+
+// pool_w / pool_part (optional, N >= 64): the node pooling of the OUTPUT, p[s,t] = sum_n pool_w[n] y[s,n,t] over its
+// [N,T] slabs (attention.py:89 on MEAM's normalised input), out of this pass: a wave's 64 consecutive rows lie in at
+// most two slabs, so every trip leaves two T-vectors -- its rows' share of the slab its first row lies in, and of the
+// next one -- in pool_part[relation][trip][2][T]; k_pool_trips adds a slab's ~N/64 shares in trip order.  The pooling
+// as its own launch read the 293 MB it had just been written: 76 us at PEMSD7 size.
 template <int T>
 __global__ __launch_bounds__(kBlock) void k_ln_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                    const float* __restrict__ b, float* __restrict__ y,
-                                                   long long rows, float eps) {
+                                                   long long rows, float eps, const float* __restrict__ pool_w = nullptr,
+                                                   float* __restrict__ pool_part = nullptr, int N = 1) {
   // blockIdx.y = relation (parameter set): its `rows` rows are contiguous, its weight / bias are row y of [R,T]
   x += (size_t)blockIdx.y * rows * T;
   y += (size_t)blockIdx.y * rows * T;
@@ -70,7 +87,41 @@ __global__ __launch_bounds__(kBlock) void k_ln_fwd(const float* __restrict__ x, 
 #pragma unroll
     for (int t = 0; t < T; ++t) v[t] = fmaf(v[t] * rstd, wv[t], bv[t]);
     rt.store(y + r0 * T, nf, v);
+    if (pool_w != nullptr) {   // kernel-uniform
+      const int lane = threadIdx.x & (kWave - 1);
+      const int ri = (int)min(r0 + lane, rows - 1);
+      const bool live = r0 + lane < rows;
+      const int slab = ri / N, n = ri - slab * N;
+      const bool inA = slab == (int)(r0 / N);
+      const float pw = live ? pool_w[(size_t)blockIdx.y * N + n] : 0.f;
+      float* out = pool_part + ((size_t)blockIdx.y * (size_t)((rows + kWave - 1) / kWave) + (size_t)(r0 / kWave)) * 2 * T;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float c = pw * v[t];
+        const float sa = ln_wave_sum63(inA ? c : 0.f), sb = ln_wave_sum63(inA ? 0.f : c);
+        if (lane == kWave - 1) { out[t] = sa; out[T + t] = sb; }
+      }
+    }
   }
+}
+
+// pooled[rel, s, t] = the shares of slab s in trip order (see k_ln_fwd): one lane per (slab, t)
+template <int T>
+__global__ __launch_bounds__(kBlock) void k_pool_trips(const float* __restrict__ part, float* __restrict__ pooled,
+                                                       long long rows, int N) {
+  const int slabs = (int)(rows / N);
+  const long long ntrip = (rows + kWave - 1) / kWave;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= slabs * T) return;
+  const int s = i / T, t = i - s * T;
+  const long long k0 = ((long long)s * N) / kWave, k1 = ((long long)(s + 1) * N - 1) / kWave;
+  const float* p = part + (size_t)blockIdx.y * (size_t)ntrip * 2 * T;
+  float acc = 0.f;
+  for (long long k = k0; k <= k1; ++k) {
+    const int first = (int)((k * kWave) / N);          // the slab trip k's first row lies in
+    acc += p[(size_t)k * 2 * T + (first == s ? 0 : T) + t];
+  }
+  pooled[((size_t)blockIdx.y * slabs + s) * T + t] = acc;
 }
 
 // pool_w / dpooled (optional): the LayerNorm output also fed a node pooling p[s,t] = sum_n pool_w[n] y[s,n,t] over its
@@ -184,18 +235,34 @@ static int ln_blocks(long long rows) {
 
 size_t layernorm_partial_floats(long long rows, int T, int R) { return (size_t)R * ln_blocks(rows / R) * 2 * T; }
 
+size_t layernorm_pool_partial_floats(long long rows, int T, int R) {   // rows = all relations' rows
+  return (size_t)R * (size_t)((rows / R + kWave - 1) / kWave) * 2 * T;
+}
+
 int launch_layernorm_fwd(const float* x, const float* w, const float* b, float* y, long long rows, int T,
-                         float eps, int R, hipStream_t s) {
+                         float eps, int R, hipStream_t s, const float* pool_w, float* pool_part, float* pooled, int N) {
   rows /= R;  // per relation
+  if (pool_w != nullptr && (pool_part == nullptr || pooled == nullptr || N < kWave || rows % N != 0 || rows > 0x7fffffffLL))
+    return MSGAT_ERR_SHAPE;
   const int nb = ln_blocks(rows);
   switch (T) {
-    case 4: hipLaunchKernelGGL(k_ln_fwd<4>, dim3(nb, R), dim3(kBlock), 0, s, x, w, b, y, rows, eps); break;
-    case 8: hipLaunchKernelGGL(k_ln_fwd<8>, dim3(nb, R), dim3(kBlock), 0, s, x, w, b, y, rows, eps); break;
-    case 12: hipLaunchKernelGGL(k_ln_fwd<12>, dim3(nb, R), dim3(kBlock), 0, s, x, w, b, y, rows, eps); break;
-    case 16: hipLaunchKernelGGL(k_ln_fwd<16>, dim3(nb, R), dim3(kBlock), 0, s, x, w, b, y, rows, eps); break;
+    case 4: hipLaunchKernelGGL(k_ln_fwd<4>, dim3(nb, R), dim3(kBlock), 0, s, x, w, b, y, rows, eps, pool_w, pool_part, N); break;
+    case 8: hipLaunchKernelGGL(k_ln_fwd<8>, dim3(nb, R), dim3(kBlock), 0, s, x, w, b, y, rows, eps, pool_w, pool_part, N); break;
+    case 12: hipLaunchKernelGGL(k_ln_fwd<12>, dim3(nb, R), dim3(kBlock), 0, s, x, w, b, y, rows, eps, pool_w, pool_part, N); break;
+    case 16: hipLaunchKernelGGL(k_ln_fwd<16>, dim3(nb, R), dim3(kBlock), 0, s, x, w, b, y, rows, eps, pool_w, pool_part, N); break;
     default: return MSGAT_ERR_UNSUPPORTED;
   }
   MSGAT_CHECK_LAUNCH();
+  if (pool_w != nullptr) {
+    const dim3 grid(cdiv((int)(rows / N) * T, kBlock), R);
+    switch (T) {
+      case 4: hipLaunchKernelGGL(k_pool_trips<4>, grid, dim3(kBlock), 0, s, pool_part, pooled, rows, N); break;
+      case 8: hipLaunchKernelGGL(k_pool_trips<8>, grid, dim3(kBlock), 0, s, pool_part, pooled, rows, N); break;
+      case 12: hipLaunchKernelGGL(k_pool_trips<12>, grid, dim3(kBlock), 0, s, pool_part, pooled, rows, N); break;
+      default: hipLaunchKernelGGL(k_pool_trips<16>, grid, dim3(kBlock), 0, s, pool_part, pooled, rows, N); break;
+    }
+    MSGAT_CHECK_LAUNCH();
+  }
   return MSGAT_OK;
 }
 

@@ -315,10 +315,15 @@ class _LnPoolTeeFunction(torch.autograd.Function):
         pw = pool_w.contiguous()
         R = 1 if w is None else w.numel() // T
         stream = _stream_handle(x.device)
-        _lib.check(L.msgat_layernorm_forward(_ptr(x), _ptr(w), _ptr(b), _ptr(y), rows, T, eps, R, stream), "msgat_layernorm_forward")
         pooled = _new(x, B, Cc, T)
         Rp = pw.numel() // N
-        _lib.check(L.msgat_node_pool(_ptr(y), _ptr(pw), _ptr(pooled), B * Cc, N, T, Rp, 0, 0, stream), "msgat_node_pool")
+        if Rp == R and N >= 64:     # the pooling's sums come out of the LayerNorm pass itself (+ a small launch adding the shares)
+            part = _new(x, max(int(L.msgat_layernorm_pool_partial_floats(rows, T, R)), 1))
+            _lib.check(L.msgat_layernorm_forward_pooled(_ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(pw), N, _ptr(pooled), _ptr(part),
+                                                        rows, T, eps, R, stream), "msgat_layernorm_forward_pooled")
+        else:
+            _lib.check(L.msgat_layernorm_forward(_ptr(x), _ptr(w), _ptr(b), _ptr(y), rows, T, eps, R, stream), "msgat_layernorm_forward")
+            _lib.check(L.msgat_node_pool(_ptr(y), _ptr(pw), _ptr(pooled), B * Cc, N, T, Rp, 0, 0, stream), "msgat_node_pool")
         ctx.eps, ctx.relu_input, ctx.has_w, ctx.has_b, ctx.R, ctx.Rp = eps, bool(relu_input), w is not None, b is not None, R, Rp
         ctx.save_for_backward(*([x, y, pw] + ([w] if w is not None else []) + ([b] if b is not None else [])))
         return y, x.view_as(x), pooled
