@@ -183,13 +183,16 @@ class CACN(nn.Module):
             in_channels, out_channels, n_nodes, n_timesteps)
         self.seq = nn.Sequential(ChannelAttention(n_nodes, n_timesteps), nn.Conv2d(in_channels, out_channels, 1))
 
-    def channel_matrix(self, signals: torch.Tensor) -> torch.Tensor:
-        """[B,Co,C] = conv.weight @ channel attention: node pooling in one pass, the rest in one launch."""
+    def channel_matrix(self, signals: torch.Tensor, pooled: torch.Tensor = None) -> torch.Tensor:
+        """[B,Co,C] = conv.weight @ channel attention: node pooling in one pass (or `pooled` [B,C,T], when the caller has
+        it already: MEAM takes it out of its LayerNorm pass), the rest in one launch."""
         ca, conv = self.seq[0], self.seq[1]
-        return ops.channel_attention_mix(ops.node_pool(signals, ca.alpha), ca.Wc, conv.weight.flatten(1))
+        if pooled is None:
+            pooled = ops.node_pool(signals, ca.alpha)
+        return ops.channel_attention_mix(pooled, ca.Wc, conv.weight.flatten(1))
 
-    def forward(self, signals: torch.Tensor) -> torch.Tensor:
-        return ops.mix(signals, self.channel_matrix(signals), self.seq[1].bias)
+    def forward(self, signals: torch.Tensor, pooled: torch.Tensor = None) -> torch.Tensor:
+        return ops.mix(signals, self.channel_matrix(signals, pooled), self.seq[1].bias)
 
 
 class MEAM(nn.Module):
@@ -217,19 +220,22 @@ class MEAM(nn.Module):
         output will do the same for it, so the block skips its own mask pass.  Defaults: plain autograd semantics."""
         # (normed, signals): the residual convolution below reads the block input again (msgat.py:130); routed
         # through the LayerNorm op, its gradient is added inside the LayerNorm-backward kernel
-        normed, signals = ops.layer_norm_t_tee(signals, self.ln.weight, self.ln.bias, self.ln.eps, relu_input)
+        # ... and CACN pools the normalised input over the nodes (attention.py:89): the pooled signal comes out of the
+        # LayerNorm pass, its gradients go back inside the LayerNorm-backward kernel (ops.layer_norm_pool_tee)
+        normed, signals, pooled_c = ops.layer_norm_pool_tee(signals, self.ln.weight, self.ln.bias, self.ln.eps, relu_input,
+                                                            self.cacn.seq[0].alpha)
         res_w = self.res.weight.flatten(1).unsqueeze(0)
         if self.in_channels <= self.out_channels // 3 or not self.dilations:
             # few input channels (the first block of a component): the graph branch aggregates before it
             # projects, nothing to merge -- branch by branch
-            branches = [self.cacn(normed), self.tacn(normed), self.gacn(normed, adjacency)]
+            branches = [self.cacn(normed, pooled_c), self.tacn(normed), self.gacn(normed, adjacency)]
         else:
-            branches = self._merged_branches(normed, adjacency)
+            branches = self._merged_branches(normed, adjacency, pooled_c)
         # relu(cat(branches) + res(signals)): the 1x1 residual convolution reads the three branch tensors as
         # its add operand (no concatenation) and applies the ReLU in its store epilogue
         return ops.mix_multi([signals], res_w, self.res.bias, adds=branches, relu=True, relu_grad_premasked=premasked)[0]
 
-    def _merged_branches(self, normed: torch.Tensor, adjacency):
+    def _merged_branches(self, normed: torch.Tensor, adjacency, pooled_c: torch.Tensor = None):
         """All channel mixings of the normalised input in ONE pass: CACN's per-sample
         matrix `conv @ att_b` (msgat.py:93-94), the two taps of TACN's first convolution (msgat.py:66-74), GACN's
         projection W (msgat.py:27, applied before the aggregation as C > out/3) and the two alpha-weighted channel
@@ -240,7 +246,7 @@ class MEAM(nn.Module):
         ca, ta, gatt = self.cacn.seq[0], self.tacn.seq[0], self.gacn.gatt
         conv_c = self.cacn.seq[1]
         rows = torch.cat([
-            self.cacn.channel_matrix(normed),                                    # [B,cb,C]   needs the node pooling first
+            self.cacn.channel_matrix(normed, pooled_c),                          # [B,cb,C]   from the pooled signal
             self.tacn.stacked_taps(0).unsqueeze(0).expand(B, -1, -1),            # [B,2cb,C]
             self.gacn.W.unsqueeze(0).expand(B, -1, -1),                          # [B,cb,C]
             gatt.alpha.view(1, 1, C).expand(B, -1, -1),                          # [B,1,C]    q of the graph attention
