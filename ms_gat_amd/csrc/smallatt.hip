@@ -39,8 +39,10 @@ __global__ __launch_bounds__(kSaBlock) void k_chanatt_fwd(const float* __restric
   float* t1 = wc + T * T;        // [C][T] = p Wc
   float* S = t1 + C * T;         // [C][C+1]
   const int g = blockIdx.x, r = g / Bg, Cs = C + 1;
+  float* cwl = S + C * Cs;       // [cb][C]: the convolution's weights (read C times per output below: from LDS, not through L1)
   for (int i = threadIdx.x; i < C * T; i += kSaBlock) p[i] = pooled[(size_t)g * C * T + i];
   for (int i = threadIdx.x; i < T * T; i += kSaBlock) wc[i] = Wc[(size_t)r * T * T + i];
+  for (int i = threadIdx.x; i < cb * C; i += kSaBlock) cwl[i] = conv[(size_t)r * cb * C + i];
   __syncthreads();
   for (int i = threadIdx.x; i < C * T; i += kSaBlock) {
     const int c = i / T, s = i - c * T;
@@ -66,11 +68,10 @@ __global__ __launch_bounds__(kSaBlock) void k_chanatt_fwd(const float* __restric
   }
   __syncthreads();
   for (int i = threadIdx.x; i < C * C; i += kSaBlock) att[(size_t)g * C * C + i] = S[(i / C) * Cs + (i % C)];
-  const float* cw = conv + (size_t)r * cb * C;
   for (int i = threadIdx.x; i < cb * C; i += kSaBlock) {
     const int o = i / C, c2 = i - o * C;
     float a = 0.f;
-    for (int c = 0; c < C; ++c) a = fmaf(cw[o * C + c], S[c * Cs + c2], a);
+    for (int c = 0; c < C; ++c) a = fmaf(cwl[o * C + c], S[c * Cs + c2], a);
     Mc[(size_t)g * cb * C + i] = a;
   }
 }
@@ -92,17 +93,18 @@ __global__ __launch_bounds__(kSaBlock) void k_chanatt_bwd(const float* __restric
   float* t1 = wc + T * T;         // [C][T]
   float* dt1 = t1 + C * T;        // [C][T]
   float* dm = dt1 + C * T;        // [cb][C]
+  float* cwl = dm + cb * C;       // [cb][C]: the convolution's weights
   const int g = blockIdx.x, r = g / Bg;
   for (int i = threadIdx.x; i < C * C; i += kSaBlock) S[(i / C) * Cs + (i % C)] = att[(size_t)g * C * C + i];
   for (int i = threadIdx.x; i < C * T; i += kSaBlock) p[i] = pooled[(size_t)g * C * T + i];
   for (int i = threadIdx.x; i < T * T; i += kSaBlock) wc[i] = Wc[(size_t)r * T * T + i];
   for (int i = threadIdx.x; i < cb * C; i += kSaBlock) dm[i] = dMc[(size_t)g * cb * C + i];
+  for (int i = threadIdx.x; i < cb * C; i += kSaBlock) cwl[i] = conv[(size_t)r * cb * C + i];
   __syncthreads();
-  const float* cw = conv + (size_t)r * cb * C;
   for (int i = threadIdx.x; i < C * C; i += kSaBlock) {  // d att = conv^T dMc
     const int c = i / C, c2 = i - c * C;
     float a = 0.f;
-    for (int o = 0; o < cb; ++o) a = fmaf(cw[o * C + c], dm[o * C + c2], a);
+    for (int o = 0; o < cb; ++o) a = fmaf(cwl[o * C + c], dm[o * C + c2], a);
     D[c * Cs + c2] = a;
   }
   for (int i = threadIdx.x; i < cb * C; i += kSaBlock) {  // d conv (this group's share) = dMc att^T
@@ -150,9 +152,11 @@ __global__ __launch_bounds__(kSaBlock) void k_chanatt_bwd(const float* __restric
   }
 }
 
-static size_t chanatt_fwd_lds(int C, int T) { return sizeof(float) * (size_t)(2 * C * T + T * T + C * (C + 1)); }
+static size_t chanatt_fwd_lds(int C, int cb, int T) {
+  return sizeof(float) * (size_t)(2 * C * T + T * T + C * (C + 1) + cb * C);
+}
 static size_t chanatt_bwd_lds(int C, int cb, int T) {
-  return sizeof(float) * (size_t)(2 * C * (C + 1) + 3 * C * T + T * T + cb * C);
+  return sizeof(float) * (size_t)(2 * C * (C + 1) + 3 * C * T + T * T + 2 * cb * C);
 }
 
 size_t chanatt_partial_floats(int G, int C, int cb, int T) { return (size_t)G * ((size_t)T * T + (size_t)cb * C); }
@@ -166,7 +170,7 @@ static int raise_lds(size_t lds) {
 
 int launch_chanatt_fwd(const float* pooled, const float* Wc, const float* conv, float* att, float* Mc, int G, int R,
                        int C, int cb, int T, hipStream_t s) {
-  const size_t lds = chanatt_fwd_lds(C, T);
+  const size_t lds = chanatt_fwd_lds(C, cb, T);
   if (lds > (size_t)kLdsMax - 1024) return MSGAT_ERR_UNSUPPORTED;
 #define MSGAT_CA_FWD(TT)                                                                                      \
   {                                                                                                           \
