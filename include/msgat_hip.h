@@ -46,7 +46,7 @@ extern "C" {
 #endif
 
 /* 6 (round 5): + msgat_contract_form_name, msgat_causal_conv{,_fused,_grad_weight}, msgat_layernorm_head_backward
- * {,_partial_floats}, msgat_layernorm_{forward,backward}_pooled, msgat_layernorm_pool_partial_floats,
+ * {,_partial_floats}, msgat_head_forward_ln, msgat_layernorm_{forward,backward}_pooled, msgat_layernorm_pool_partial_floats,
  * msgat_contract_mix_partial_floats; no existing signature or structure changed since 5. */
 #define MSGAT_ABI_VERSION 6
 
@@ -469,6 +469,15 @@ int msgat_head_grad_signal(const float* dout, const float* W, float* dx, int32_t
 size_t msgat_head_grad_weight_partial_floats(int32_t C, int32_t T, int32_t T_out, int32_t R);
 int msgat_head_grad_weight(const float* dout, const float* x, float* dWc, float* partials, int32_t B, int32_t C,
                            int32_t N, int32_t T, int32_t T_out, int32_t R, void* stream);
+/* msgat_head_forward_ln: msgat_head_forward on LayerNorm(x) with x the LayerNorm's INPUT (ln_weight, ln_bias [R,T] or
+ * NULL): a row's T values lie in neighbouring lanes of the kernel's load layout, so it normalises what it loads (two lane
+ * sums per row) -- one pass over x where msgat_layernorm_forward + msgat_head_forward made three (read, write, read).
+ * normalised [B,C,N,T] or NULL: receives LayerNorm(x) when something else needs it (training: msgat_head_grad_weight
+ * reads it); with NULL -- inference -- the LayerNorm output, an activation only the head reads (msgat.py:158-159), is never
+ * written.  Other buffers as for msgat_head_forward. */
+int msgat_head_forward_ln(const float* x, const float* ln_weight, const float* ln_bias, float eps, const float* W,
+                          const float* bias, float* out, float* normalised, float* partials, int32_t B, int32_t C,
+                          int32_t N, int32_t T, int32_t T_out, int32_t R, void* stream);
 /* msgat_layernorm_head_backward: the head's input gradient (msgat_head_grad_signal) AND the backward of the LayerNorm in
  * front of it (msgat.py:158-159: fc(ln(x).transpose(1, 3))) in ONE pass over x: the [B,C,N,T] gradient between the two is
  * built row by row in registers and consumed on the spot.  x is the LayerNorm's INPUT; relu_mask as in

