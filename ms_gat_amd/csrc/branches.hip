@@ -636,6 +636,9 @@ __global__ __launch_bounds__(kBlock) void k_lnhead_bwd(const float* __restrict__
 // dW partial[c, j, o, t] = sum over the j-th share of samples, all nodes: dout[b,n,o] x[b,c,n,t] -- like k_tmix_dA a
 // [To x T] outer-product sum over rows (b, n), on the matrix cores: lane (m, kq) supplies dout[b][n = 4s + kq][o = m]
 // and x[b][c][n = 4s + kq][t = m] (the VALU form held To*T = 192 accumulators per lane: 193 us for 293 MB).
+// x is LayerNorm(x) as k_head_fwd<T, true> wrote it.  Normalising here instead lost twice in round 5: two 16-lane DPP
+// sums per loaded element made this latency-bound kernel (864 blocks) 427 us from 114, and a [B,C,N,2] (mean, 1/std)
+// buffer left by k_lnhead_bwd cost that kernel 126 -> 265 us and this one a third load stream (259 us).
 constexpr int kHeadChunks = 4;
 
 template <int T>
