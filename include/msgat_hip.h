@@ -46,7 +46,7 @@ extern "C" {
 #endif
 
 /* 6 (round 5): + msgat_contract_form_name, msgat_causal_conv{,_fused,_grad_weight}, msgat_layernorm_head_backward
- * {,_partial_floats}, msgat_head_forward_ln, msgat_layernorm_{forward,backward}_pooled, msgat_layernorm_pool_partial_floats,
+ * {,_partial_floats}, msgat_head_forward_ln, msgat_gate_sum{,_backward}, msgat_layernorm_{forward,backward}_pooled, msgat_layernorm_pool_partial_floats,
  * msgat_contract_mix_partial_floats; no existing signature or structure changed since 5. */
 #define MSGAT_ABI_VERSION 6
 
@@ -543,6 +543,21 @@ int msgat_temporal_attention_backward(const float* dtaps, const float* att, cons
  *     table, as above, but of GRADIENT pointers) and flat[weight_index] = scale (weight_index < 0: not written).
  *     With scale = the rank's sample count and weight_index = the buffer's last element, ONE all-reduce of `flat`
  *     yields sum_r(w_r g_r) and sum_r(w_r); msgat_adam_step(grad_divisor = flat + weight_index) finishes the mean. */
+/* msgat_gate_sum: the model's last line, out = sum_r pred_r * gate_r (msgat.py:203-205) with the gate built on the fly
+ *     from the two embedding tables (embeddings.py:36-39: gate[b] = h_ebd(H[b]) + d_ebd(D[b]) viewed [R,N,T_out]):
+ *       out[b,e] = sum_r pred[r,b,e] * (h_w[H[b]][r,e] + d_w[D[b]][r,e]),   e < E = N * T_out, summed in the order of r.
+ *     pred [R,B,E] (the R components' predictions, relation-major); H, D [B] int64 (torch's index type); h_w [nh, R*E],
+ *     d_w [nd, R*E] row-major as nn.Embedding keeps them.  Indices are clamped into [0, nh) / [0, nd) (torch's gather
+ *     traps on the device instead).  Static gate (msgat.py:189): H = D = d_w = NULL, nh = 1, h_w = W [R,E].
+ * msgat_gate_sum_backward: dpred [R,B,E] = dout * gate, and the DENSE table gradients dh_w [nh, R*E], dd_w [nd, R*E]
+ *     (every row written; a row's samples are added in sample order).  Any output may be NULL.
+ *     Reference: 5 launches forward, 12 backward (gathers, multiplies, a transposing copy, two zero-fill + scatter
+ *     embedding gradients); one each here. */
+int msgat_gate_sum(const float* pred, const int64_t* H, const int64_t* D, const float* h_w, const float* d_w, float* out,
+                   int32_t R, int32_t B, int64_t E, int32_t nh, int32_t nd, void* stream);
+int msgat_gate_sum_backward(const float* dout, const float* pred, const int64_t* H, const int64_t* D, const float* h_w,
+                            const float* d_w, float* dpred, float* dh_w, float* dd_w, int32_t R, int32_t B, int64_t E,
+                            int32_t nh, int32_t nd, void* stream);
 size_t msgat_huber_partial_doubles(int64_t n);
 int msgat_huber_metrics(const float* pred, const float* truth, int64_t n, float delta, float mask_value,
                         double* partials, float* loss, double* sums, float loss_weight, void* stream);

@@ -116,6 +116,8 @@ _PROTOTYPES = {
     "msgat_head_forward_partial_floats": (C.c_size_t, [C.c_int32] * 4),
     "msgat_head_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p]),
     "msgat_head_forward_ln": (C.c_int, [C.c_void_p] * 3 + [C.c_float] + [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p]),
+    "msgat_gate_sum": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "msgat_gate_sum_backward": (C.c_int, [C.c_void_p] * 9 + [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "msgat_head_grad_signal": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 6 + [C.c_void_p]),
     "msgat_head_grad_weight_partial_floats": (C.c_size_t, [C.c_int32] * 4),
     "msgat_head_grad_weight": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 6 + [C.c_void_p]),

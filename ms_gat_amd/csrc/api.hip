@@ -882,6 +882,34 @@ extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t*
   return launch_reduce_jobs(jobs, s);
 }
 
+// ---- the gated sum over the components (msgat.py:203-205) --------------------------------------------------------
+static int check_gate(const float* h_w, const int64_t* H, const int64_t* D, const float* d_w, int32_t R, int32_t B, int64_t E,
+                      int32_t nh, int32_t nd) {
+  if (!h_w) return MSGAT_ERR_NULL;
+  if (R <= 0 || B <= 0 || E <= 0 || nh <= 0 || (long long)R * B * E > 0x7fffffffLL * 64) return MSGAT_ERR_SHAPE;
+  if (E > 0x7fffffff / (R > nh + nd ? R : nh + nd + 1)) return MSGAT_ERR_SHAPE;   // 32-bit (row, r, e) arithmetic
+  if ((d_w != nullptr) != (D != nullptr) || (d_w && nd <= 0)) return MSGAT_ERR_SHAPE;
+  if (!H && nh != 1) return MSGAT_ERR_SHAPE;                                      // static gate: one row
+  return MSGAT_OK;
+}
+
+extern "C" int msgat_gate_sum(const float* pred, const int64_t* H, const int64_t* D, const float* h_w, const float* d_w,
+                              float* out, int32_t R, int32_t B, int64_t E, int32_t nh, int32_t nd, void* stream) {
+  if (!pred || !out) return MSGAT_ERR_NULL;
+  if (int st = check_gate(h_w, H, D, d_w, R, B, E, nh, nd)) return st;
+  return launch_gate_sum(pred, (const long long*)H, (const long long*)D, h_w, d_w, out, R, B, (int)E, nh, nd,
+                         (hipStream_t)stream);
+}
+
+extern "C" int msgat_gate_sum_backward(const float* dout, const float* pred, const int64_t* H, const int64_t* D,
+                                       const float* h_w, const float* d_w, float* dpred, float* dh_w, float* dd_w,
+                                       int32_t R, int32_t B, int64_t E, int32_t nh, int32_t nd, void* stream) {
+  if (!dout || !pred) return MSGAT_ERR_NULL;
+  if (int st = check_gate(h_w, H, D, d_w, R, B, E, nh, nd)) return st;
+  return launch_gate_sum_bwd(dout, pred, (const long long*)H, (const long long*)D, h_w, d_w, dpred, dh_w, dd_w, R, B, (int)E,
+                             nh, nd, (hipStream_t)stream);
+}
+
 // ---- step tail: fused Huber loss + metric sums, flat Adam ------------------------------------------------------
 extern "C" size_t msgat_huber_partial_doubles(int64_t n) { return n > 0 ? huber_partial_doubles(n) : 0; }
 

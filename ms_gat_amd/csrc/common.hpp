@@ -404,6 +404,11 @@ int launch_tempatt_bwd(const float* dtaps, const float* att, const float* lr, co
                        const float* Wt2, float* dpooled, float* dWt1, float* dWt2, float* part, int G, int R, int N,
                        int K, int T, int dil, hipStream_t s);
 // step tail (tail.hip)
+int launch_gate_sum(const float* pred, const long long* H, const long long* D, const float* h_w, const float* d_w, float* out,
+                    int R, int B, int E, int nh, int nd, hipStream_t s);
+int launch_gate_sum_bwd(const float* dout, const float* pred, const long long* H, const long long* D, const float* h_w,
+                        const float* d_w, float* dpred, float* dh_w, float* dd_w, int R, int B, int E, int nh, int nd,
+                        hipStream_t s);
 size_t huber_partial_doubles(long long n);
 int launch_huber_metrics(const float* pred, const float* truth, long long n, float delta, float mask_value,
                          double* part, float* loss, double* sums, float loss_weight, hipStream_t s);

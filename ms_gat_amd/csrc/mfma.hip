@@ -373,6 +373,13 @@ int launch_project_mfma(const SegList& in, const float* M, int m_in_major, const
   }
 }
 
+#ifdef MSGAT_LAB
+static int lab_env(const char* name, int dflt) {   // lab builds only: a launch parameter from the environment
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+#endif
+
 // ---- the same convolution with ONE load per input float4 (Cr % 4 == 0: the widths of the reference's models) ---------
 // k_project_mfma<.., TAPS> loads every input row twice (the plain and the shifted operand): 12 loads per lane for 24
 // channels, half of them unaligned -- it ran at 2.9 TB/s of its algorithmic bytes.  Here a wave covers GP4 = the largest
@@ -384,7 +391,7 @@ template <int MG, int kMaxK>   // kMaxK: k-steps the registers hold (8: Cr <= 32
 __global__ __launch_bounds__(kBlock, 2) void k_causal_conv(
     const float* __restrict__ in, int in_gstride, const float* __restrict__ taps, int m_in_major,
     const float* __restrict__ bias, int bias_rstride, float* __restrict__ out, int Bg, int P4, int Cr, int Co,
-    int tshift, int T) {
+    int tshift, int T, int tiles, int per_block) {
   extern __shared__ float lds[];
   const int Ci = 2 * Cr;                      // virtual channels [shifted | plain]
   const int K4r = Cr >> 2;                    // k-steps over the REAL channels (Cr % 4 == 0, host-checked)
@@ -397,15 +404,21 @@ __global__ __launch_bounds__(kBlock, 2) void k_causal_conv(
   const int j = lane & 15, kq = lane >> 4;
   const int F = T >> 2;                       // float4s per row of T
   const int GP4 = (16 / F) * F;               // float4s a wave covers: whole rows only
-  const int p4 = (blockIdx.x * 4 + wave) * GP4 + j;
-  const bool pvalid = j < GP4 && p4 < P4;
-  const int p4c = min(p4, P4 - 1);
-  const float* base = in + (size_t)g * in_gstride * (4 * (size_t)P4) + 4 * (size_t)p4c;
+  const float* gbase = in + (size_t)g * in_gstride * (4 * (size_t)P4);
+  // a block works on `per_block` consecutive tiles (4 waves x GP4 float4s each); the next tile's input is requested before
+  // the current one is multiplied, so only the first tile's round trip and one matrix staging are exposed per block (one
+  // tile per block, 4320 blocks of 46 KB each at PEMSD7 size, ran at 2.9 TB/s)
+  const int tile0 = blockIdx.x * per_block, tile1 = min(tile0 + per_block, tiles);
 
-  float4 own[kMaxK];
+  float4 own[kMaxK], nxt[kMaxK];
+  auto fetch = [&](int tile, float4 (&dst)[kMaxK]) {
+    const int p4c = min((tile * 4 + wave) * GP4 + j, P4 - 1);
+    const float* base = gbase + 4 * (size_t)p4c;
 #pragma unroll
-  for (int k = 0; k < kMaxK; ++k)             // the whole input of the tile, requested before the matrix is staged
-    if (k < K4r) own[k] = load_global(base + (size_t)(4 * k + kq) * (4 * (size_t)P4));   // kernel-uniform guard
+    for (int k = 0; k < kMaxK; ++k)
+      if (k < K4r) dst[k] = load_global(base + (size_t)(4 * k + kq) * (4 * (size_t)P4));   // kernel-uniform guard
+  };
+  fetch(tile0, own);                          // requested before the matrix is staged
 
   for (int i = threadIdx.x; i < Mrows * Kpad; i += kBlock) {
     const int co = i / Kpad, k = i - co * Kpad;
@@ -443,37 +456,44 @@ __global__ __launch_bounds__(kBlock, 2) void k_causal_conv(
                        b == 0 ? A.w : (b == 1 ? B.x : (b == 2 ? B.y : B.z)));
   };
 
-  f32x4 acc[MG][4];
-#pragma unroll
-  for (int mg = 0; mg < MG; ++mg)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[mg][i] = zero4();
   const float* wrow = Wl + j * Kpad + kq;     // row co = tile*16 + j; column 4k + kq (shifted half), Cr + 4k + kq (plain half)
+  for (int tile = tile0; tile < tile1; ++tile) {
+    if (tile + 1 < tile1) fetch(tile + 1, nxt);   // block-uniform
+    f32x4 acc[MG][4];
 #pragma unroll
-  for (int k = 0; k < kMaxK; ++k) {
-    if (k < K4r) {                            // kernel-uniform; MFMAs, shuffles and LDS reads only
-      const float4 pl = own[k];
-      const float4 sh = shifted(pl);
+    for (int mg = 0; mg < MG; ++mg)
 #pragma unroll
-      for (int mg = 0; mg < MG; ++mg) {
-        const float a0 = wrow[mg * 16 * Kpad + 4 * k];
-        const float a1 = wrow[mg * 16 * Kpad + Cr + 4 * k];
-        acc[mg][0] = mfma16(a0, sh.x, acc[mg][0]); acc[mg][1] = mfma16(a0, sh.y, acc[mg][1]);
-        acc[mg][2] = mfma16(a0, sh.z, acc[mg][2]); acc[mg][3] = mfma16(a0, sh.w, acc[mg][3]);
-        acc[mg][0] = mfma16(a1, pl.x, acc[mg][0]); acc[mg][1] = mfma16(a1, pl.y, acc[mg][1]);
-        acc[mg][2] = mfma16(a1, pl.z, acc[mg][2]); acc[mg][3] = mfma16(a1, pl.w, acc[mg][3]);
+      for (int i = 0; i < 4; ++i) acc[mg][i] = zero4();
+#pragma unroll
+    for (int k = 0; k < kMaxK; ++k) {
+      if (k < K4r) {                            // kernel-uniform; MFMAs, shuffles and LDS reads only
+        const float4 pl = own[k];
+        const float4 sh = shifted(pl);
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) {
+          const float a0 = wrow[mg * 16 * Kpad + 4 * k];
+          const float a1 = wrow[mg * 16 * Kpad + Cr + 4 * k];
+          acc[mg][0] = mfma16(a0, sh.x, acc[mg][0]); acc[mg][1] = mfma16(a0, sh.y, acc[mg][1]);
+          acc[mg][2] = mfma16(a0, sh.z, acc[mg][2]); acc[mg][3] = mfma16(a0, sh.w, acc[mg][3]);
+          acc[mg][0] = mfma16(a1, pl.x, acc[mg][0]); acc[mg][1] = mfma16(a1, pl.y, acc[mg][1]);
+          acc[mg][2] = mfma16(a1, pl.z, acc[mg][2]); acc[mg][3] = mfma16(a1, pl.w, acc[mg][3]);
+        }
       }
     }
+    const int p4 = (tile * 4 + wave) * GP4 + j;
+    const bool pvalid = j < GP4 && p4 < P4;
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int co = mg * 16 + 4 * kq + reg;
+        const float bb = bl[co];
+        const float4 v = make_float4(acc[mg][0][reg] + bb, acc[mg][1][reg] + bb, acc[mg][2][reg] + bb, acc[mg][3][reg] + bb);
+        if (co < Co && pvalid) store_global(out + ((size_t)g * Co + co) * (4 * (size_t)P4) + 4 * (size_t)p4, v);
+      }
+#pragma unroll
+    for (int k = 0; k < kMaxK; ++k) own[k] = nxt[k];
   }
-#pragma unroll
-  for (int mg = 0; mg < MG; ++mg)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int co = mg * 16 + 4 * kq + reg;
-      const float bb = bl[co];
-      const float4 v = make_float4(acc[mg][0][reg] + bb, acc[mg][1][reg] + bb, acc[mg][2][reg] + bb, acc[mg][3][reg] + bb);
-      if (co < Co && pvalid) store_global(out + ((size_t)g * Co + co) * (4 * (size_t)P4) + 4 * (size_t)p4, v);
-    }
 }
 
 // The causal dilated convolution in one pass (k_project_mfma<.., TAPS>): in [G,Cr,P] (a channel slice of a wider
@@ -500,14 +520,22 @@ int launch_project_taps(const float* in, int in_gstride, const float* taps, int 
 #ifndef MSGAT_TAPS_TWO_LOADS
   if (Cr % 4 == 0 && Cr <= 64 && MG <= 4) {   // one load per input float4, the shifted operand by lane shuffles
     const int F = T / 4, GP4 = (16 / F) * F;
-    const dim3 grid1(cdiv(P4, 4 * GP4), G);
+    const int tiles = cdiv(P4, 4 * GP4);
+    // consecutive tiles per block (lab builds: MSGAT_LAB_CCPB).  Cold operands, G = 96, 24 -> 24 channels, tools/
+    // causal_conv_time.py: N = 883 (4320 tiles) 98.6 / 85.8 / 83.3 / 92.1 us at 1 / 2 / 3 / 4; N = 307 (1536 tiles) 38.4 /
+    // 35.0 / 40.8 / 39.5
+    int per_block = std::max(1, std::min(3, (int)((long long)tiles * G / 768)));
+#ifdef MSGAT_LAB
+    per_block = lab_env("MSGAT_LAB_CCPB", per_block);
+#endif
+    const dim3 grid1(cdiv(tiles, per_block), G);
     const int gs = in_gstride > Cr ? in_gstride : Cr;
 #define MSGAT_CC(mg, kk)                                                                                               \
   {                                                                                                                   \
     static LdsGrant granted;                                                                                          \
     if (int st_ = grant_dynamic_lds(&k_causal_conv<mg, kk>, lds, granted)) return st_;                                 \
     hipLaunchKernelGGL((k_causal_conv<mg, kk>), grid1, dim3(kBlock), lds, s, in, gs, taps, m_in_major, bias,           \
-                       bias_rstride, out, Bg, P4, Cr, Co, tshift, T);                                                 \
+                       bias_rstride, out, Bg, P4, Cr, Co, tshift, T, tiles, per_block);                               \
   }
 #define MSGAT_CC2(mg) case mg: if (Cr <= 32) MSGAT_CC(mg, 8) else MSGAT_CC(mg, 16) break;
     switch (MG) { MSGAT_CC2(1) MSGAT_CC2(2) MSGAT_CC2(3) MSGAT_CC2(4) }
@@ -1215,13 +1243,6 @@ static size_t chanpair_glds_lds(int Ca, int Cb) {
   const int rows = min(cdiv(Ca, nza), Ca) + min(cdiv(Cb, nzb), Cb);
   return sizeof(float4) * (size_t)NBUF * (cdiv(rows, 256 / TILE) + 2) * kGGroupF4;
 }
-
-#ifdef MSGAT_LAB
-static int lab_env(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-#endif
 
 template <int MA, int NB, int TILE, int NBUF, int MODE = 0>
 static int launch_chanpair_glds_t(const SegList& A, const float* B, float* part, int R, int Bg, int Cb, int P,

@@ -110,6 +110,96 @@ int launch_huber_grad(const float* pred, const float* truth, const float* dloss,
   return MSGAT_OK;
 }
 
+// ---- the gated sum over the components (msgat.py:203-205, embeddings.py:36-39) --------------------------------------
+//   out[b,e] = sum_r pred[r,b,e] * (h_w[H[b]][r,e] + d_w[D[b]][r,e])        e = (node, output step)
+// The reference runs two embedding gathers, an add, R multiplies and R - 1 adds forward and, backward, R + R multiplies,
+// a transposing copy and two dense embedding gradients (a zero fill and a scatter each): 17 launches for 4 MB tensors.
+// Here one launch each way.  Indices are clamped into the tables (torch's gather would trap on the device instead).
+// Static gate (msgat.py:189): H = D = nullptr, h_w = W[R,E] as a one-row table, d_w = nullptr.
+__device__ __forceinline__ int gate_row(const long long* idx, int b, int rows) {
+  if (idx == nullptr) return 0;
+  const long long v = idx[b];
+  return (int)(v < 0 ? 0 : (v >= rows ? rows - 1 : v));
+}
+
+__global__ __launch_bounds__(kTailBlock) void k_gate_sum(const float* __restrict__ pred, const long long* __restrict__ H,
+                                                         const long long* __restrict__ D, const float* __restrict__ h_w,
+                                                         const float* __restrict__ d_w, float* __restrict__ out, int R,
+                                                         int B, int E, int nh, int nd) {
+  const long long i = (long long)blockIdx.x * kTailBlock + threadIdx.x;
+  if (i >= (long long)B * E) return;
+  const int b = (int)(i / E), e = (int)(i - (long long)b * E);
+  const float* hr = h_w + (size_t)gate_row(H, b, nh) * R * E + e;
+  const float* dr = d_w ? d_w + (size_t)gate_row(D, b, nd) * R * E + e : nullptr;
+  float acc = 0.f;
+  {
+#pragma clang fp contract(off)   // the reference's ops round the product and the sum separately (hipcc would fuse them)
+    for (int r = 0; r < R; ++r) {   // and add in this order: term_0 + term_1 + ...
+      const float gate = dr ? hr[(size_t)r * E] + dr[(size_t)r * E] : hr[(size_t)r * E];
+      const float term = pred[((size_t)r * B + b) * E + e] * gate;
+      acc = r == 0 ? term : acc + term;
+    }
+  }
+  out[i] = acc;
+}
+
+// blocks [0, nblkA): dpred[r,b,e] = dout[b,e] * gate; the rest: a table row's gradient, summed over the samples that
+// selected it in sample order (thread per (row, r, e); rows [0, nh) of h_w, then [nh, nh + nd) of d_w)
+__global__ __launch_bounds__(kTailBlock) void k_gate_sum_bwd(const float* __restrict__ dout, const float* __restrict__ pred,
+                                                             const long long* __restrict__ H, const long long* __restrict__ D,
+                                                             const float* __restrict__ h_w, const float* __restrict__ d_w,
+                                                             float* __restrict__ dpred, float* __restrict__ dh_w,
+                                                             float* __restrict__ dd_w, int R, int B, int E, int nh, int nd,
+                                                             int nblkA) {
+  if ((int)blockIdx.x < nblkA) {
+    const long long i = (long long)blockIdx.x * kTailBlock + threadIdx.x;
+    if (dpred == nullptr || i >= (long long)R * B * E) return;
+    const int e = (int)(i % E), b = (int)((i / E) % B), r = (int)(i / ((long long)E * B));
+    float gate = h_w[((size_t)gate_row(H, b, nh) * R + r) * E + e];
+    if (d_w) gate += d_w[((size_t)gate_row(D, b, nd) * R + r) * E + e];
+    dpred[i] = dout[(size_t)b * E + e] * gate;
+    return;
+  }
+  const long long i = (long long)(blockIdx.x - nblkA) * kTailBlock + threadIdx.x;
+  const long long RE = (long long)R * E;
+  if (i >= (long long)(nh + nd) * RE) return;
+  int row = (int)(i / RE);
+  const long long re = i - (long long)row * RE;
+  const int r = (int)(re / E), e = (int)(re - (long long)r * E);
+  const bool day = row >= nh;
+  row -= day ? nh : 0;
+  float* dst = day ? dd_w : dh_w;
+  if (dst == nullptr) return;
+  const long long* idx = day ? D : H;
+  const int rows = day ? nd : nh;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b)
+    if (gate_row(idx, b, rows) == row) acc = fmaf(dout[(size_t)b * E + e], pred[((size_t)r * B + b) * E + e], acc);
+  dst[(size_t)row * RE + re] = acc;
+}
+
+int launch_gate_sum(const float* pred, const long long* H, const long long* D, const float* h_w, const float* d_w, float* out,
+                    int R, int B, int E, int nh, int nd, hipStream_t s) {
+  const long long n = (long long)B * E;
+  hipLaunchKernelGGL(k_gate_sum, dim3((unsigned)((n + kTailBlock - 1) / kTailBlock)), dim3(kTailBlock), 0, s, pred, H, D, h_w,
+                     d_w, out, R, B, E, nh, nd);
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
+}
+
+int launch_gate_sum_bwd(const float* dout, const float* pred, const long long* H, const long long* D, const float* h_w,
+                        const float* d_w, float* dpred, float* dh_w, float* dd_w, int R, int B, int E, int nh, int nd,
+                        hipStream_t s) {
+  const long long nA = dpred ? (long long)R * B * E : 0, nB = (long long)(nh + (d_w ? nd : 0)) * R * E;
+  const int nblkA = (int)((nA + kTailBlock - 1) / kTailBlock);
+  const long long nblk = nblkA + (nB + kTailBlock - 1) / kTailBlock;
+  if (nblk == 0) return MSGAT_OK;
+  hipLaunchKernelGGL(k_gate_sum_bwd, dim3((unsigned)nblk), dim3(kTailBlock), 0, s, dout, pred, H, D, h_w, d_w, dpred, dh_w,
+                     dd_w, R, B, E, nh, d_w ? nd : 0, nblkA);
+  MSGAT_CHECK_LAUNCH();
+  return MSGAT_OK;
+}
+
 // ---- Adam ---------------------------------------------------------------------------------------------------------
 // Chunk c covers chunk_len[c] <= kAdamChunk elements of parameter tensor chunk_tensor[c], starting at chunk_param[c];
 // its gradient and moments sit at chunk_off[c] of the flat buffers.  steps[t] = updates tensor t has received (torch

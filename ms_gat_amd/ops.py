@@ -972,6 +972,77 @@ def head(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None) 
     return _HeadFunction.apply(x, W, bias)
 
 
+class _GateSumFunction(torch.autograd.Function):
+    """pred [R,B,N,To], H [B], D [B], h_w [nh, R*N*To], d_w [nd, R*N*To] -> sum_r pred_r * (h_w[H] + d_w[D])_r
+    (msgat.py:203-205 with embeddings.py:36-39 inside); H = D = d_w = None: the static gate h_w = W [R,N,To]."""
+
+    @staticmethod
+    def forward(ctx, pred, H, D, h_w, d_w):
+        L = _lib.lib()
+        pred, h_w = pred.contiguous(), h_w.contiguous()
+        d_w = None if d_w is None else d_w.contiguous()
+        R, B = pred.shape[:2]
+        E = pred[0, 0].numel()
+        nh = h_w.shape[0] if H is not None else 1
+        nd = d_w.shape[0] if d_w is not None else 0
+        out = _new(pred, *pred.shape[1:])
+        st = L.msgat_gate_sum(_ptr(pred), _ptr(H), _ptr(D), _ptr(h_w), _ptr(d_w), _ptr(out), R, B, E, nh, nd,
+                              _stream_handle(pred.device))
+        _lib.check(st, "msgat_gate_sum")
+        ctx.dims = (R, B, E, nh, nd)
+        ctx.has_idx, ctx.has_day = H is not None, d_w is not None
+        ctx.save_for_backward(*([pred, h_w] + ([H, D] if H is not None else []) + ([d_w] if d_w is not None else [])))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        saved = list(ctx.saved_tensors)
+        pred, h_w = saved[:2]
+        H, D = (saved[2], saved[3]) if ctx.has_idx else (None, None)
+        d_w = saved[-1] if ctx.has_day else None
+        R, B, E, nh, nd = ctx.dims
+        need = ctx.needs_input_grad
+        dout = dout.contiguous()
+        dpred = torch.empty_like(pred) if need[0] else None
+        dh = torch.empty_like(h_w) if need[3] else None
+        dd = torch.empty_like(d_w) if (d_w is not None and need[4]) else None
+        st = L.msgat_gate_sum_backward(_ptr(dout), _ptr(pred), _ptr(H), _ptr(D), _ptr(h_w), _ptr(d_w), _ptr(dpred), _ptr(dh),
+                                       _ptr(dd), R, B, E, nh, nd, _stream_handle(pred.device))
+        _lib.check(st, "msgat_gate_sum_backward")
+        return dpred, None, None, dh, dd
+
+
+def gate_sum(pred: torch.Tensor, H: Optional[torch.Tensor], D: Optional[torch.Tensor], h_weight: torch.Tensor,
+             d_weight: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`sum_r pred[r] * gate[:, r]` with `gate = (h_ebd(H) + d_ebd(D)).view(B, R, N, T_out)` -- the model's last line
+    (msgat.py:203-205, embeddings.py:36-39) -- as one launch forward and one backward; the embedding tables receive
+    dense gradients, as nn.Embedding's do.  `H = D = d_weight = None`: the static gate `h_weight = W [R,N,T_out]`
+    (msgat.py:189).  Indices outside a table are clamped to its ends (torch's gather traps on the device)."""
+    _require_device_tensor("pred", pred)
+    _require_device_tensor("h_weight", h_weight, pred.device)
+    if pred.dim() < 3:
+        raise ValueError(f"gate_sum: pred {tuple(pred.shape)} must be [R, B, ...]")
+    R, B = pred.shape[:2]
+    RE = pred[:, 0].numel()
+    if (H is None) != (D is None) or (H is None) != (d_weight is None):
+        raise ValueError("gate_sum: H, D and d_weight come together (time embedding) or not at all (static gate)")
+    if H is None:
+        if h_weight.numel() != RE:
+            raise ValueError(f"gate_sum: static gate {tuple(h_weight.shape)} does not match pred {tuple(pred.shape)}")
+    else:
+        _require_device_tensor("d_weight", d_weight, pred.device)
+        if H.dtype in (torch.int32, torch.int16, torch.uint8) and D.dtype in (torch.int32, torch.int16, torch.uint8):
+            H, D = H.long(), D.long()                      # nn.Embedding takes these too
+        if (h_weight.dim() != 2 or d_weight.dim() != 2 or h_weight.shape[1] != RE or d_weight.shape[1] != RE
+                or H.shape != (B,) or D.shape != (B,) or H.dtype != torch.int64 or D.dtype != torch.int64
+                or H.device != pred.device or D.device != pred.device):
+            raise ValueError(f"gate_sum: pred {tuple(pred.shape)}, H {tuple(H.shape)} {H.dtype}, D {tuple(D.shape)} {D.dtype}, "
+                             f"tables {tuple(h_weight.shape)} / {tuple(d_weight.shape)} do not match")
+        H, D = H.contiguous(), D.contiguous()
+    return _GateSumFunction.apply(pred, H, D, h_weight, d_weight)
+
+
 # ---- channel axes assembled from several tensors: one pass instead of cat / several mixes -------------------
 
 def _sliced_grad(dz: torch.Tensor, accepts):

@@ -233,5 +233,7 @@ def forward(model, X: torch.Tensor, H: torch.Tensor, D: torch.Tensor) -> torch.T
     pred = ops.ln_head(x, P("ln.weight"), P("ln.bias"), tpcs[0].ln.eps, P("fc.weight"), P("fc.bias"),
                        relu_input=len(tpcs[0].tgacns) > 0)                             # [R*B,N,T_out]
     pred = pred.view(R, B, *pred.shape[1:])
-    gate = model.te(H, D).transpose(0, 1) if model.te is not None else model.W.unsqueeze(1)          # [R,B|1,N,T_out]
-    return (pred * gate).sum(dim=0)
+    # sum_r pred_r * gate_r (msgat.py:203-205), the gate built from the embedding tables inside the kernel
+    if model.te is not None:
+        return ops.gate_sum(pred, H, D, model.te.h_ebd.weight, model.te.d_ebd.weight)
+    return ops.gate_sum(pred, None, None, model.W)

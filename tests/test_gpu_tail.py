@@ -186,3 +186,55 @@ def test_msgat72_training_step_under_autocast_like_the_reference_engine(tmp_path
     scaler.update()
     assert loss.dtype == torch.float32 and abs(float(loss) - float(ref)) < 2e-3 * abs(float(ref))
     assert all(torch.isfinite(p).all() for p in net.parameters())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,B,N,To,te", [(3, 32, 883, 12, True), (1, 2, 5, 3, True), (5, 7, 33, 12, True), (3, 4, 50, 12, False)])
+def test_gate_sum_is_the_models_last_line(R, B, N, To, te):
+    """ops.gate_sum = sum_r pred_r * (h_ebd(H) + d_ebd(D)).view(B,R,N,To)[:, r] (msgat.py:203-205, embeddings.py:36-39):
+    the forward bit for bit against the same torch ops in the reference's order, the gradients (pred and both DENSE
+    embedding-table gradients) against float64."""
+    from ms_gat_amd import ops
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(R * 100 + B)
+    pred = torch.randn(R, B, N, To, generator=gen).to(dev).requires_grad_(True)
+    dout = torch.randn(B, N, To, generator=gen).to(dev)
+    if te:
+        h_w = torch.randn(24, R * N * To, generator=gen).to(dev).requires_grad_(True)
+        d_w = torch.randn(7, R * N * To, generator=gen).to(dev).requires_grad_(True)
+        H = torch.randint(0, 24, (B,), generator=gen).to(dev)
+        D = torch.randint(0, 7, (B,), generator=gen).to(dev)
+        out = ops.gate_sum(pred, H, D, h_w, d_w)
+        params = [pred, h_w, d_w]
+    else:
+        W = torch.randn(R, N, To, generator=gen).to(dev).requires_grad_(True)
+        out = ops.gate_sum(pred, None, None, W)
+        params = [pred, W]
+    out.backward(dout)
+    got = [out.detach()] + [p.grad for p in params]
+
+    def reference(dtype):
+        ps = [p.detach().to(dtype).requires_grad_(True) for p in params]
+        if te:
+            gate = (torch.nn.functional.embedding(H, ps[1]) + torch.nn.functional.embedding(D, ps[2])).view(B, R, N, To)
+            gates = gate.unbind(1)
+        else:
+            gates = ps[1].unbind(0)
+        o = None
+        for r in range(R):                                   # msgat.py:204-205: the generator summed left to right
+            term = ps[0][r] * gates[r]
+            o = term if o is None else o + term
+        o.backward(dout.to(dtype))
+        return [o.detach()] + [p.grad for p in ps]
+
+    same = reference(torch.float32)
+    assert torch.equal(got[0], same[0])
+    ref = reference(torch.float64)
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape
+        err = (a.double() - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+        assert err < 1e-5, err
+    if te:     # rows no sample selected: exactly zero, like nn.Embedding's dense gradient
+        unused = torch.ones(24, dtype=torch.bool, device=dev)
+        unused[H] = False
+        assert not got[2][unused].any()
