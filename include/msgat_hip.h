@@ -400,6 +400,9 @@ int msgat_node_pool_grad_weight(const float* x, const float* dpooled, float* dw,
  *   msgat_contract_segments: dst[r,a,c] = sum_{g in r, p} cat(A_segments)[g,a,p] B[g,c,p]; with_ones = 1 appends a
  *       virtual channel of ones to B: dst is [R, Ca, Cb+1] and dst[r,a,Cb] = sum_{g,p} A[g,a,p] -- the bias gradient of
  *       a 1x1 convolution out of the pass that computes its weight gradient (size the partials for Cb+1).
+ *       with_ones = 2 (ABI 6; also msgat_contract_mix_segments and msgat_causal_conv_grad_weight): the same sums delivered
+ *       apart -- dst holds the plain [R, Ca, Cb] matrix followed by the ones column as [R, Ca], R*Ca*(Cb+1) floats in all
+ *       -- so weight and bias gradient are two contiguous tensors without a copy each.
  * At most 6 segments per list. */
 typedef struct {
   float* ptr;

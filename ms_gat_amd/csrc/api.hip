@@ -317,16 +317,19 @@ extern "C" int msgat_causal_conv_grad_weight(const float* dout, int32_t dout_gro
   if (!dout || !h || !partials || !dtaps) return MSGAT_ERR_NULL;
   int st = check_rgnt(R, Bg, N, T);
   if (st) return st;
-  if (Ci <= 0 || Co <= 0 || Ci > kMaxC || 2 * Co > kMaxC || dilation <= 0 || (with_ones != 0 && with_ones != 1))
+  if (Ci <= 0 || Co <= 0 || Ci > kMaxC || 2 * Co > kMaxC || dilation <= 0 || with_ones < 0 || with_ones > 2)
     return MSGAT_ERR_SHAPE;
   if (dout_group_stride != 0 && (dout_group_stride < Co || dout_group_stride > 4 * kMaxC)) return MSGAT_ERR_SHAPE;
   SegList A = seg_single(dout, Co);
   if (dout_group_stride > Co) A.gstride[0] = dout_group_stride;
+  const int apart = with_ones == 2;
+  with_ones = with_ones != 0;
   const int Cbx = Ci + with_ones;
   hipStream_t s = (hipStream_t)stream;
   int nblk = 0;
   st = launch_chanpair_shifted(A, h, partials, R, Bg, Cbx, N * T, chanpair_mfma_blocks(R), with_ones, dilation, T, s, &nblk);
   if (st) return st;
+  if (apart) return launch_reduce_lastcol(partials, R, nblk, 2 * Co, Cbx, dtaps, s);
   return launch_reduce_groups(partials, R, nblk, 2 * Co * Cbx, dtaps, s);
 }
 
@@ -434,13 +437,13 @@ extern "C" int msgat_contract_segments(int32_t R, int32_t Bg, int32_t N, int32_t
   int st = check_rgnt(R, Bg, N, T);
   if (st) return st;
   if (!B || !partials || !dst) return MSGAT_ERR_NULL;
-  if (Cb <= 0 || Cb > kMaxC || (with_ones != 0 && with_ones != 1)) return MSGAT_ERR_SHAPE;
+  if (Cb <= 0 || Cb > kMaxC || with_ones < 0 || with_ones > 2) return MSGAT_ERR_SHAPE;
   SegList sa;
   if ((st = to_seglist(A, n_a, &sa))) return st;
   if (sa.n == 0) return MSGAT_ERR_SHAPE;
-  const int Cbx = Cb + with_ones;
+  const int ones = with_ones != 0, Cbx = Cb + ones;
   return launch_chanpair_seg(sa, B, partials, dst, sa.total() * Cbx, nullptr, 0, R * Bg, Bg, Cbx, N * T,
-                             (hipStream_t)stream, with_ones);
+                             (hipStream_t)stream, ones, nullptr, with_ones == 2);
 }
 
 extern "C" int msgat_contract_form_name(int32_t Ca, int32_t Cb, int32_t with_ones, int32_t n_positions, int32_t with_mix,
@@ -472,10 +475,12 @@ extern "C" int msgat_contract_mix_segments(int32_t R, int32_t Bg, int32_t N, int
   int st = check_rgnt(R, Bg, N, T);
   if (st) return st;
   if (!B || !partials || !dst || !M || !mixout) return MSGAT_ERR_NULL;
-  if (Cb <= 0 || Cb > kMaxC || (with_ones != 0 && with_ones != 1)) return MSGAT_ERR_SHAPE;
+  if (Cb <= 0 || Cb > kMaxC || with_ones < 0 || with_ones > 2) return MSGAT_ERR_SHAPE;
   SegList sa;
   if ((st = to_seglist(A, n_a, &sa))) return st;
   if (sa.n == 0) return MSGAT_ERR_SHAPE;
+  const int apart = with_ones == 2;          // the ones column's sums delivered behind the matrix, not inside it
+  with_ones = with_ones != 0;
   const int Cbx = Cb + with_ones, Ca = sa.total(), P = N * T;
   hipStream_t s = (hipStream_t)stream;
   // a convolution with 1..3 input channels (the first block of every component: 1 or 3 features): ONE pass over the
@@ -483,13 +488,13 @@ extern "C" int msgat_contract_mix_segments(int32_t R, int32_t Bg, int32_t N, int
   // msgat_contract_mix_partial_floats, which knows this form
   if (Cbx <= kAggFirstMaxC && sa.n == 1 && P % 4 == 0)
     return launch_aggfirst_bwd(sa.ptr[0], M, B, mixout, partials, dst, R * Bg, Bg, Cb, Ca, P, s, nullptr, sa.gstride[0],
-                               with_ones);
+                               with_ones + apart);
   int nblk = 0, both = 0;
   st = launch_chanpair_mix_wide(sa, B, partials, R, Bg, Cbx, P, chanpair_mfma_blocks(R), with_ones, M, mixout, s, &nblk, &both);
   if (st) return st;
-  if (both) return launch_reduce_groups(partials, R, nblk, Ca * Cbx, dst, s);
+  if (both) return apart ? launch_reduce_lastcol(partials, R, nblk, Ca, Cbx, dst, s) : launch_reduce_groups(partials, R, nblk, Ca * Cbx, dst, s);
   // no fused form for this shape: the two passes
-  st = launch_chanpair_seg(sa, B, partials, dst, Ca * Cbx, nullptr, 0, R * Bg, Bg, Cbx, P, s, with_ones);
+  st = launch_chanpair_seg(sa, B, partials, dst, Ca * Cbx, nullptr, 0, R * Bg, Bg, Cbx, P, s, with_ones, nullptr, apart);
   if (st) return st;
   return launch_project_seg(sa, M, 1, nullptr, nullptr, nullptr, seg_single(mixout, Cb), nullptr, R * Bg, Bg, P, MixEpilogue(), s);
 }

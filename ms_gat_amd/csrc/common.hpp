@@ -310,6 +310,8 @@ struct ReduceJob {
   int n0;
   float* dst1;
   int n1;
+  int rw = 0;   // > 0: the Wd sums are rows of rw columns; a row's first rw - 1 go to dst0 [R, Wd/rw, rw - 1], its last to
+                // dst1 [R, Wd/rw] (a bias gradient riding as the last column of a matrix gradient, delivered apart)
 };
 constexpr int kMaxReduceJobs = 4;
 struct ReduceJobs {
@@ -338,7 +340,8 @@ int launch_chanpair_mix(const float* du, const float* dq, const float* x, const 
                         float* part, float* dW, float* dalpha, int G, int Bg, int Co, int C, int P, hipStream_t s,
                         ReduceJobs* defer, int* done);
 int launch_chanpair_seg(const SegList& A, const float* B, float* part, float* dst0, int n0, float* dst1, int n1,
-                        int G, int Bg, int Cb, int P, hipStream_t s, int b_ones = 0, ReduceJobs* defer = nullptr);
+                        int G, int Bg, int Cb, int P, hipStream_t s, int b_ones = 0, ReduceJobs* defer = nullptr,
+                        int lastcol_apart = 0);
 // AGG_FIRST backward with few input channels (C <= kAggFirstMaxC): dy = W^T dz and the partials of dW = dz y^T in ONE
 // pass over dz (project.hip); partials [G * aggfirst_blocks(P)][Co*C], summed per relation by the queued job
 constexpr int kAggFirstMaxC = 4;
@@ -350,6 +353,8 @@ int launch_reduce_rows(const float* part, int J, int Wd, float* dst0, int n0, fl
                        hipStream_t s);
 // out[r,i] = sum_j part[r,j,i]
 int launch_reduce_groups(const float* part, int R, int J, int Wd, float* dst, hipStream_t s);
+// out[r] = sum_j part[r,j] of [rows, rw] matrices, written as [R, rows, rw - 1] at dst followed by [R, rows] (the last column)
+int launch_reduce_lastcol(const float* part, int R, int J, int rows, int rw, float* dst, hipStream_t s, ReduceJobs* defer = nullptr);
 int launch_reduce_groups_defer(const float* part, int R, int J, int Wd, float* dst, hipStream_t s, ReduceJobs* defer);
 // temporal / channel branch kernels (branches.hip)
 int launch_tmix(const float* src, const float* A, int per_group, const float* bias, float* dst, int G, int Co,

@@ -137,6 +137,7 @@ int launch_aggfirst_bwd(const float* dz, const float* W, const float* y, float* 
   }
 #undef MSGAT_AF
   MSGAT_CHECK_LAUNCH();
+  if (ones == 2) return launch_reduce_lastcol(part, G / Bg, Bg * nb, Co, CT, dW, s, defer);
   return launch_reduce_groups_defer(part, G / Bg, Bg * nb, Co * CT, dW, s, defer);
 }
 

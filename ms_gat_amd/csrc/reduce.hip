@@ -62,7 +62,11 @@ __global__ __launch_bounds__(kRedBlock) void k_reduce_partials(ReduceJobs jobs) 
   if (w != 0 || sub != 0 || i >= Wd) return;
   float v = 0.f;
   for (int ww = 0; ww < kRedWaves; ++ww) v += red[ww][col];
-  if (i < jb.n0) {
+  if (jb.rw > 0) {
+    const int row = i / jb.rw, c = i - row * jb.rw;
+    if (c < jb.rw - 1) jb.dst0[(size_t)r * jb.n0 + row * (jb.rw - 1) + c] = v;
+    else jb.dst1[(size_t)r * jb.n1 + row] = v;
+  } else if (i < jb.n0) {
     if (jb.dst0 != nullptr) jb.dst0[(size_t)r * jb.n0 + i] = v;
   } else if (jb.dst1 != nullptr && i - jb.n0 < jb.n1) {
     jb.dst1[(size_t)r * jb.n1 + (i - jb.n0)] = v;
@@ -112,6 +116,12 @@ int launch_reduce_split(const float* part, int R, int J, int Wd, float* dst0, in
   return launch_reduce_partials(part, R, J, Wd, dst0, n0, dst1, n1, s);
 }
 
+int launch_reduce_lastcol(const float* part, int R, int J, int rows, int rw, float* dst, hipStream_t s, ReduceJobs* defer) {
+  ReduceJob jb{part, R, J, rows * rw, dst, rows * (rw - 1), dst + (size_t)R * rows * (rw - 1), rows};
+  jb.rw = rw;
+  return reduce_or_defer(jb, defer, s);
+}
+
 int launch_reduce_groups(const float* part, int R, int J, int Wd, float* dst, hipStream_t s) {
   return launch_reduce_partials(part, R, J, Wd, dst, Wd, nullptr, 0, s);
 }
@@ -125,11 +135,12 @@ size_t chanpair_partial_floats(int G, int Bg, int Ca, int Cb) {
 }
 
 int launch_chanpair_seg(const SegList& A, const float* B, float* part, float* dst0, int n0, float* dst1, int n1,
-                        int G, int Bg, int Cb, int P, hipStream_t s, int b_ones, ReduceJobs* defer) {
+                        int G, int Bg, int Cb, int P, hipStream_t s, int b_ones, ReduceJobs* defer, int lastcol_apart) {
   const int R = G / Bg;
   int nblk = 0;
   const int st = launch_chanpair_mfma(A, B, part, R, Bg, Cb, P, chanpair_mfma_blocks(R), b_ones, s, &nblk);
   if (st) return st;
+  if (lastcol_apart) return launch_reduce_lastcol(part, R, nblk, A.total(), Cb, dst0, s, defer);
   return launch_reduce_partials(part, R, nblk, A.total() * Cb, dst0, n0, dst1, n1, s, defer);
 }
 

@@ -628,15 +628,16 @@ class _CausalConvFunction(torch.autograd.Function):
             # d[W0; W1] = [dout[t+d]; dout] h^T with the 2 Co gradient rows read as time-shifted views of dout inside the
             # contraction (and a virtual channel of ones: the bias gradient is its tap-1 half)
             ones = int(bool(want_bias))
-            dM = _new(h, R, 2 * Co, Ci + ones)
+            buf = _new(h, R * 2 * Co * (Ci + ones))
             part = _new(h, max(int(L.msgat_contract_segments_partial_floats(R, 2 * Co, Ci + ones)), 1))
-            st = L.msgat_causal_conv_grad_weight(seg.ptr, seg.group_stride, _ptr(h), _ptr(part), _ptr(dM), R, G // R, Ci, Co,
-                                                 N, T, ctx.dilation, ones, stream)
+            # with_ones = 2: the matrix [R,2Co,Ci] and, behind it, the ones column [R,2Co] (no slice copies)
+            st = L.msgat_causal_conv_grad_weight(seg.ptr, seg.group_stride, _ptr(h), _ptr(part), _ptr(buf), R, G // R, Ci, Co,
+                                                 N, T, ctx.dilation, 2 * ones, stream)
             _lib.check(st, "msgat_causal_conv_grad_weight")
+            dM = buf[: R * 2 * Co * Ci].view(R, 2 * Co, Ci)
             if ones:
-                colsum = dM[:, Co:, Ci].contiguous()                      # [R,Co]: sum of dout over the relation's groups and positions
+                colsum = buf[R * 2 * Co * Ci:].view(R, 2, Co)[:, 1]      # [R,Co]: sum of dout over the relation's groups and positions
                 dbias = colsum if ctx.bias_R else colsum.sum(dim=0)
-                dM = dM[:, :, :Ci].contiguous()
             dtaps = dM if need[1] else None
         return dh, dtaps, dbias, None
 
@@ -1140,24 +1141,23 @@ class _MixMultiFunction(torch.autograd.Function):
             for i, (x, c) in enumerate(zip(ins, in_channels)):
                 x = x.contiguous()
                 ones = int(want_bias and i == 0)   # the bias gradient = contraction with a virtual channel of ones
-                dMi = _new(like, R, Co, c + ones)
+                buf = _new(like, R * Co * (c + ones))
                 nfl = (L.msgat_contract_mix_partial_floats(R, G // R, N, T, Co, c + ones) if both
                        else L.msgat_contract_segments_partial_floats(R, Co, c + ones))
                 part = _new(like, max(int(nfl), 1))
+                # with_ones = 2: the matrix [R,Co,c] and, behind it, the ones column [R,Co] -- two contiguous tensors (a
+                # column slice handed down to the components' parameters would cost a copy per component in AccumulateGrad)
                 if both:
-                    st = L.msgat_contract_mix_segments(R, G // R, N, T, ad, nd, _ptr(x), c, ones, _ptr(M), _ptr(part),
-                                                       _ptr(dMi), _ptr(d_ins[0]), stream)
+                    st = L.msgat_contract_mix_segments(R, G // R, N, T, ad, nd, _ptr(x), c, 2 * ones, _ptr(M), _ptr(part),
+                                                       _ptr(buf), _ptr(d_ins[0]), stream)
                     _lib.check(st, "msgat_contract_mix_segments")
                 else:
-                    st = L.msgat_contract_segments(R, G // R, N, T, ad, nd, _ptr(x), c, ones, _ptr(part), _ptr(dMi), stream)
+                    st = L.msgat_contract_segments(R, G // R, N, T, ad, nd, _ptr(x), c, 2 * ones, _ptr(part), _ptr(buf), stream)
                     _lib.check(st, "msgat_contract_segments")
                 if ones:
-                    # contiguous once per stacked tensor (see the head's weight gradient): a column slice handed down to the
-                    # components' parameters costs one copy per component in AccumulateGrad
-                    colsum = dMi[:, :, c].contiguous()                     # [R,Co]: sum over the relation's groups and positions
+                    colsum = buf[R * Co * c:].view(R, Co)                   # [R,Co]: sum over the relation's groups and positions
                     dbias = colsum if has_bias > 0 else colsum.sum(dim=0)
-                    dMi = dMi[:, :, :c].contiguous()
-                parts.append(dMi)
+                parts.append(buf[: R * Co * c].view(R, Co, c))
             dM = parts[0] if len(parts) == 1 else torch.cat(parts, dim=2)
         elif want_bias:
             dbias = torch.cat([_channel_sums(k.contiguous(), max(has_bias, 0)) for k in kd], dim=-1)
@@ -1358,6 +1358,30 @@ def temporal_attention_taps(pooled: torch.Tensor, Wt1: torch.Tensor, Wt2: torch.
     if Wt1.shape != Wt2.shape or Wt1.dim() != 3 or Wt1.shape[2] != N or G % Wt1.shape[0] or 2 * T * Wt1.shape[1] > 256:
         raise ValueError(f"temporal_attention_taps: pooled {tuple(pooled.shape)}, Wt1 {tuple(Wt1.shape)}, Wt2 {tuple(Wt2.shape)}")
     return _TemporalAttentionTapsFunction.apply(pooled, Wt1, Wt2, int(dilation))
+
+
+class _BiasJoinFunction(torch.autograd.Function):
+    """wide [R,Co] + narrow [R,cb] added into its first cb columns: CACN's convolution bias joining the residual bias in
+    front of MEAM's ReLU (both per-channel constants, msgat.py:94,123-131).  pad + add cost three launches forward and a
+    slice copy backward; here a copy and an in-place add, and backward hands out views of the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, wide, narrow):
+        out = wide.clone()
+        out[:, : narrow.shape[1]].add_(narrow)
+        ctx.cb = narrow.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g[:, : ctx.cb]
+
+
+def bias_join(wide: torch.Tensor, narrow: torch.Tensor) -> torch.Tensor:
+    """`wide + pad(narrow)`: [R,Co] plus [R,cb <= Co] in the leading columns."""
+    if wide.dim() != 2 or narrow.dim() != 2 or wide.shape[0] != narrow.shape[0] or narrow.shape[1] > wide.shape[1]:
+        raise ValueError(f"bias_join: {tuple(wide.shape)} and {tuple(narrow.shape)}")
+    return _BiasJoinFunction.apply(wide, narrow)
 
 
 class _AssembleRowsFunction(torch.autograd.Function):

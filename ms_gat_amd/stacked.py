@@ -214,8 +214,7 @@ def _meam(P, prefix: str, m0, x: torch.Tensor, adjacency, R: int, B: int, relu_i
         # pooled_t, q: [G,1,N,T] -> [G,N,T] as views (a `[:, 0]` select costs a zero-fill + copy in backward)
         tacn = _tacn_finish(P, prefix, m0.dilations, mixed, _first_taps(P, prefix, pooled_t.flatten(1, 2), T, d0))
         gacn = ops.attention_core(u, q.flatten(1, 2), Wg, adjacency)
-        res_b = P(prefix + "res.bias")
-        tail_bias = res_b + torch.nn.functional.pad(conv_b, (0, res_b.shape[1] - cb))
+        tail_bias = ops.bias_join(P(prefix + "res.bias"), conv_b)
         return ops.mix_multi([x], P(prefix + "res.weight").flatten(2), tail_bias, adds=[cacn, tacn, gacn], relu=True,
                              relu_grad_premasked=True)[0]
     return ops.mix_multi([x], P(prefix + "res.weight").flatten(2), P(prefix + "res.bias"),

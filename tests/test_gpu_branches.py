@@ -558,6 +558,45 @@ def test_contract_mix_segments_gives_matrix_bias_and_input_gradients_in_one_pass
         assert err < 1e-5, key
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("segs,Cb,N,Bg,mix", [((72,), 72, 883, 1, True), ((24, 48, 24, 1, 1), 72, 883, 2, False), ((72,), 3, 307, 2, True),
+                                             ((24,), 1, 50, 3, True), ((72,), 72, 13, 2, True), ((33,), 40, 307, 2, False)])
+def test_with_ones_2_delivers_the_bias_column_apart(segs, Cb, N, Bg, mix):
+    """with_ones = 2 (msgat_contract_segments, msgat_contract_mix_segments): the sums of with_ones = 1, bit for bit, as the
+    plain [R,Ca,Cb] matrix followed by the ones column [R,Ca] -- every form of the reduction behind the two entry points
+    (fused one-pass, two passes, the few-input-channel kernel)."""
+    from ms_gat_amd import _lib
+    L = _lib.lib()
+    dev, R, T = _dev(), 2, 12
+    G, Ca = R * Bg, sum(segs)
+    g = torch.Generator().manual_seed(17)
+    tens = [torch.randn(G, c, N, T, generator=g).to(dev) for c in segs]
+    B = torch.randn(G, Cb, N, T, generator=g).to(dev)
+    M = (torch.randn(R, Ca, Cb, generator=g) * 0.2).to(dev)
+    arr = (_lib.Seg * len(segs))(*[_lib.Seg(t.data_ptr(), c, 0) for t, c in zip(tens, segs)])
+    nfl = (L.msgat_contract_mix_partial_floats(R, Bg, N, T, Ca, Cb + 1) if mix else L.msgat_contract_segments_partial_floats(R, Ca, Cb + 1))
+    part = torch.empty(max(int(nfl), 1), device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    got = {}
+    for ones in (1, 2):
+        dst = torch.full((R * Ca * (Cb + 1),), float("nan"), device=dev)
+        dx = torch.full((G, Cb, N, T), float("nan"), device=dev)
+        if mix:
+            _lib.check(L.msgat_contract_mix_segments(R, Bg, N, T, arr, len(segs), B.data_ptr(), Cb, ones, M.data_ptr(), part.data_ptr(),
+                                                     dst.data_ptr(), dx.data_ptr(), st), "msgat_contract_mix_segments")
+        else:
+            _lib.check(L.msgat_contract_segments(R, Bg, N, T, arr, len(segs), B.data_ptr(), Cb, ones, part.data_ptr(), dst.data_ptr(),
+                                                 st), "msgat_contract_segments")
+        got[ones] = (dst, dx)
+    inside = got[1][0].view(R, Ca, Cb + 1)
+    assert torch.equal(got[2][0][: R * Ca * Cb].view(R, Ca, Cb), inside[:, :, :Cb])
+    assert torch.equal(got[2][0][R * Ca * Cb:].view(R, Ca), inside[:, :, Cb])
+    if mix:
+        assert torch.equal(got[1][1], got[2][1])
+    want = torch.cat(tens, dim=1).double().view(R, Bg, Ca, N * T).sum(dim=(1, 3))
+    assert rel_err(got[2][0][R * Ca * Cb:].view(R, Ca), want) < 1e-5
+
+
 @pytest.mark.parametrize("R,Bg,C,Co,N", [(3, 2, 72, 24, 883), (2, 2, 72, 24, 13), (1, 3, 48, 16, 307), (2, 1, 80, 31, 64),
                                          (3, 2, 48, 16, 883), (3, 2, 96, 32, 883), (1, 2, 64, 20, 64), (2, 1, 90, 40, 307)])
 def test_stage_project_backward_matches_float64(R, Bg, C, Co, N):
