@@ -408,10 +408,13 @@ __global__ __launch_bounds__(kBlock, 2) void k_causal_conv(
   // a block works on `per_block` consecutive tiles (4 waves x GP4 float4s each); the next tile's input is requested before
   // the current one is multiplied, so only the first tile's round trip and one matrix staging are exposed per block (one
   // tile per block, 4320 blocks of 46 KB each at PEMSD7 size, ran at 2.9 TB/s)
-  const int tile0 = blockIdx.x * per_block, tile1 = min(tile0 + per_block, tiles);
+  // the second register set fits beside the accumulators up to here (3 x 16 and 4 x 16 spill: those take one tile per
+  // block, host-side per_block = 1, and a loop the compiler sees through)
+  constexpr bool kPrefetch = kMaxK == 8 || MG <= 2;
+  const int tile0 = blockIdx.x * (kPrefetch ? per_block : 1), tile1 = kPrefetch ? min(tile0 + per_block, tiles) : tile0 + 1;
 
-  float4 own[kMaxK], nxt[kMaxK];
-  auto fetch = [&](int tile, float4 (&dst)[kMaxK]) {
+  float4 own[kMaxK], nxt[kPrefetch ? kMaxK : 1];
+  auto fetch = [&](int tile, auto& dst) {
     const int p4c = min((tile * 4 + wave) * GP4 + j, P4 - 1);
     const float* base = gbase + 4 * (size_t)p4c;
 #pragma unroll
@@ -458,7 +461,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_causal_conv(
 
   const float* wrow = Wl + j * Kpad + kq;     // row co = tile*16 + j; column 4k + kq (shifted half), Cr + 4k + kq (plain half)
   for (int tile = tile0; tile < tile1; ++tile) {
-    if (tile + 1 < tile1) fetch(tile + 1, nxt);   // block-uniform
+    if constexpr (kPrefetch) {
+      if (tile + 1 < tile1) fetch(tile + 1, nxt);   // block-uniform
+    }
     f32x4 acc[MG][4];
 #pragma unroll
     for (int mg = 0; mg < MG; ++mg)
@@ -491,8 +496,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_causal_conv(
         const float4 v = make_float4(acc[mg][0][reg] + bb, acc[mg][1][reg] + bb, acc[mg][2][reg] + bb, acc[mg][3][reg] + bb);
         if (co < Co && pvalid) store_global(out + ((size_t)g * Co + co) * (4 * (size_t)P4) + 4 * (size_t)p4, v);
       }
+    if constexpr (kPrefetch) {
 #pragma unroll
-    for (int k = 0; k < kMaxK; ++k) own[k] = nxt[k];
+      for (int k = 0; k < kMaxK; ++k) own[k] = nxt[k];
+    }
   }
 }
 
@@ -525,6 +532,7 @@ int launch_project_taps(const float* in, int in_gstride, const float* taps, int 
     // causal_conv_time.py: N = 883 (4320 tiles) 98.6 / 85.8 / 83.3 / 92.1 us at 1 / 2 / 3 / 4; N = 307 (1536 tiles) 38.4 /
     // 35.0 / 40.8 / 39.5
     int per_block = std::max(1, std::min(3, (int)((long long)tiles * G / 768)));
+    if (Cr > 32 && MG > 2) per_block = 1;      // no room for the prefetched tile's registers (kPrefetch)
 #ifdef MSGAT_LAB
     per_block = lab_env("MSGAT_LAB_CCPB", per_block);
 #endif
