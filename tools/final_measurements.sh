@@ -7,6 +7,9 @@ bash tools/profile_round.sh r05 "hot full" > gpurun_out/profile_round_r05b.log 2
 python3 tools/train_kernels.py --R 3 --top 60 > gpurun_out/r05/train_kernels_stacked_final.txt 2>/dev/null
 python3 tools/train_kernels.py --R 3 --hidden 48 --top 30 > gpurun_out/r05/train_kernels_msgat48.txt 2>/dev/null
 python3 tools/train_kernels.py --R 3 --hidden 96 --top 30 > gpurun_out/r05/train_kernels_msgat96.txt 2>/dev/null
+python3 tools/train_kernels.py --R 3 --ops --top 0 2>/dev/null | grep -E "aten::|torch operators" > gpurun_out/r05/train_step_torch_ops.txt
+python3 tools/host_overhead_train.py --small > gpurun_out/r05/host_overhead_train_small.txt 2>&1
+python3 tools/causal_conv_time.py > gpurun_out/r05/causal_conv_cold.txt 2>&1
 python bench.py --steps 20 --warmup 5 > gpurun_out/r05/bench_driver_args.json 2> gpurun_out/r05/bench_driver_args.err
 python bench.py > gpurun_out/r05/bench_plain.json 2> gpurun_out/r05/bench_plain.err
 MSGAT_BENCH_SHARE_GPU=1 timeout -k 10 400 python bench.py --gpus 5 --steps 10 --warmup 3 > gpurun_out/r05/bench_share_gpu_5ranks.json 2> gpurun_out/r05/bench_share_gpu_5ranks.err

@@ -18,9 +18,14 @@ import bench  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--R", type=int, default=3)
 ap.add_argument("--steps", type=int, default=40)
+ap.add_argument("--small", action="store_true", help="N = 64, B = 2: the GPU work is negligible, so the wall time per step IS "
+                "the host time to enqueue it (same launch sequence)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
-ts = bench.TrainStep(dict(bench.CFG4, R=a.R), dev)
+cfg = dict(bench.CFG4, R=a.R)
+if a.small:
+    cfg.update(N=64, E=60, B=2)
+ts = bench.TrainStep(cfg, dev)
 ts.run(10)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
