@@ -421,3 +421,18 @@ def test_product_package_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "dense_torch" not in text and "gat_oracle" not in text, f
+
+
+def test_gate_sum_and_bias_join_reject_mismatched_operands():
+    """Host-side argument checks of the two step-tail ops (no device work: they fail before any launch)."""
+    from ms_gat_amd import ops
+    pred = torch.zeros(3, 4, 5, 2)
+    with pytest.raises((ValueError, RuntimeError)):
+        ops.gate_sum(pred, None, None, torch.zeros(3, 5, 2))          # CPU tensors: the product has no CPU path
+    wide, narrow = torch.zeros(3, 8), torch.zeros(3, 9)
+    with pytest.raises(ValueError):
+        ops.bias_join(wide, narrow)                                   # the narrow bias must fit the wide one
+    with pytest.raises(ValueError):
+        ops.bias_join(torch.zeros(2, 8), torch.zeros(3, 4))           # one row per relation in both
+    out = ops.bias_join(torch.ones(2, 4), torch.full((2, 3), 2.0))    # plain torch ops: runs anywhere
+    assert out.tolist() == [[3.0, 3.0, 3.0, 1.0]] * 2
