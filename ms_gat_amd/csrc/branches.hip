@@ -639,7 +639,7 @@ __global__ __launch_bounds__(kBlock) void k_lnhead_bwd(const float* __restrict__
 // x is LayerNorm(x) as k_head_fwd<T, true> wrote it.  Normalising here instead lost twice in round 5: two 16-lane DPP
 // sums per loaded element made this latency-bound kernel (864 blocks) 427 us from 114, and a [B,C,N,2] (mean, 1/std)
 // buffer left by k_lnhead_bwd cost that kernel 126 -> 265 us and this one a third load stream (259 us).
-constexpr int kHeadChunks = 4;
+constexpr int kHeadChunks = 8;    // sample chunks per (relation, channel): 95.7 / 90.0 / 88.7 us at 4 / 8 / 16 (PEMSD7 size)
 
 template <int T>
 __global__ __launch_bounds__(kBlock) void k_head_dW(const float* __restrict__ dout, const float* __restrict__ x,
