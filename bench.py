@@ -705,6 +705,17 @@ def widths_object(hidden, dev, steps=20):
             "residual_convolution": _lib.contract_form_name(hidden, hidden, True, P, True)}}
     del ts
     torch.cuda.empty_cache()
+    # the same step replayed as ONE HIP graph (engine.Trainer(hip_graph=True)): msgat48 is 2.8 ms of GPU work in ~125
+    # launches, which a slow or shared host cannot enqueue in time -- the replay is the GPU-side figure
+    try:
+        tg = TrainStep(dict(CFG4, R=wl["R"], hidden=hidden), dev, hip_graph=True)
+        wg, perg = time_train_step(tg, 20, 8, sync)
+        obj["train_step"]["hip_graph_replay_ms_per_step"] = round(wg / 20 * 1e3, 3)
+        obj["train_step"]["hip_graph_replay_ms_per_step_median_hip_events"] = round(statistics.median(perg), 3)
+        del tg
+    except Exception as exc:  # noqa: BLE001 -- an extra figure: the eager one above stands on its own
+        obj["train_step"]["hip_graph_replay_error"] = f"{type(exc).__name__}: {exc}"[:200]
+    torch.cuda.empty_cache()
     return obj
 
 
