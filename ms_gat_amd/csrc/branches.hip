@@ -133,6 +133,9 @@ constexpr int kTdaUnroll = 8;  // k-steps (of 4 rows) whose loads are in flight 
 // wave-instruction reads 4 T contiguous floats.  The VALU form kept T*T accumulators per lane (144 registers at
 // T = 12, two waves per SIMD) and ran at 108 us for 294 MB; this one needs 4 + the loads in flight.
 // Columns m >= T and rows past the chunk's end are clamped addresses times a 0/1 mask (no load in a branch).
+// (Round 5 lab: sixteen rows per step as v_mfma_f32_4x4x1_16B_f32 blocks -- lane (row, quarter) loads one dwordx3 of dout
+// and of y, nine 8-cycle instructions per 16 rows instead of four 32-cycle ones and two load instructions instead of
+// eight -- ran at 83 us against 78: this pass is at its bytes, 390 MB at 5 TB/s, not at its instruction count.)
 template <int T>
 __global__ __launch_bounds__(kBlock) void k_tmix_dA(const float* __restrict__ dout, const float* __restrict__ y,
                                                     float* __restrict__ part, int Co, int K, int N, int dout_gs) {
