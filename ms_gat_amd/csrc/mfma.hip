@@ -1301,7 +1301,8 @@ static int launch_chanpair_glds_t(const SegList& A, const float* B, float* part,
 // XCD's L2) and write FEW mix channels over the run's whole position range
 #ifdef MSGAT_LAB
 #define MSGAT_GLDS_LAB_FORMS(X) \
-  X(2, 1, 128, 1) X(2, 2, 128, 1) X(7, 1, 64, 2) X(7, 2, 64, 2) X(7, 3, 64, 2) X(5, 1, 64, 2) X(5, 2, 64, 2) X(5, 3, 64, 2)
+  X(2, 1, 128, 1) X(2, 2, 128, 1) X(7, 1, 64, 2) X(7, 2, 64, 2) X(7, 3, 64, 2) X(5, 1, 64, 2) X(5, 2, 64, 2) X(5, 3, 64, 2) \
+  X(6, 5, 64, 2)   /* 96 x 73: what the merged gradient would cost without its two single-channel rows */
 #else
 #define MSGAT_GLDS_LAB_FORMS(X)
 #endif

@@ -195,6 +195,20 @@ def main():
         return run
     reg("cmix98       d98,x->dW[98,73],dx", 4 * G * P * (Cm + 2 * Cc), cmix(Cm, ys, oxs))
     reg("cmix72       d72,x->dW[72,73],dx", 4 * G * P * (3 * Cc), cmix(Cc, oxs, ys))
+
+    def cmix96():   # the first 96 of the 98 gradient rows (a channel slice): a six-tile block where a lab build has one
+        Ca = Cm - 2
+        nf = L.msgat_contract_segments_partial_floats(R, Ca, Cc + 1)
+        pt, dM = torch.empty(nf, device=dev), torch.empty(R, Ca, Cc + 1, device=dev)
+        Mx = rnd(R, Ca, Cc) * 0.1
+
+        def run():
+            t = rot(ys)
+            arr = (_lib.Seg * 1)(_lib.Seg(t.data_ptr(), Ca, Cm))
+            _lib.check(L.msgat_contract_mix_segments(R, B, N, T, arr, 1, ptr(rot(xs)), Cc, 1, ptr(Mx), ptr(pt), ptr(dM),
+                                                     ptr(rot(oxs)), st()), "cm96")
+        return run
+    reg("cmix96       d96,x->dW[96,73],dx", 4 * G * P * (Cm - 2 + 2 * Cc), cmix96())
     only = [s for s in a.only.split(",") if s]
     for name, (nbytes, fn) in stages.items():
         if only and not any(o in name for o in only):
