@@ -559,6 +559,41 @@ def test_contract_mix_segments_gives_matrix_bias_and_input_gradients_in_one_pass
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("R,segs,Cb,N", [(96, (24, 48, 24, 1, 1), 72, 883), (40, (72,), 72, 307), (160, (24,), 72, 64), (7, (16, 32, 16, 1, 1), 48, 883)])
+def test_contract_mix_with_one_matrix_per_group(R, segs, Cb, N):
+    """Every group its own relation (a per-sample matrix: CACN's rows in the merged channel mixing, R = B x components):
+    the block count per relation then comes from the fill of the CU rounds (chanpair_mfma_blocks), several blocks per
+    group and several rounds per launch.  dM and dx against float64; two runs agree bit for bit."""
+    from ms_gat_amd import _lib
+    L = _lib.lib()
+    dev, T, Bg = _dev(), 12, 1
+    G, Ca = R, sum(segs)
+    g = torch.Generator().manual_seed(R + N)
+    tens = [torch.randn(G, c, N, T, generator=g).to(dev) for c in segs]
+    B = torch.randn(G, Cb, N, T, generator=g).to(dev)
+    M = (torch.randn(R, Ca, Cb, generator=g) * 0.2).to(dev)
+    arr = (_lib.Seg * len(segs))(*[_lib.Seg(t.data_ptr(), c, 0) for t, c in zip(tens, segs)])
+    part = torch.empty(max(int(L.msgat_contract_mix_partial_floats(R, Bg, N, T, Ca, Cb)), 1), device=dev)
+    outs = []
+    for rep in range(2):
+        part.fill_(float("nan"))
+        dst = torch.full((R, Ca, Cb), float("nan"), device=dev)
+        dx = torch.full((G, Cb, N, T), float("nan"), device=dev)
+        _lib.check(L.msgat_contract_mix_segments(R, Bg, N, T, arr, len(segs), B.data_ptr(), Cb, 0, M.data_ptr(), part.data_ptr(),
+                                                 dst.data_ptr(), dx.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                   "msgat_contract_mix_segments")
+        outs.append((dst, dx))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    A64 = torch.cat(tens, dim=1).double().view(R, Ca, N * T)
+    want = torch.einsum("rap,rcp->rac", A64, B.double().view(R, Cb, N * T))
+    want_dx = torch.einsum("rac,rap->rcp", M.double(), A64).reshape(G, Cb, N, T)
+    for key, got, ref in (("dM", outs[0][0], want), ("dx", outs[0][1], want_dx)):
+        err = rel_err(got, ref)
+        record_err(f"contract_mix per-group R={R} {segs}x{Cb} N={N}", key, err, 1e-5)
+        assert err < 1e-5, key
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("segs,Cb,N,Bg,mix", [((72,), 72, 883, 1, True), ((24, 48, 24, 1, 1), 72, 883, 2, False), ((72,), 3, 307, 2, True),
                                              ((24,), 1, 50, 3, True), ((72,), 72, 13, 2, True), ((33,), 40, 307, 2, False)])
 def test_with_ones_2_delivers_the_bias_column_apart(segs, Cb, N, Bg, mix):
