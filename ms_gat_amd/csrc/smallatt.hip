@@ -28,8 +28,12 @@ __device__ __forceinline__ float block_row_softmax_prep(const float* row, int n,
 }
 
 // ---- channel attention -----------------------------------------------------------------------------------------
+// One block per group is 96 blocks for 256 CUs at PEMSD7 size, so the block is the machine: 1024 lanes (four waves per
+// SIMD) over the [C x C] loops instead of 256 (one wave per SIMD, nothing to hide a latency behind): both blocks of a training step together forward 28.5 -> 23.7 us,
+// backward 43.8 -> 31.2 us.
+constexpr int kCaBlock = 1024;
 template <int T>
-__global__ __launch_bounds__(kSaBlock) void k_chanatt_fwd(const float* __restrict__ pooled,
+__global__ __launch_bounds__(kCaBlock) void k_chanatt_fwd(const float* __restrict__ pooled,
                                                           const float* __restrict__ Wc,
                                                           const float* __restrict__ conv, float* __restrict__ att,
                                                           float* __restrict__ Mc, int Bg, int C, int cb) {
@@ -40,11 +44,11 @@ __global__ __launch_bounds__(kSaBlock) void k_chanatt_fwd(const float* __restric
   float* S = t1 + C * T;         // [C][C+1]
   const int g = blockIdx.x, r = g / Bg, Cs = C + 1;
   float* cwl = S + C * Cs;       // [cb][C]: the convolution's weights (read C times per output below: from LDS, not through L1)
-  for (int i = threadIdx.x; i < C * T; i += kSaBlock) p[i] = pooled[(size_t)g * C * T + i];
-  for (int i = threadIdx.x; i < T * T; i += kSaBlock) wc[i] = Wc[(size_t)r * T * T + i];
-  for (int i = threadIdx.x; i < cb * C; i += kSaBlock) cwl[i] = conv[(size_t)r * cb * C + i];
+  for (int i = threadIdx.x; i < C * T; i += kCaBlock) p[i] = pooled[(size_t)g * C * T + i];
+  for (int i = threadIdx.x; i < T * T; i += kCaBlock) wc[i] = Wc[(size_t)r * T * T + i];
+  for (int i = threadIdx.x; i < cb * C; i += kCaBlock) cwl[i] = conv[(size_t)r * cb * C + i];
   __syncthreads();
-  for (int i = threadIdx.x; i < C * T; i += kSaBlock) {
+  for (int i = threadIdx.x; i < C * T; i += kCaBlock) {
     const int c = i / T, s = i - c * T;
     float a = 0.f;
 #pragma unroll
@@ -52,7 +56,7 @@ __global__ __launch_bounds__(kSaBlock) void k_chanatt_fwd(const float* __restric
     t1[i] = a;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C * C; i += kSaBlock) {
+  for (int i = threadIdx.x; i < C * C; i += kCaBlock) {
     const int c = i / C, c2 = i - c * C;
     float a = 0.f;
 #pragma unroll
@@ -67,8 +71,8 @@ __global__ __launch_bounds__(kSaBlock) void k_chanatt_fwd(const float* __restric
     for (int i = 0; i < C; ++i) row[i] = __expf(row[i] - m) * inv;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C * C; i += kSaBlock) att[(size_t)g * C * C + i] = S[(i / C) * Cs + (i % C)];
-  for (int i = threadIdx.x; i < cb * C; i += kSaBlock) {
+  for (int i = threadIdx.x; i < C * C; i += kCaBlock) att[(size_t)g * C * C + i] = S[(i / C) * Cs + (i % C)];
+  for (int i = threadIdx.x; i < cb * C; i += kCaBlock) {
     const int o = i / C, c2 = i - o * C;
     float a = 0.f;
     for (int c = 0; c < C; ++c) a = fmaf(cwl[o * C + c], S[c * Cs + c2], a);
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(kSaBlock) void k_chanatt_fwd(const float* __restric
 }
 
 template <int T>
-__global__ __launch_bounds__(kSaBlock) void k_chanatt_bwd(const float* __restrict__ dMc,
+__global__ __launch_bounds__(kCaBlock) void k_chanatt_bwd(const float* __restrict__ dMc,
                                                           const float* __restrict__ att,
                                                           const float* __restrict__ pooled,
                                                           const float* __restrict__ Wc,
@@ -95,25 +99,25 @@ __global__ __launch_bounds__(kSaBlock) void k_chanatt_bwd(const float* __restric
   float* dm = dt1 + C * T;        // [cb][C]
   float* cwl = dm + cb * C;       // [cb][C]: the convolution's weights
   const int g = blockIdx.x, r = g / Bg;
-  for (int i = threadIdx.x; i < C * C; i += kSaBlock) S[(i / C) * Cs + (i % C)] = att[(size_t)g * C * C + i];
-  for (int i = threadIdx.x; i < C * T; i += kSaBlock) p[i] = pooled[(size_t)g * C * T + i];
-  for (int i = threadIdx.x; i < T * T; i += kSaBlock) wc[i] = Wc[(size_t)r * T * T + i];
-  for (int i = threadIdx.x; i < cb * C; i += kSaBlock) dm[i] = dMc[(size_t)g * cb * C + i];
-  for (int i = threadIdx.x; i < cb * C; i += kSaBlock) cwl[i] = conv[(size_t)r * cb * C + i];
+  for (int i = threadIdx.x; i < C * C; i += kCaBlock) S[(i / C) * Cs + (i % C)] = att[(size_t)g * C * C + i];
+  for (int i = threadIdx.x; i < C * T; i += kCaBlock) p[i] = pooled[(size_t)g * C * T + i];
+  for (int i = threadIdx.x; i < T * T; i += kCaBlock) wc[i] = Wc[(size_t)r * T * T + i];
+  for (int i = threadIdx.x; i < cb * C; i += kCaBlock) dm[i] = dMc[(size_t)g * cb * C + i];
+  for (int i = threadIdx.x; i < cb * C; i += kCaBlock) cwl[i] = conv[(size_t)r * cb * C + i];
   __syncthreads();
-  for (int i = threadIdx.x; i < C * C; i += kSaBlock) {  // d att = conv^T dMc
+  for (int i = threadIdx.x; i < C * C; i += kCaBlock) {  // d att = conv^T dMc
     const int c = i / C, c2 = i - c * C;
     float a = 0.f;
     for (int o = 0; o < cb; ++o) a = fmaf(cwl[o * C + c], dm[o * C + c2], a);
     D[c * Cs + c2] = a;
   }
-  for (int i = threadIdx.x; i < cb * C; i += kSaBlock) {  // d conv (this group's share) = dMc att^T
+  for (int i = threadIdx.x; i < cb * C; i += kCaBlock) {  // d conv (this group's share) = dMc att^T
     const int o = i / C, c = i - o * C;
     float a = 0.f;
     for (int c2 = 0; c2 < C; ++c2) a = fmaf(dm[o * C + c2], S[c * Cs + c2], a);
     dconv_part[(size_t)g * cb * C + i] = a;
   }
-  for (int i = threadIdx.x; i < C * T; i += kSaBlock) {
+  for (int i = threadIdx.x; i < C * T; i += kCaBlock) {
     const int c = i / T, s = i - c * T;
     float a = 0.f;
 #pragma unroll
@@ -129,14 +133,14 @@ __global__ __launch_bounds__(kSaBlock) void k_chanatt_bwd(const float* __restric
     for (int i = 0; i < C; ++i) d[i] = a[i] * (d[i] - dot);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C * T; i += kSaBlock) {  // d t1 = dS p
+  for (int i = threadIdx.x; i < C * T; i += kCaBlock) {  // d t1 = dS p
     const int c = i / T, s = i - c * T;
     float a = 0.f;
     for (int c2 = 0; c2 < C; ++c2) a = fmaf(D[c * Cs + c2], p[c2 * T + s], a);
     dt1[i] = a;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C * T; i += kSaBlock) {  // d p = dS^T t1 + d t1 Wc^T
+  for (int i = threadIdx.x; i < C * T; i += kCaBlock) {  // d p = dS^T t1 + d t1 Wc^T
     const int c = i / T, t = i - c * T;
     float a = 0.f;
     for (int c1 = 0; c1 < C; ++c1) a = fmaf(D[c1 * Cs + c], t1[c1 * T + t], a);
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(kSaBlock) void k_chanatt_bwd(const float* __restric
     for (int s = 0; s < T; ++s) a = fmaf(dt1[c * T + s], wc[t * T + s], a);
     dpooled[(size_t)g * C * T + i] = a;
   }
-  for (int i = threadIdx.x; i < T * T; i += kSaBlock) {  // d Wc (this group's share) = p^T d t1
+  for (int i = threadIdx.x; i < T * T; i += kCaBlock) {  // d Wc (this group's share) = p^T d t1
     const int t = i / T, s = i - t * T;
     float a = 0.f;
     for (int c = 0; c < C; ++c) a = fmaf(p[c * T + t], dt1[c * T + s], a);
@@ -176,7 +180,7 @@ int launch_chanatt_fwd(const float* pooled, const float* Wc, const float* conv, 
   {                                                                                                           \
     int st = raise_lds<decltype(&k_chanatt_fwd<TT>), &k_chanatt_fwd<TT>>(lds);                                                              \
     if (st) return st;                                                                                        \
-    hipLaunchKernelGGL(k_chanatt_fwd<TT>, dim3(G), dim3(kSaBlock), lds, s, pooled, Wc, conv, att, Mc, G / R, C, cb); \
+    hipLaunchKernelGGL(k_chanatt_fwd<TT>, dim3(G), dim3(kCaBlock), lds, s, pooled, Wc, conv, att, Mc, G / R, C, cb); \
   }
   switch (T) {
     case 4: MSGAT_CA_FWD(4) break;
@@ -201,7 +205,7 @@ int launch_chanatt_bwd(const float* dMc, const float* att, const float* pooled, 
   {                                                                                                            \
     int st = raise_lds<decltype(&k_chanatt_bwd<TT>), &k_chanatt_bwd<TT>>(lds);                                                               \
     if (st) return st;                                                                                         \
-    hipLaunchKernelGGL(k_chanatt_bwd<TT>, dim3(G), dim3(kSaBlock), lds, s, dMc, att, pooled, Wc, conv, dpooled, pWc, \
+    hipLaunchKernelGGL(k_chanatt_bwd<TT>, dim3(G), dim3(kCaBlock), lds, s, dMc, att, pooled, Wc, conv, dpooled, pWc, \
                        pconv, G / R, C, cb);                                                                   \
   }
   switch (T) {
@@ -220,7 +224,7 @@ int launch_chanatt_bwd(const float* dMc, const float* att, const float* pooled, 
 
 // ---- temporal attention -> taps of the first causal convolution ---------------------------------------------------
 constexpr int kTaRankMax = 16;
-constexpr int kTaTile = 64;  // nodes per LDS tile of the projections
+constexpr int kTaTile = 128;  // nodes per LDS tile of the projections (64: 14 trips = 26.2 us at N = 883; 128: 7 trips = 18.2 us)
 
 template <int T>
 __global__ __launch_bounds__(kSaBlock) void k_tempatt_fwd(const float* __restrict__ pooled,
@@ -326,8 +330,12 @@ __global__ __launch_bounds__(kSaBlock) void k_tempatt_fwd(const float* __restric
   }
 }
 
+// 1024 lanes: the node loop below is one lane per node with a dependent burst of loads per trip, and one block per group
+// leaves 160 of 256 CUs idle anyway -- four waves per SIMD take N = 883 in one trip instead of four (27.7 -> 13.7 us).
+constexpr int kTbBlock = 1024;
+
 template <int T>
-__global__ __launch_bounds__(kSaBlock) void k_tempatt_bwd(const float* __restrict__ dtaps,
+__global__ __launch_bounds__(kTbBlock) void k_tempatt_bwd(const float* __restrict__ dtaps,
                                                           const float* __restrict__ att,
                                                           const float* __restrict__ lr,
                                                           const float* __restrict__ pooled,
@@ -372,7 +380,7 @@ __global__ __launch_bounds__(kSaBlock) void k_tempatt_bwd(const float* __restric
   const float* q = pooled + (size_t)g * N * T;
   const float* W1 = Wt1 + (size_t)r * K * N;
   const float* W2 = Wt2 + (size_t)r * K * N;
-  for (int n = threadIdx.x; n < N; n += kSaBlock) {  // lane = node: its q row, its column of both projections
+  for (int n = threadIdx.x; n < N; n += kTbBlock) {  // lane = node: its q row, its column of both projections
     float qv[T], dq[T];
 #pragma unroll
     for (int t4 = 0; t4 < T / 4; ++t4) {
@@ -435,10 +443,10 @@ int launch_tempatt_bwd(const float* dtaps, const float* att, const float* lr, co
   float* p1 = part;
   float* p2 = part + (size_t)G * K * N;
   switch (T) {
-    case 4: hipLaunchKernelGGL(k_tempatt_bwd<4>, dim3(G), dim3(kSaBlock), 0, s, dtaps, att, lr, pooled, Wt1, Wt2, dpooled, p1, p2, G / R, N, K, dil); break;
-    case 8: hipLaunchKernelGGL(k_tempatt_bwd<8>, dim3(G), dim3(kSaBlock), 0, s, dtaps, att, lr, pooled, Wt1, Wt2, dpooled, p1, p2, G / R, N, K, dil); break;
-    case 12: hipLaunchKernelGGL(k_tempatt_bwd<12>, dim3(G), dim3(kSaBlock), 0, s, dtaps, att, lr, pooled, Wt1, Wt2, dpooled, p1, p2, G / R, N, K, dil); break;
-    case 16: hipLaunchKernelGGL(k_tempatt_bwd<16>, dim3(G), dim3(kSaBlock), 0, s, dtaps, att, lr, pooled, Wt1, Wt2, dpooled, p1, p2, G / R, N, K, dil); break;
+    case 4: hipLaunchKernelGGL(k_tempatt_bwd<4>, dim3(G), dim3(kTbBlock), 0, s, dtaps, att, lr, pooled, Wt1, Wt2, dpooled, p1, p2, G / R, N, K, dil); break;
+    case 8: hipLaunchKernelGGL(k_tempatt_bwd<8>, dim3(G), dim3(kTbBlock), 0, s, dtaps, att, lr, pooled, Wt1, Wt2, dpooled, p1, p2, G / R, N, K, dil); break;
+    case 12: hipLaunchKernelGGL(k_tempatt_bwd<12>, dim3(G), dim3(kTbBlock), 0, s, dtaps, att, lr, pooled, Wt1, Wt2, dpooled, p1, p2, G / R, N, K, dil); break;
+    case 16: hipLaunchKernelGGL(k_tempatt_bwd<16>, dim3(G), dim3(kTbBlock), 0, s, dtaps, att, lr, pooled, Wt1, Wt2, dpooled, p1, p2, G / R, N, K, dil); break;
     default: return MSGAT_ERR_UNSUPPORTED;
   }
   MSGAT_CHECK_LAUNCH();
