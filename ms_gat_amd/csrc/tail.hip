@@ -116,6 +116,8 @@ int launch_huber_grad(const float* pred, const float* truth, const float* dloss,
 // a transposing copy and two dense embedding gradients (a zero fill and a scatter each): 17 launches for 4 MB tensors.
 // Here one launch each way.  Indices are clamped into the tables (torch's gather would trap on the device instead).
 // Static gate (msgat.py:189): H = D = nullptr, h_w = W[R,E] as a one-row table, d_w = nullptr.
+constexpr int kGateMaxB = 1024;   // samples whose table rows a block of the backward keeps in LDS
+
 __device__ __forceinline__ int gate_row(const long long* idx, int b, int rows) {
   if (idx == nullptr) return 0;
   const long long v = idx[b];
@@ -160,6 +162,17 @@ __global__ __launch_bounds__(kTailBlock) void k_gate_sum_bwd(const float* __rest
     dpred[i] = dout[(size_t)b * E + e] * gate;
     return;
   }
+  // the samples' table rows, once per block in LDS (read from global inside the loop below -- B dependent round trips per
+  // thread -- this half of the launch took 25 us for 4 MB tensors)
+  __shared__ int rows_h[kGateMaxB], rows_d[kGateMaxB];
+  const bool staged = B <= kGateMaxB;   // kernel-uniform
+  if (staged) {
+    for (int b = threadIdx.x; b < B; b += kTailBlock) {
+      rows_h[b] = gate_row(H, b, nh);
+      rows_d[b] = D ? gate_row(D, b, nd) : 0;
+    }
+    __syncthreads();
+  }
   const long long i = (long long)(blockIdx.x - nblkA) * kTailBlock + threadIdx.x;
   const long long RE = (long long)R * E;
   if (i >= (long long)(nh + nd) * RE) return;
@@ -172,9 +185,12 @@ __global__ __launch_bounds__(kTailBlock) void k_gate_sum_bwd(const float* __rest
   if (dst == nullptr) return;
   const long long* idx = day ? D : H;
   const int rows = day ? nd : nh;
+  const int* staged_rows = day ? rows_d : rows_h;
   float acc = 0.f;
-  for (int b = 0; b < B; ++b)
-    if (gate_row(idx, b, rows) == row) acc = fmaf(dout[(size_t)b * E + e], pred[((size_t)r * B + b) * E + e], acc);
+  for (int b = 0; b < B; ++b) {
+    const int rb = staged ? staged_rows[b] : gate_row(idx, b, rows);
+    if (rb == row) acc = fmaf(dout[(size_t)b * E + e], pred[((size_t)r * B + b) * E + e], acc);
+  }
   dst[(size_t)row * RE + re] = acc;
 }
 
