@@ -347,13 +347,15 @@ def test_cfg4_per_rank_workload_full_training_step(tmp_path):
     ref = {k: rel_err(g32[k].double(), g64[k]) for k in g64}
     # Free ReLU masks: RECORDED, not asserted (round-4 review: "no worse than the reference's fp32" had a margin of 1.0x and
     # could never fail usefully).  A handful of the 2.4e8 pre-activations sit within an ulp of zero and any two fp32
-    # implementations mask them differently; the assertion on the gradients is the forced-mask run below, at the fixed
-    # 1e-4 bar.  What IS asserted here is the smooth part: the median tensor.
+    # implementations mask them differently; one flipped unit moves most gradient tensors of ITS component by ~1e-4, so
+    # the median over all tensors jumps when a third component gets a flip (3.6e-6, 8.1e-6 and 9.7e-5 for three builds of
+    # rounds 4-5 whose forced-mask errors below were the same 1.2e-5).  The assertions on the gradients are the
+    # forced-mask comparisons below, at the fixed 1e-4 bar, for the component loop AND the stacked schedule.
     record_err(what, "gradients, worst tensor, free masks (library; recorded only)", max(lib.values()), float("inf"))
     record_err(what, "gradients, worst tensor, free masks (dense fp32 eager ops; recorded only)", max(ref.values()), float("inf"))
-    record_err(what, "gradients, median tensor (library)", float(np.median(list(lib.values()))), TOL)
-    record_err(what, "gradients, median tensor (dense fp32 eager ops)", float(np.median(list(ref.values()))), TOL)
-    assert float(np.median(list(lib.values()))) < TOL
+    record_err(what, "gradients, median tensor, free masks (library; recorded only)", float(np.median(list(lib.values()))), float("inf"))
+    record_err(what, "gradients, median tensor, free masks (dense fp32 eager ops; recorded only)", float(np.median(list(ref.values()))),
+               float("inf"))
 
     # The mask-flip explanation as a test: the float64 op sequence again, but with every ReLU applying the set of active
     # units the LIBRARY chose (the component-loop run above).  With the borderline pre-activations out of the comparison
@@ -370,6 +372,12 @@ def test_cfg4_per_rank_workload_full_training_step(tmp_path):
     record_err(what, "gradients, median tensor", float(np.median(list(fixed.values()))), TOL)
     assert rel_err(p_l.double(), p64m) < TOL and abs(l_l - l64m) < TOL * abs(l64m)
     assert fixed[worst] < TOL, (worst, fixed[worst])
+    # the stacked schedule against the same float64 run: it shares all but a few borderline units with the loop (the
+    # worst tensor above), so its median tensor must meet the bar too -- and, unlike the free-mask median, stays put
+    fixed_s = {k: float((g_s[k].double() - g64m[k]).abs().max()) / max(float(g64m[k].abs().max()), 1e-2 * gs64) for k in g64m}
+    record_err(what, "gradients, median tensor (stacked schedule)", float(np.median(list(fixed_s.values()))), TOL)
+    record_err(what, "gradients, worst tensor (stacked schedule; recorded only)", max(fixed_s.values()), float("inf"))
+    assert float(np.median(list(fixed_s.values()))) < TOL
 
     before = [p.detach().clone() for p in net.parameters() if p.requires_grad]
     loss = ts.run(1)
