@@ -930,8 +930,12 @@ def main():
         # FlatAdam), its HIP-graph replay and the eager PyTorch-ROCm op sequence of the same step
         try:
             cfg3 = dict(CFG4, R=wl["R"])
+            torch.cuda.empty_cache()
+            torch.cuda.reset_peak_memory_stats(dev)
+            mem0 = torch.cuda.memory_allocated(dev)
             ts = TrainStep(cfg3, dev)
             wall, per = time_train_step(ts, 20, 5, sync)
+            peak_lib = (torch.cuda.max_memory_allocated(dev) - mem0) / 2**20
             out["full_step_cfg3"] = {
                 "workload": f"msgat72 training step (engine.Trainer), N={cfg3['N']}, R={cfg3['R']}, B={cfg3['B']}, T={cfg3['T']}",
                 "ms_per_step": round(wall / 20 * 1e3, 3), "ms_per_step_median_hip_events": round(statistics.median(per), 3),
@@ -944,9 +948,16 @@ def main():
             wall, per = time_train_step(ts, 20, 5, sync)
             out["full_step_cfg3"]["hip_graph_replay_ms_per_step"] = round(wall / 20 * 1e3, 3)
             del ts
+            torch.cuda.empty_cache()
+            torch.cuda.reset_peak_memory_stats(dev)
+            mem0 = torch.cuda.memory_allocated(dev)
             ts = TrainStep(cfg3, dev, dense=True)
             wall, per = time_train_step(ts, 10, 3, sync)
             out["full_step_cfg3"]["eager_rocm_ms_per_step"] = round(wall / 10 * 1e3, 3)
+            # peak device memory of a step above what was allocated before the model was built (parameters, optimizer state,
+            # batch, saved activations, workspaces): the library's step and the reference op sequence
+            out["full_step_cfg3"]["peak_device_memory_mib"] = round(peak_lib, 1)
+            out["full_step_cfg3"]["eager_rocm_peak_device_memory_mib"] = round((torch.cuda.max_memory_allocated(dev) - mem0) / 2**20, 1)
             del ts
             torch.cuda.empty_cache()
         except RuntimeError as e:
