@@ -444,14 +444,18 @@ def time_dense_kernels(hp, reps=20):
     delta = torch.randn(G, N, device=dev, generator=g) * 1e-3
     gE = torch.randn(G, nnz, device=dev, generator=g) * 1e-3
     stream = torch.cuda.current_stream(dev)
+    ndense = int(L.msgat_dense_scratch_bytes(C.byref(shape)))   # > 0: the passes run on split bf16 / fp16 operands (large N)
+    dense = torch.empty(max(ndense, 1), device=dev, dtype=torch.uint8)
+    dense_ptr = dense.data_ptr() if ndense else None
 
     def scores():
         _lib.check(L.msgat_stage_scores(C.byref(shape), C.byref(gs), q.data_ptr(), Wg.data_ptr(), kW.data_ptr(),
-                                        lse.data_ptr(), pq.data_ptr(), E.data_ptr(), None, stream.cuda_stream), "msgat_stage_scores")
+                                        lse.data_ptr(), pq.data_ptr(), E.data_ptr(), None, dense_ptr, stream.cuda_stream),
+                   "msgat_stage_scores")
 
     def column():
         _lib.check(L.msgat_stage_dense_column_pass(C.byref(shape), C.byref(gs), q.data_ptr(), kW.data_ptr(), lse.data_ptr(),
-                                                   delta.data_ptr(), gE.data_ptr(), dq.data_ptr(), stream.cuda_stream),
+                                                   delta.data_ptr(), gE.data_ptr(), dq.data_ptr(), dense_ptr, stream.cuda_stream),
                    "msgat_stage_dense_column_pass")
 
     n = reps if G * N * N < (1 << 32) else 3

@@ -21,7 +21,9 @@
  *     entry: for them the driver calls are simply repeated on every launch.
  *   - return value: 0 (MSGAT_OK) or a negative MSGAT_ERR_* code; hipError_t e from a
  *     launch is reported as MSGAT_ERR_HIP_BASE - e.  No exceptions cross the ABI.
- *   - all floating point is IEEE fp32; tensors are dense, contiguous, row-major.
+ *   - all floating point is IEEE fp32; tensors are dense, contiguous, row-major.  (From N = 1536 nodes the two dense
+ *     passes of the attention multiply on the bf16 / fp16 matrix core with every fp32 operand split into three bf16 or two
+ *     scaled fp16 terms and fp32 accumulation -- fp32-class accuracy, see msgat_dense_scratch_bytes.)
  *
  * Vocabulary
  *   relation r in [0,R)  one independent parameter set (alpha_r, Wg_r, W_r).  The
@@ -45,10 +47,13 @@
 extern "C" {
 #endif
 
-/* 6 (round 5): + msgat_contract_form_name, msgat_causal_conv{,_fused,_grad_weight}, msgat_layernorm_head_backward
+/* 7 (round 6): + msgat_dense_scratch_bytes; msgat_fwd_t.dense_scratch (new last field); msgat_stage_scores and
+ * msgat_stage_dense_column_pass take a dense_scratch pointer in front of the stream.  The one process-wide environment switch,
+ * MSGAT_DENSE_SPLIT = 0 | 1, forces the arithmetic of the dense passes for A/B runs and tests (read once).
+ * 6 (round 5): + msgat_contract_form_name, msgat_causal_conv{,_fused,_grad_weight}, msgat_layernorm_head_backward
  * {,_partial_floats}, msgat_head_forward_ln, msgat_gate_sum{,_backward}, msgat_layernorm_{forward,backward}_pooled, msgat_layernorm_pool_partial_floats,
  * msgat_contract_mix_partial_floats; no existing signature or structure changed since 5. */
-#define MSGAT_ABI_VERSION 6
+#define MSGAT_ABI_VERSION 7
 
 enum {
   MSGAT_OK = 0,
@@ -147,6 +152,8 @@ typedef struct msgat_fwd {
                              layout the aggregate will use: E re-ordered for it); may be NULL then */
   float* Ec;          /* out [G,nnz]      E in CSC order (Ec[g, cpos[e]] = E[g, e]), written by the score kernel
                              itself; optional (NULL: not written).  Hand it to msgat_bwd_t.Ec */
+  void* dense_scratch; /* tmp msgat_dense_scratch_bytes() bytes, 256-byte aligned (0 for the PEMS-sized graphs: may be
+                             NULL then): the operand images of the score pass on large graphs (ABI v7) */
 } msgat_fwd_t;
 
 typedef struct msgat_bwd {
@@ -211,6 +218,11 @@ int msgat_graph_sell_build(const int32_t* ptr, const int32_t* idx, const int32_t
  * msgat_gacn_backward replaces the autograd of those lines (adj gets no gradient,
  * msgat.py:190). */
 size_t msgat_edge_scratch_floats(const msgat_shape_t* shape, const msgat_graph_t* graph);
+/* Scratch of the two dense passes over all N columns of a row (the softmax denominator of attention.py:34 and its
+ * backward).  From N = 1536 nodes (T = 12) they run on the bf16 / fp16 matrix core with every fp32 operand split into
+ * bf16 / fp16 terms (fp32 accuracy, fp32 accumulate) and first write those operand "images" here; 0 below that.
+ * msgat_gacn_backward / msgat_attention_backward carry their share inside their workspace. */
+size_t msgat_dense_scratch_bytes(const msgat_shape_t* shape);
 int msgat_gacn_forward(const msgat_shape_t* shape, const msgat_graph_t* graph,
                        const msgat_fwd_t* io, void* stream);
 size_t msgat_bwd_workspace_bytes(const msgat_shape_t* shape, const msgat_graph_t* graph);
@@ -229,10 +241,10 @@ int msgat_stage_project(const msgat_shape_t* shape, const float* x, const float*
                         const float* W, float* q, float* u, void* stream);
 /* attention.py:34 + the edge part of :36: kW = q Wg, lse = row log-sum-exp over ALL N
  * columns of kW q^T (log2 units), pq = softmax @ q (optional), E = softmax * adj at the edges (Ec, optional: the
- * same values in CSC order). */
+ * same values in CSC order).  dense_scratch: msgat_dense_scratch_bytes() bytes (NULL when that is 0). */
 int msgat_stage_scores(const msgat_shape_t* shape, const msgat_graph_t* graph,
                        const float* q, const float* Wg, float* kW, float* lse, float* pq,
-                       float* E, float* Ec, void* stream);
+                       float* E, float* Ec, void* dense_scratch, void* stream);
 /* attention.py:36: v[g,c,n,:] = sum_{e in row n} E[g,e] u[g,c,col_e,:] over Cu channels.
  * edge_scratch: msgat_edge_scratch_floats() floats (NULL when that is 0). */
 int msgat_stage_aggregate(const msgat_shape_t* shape, const msgat_graph_t* graph,
@@ -247,10 +259,11 @@ int msgat_stage_aggregate_project(const msgat_shape_t* shape, const msgat_graph_
 /* The dense column pass of the backward (autograd of the softmax of attention.py:34): given the row sums
  * delta[G,N] of the edge gradients and the edge gradients gE[G,nnz] (CSR order),
  *     dq[g,m,:] += sum_{e -> m} gE_e kW[row_e,:] - sum_n P[n,m] delta[n] kW[n,:],   P = 2^(S log2e - lse)
- * re-creating P with the forward's operands and k order (bit-identical to the forward's).  dq is updated in place. */
+ * re-creating P with the forward's operands and k order (bit-identical to the forward's).  dq is updated in place.
+ * dense_scratch: msgat_dense_scratch_bytes() bytes (NULL when that is 0). */
 int msgat_stage_dense_column_pass(const msgat_shape_t* shape, const msgat_graph_t* graph, const float* q,
                                   const float* kW, const float* lse, const float* delta, const float* gE,
-                                  float* dq, void* stream);
+                                  float* dq, void* dense_scratch, void* stream);
 
 /* Backward building blocks (also what msgat_gacn_backward enqueues).
  * msgat_stage_mix:      out[g,co,p] = sum_ci M[r,..] in[g,ci,p] (+ addvec[r,co] extra[g,p]);

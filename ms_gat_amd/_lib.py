@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libmsgat_hip.so")
 
 MSGAT_OK = 0
-ABI_VERSION = 6  # MSGAT_ABI_VERSION of include/msgat_hip.h
+ABI_VERSION = 7  # MSGAT_ABI_VERSION of include/msgat_hip.h
 MODE_PLAIN, MODE_AGG_FIRST, MODE_PROJ_FIRST = 0, 1, 2
 
 c_float_p = C.POINTER(C.c_float)
@@ -48,7 +48,7 @@ class Shape(C.Structure):
 
 class Fwd(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x", "alpha", "Wg", "W", "z", "q", "kW", "lse", "pq", "E", "u")] + [
-        ("need_bwd", C.c_int32), ("edge_scratch", C.c_void_p), ("Ec", C.c_void_p)]
+        ("need_bwd", C.c_int32), ("edge_scratch", C.c_void_p), ("Ec", C.c_void_p), ("dense_scratch", C.c_void_p)]
 
 
 class Bwd(C.Structure):
@@ -75,8 +75,9 @@ _PROTOTYPES = {
     "msgat_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Shape), C.POINTER(Graph)]),
     "msgat_gacn_backward": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph), C.POINTER(Bwd), C.c_void_p]),
     "msgat_stage_project": (C.c_int, [C.POINTER(Shape)] + [C.c_void_p] * 6),
-    "msgat_stage_scores": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)] + [C.c_void_p] * 8),
-    "msgat_stage_dense_column_pass": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)] + [C.c_void_p] * 7),
+    "msgat_stage_scores": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)] + [C.c_void_p] * 9),
+    "msgat_stage_dense_column_pass": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)] + [C.c_void_p] * 8),
+    "msgat_dense_scratch_bytes": (C.c_size_t, [C.POINTER(Shape)]),
     "msgat_stage_aggregate": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph), C.c_int32] + [C.c_void_p] * 5),
     "msgat_stage_aggregate_project": (C.c_int, [C.POINTER(Shape), C.POINTER(Graph)] + [C.c_void_p] * 6),
     "msgat_stage_mix": (C.c_int, [C.POINTER(Shape), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,

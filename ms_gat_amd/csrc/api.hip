@@ -40,7 +40,7 @@ inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 // backward workspace layout, shared by the size query and the run
 struct BwdPlan {
   int mode, G, Cu, nch;
-  size_t off_dEp, off_gE, off_Ec, off_delta, off_dkW, off_dq, off_dv, off_dwg, off_cp, off_cp2, total;
+  size_t off_dEp, off_gE, off_Ec, off_delta, off_dkW, off_dq, off_dv, off_dwg, off_cp, off_cp2, off_dense, total;
 };
 
 // the graph decides the edge layout (CSR, or SELL for large N) and with it the size of the per-edge buffers
@@ -85,6 +85,7 @@ BwdPlan plan_bwd(const msgat_shape_t& sh, const msgat_graph_t& gr) {
   }
   p.off_cp = take(cp);
   p.off_cp2 = take(cp2);
+  p.off_dense = take((dense_scratch_bytes(p.G, sh.N, sh.T) + 3) / 4);   // operand images of the dense column pass (large N)
   p.total = off;
   return p;
 }
@@ -126,14 +127,15 @@ extern "C" int msgat_stage_project(const msgat_shape_t* sh, const float* x, cons
 
 extern "C" int msgat_stage_scores(const msgat_shape_t* sh, const msgat_graph_t* gr, const float* q,
                                   const float* Wg, float* kW, float* lse, float* pq, float* E, float* Ec,
-                                  void* stream) {
+                                  void* dense_scratch, void* stream) {
   int st = check_shape(sh);
   if (st) return st;
   st = check_graph(sh, gr);
   if (st) return st;
   if (!q || !Wg || !kW || !lse) return MSGAT_ERR_NULL;
   if (gr->nnz > 0 && !E) return MSGAT_ERR_NULL;
-  return launch_scores(*gr, q, Wg, kW, lse, pq, E, Ec, sh->R * sh->Bg, sh->Bg, sh->N, sh->T, (hipStream_t)stream);
+  return launch_scores(*gr, q, Wg, kW, lse, pq, E, Ec, sh->R * sh->Bg, sh->Bg, sh->N, sh->T, (hipStream_t)stream, nullptr, nullptr, 0,
+                       nullptr, nullptr, 0, nullptr, nullptr, dense_scratch);
 }
 
 // forward aggregate over the CSR: on the SELL layout when the graph carries a usable one (E re-ordered into
@@ -170,6 +172,11 @@ static int aggregate_cols(const msgat_shape_t* sh, const msgat_graph_t* gr, int 
   }
   return launch_aggregate(gr->colptr, gr->crow, gr->nnz, sell ? &gr->sell_cols : nullptr, dv, Eo, addvec, extra, out,
                           G, sh->Bg, Cu, sh->N, sh->T, s, xdot, dap, dot_done);
+}
+
+extern "C" size_t msgat_dense_scratch_bytes(const msgat_shape_t* sh) {
+  if (check_shape(sh) != MSGAT_OK) return 0;
+  return dense_scratch_bytes(sh->R * sh->Bg, sh->N, sh->T);
 }
 
 extern "C" size_t msgat_edge_scratch_floats(const msgat_shape_t* sh, const msgat_graph_t* gr) {
@@ -560,7 +567,7 @@ extern "C" int msgat_attention_backward(const msgat_shape_t* shp, const msgat_gr
   st = launch_bwd_rows(*gr, dEp, p.nch, fused ? Ecsc : nullptr, direct_c, u, dv, E, q, pq, Wg, gE, delta, dkW, dq, dwgp, dWg, G, Bg, N,
                        T, s);
   if (st) return st;
-  st = launch_bwd_dense_col(*gr, q, kW, lse, delta, gE, dq, G, N, T, s);
+  st = launch_bwd_dense_col(*gr, q, kW, lse, delta, gE, dq, G, N, T, s, ws + p.off_dense);
   if (st) return st;
   return fused ? MSGAT_OK : aggregate_cols(sh, gr, sh->C, dv, E, Ec, nullptr, nullptr, du, s, nullptr, nullptr, nullptr, Ec_in);
 }
@@ -569,13 +576,13 @@ extern "C" int msgat_attention_backward(const msgat_shape_t* shp, const msgat_gr
 // edge gradients): dq[g,m] -= sum_n P[n,m] delta[n] kW[n] (+ the CSC edge term from gE).  For profiling and bench.py.
 extern "C" int msgat_stage_dense_column_pass(const msgat_shape_t* sh, const msgat_graph_t* gr, const float* q,
                                              const float* kW, const float* lse, const float* delta, const float* gE,
-                                             float* dq, void* stream) {
+                                             float* dq, void* dense_scratch, void* stream) {
   int st = check_shape(sh);
   if (st) return st;
   st = check_graph(sh, gr);
   if (st) return st;
   if (!q || !kW || !lse || !delta || !dq || (gr->nnz > 0 && !gE)) return MSGAT_ERR_NULL;
-  return launch_bwd_dense_col(*gr, q, kW, lse, delta, gE, dq, sh->R * sh->Bg, sh->N, sh->T, (hipStream_t)stream);
+  return launch_bwd_dense_col(*gr, q, kW, lse, delta, gE, dq, sh->R * sh->Bg, sh->N, sh->T, (hipStream_t)stream, dense_scratch);
 }
 
 // ---- prediction head ----------------------------------------------------------------------------------
@@ -723,9 +730,11 @@ extern "C" int msgat_gacn_forward(const msgat_shape_t* sh, const msgat_graph_t* 
 
   // q = alpha . x: out of the projection pass (PROJ_FIRST), inside the score kernel (one input channel; three when the
   // kernel also finishes an AGG_FIRST layer), or from its own small pass
-  const bool tail = mode == MSGAT_MODE_AGG_FIRST && sh->Co <= 64 && scores_take_x(sh->C, true) &&
+  const bool split = dense_split_selected(sh->N, sh->T);   // the split-operand score kernel reads q from memory
+  if (split && !io->dense_scratch) return MSGAT_ERR_WORKSPACE;
+  const bool tail = !split && mode == MSGAT_MODE_AGG_FIRST && sh->Co <= 64 && scores_take_x(sh->C, true) &&
                     !sell_usable(gr->sell_rows, gr->nnz, sh->N, sh->T);
-  const bool q_in_scores = mode != MSGAT_MODE_PROJ_FIRST && scores_take_x(sh->C, tail);
+  const bool q_in_scores = !split && mode != MSGAT_MODE_PROJ_FIRST && scores_take_x(sh->C, tail);
   if (mode == MSGAT_MODE_PROJ_FIRST)
     st = launch_project(io->x, io->W, 0, io->alpha, nullptr, nullptr, io->u, io->q, G, sh->Bg, sh->C, sh->Co, P, s);
   else if (!q_in_scores)
@@ -737,7 +746,8 @@ extern "C" int msgat_gacn_forward(const msgat_shape_t* sh, const msgat_graph_t* 
                        sh->C, io->q, tail ? io->W : nullptr, tail ? sh->Co : 0, (tail && io->need_bwd) ? io->u : nullptr,
                        tail ? io->z : nullptr);
   else
-    st = launch_scores(*gr, io->q, io->Wg, io->kW, io->lse, pq, io->E, io->Ec, G, sh->Bg, sh->N, sh->T, s);
+    st = launch_scores(*gr, io->q, io->Wg, io->kW, io->lse, pq, io->E, io->Ec, G, sh->Bg, sh->N, sh->T, s, nullptr, nullptr, 0,
+                       nullptr, nullptr, 0, nullptr, nullptr, io->dense_scratch);
   if (st) return st;
   if (tail) return MSGAT_OK;   // z (and y) came out of the score kernel
 
@@ -847,7 +857,7 @@ extern "C" int msgat_gacn_backward(const msgat_shape_t* sh, const msgat_graph_t*
   st = launch_bwd_rows(*gr, dEp, p.nch, fused ? Ecsc : nullptr, direct_c, u, dv, io->E, io->q, io->pq, io->Wg, gE, delta, dkW, dq, dwgp,
                        io->dWg, G, Bg, N, T, s, &jobs);
   if (st) return st;
-  st = launch_bwd_dense_col(*gr, io->q, io->kW, io->lse, delta, gE, dq, G, N, T, s);
+  st = launch_bwd_dense_col(*gr, io->q, io->kW, io->lse, delta, gE, dq, G, N, T, s, ws + p.off_dense);
   if (st) return st;
 
   if (p.mode == MSGAT_MODE_PROJ_FIRST) {

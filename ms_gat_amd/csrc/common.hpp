@@ -267,7 +267,11 @@ bool scores_take_x(int C, bool with_tail);
 int launch_scores(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW, float* lse,
                   float* pq, float* E, float* Ec, int G, int Bg, int N, int T, hipStream_t s,
                   const float* x = nullptr, const float* alpha = nullptr, int C = 0, float* qout = nullptr,
-                  const float* apW = nullptr, int apCo = 0, float* apY = nullptr, float* apZ = nullptr);
+                  const float* apW = nullptr, int apCo = 0, float* apY = nullptr, float* apZ = nullptr, void* scratch = nullptr);
+// The dense passes (launch_scores, launch_bwd_dense_col) of large graphs run on the bf16 / fp16 matrix core with split
+// operands (dense_bf16.hip) and then need `scratch` (dense_scratch_bytes() > 0): the operand images of one pass.
+bool dense_split_selected(int N, int T);
+size_t dense_scratch_bytes(int G, int N, int T);
 // v[g,c,n,:] = sum_{e in ptr[n]..ptr[n+1]} E[g,e] u[g,c,idx[e],:] (+ addvec[r,c]*extra[g,n,:])
 // sell != nullptr: E is in that layout's position order (permuted by sell->src, row stride sell->n_pos, with
 // MSGAT_SELL_SLACK readable floats behind the last row) and the SELL kernel runs
@@ -299,7 +303,7 @@ int launch_agg_sddmm(const msgat_graph_t& gr, const float* dv, const float* Ec, 
                      int G, int Cu, int N, int T, hipStream_t s, int dv_group_channels = 0);
 int launch_bwd_dense_col(const msgat_graph_t& gr, const float* q, const float* kW,
                          const float* lse, const float* delta, const float* gE, float* dq, int G,
-                         int N, int T, hipStream_t s);
+                         int N, int T, hipStream_t s, void* scratch = nullptr);
 // A fixed-order sum of partials, out[r,i] = sum_j part[r,j,i] split over dst0 (first n0 columns) and dst1 (next n1),
 // that may wait for the end of a backward pass: the launchers below queue their reduction in `defer` when given one,
 // and launch_reduce_jobs runs the queue as ONE launch (each reduction alone is a 4-5 us launch of a few blocks).

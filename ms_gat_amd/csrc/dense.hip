@@ -26,6 +26,8 @@
 // computes the edge scores, so edge pass and backward agree on every score bit for bit.
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace msgat {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -705,9 +707,32 @@ static int launch_scores_t(const msgat_graph_t& gr, const float* q, const float*
 // the kernel what the k_qonly launch costs (17.1 us against 12.1 + 4.7 at N = 307), with the tail a launch of 9.3 us goes too.
 bool scores_take_x(int C, bool with_tail) { return C == 1 || (C == 3 && with_tail); }
 
+// dense_bf16.hip: the same two passes on the bf16 / fp16 matrix core (split operands, fp32 accumulate)
+size_t dense_split_scratch_bytes(int G, int N, int T);
+int launch_scores_b(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW, float* lse, float* pq, float* E,
+                    float* Ec, int G, int Bg, int N, hipStream_t s, void* scratch);
+int launch_bwd_dense_col_b(const msgat_graph_t& gr, const float* q, const float* kW, const float* lse, const float* delta,
+                           const float* gE, float* dq, int G, int N, hipStream_t s, void* scratch);
+
+// Which arithmetic the dense passes of a shape run in -- a function of the shape alone, so that forward and backward of one
+// layer always agree (backward re-creates the forward's score bits).  The split form pays two small launches per pass for
+// its operand images (~14 us at PEMSD7 size, where the pass itself goes 57 -> 44 us: a tie, profiles/r06/dense_split_lab.txt)
+// and wins from there on: N = 8192, 9.0 -> 5.8 ms.  MSGAT_DENSE_SPLIT=0 / 1 forces the choice (A/B runs, small-N tests).
+bool dense_split_selected(int N, int T) {
+  static const int force = [] { const char* e = getenv("MSGAT_DENSE_SPLIT"); return e == nullptr ? -1 : (e[0] == '1' ? 1 : 0); }();
+  if (T != 12 || force == 0) return false;
+  return force == 1 || N >= 1536;
+}
+size_t dense_scratch_bytes(int G, int N, int T) { return dense_split_selected(N, T) ? dense_split_scratch_bytes(G, N, T) : 0; }
+
 int launch_scores(const msgat_graph_t& gr, const float* q, const float* Wg, float* kW, float* lse,
                   float* pq, float* E, float* Ec, int G, int Bg, int N, int T, hipStream_t s, const float* x,
-                  const float* alpha, int C, float* qout, const float* apW, int apCo, float* apY, float* apZ) {
+                  const float* alpha, int C, float* qout, const float* apW, int apCo, float* apY, float* apZ, void* scratch) {
+  if (dense_split_selected(N, T)) {
+    if (x != nullptr) return MSGAT_ERR_UNSUPPORTED;   // the caller computes q first (api.hip)
+    if (scratch == nullptr) return MSGAT_ERR_WORKSPACE;
+    return launch_scores_b(gr, q, Wg, kW, lse, pq, E, Ec, G, Bg, N, s, scratch);
+  }
   if (x != nullptr && (!scores_take_x(C, apZ != nullptr) || alpha == nullptr || qout == nullptr)) return MSGAT_ERR_UNSUPPORTED;
   if (apZ != nullptr && (x == nullptr || apW == nullptr || apCo <= 0)) return MSGAT_ERR_UNSUPPORTED;
   switch (T) {
@@ -1030,7 +1055,11 @@ __global__ __launch_bounds__(kDBlock) void k_bwd_dense_col7(
 
 int launch_bwd_dense_col(const msgat_graph_t& gr, const float* q, const float* kW,
                          const float* lse, const float* delta, const float* gE, float* dq, int G,
-                         int N, int T, hipStream_t s) {
+                         int N, int T, hipStream_t s, void* scratch) {
+  if (dense_split_selected(N, T)) {
+    if (scratch == nullptr) return MSGAT_ERR_WORKSPACE;
+    return launch_bwd_dense_col_b(gr, q, kW, lse, delta, gE, dq, G, N, s, scratch);
+  }
 #ifndef MSGAT_NO_SCORES7
   if (const int Ra = scores7_owner_columns(N, G)) {   // the same split, over rows
     dim3 grid7(cdiv(N, kHRows), G);

@@ -50,7 +50,7 @@ class _GacnPlan:
     the shape / graph structures handed to the library, the layout of the one buffer that carries what a forward saves
     (q, kW, lse, pq, E, E in CSC order, u, the SELL scratch) and the backward workspace size.  Built once per
     (graph, device, dims, need_bwd): the library queries and the offset arithmetic were ~10 us of host time per call."""
-    __slots__ = ("shape", "gstruct", "keep", "mode", "sizes", "offs", "total", "bwd_bytes", "z_channels", "nscratch")
+    __slots__ = ("shape", "gstruct", "keep", "mode", "sizes", "offs", "total", "bwd_bytes", "z_channels", "nscratch", "ndense")
 
     def __init__(self, graph, dev, R, Bg, Cin, Co, N, T, need_bwd):
         L = _lib.lib()
@@ -69,6 +69,8 @@ class _GacnPlan:
         # (the SELL scratch is the forward's own workspace: allocated per call and dropped at its end, not carved from the
         # saved buffer -- it is at least the size of E and would stay resident until backward for every GACN layer)
         self.nscratch = nscratch
+        # operand images of the score pass on large graphs (msgat_dense_scratch_bytes; 0 at PEMS sizes): per call as well
+        self.ndense = int(L.msgat_dense_scratch_bytes(C.byref(self.shape)))
         self.sizes = (G * N * T, G * N * T, G * N, G * N * T if need_bwd else 0, G * nnz, G * nnz if need_bwd else 0, n_u)
         offs, total = [], 0
         for n in self.sizes:                 # 256-byte aligned pieces
@@ -126,7 +128,9 @@ class _GACNFunction(torch.autograd.Function):
         q, kW, lse, pq, E, Ec, u = (None if o < 0 else base + 4 * o for o in plan.offs)
         scratch_t = torch.empty(plan.nscratch, device=dev, dtype=torch.float32) if plan.nscratch else None
         scratch = _ptr(scratch_t)
-        io = _lib.Fwd(_ptr(x), _ptr(alpha), _ptr(Wg), _ptr(W), _ptr(z), q, kW, lse, pq, E, u, int(need_bwd), scratch, Ec)
+        dense_t = torch.empty(plan.ndense, device=dev, dtype=torch.uint8) if plan.ndense else None
+        io = _lib.Fwd(_ptr(x), _ptr(alpha), _ptr(Wg), _ptr(W), _ptr(z), q, kW, lse, pq, E, u, int(need_bwd), scratch, Ec,
+                      _ptr(dense_t))
         st = L.msgat_gacn_forward(C.byref(plan.shape), C.byref(plan.gstruct), C.byref(io), _stream_handle(dev))
         _lib.check(st, "msgat_gacn_forward")
 
@@ -140,6 +144,12 @@ class _GACNFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dz):
+        # All four gradients are computed whatever `ctx.needs_input_grad` says: they are by-products of shared passes, not
+        # separate work.  PROJ_FIRST: dW, dalpha AND dx leave ONE launch that reads du, dq and x once
+        # (msgat_stage_project_backward); AGG_FIRST: dW rides in the pass that forms dy, dalpha in the transposed aggregate
+        # that forms dx; dWg is a [T,T] partial of the row pass that every other gradient needs.  The only input that
+        # is ever frozen in the reference's models is none of these (adj, msgat.py:190, gets no gradient here at all), and
+        # x always requires one (it is a LayerNorm output with learnable weights, msgat.py:122).
         L = _lib.lib()
         saved = ctx.saved_tensors
         x, alpha, Wg, buf = saved[:4]
@@ -1219,8 +1229,10 @@ class _AttentionCoreFunction(torch.autograd.Function):
         Ec = _new(u, G, max(graph.nnz, 1)) if need_bwd else None     # E in CSC order, for backward's transposed pass
         z = torch.empty_like(u)
         stream = _stream_handle(dev)
+        ndense = int(L.msgat_dense_scratch_bytes(C.byref(shape)))   # operand images of the score pass (large graphs only)
+        dense_t = torch.empty(ndense, device=dev, dtype=torch.uint8) if ndense else None
         _lib.check(L.msgat_stage_scores(C.byref(shape), C.byref(gstruct), _ptr(q), _ptr(Wg), _ptr(kW), _ptr(lse), _ptr(pq),
-                                        _ptr(E), _ptr(Ec), stream), "msgat_stage_scores")
+                                        _ptr(E), _ptr(Ec), _ptr(dense_t), stream), "msgat_stage_scores")
         nscratch = int(L.msgat_edge_scratch_floats(C.byref(shape), C.byref(gstruct)))
         scratch = _new(u, nscratch) if nscratch else None
         _lib.check(L.msgat_stage_aggregate(C.byref(shape), C.byref(gstruct), Cu, _ptr(u), _ptr(E), _ptr(z), _ptr(scratch),
@@ -1536,7 +1548,13 @@ def _guard(fn, is_forward: bool):
     return backward
 
 
+# (c) every backward here launches library kernels on raw pointers: it cannot be differentiated a second time.
+#     `once_differentiable` says so to autograd -- `backward(create_graph=True)` / a grad-of-grad then fails AT this node
+#     with PyTorch's own message ("trying to differentiate twice a function that was marked with @once_differentiable")
+#     instead of silently returning gradients that are constants of the outer graph.
+from torch.autograd.function import once_differentiable  # noqa: E402
+
 for _name, _cls in list(globals().items()):
     if isinstance(_cls, type) and issubclass(_cls, torch.autograd.Function) and _cls is not torch.autograd.Function:
         _cls.forward = staticmethod(_guard(_cls.forward, True))
-        _cls.backward = staticmethod(_guard(_cls.backward, False))
+        _cls.backward = staticmethod(once_differentiable(_guard(_cls.backward, False)))

@@ -33,10 +33,14 @@ Fixtures:
   meam_96to96_n64.npz      MEAM(96 -> 96), dilations [4,4] (the second block of msgat96), fwd+bwd at N = 64: the forms
                            <9,4,64,3,2> (130 x 97 merged mixing) and <6,4,64,3,2> (96 x 97 residual convolution).
   meam_48to48_n64.npz      MEAM(48 -> 48), dilations [2,4] (second block of msgat48): <5,4,64,3,2> and <3,4,128,3,1>.
+  msgat72_traj_n32.npz     msgat72 (three components, N = 32, B = 2) stepped FIVE times by the reference loop's own sequence
+                           (engine.py:56-63,106: zero_grad, backward, Adam(lr 1e-3, weight_decay 5e-4); HuberLoss(50)), one batch
+                           per step: initial state_dict, the batches, the five losses, every parameter after step 5.
 
     python tests/golden/make_golden.py --only headline     # just that one
     python tests/golden/make_golden.py --only meam64
     python tests/golden/make_golden.py --only widths       # gacn_w48/w96 and meam_48to48 / meam_96to96
+    python tests/golden/make_golden.py --only trajectory   # msgat72_traj_n32
 """
 import os
 import sys
@@ -218,6 +222,35 @@ def msgat_case(seed):
     save("msgat72_n32.npz", X=X, H=H, D=D, Y=Y, pred=pred, loss=loss, **arrays)
 
 
+def trajectory_case(seed, steps=5):
+    """The reference model stepped `steps` times the way its training loop does (engine.py:56-63 with the optimizer of
+    engine.py:106 and the loss of loss.py:51-52), on the CPU in fp32: no autocast, and a GradScaler that is disabled off
+    CUDA, i.e. zero_grad / backward / Adam.step.  One batch per step.  Stored: the initial state_dict, the batches, the
+    loss of every step and EVERY parameter after the last step."""
+    torch.manual_seed(seed)
+    N, B, R, C, T = 32, 2, 3, 3, 12
+    adj = synthetic_adjacency(N, N, seed + 1)
+    net = msgat72(n_components=R, in_channels=C, in_timesteps=T, out_timesteps=T, use_te=True, adj=t(adj))
+    net.train()
+    arrays = {f"p.{k}": v.clone() for k, v in net.state_dict().items()}
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=5e-4)
+    loss_fn = HuberLoss(50.0)
+    X = torch.randn(steps, B, R, C, N, T).half().float()
+    H = torch.randint(0, 24, (steps, B))
+    D = torch.randint(0, 7, (steps, B))
+    Y = (torch.randn(steps, B, N, T) * 60.0).half().float()
+    losses = []
+    for k in range(steps):
+        pred = net(X[k], H[k], D[k])
+        loss = loss_fn(pred, Y[k])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    arrays.update({f"f.{k}": v for k, v in net.named_parameters()})
+    save("msgat72_traj_n32.npz", X=X.half(), H=H, D=D, Y=Y.half(), losses=np.asarray(losses, np.float64), **arrays)
+
+
 def cfg1_case(seed):
     """BASELINE.json configs[0]: PEMSD4-like (307 nodes, 3 features, T=12, B=4), the reference's default five
     components (main.py:14, `-i 1,2,3,24,168`), full msgat72 forward on the CPU.  The time-embedding tables are
@@ -337,6 +370,9 @@ if __name__ == "__main__":
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "headline":
         headline_case(1100)
         sys.exit(0)
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "trajectory":
+        trajectory_case(1700)
+        sys.exit(0)
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "meam64":
         meam_case("72to72_n64", 72, 72, 64, 2, 1200, half_inputs=True)
         sys.exit(0)
@@ -363,3 +399,4 @@ if __name__ == "__main__":
     gacn_width_case("w96_n64", 96, 32, 64, 2, 1400)
     meam_case("48to48_n64", 48, 48, 64, 2, 1500, half_inputs=True, dilations=(2, 4))
     meam_case("96to96_n64", 96, 96, 64, 2, 1600, half_inputs=True, dilations=(4, 4))
+    trajectory_case(1700)

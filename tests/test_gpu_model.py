@@ -68,6 +68,37 @@ def test_msgat72_forward_loss_and_all_gradients_match_reference():
     assert net.tpcs[0].tgacns[1].gacn.gatt.Wg.grad.abs().sum() > 0
 
 
+@pytest.mark.parametrize("hip_graph", [False, True])
+def test_five_optimizer_steps_track_the_reference_training_loop(tmp_path, hip_graph):
+    """engine.Trainer / FlatAdam against the REFERENCE model stepped five times by the reference loop's own sequence
+    (engine.py:56-63 with the optimizer of engine.py:106 and loss.py:51-52; tests/golden/make_golden.py::trajectory_case):
+    every step's loss to 1e-4 and every parameter after step 5 to 1e-5 of the largest entry (a step moves an entry by
+    ~lr = 1e-3, five of them by up to 5e-3: a gradient with the wrong sign anywhere would show as 2e-3)."""
+    from ms_gat_amd import engine, model
+    g = load_golden("msgat72_traj_n32.npz")
+    net = model.msgat72(n_components=3, in_channels=3, in_timesteps=12, out_timesteps=12, use_te=True,
+                        adj=torch.from_numpy(g["p.adj"]))
+    net.load_state_dict(_state(g))
+    net.to(_dev())
+    tr = engine.Trainer(net, 50.0, str(tmp_path), hip_graph=hip_graph)
+    X, Y = torch.from_numpy(g["X"]).float(), torch.from_numpy(g["Y"]).float()
+    H, D = torch.from_numpy(g["H"]), torch.from_numpy(g["D"])
+    what = "msgat72_traj_n32 " + ("replayed" if hip_graph else "eager")
+    for k in range(X.shape[0]):
+        loss = tr.run_epoch([[X[k], H[k], D[k], Y[k]]], gpu_id=0, epoch=k + 1, mode="train")
+        want = float(g["losses"][k])
+        record_err(what, f"loss[{k}]", abs(loss - want) / abs(want), 1e-4)
+        assert abs(loss - want) < 1e-4 * abs(want), (k, loss, want)
+    checked = 0
+    for name, p in net.named_parameters():
+        want = g[f"f.{name}"]
+        e = rel_err(p.detach().cpu(), want)
+        record_err(what, name, e, 1e-5)
+        assert e < 1e-5, f"{name}: {e:.3e} after five steps"
+        checked += 1
+    assert checked == sum(1 for k in g if k.startswith("f."))
+
+
 def test_trainer_runs_an_epoch_on_the_device(tmp_path):
     from ms_gat_amd import data, engine, model
     torch.manual_seed(0)

@@ -105,6 +105,8 @@ def main():
     ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
     nscr = int(L.msgat_edge_scratch_floats(sp, gp))
     escr = torch.empty(nscr, device=dev) if nscr else None
+    ndense = int(L.msgat_dense_scratch_bytes(sp))
+    dscr = torch.empty(ndense, device=dev, dtype=torch.uint8) if ndense else None
     stages = {}
 
     def reg(name, nbytes, fn):
@@ -113,9 +115,9 @@ def main():
     reg("project_fwd  x->u,q", 4 * G * P * (Cc + Co + 1),
         lambda: _lib.check(L.msgat_stage_project(sp, ptr(rot(xs)), ptr(alpha), ptr(W), ptr(q), ptr(rot(ous)), st()), "p"))
     reg("scores       q->kW,lse,pq,E", 4 * G * P * 4,
-        lambda: _lib.check(L.msgat_stage_scores(sp, gp, ptr(q), ptr(Wg), ptr(kW), ptr(lse), ptr(pq), ptr(E), None, st()), "s"))
+        lambda: _lib.check(L.msgat_stage_scores(sp, gp, ptr(q), ptr(Wg), ptr(kW), ptr(lse), ptr(pq), ptr(E), None, ptr(dscr), st()), "s"))
     reg("scores_nopq  q->kW,lse,E", 4 * G * P * 3,
-        lambda: _lib.check(L.msgat_stage_scores(sp, gp, ptr(q), ptr(Wg), ptr(kW), ptr(lse), None, ptr(E), None, st()), "s"))
+        lambda: _lib.check(L.msgat_stage_scores(sp, gp, ptr(q), ptr(Wg), ptr(kW), ptr(lse), None, ptr(E), None, ptr(dscr), st()), "s"))
     reg("aggregate    u->z (Cu=Co)", 8 * G * Co * P,
         lambda: _lib.check(L.msgat_stage_aggregate(sp, gp, Co, ptr(rot(us)), ptr(E), ptr(rot(ous)), ptr(escr), st()), "a"))
     reg("mix_bwd      du,dq->dx", 4 * G * P * (Co + 1 + Cc),
