@@ -51,6 +51,7 @@ sys.path.insert(0, ROOT)
 
 METRIC = "MS-GAT fwd+bwd samples/sec (B×T node-updates/s), PEMSD7 N=883 T=12"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 / fp16 MFMA (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix-core peak (MI355X_MICROARCH.md; tools/mfma_rate.hip measures 156)
 
 # rehearsal switch: the multi-GPU mode (process group, flat gradient all-reduce, MAX over ranks) with one rank on a
@@ -473,7 +474,24 @@ def time_dense_kernels(hp, reps=20):
         sec = t0.elapsed_time(t1) * 1e-3 / n
         out[name] = {"us_per_launch": round(sec * 1e6, 2), "flops": flops, "exps": float(G) * N * N,
                      "achieved": round(flops / sec / 1e12, 2), "frac": round(flops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
+        if ndense:
+            # what the matrix core is actually given: per 16x16 tile three 16x16x32 bf16 MFMAs for the scores (72 of 96 slots
+            # used: 3 terms x 3 terms, 6 products kept, K = 12) and two 16x16x32 fp16 MFMAs for the payload (2 x 2 terms)
+            issued = float(G) * (-(-N // 16)) ** 2 * 5 * 2 * 16 * 16 * 32
+            out[name].update(flops_issued=issued, achieved_issued=round(issued / sec / 1e12, 1),
+                             frac_of_bf16_peak=round(issued / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                             includes="the pass's two operand-image launches (k_dense_absmax, k_dense_images)")
+    if ndense:
+        return {"bound": "mfma", "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "matrix": "bf16 split x6 (scores: 3 x v_mfma_f32_16x16x32_bf16 per tile) + fp16 split x4 (payload: 2 x "
+                          "v_mfma_f32_16x16x32_f16), fp32 accumulate",
+                "dtype": "f32 operands as three bf16 / two scaled fp16 terms; `frac` = useful fp32-equivalent flops over the FP32 "
+                         "matrix peak (what the round-5 kernels were priced against), `frac_of_bf16_peak` = issued flops over "
+                         f"{MFMA_BF16_PEAK_TFLOPS:.0f} TFLOP/s dense bf16: the passes are bound by instruction issue (4 v_exp, 8 split "
+                         "and ~10 other vector instructions per tile beside 5 MFMAs), not by the pipe",
+                "kernels": out}
     return {"bound": "mfma", "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "dtype": "f32 (v_mfma_f32_16x16x4_f32)",
+            "matrix": "fp32 (v_mfma_f32_16x16x4_f32): below N = 1536 the split form's operand images cost what it gains",
             "kernels": out}
 
 
@@ -990,10 +1008,52 @@ def main():
                 out["stress"] = {"error": str(e).splitlines()[0][:160]}
         out.update(cpu_baseline(hp, wl))
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(ordered_for_the_record(out)), flush=True)
     if multi:
         barrier()
         dist.destroy_process_group()
+
+
+def ordered_for_the_record(out: dict) -> dict:
+    """The same line, keys re-ordered: the driver's record keeps the TAIL of stdout, and the line is ~12 KB.  Large tables
+    first; then a `summary` of the figures a reader looks for (every step time of the line in one place); the contract's own
+    keys, `config`, `roofline` and `cpu_baseline` last -- all inside the final 2 KB."""
+    contract = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config"]
+    last = ["roofline", "cpu_baseline"]
+    def get(path, default=None):
+        cur = out
+        for k in path.split("."):
+            if not isinstance(cur, dict) or k not in cur:
+                return default
+            cur = cur[k]
+        return cur
+    summary = {k: v for k, v in {
+        "ms_per_step": out.get("ms_per_step"),
+        "ms_per_step_median_hip_events": out.get("ms_per_step_median_hip_events"),
+        "full_step_cfg3_ms": get("full_step_cfg3.ms_per_step"),
+        "full_step_cfg3_hip_graph_ms": get("full_step_cfg3.hip_graph_replay_ms_per_step"),
+        "full_step_cfg4_ms": get("full_step_cfg4.ms_per_step"),
+        "full_step_cfg4_samples_per_s": get("full_step_cfg4.value"),
+        "stress_ms_per_step": get("stress.ms_per_step"),
+        "stress_dense_us": [get("stress.roofline_dense.kernels.k_scores.us_per_launch"),
+                            get("stress.roofline_dense.kernels.k_bwd_dense_col.us_per_launch")],
+        "stress_matrix": get("stress.roofline_dense.matrix"),
+        "dense_us": [get("roofline_dense.kernels.k_scores.us_per_launch"), get("roofline_dense.kernels.k_bwd_dense_col.us_per_launch")],
+        "dense_matrix": get("roofline_dense.matrix"),
+        "pemsd4_ms_per_step": get("pemsd4.ms_per_step"),
+        "dropin_loop_ms": get("dropin_loop.ms_per_step"),
+        "allreduce_us": out.get("allreduce_us"),
+    }.items() if v is not None and v != [None, None]}
+    size = lambda k: len(json.dumps(out[k]))  # noqa: E731
+    rest = [k for k in out if k not in contract and k not in last]
+    rest.sort(key=lambda k: -size(k))          # the bulky tables first
+    ordered = {k: out[k] for k in rest}
+    ordered["summary"] = summary
+    for k in contract + last:
+        if k in out:
+            ordered[k] = out[k]
+    return ordered
 
 
 if __name__ == "__main__":

@@ -22,7 +22,7 @@ OBJDIR = os.path.join(ROOT, "build", "obj")
 LIB = os.path.join(PKG, "libmsgat_hip.so")
 
 SOURCES = ["api.hip", "project.hip", "mfma.hip", "dense.hip", "dense_bf16.hip", "scores.hip", "aggregate.hip", "reduce.hip", "layernorm.hip", "branches.hip", "smallatt.hip", "tail.hip", "graph_host.cpp"]
-HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "sell.hpp"), os.path.join(CSRC, "rowtile.hpp"), os.path.join(INCLUDE, "msgat_hip.h")]
+HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "sell.hpp"), os.path.join(CSRC, "rowtile.hpp"), os.path.join(CSRC, "halfsplit.hpp"), os.path.join(INCLUDE, "msgat_hip.h")]
 # diagnostic translation units (never part of the product library): `build(lab=True)` / `--lab` adds them and their
 # extra, undeclared entry points for tools/stress_kernels.py --lab
 LAB_SOURCES = [os.path.join(ROOT, "tools", "agg_sell_lab.hip"), os.path.join(ROOT, "tools", "bwd_sell_lab.hip")]

@@ -41,37 +41,16 @@
 // so a lane's fragment is one ds_read_b128 at slot (item or s) of a 256-byte plane: conflict-free for the four 16-lane
 // groups of that instruction, and a chunk of records lands in LDS by LDS-DMA with no register or VALU in between.
 #include "common.hpp"
+#include "halfsplit.hpp"
 
 namespace msgat {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x4 mfma_bf(const uint4& a, const uint4& b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x4 mfma_h(const uint4& a, const uint4& b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-// two fp32 -> two fp16 (round to nearest even), first argument in the low half: v_cvt_pk_f16_f32
-__device__ __forceinline__ uint32_t cvt_pk_f16(float lo, float hi) {
-  const f32x2 v = {lo, hi};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
-}
-// x = h + m in fp16 (x already scaled into range): the pair of terms of four values as (h0 h1 | h2 h3), (m0 m1 | m2 m3).
-// `one` is 1.0f that the compiler cannot see through: fma(float(h), -one, x) then selects v_fma_mix_f32, which reads the
-// half-precision operand in place (a plain x - float(h) is a v_cvt_f32_f16 and a v_sub per value).
-__device__ __forceinline__ void split2_f16(const float* x, float one, uint32_t& H01, uint32_t& H23, uint32_t& M01, uint32_t& M23) {
-  H01 = cvt_pk_f16(x[0], x[1]);
-  H23 = cvt_pk_f16(x[2], x[3]);
-  const f16x2 a = __builtin_bit_cast(f16x2, H01), b = __builtin_bit_cast(f16x2, H23);
-  const float r0 = __builtin_fmaf((float)a[0], -one, x[0]), r1 = __builtin_fmaf((float)a[1], -one, x[1]);
-  const float r2 = __builtin_fmaf((float)b[0], -one, x[2]), r3 = __builtin_fmaf((float)b[1], -one, x[3]);
-  M01 = cvt_pk_f16(r0, r1);
-  M23 = cvt_pk_f16(r2, r3);
 }
 // The operand split.  EVERY score operand of both passes goes through this one function (image builder, own rows, own
 // columns), so the two passes see the same bf16 numbers.  Terms are returned in fp32 format (low 16 bits zero).
@@ -94,7 +73,6 @@ constexpr int kRecSA = 5 * kPlane, kRecSB = 8 * kPlane, kRecP = 4 * kPlane;
 constexpr int kRecA = kRecSA + kRecP;         // 2304 B: forward record (16 columns)
 constexpr int kRecB = kRecSB + kRecP + kPlane; // 3328 B: backward record (16 rows) + their lse2 - 14 (64 B, padded to a plane)
 constexpr int kChunkTiles = 4;                // records per staged chunk: 9 / 13 KiB, whole 1-KiB LDS-DMA pieces
-constexpr float kPOffF = 7.f, kPOffB = 14.f;  // P is carried times 2^7 (forward) / 2^14 (backward) through the fp16 product
 constexpr int kBWaves = 8;
 constexpr int kBBlock = 64 * kBWaves;
 constexpr int kBRows = 16 * kBWaves;
@@ -142,13 +120,8 @@ __global__ __launch_bounds__(kImgBlock) void k_dense_absmax(const float* __restr
     gmaxp[(size_t)g * gridDim.x + blockIdx.x] = mx;
   }
 }
-// the power of two that puts `absmax` at 2^13 .. 2^14 (1 for an all-zero group; clamped for absurd magnitudes)
-__device__ __forceinline__ float payload_scale(float absmax) {
-  int e = (int)((__float_as_uint(absmax) >> 23) & 0xffu);   // biased exponent: absmax in [2^(e-127), 2^(e-126))
-  if (absmax == 0.f) e = 127 + 13;
-  e = min(max(e, 30), 240);
-  return __uint_as_float((uint32_t)(127 + 13 - (e - 127)) << 23);
-}
+// the power of two that puts `absmax` at 2^13 .. 2^14 (1 for an all-zero group)
+__device__ __forceinline__ float payload_scale(float absmax) { return absmax == 0.f ? 1.f : pow2i(payload_scale_exp(absmax)); }
 
 template <bool BWD>
 __global__ __launch_bounds__(kImgBlock) void k_dense_images(const float* __restrict__ src, const float* __restrict__ delta,
@@ -242,15 +215,6 @@ __device__ __forceinline__ void lds_dma16(const void* gptr, void* lds_base) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "s"(la), "v"(gptr) : "memory");
 }
-
-// P of one tile (4 values per lane, fp32, already times 2^7 or 2^14) -> the B fragment of both payload MFMAs: (Ph | Pm)
-__device__ __forceinline__ uint4 split_p(const float* p, float one) {
-  uint4 F;
-  split2_f16(p, one, F.x, F.y, F.z, F.w);
-  return F;
-}
-
-__device__ __forceinline__ uint4 swap_halves(const uint4& f) { return make_uint4(f.z, f.w, f.x, f.y); }   // (h | m) -> (m | h)
 
 // the role-A / role-B fragments of ONE node's T values for this lane's quad (own rows / own columns; registers)
 struct FragA { uint4 hm, hl; };          // (h | m), (h | l)
