@@ -477,6 +477,7 @@ class Engine:
         # shards are taken to be even
         global_sizes = iter(sampler.global_batch_sizes()) if presharded and hasattr(sampler, "global_batch_sizes") else None
         guard = torch.cuda.device(device) if device.type == "cuda" else _NullContext()
+        pred = loss = None
         with guard, torch.set_grad_enabled(training):
             for batch in data:
                 n_global = batch[0].shape[0]
@@ -500,6 +501,10 @@ class Engine:
                         seen = self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
                         capture = seen > self.graph_after
                     if capture:
+                        # nothing may keep the autograd graph of an eager step alive across a capture: its AccumulateGrad nodes
+                        # belong to the default stream, and a backward that meets them on the capturing stream breaks the
+                        # capture (hipStreamEndCapture crashes) -- the previous iteration's `loss` / `pred` do exactly that
+                        pred = loss = None
                         with torch.enable_grad():
                             graphed = self._graphs[key] = _GraphedStep(self, batch, training, step_in_graph=world == 1,
                                                                        loss_weight=loss_weight)
