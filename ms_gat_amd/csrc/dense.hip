@@ -25,6 +25,7 @@
 // The MFMA is a k-ordered fmaf chain starting from C, the same order as the VALU chain that
 // computes the edge scores, so edge pass and backward agree on every score bit for bit.
 #include "common.hpp"
+#include "halfsplit.hpp"
 
 #include <cstdlib>
 
@@ -149,6 +150,59 @@ constexpr int kPS = 20;                // floats per staged payload row: T <= 16
                                        // 20 makes the payload fragment read bank-conflict free
 constexpr float kDefer = 8.f;          // re-base the running max only when a score exceeds it by 2^8
 
+// ---- the payload product on the fp16 matrix core (round 6; halfsplit.hpp) ---------------------------------------------------
+// The score product stays on v_mfma_f32_16x16x4_f32 (exact fp32: edge pass, forward tile and backward tile agree bit for
+// bit), but its four payload MFMAs per tile -- 128 of a tile's ~320 clocks, at the vector rate and on the VALU's issue port --
+// become two v_mfma_f32_16x16x32_f16 on P split into two fp16 terms (8 VALU instructions per tile).  The payload matrix of a
+// staged chunk (q rows forward, delta kW rows backward; fp32 in LDS for the score product anyway) is converted ONCE per chunk
+// by the block into fp16 "planes" [tile of 16 items][quad][row s] x 16 B = the terms (h | m) of items 4 quad .. 4 quad + 3 at
+// payload row s: a lane's A fragment is one conflict-free ds_read_b128.  fp16 has no range to spare, so the planes carry a
+// power-of-two scale that follows the largest entry seen so far (chunk maxima ride along with the staging; when a chunk
+// raises the maximum the accumulators are re-scaled, like the running maximum of the softmax), and P is carried times 2^7
+// (forward) / 2^14 (backward).  What fp16 drops is below 2^-23 of a value or 2^-38 of the largest payload entry.
+constexpr int kPlaneU4 = (kDMC / 16) * 4 * 16;   // uint4 per chunk of kDMC staged items
+
+// rows [items][stride] fp32 (T payload values each, zero past `items`) -> planes; ONES_ROW: row s = T carries 1 for live items
+// (the payload product then leaves the row sum of P at D2[s = T]).  Rows s > T of the planes are zeroed once per kernel.
+template <int T, bool ONES_ROW>
+__device__ __forceinline__ void build_payload_planes(const float* rows, int stride, int items, float scale, float one,
+                                                     uint4* planes, int tid, int nthreads) {
+  constexpr int RW = T + (ONES_ROW ? 1 : 0);
+  const int ntq = ((items + 15) >> 4) * 4;
+  for (int u = tid; u < ntq * RW; u += nthreads) {
+    const int tq = u / RW, sr = u - tq * RW;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 4 * tq + r;
+      v[r] = (sr < T) ? rows[c * stride + sr] * scale : ((c < items) ? 1.f : 0.f);
+    }
+    uint4 f;
+    split2_f16(v, one, f.x, f.y, f.z, f.w);
+    planes[tq * 16 + sr] = f;
+  }
+}
+// The whole grid of a dense pass is resident, 2-3 blocks to a CU, and a SIMD arbitrates its waves by priority, then AGE: at equal
+// priority the block dispatched first takes most of the issue slots, finishes at ~60 % of the kernel, and the last block of a
+// CU runs the final quarter alone at two waves per SIMD (in-kernel stamps at PEMSD7 size: blocks take 65 K .. 113 K clocks,
+// 768 / 512 / 256 of them alive over time).  A wave therefore LOWERS its priority as it advances through its chunks: whoever
+// is behind gets the slots, and the blocks of a CU finish together.
+__device__ __forceinline__ void prio_by_progress(int done, int total) {
+  const int lvl = 3 - min(3, (4 * done) / max(total, 1));
+  if (lvl == 3) __builtin_amdgcn_s_setprio(3);
+  else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
+  else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+}
+// largest |entry| of the block's next chunk: every lane's own maximum -> wave maximum -> wmax[wave] (read by all after the
+// staging barrier)
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float max_abs4(const float4& v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+
 // Every block of these grids does the same work and the whole grid is resident at once, but the
 // dispatcher packs workgroups onto a CU until a resource runs out (in-kernel stamps: some CUs held
 // 8 blocks, others 3, and the kernel ran 1.7x longer than its median block).  Asking for unused
@@ -185,9 +239,12 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
     float* __restrict__ kW, float* __restrict__ lse, float* __restrict__ pq, float* __restrict__ E,
     const int* __restrict__ cpos, float* __restrict__ Ec, int Bg, int N, int nnz,
     const float* __restrict__ alpha, float* __restrict__ qout,   // XC > 0: `q` is x[G,XC,N,T], the q rows go to qout
-    const float* __restrict__ apW, int apCo, float* __restrict__ apY, float* __restrict__ apZ) {   // XC > 0 and apZ: the aggregate + projection tail
+    const float* __restrict__ apW, int apCo, float* __restrict__ apY, float* __restrict__ apZ,   // XC > 0 and apZ: the aggregate + projection tail
+    float one) {   // 1.0f, opaque to the compiler (split2_f16)
   constexpr int T4 = T / 4;
   __shared__ float4 qs4[kDMC * kPS / 4];  // staged columns: [column][q(T) | zeros]
+  __shared__ uint4 pl4[WITH_PQ ? kPlaneU4 : 1];   // their payload planes (fp16 terms, see build_payload_planes)
+  __shared__ float wmax[kDWaves];
   __shared__ float kw2s[kDRows][T];       // the block's rows, log2-scaled, for the edge pass
   __shared__ float lse2s[kDRows];
   const float* qsw = reinterpret_cast<const float*>(qs4);
@@ -231,9 +288,14 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
   // column m carries a 1 behind its T values of q, so D2[s = T][row] accumulates sum_m p[row][m] on the matrix core
   // and three v_add per tile leave the VALU stream (which the fp32 MFMAs share an issue port with)
   constexpr bool ONES = WITH_PQ && T < 16;
+  constexpr float kPOff = WITH_PQ ? kPOffF : 0.f;   // P = 2^(S - m) is carried times 2^kPOff through the fp16 payload product
   float m = -3.0e38f;  // running max of the row, identical in its 4 quads; finite floor, not -inf
-  float lsum = 0.f;    // this quad's share of sum_m 2^(S - m) (unused with ONES)
-  f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = da, dc = da, dd = da;  // payload accumulators (four independent chains)
+  float mo = m;        // m - kPOff: what the exponent subtracts
+  float lsum = 0.f;    // this quad's share of sum_m 2^(S - mo) (unused with ONES)
+  f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = da;  // payload accumulators (tile a / tile b of a trip)
+  int sexp = 100;      // the payload planes carry q * 2^sexp (block-uniform; follows the largest |q| staged so far)
+  if (WITH_PQ)
+    for (int i = threadIdx.x; i < kPlaneU4; i += kDBlock) pl4[i] = make_uint4(0u, 0u, 0u, 0u);   // rows past the ones row stay zero
 
   // Staging is double-buffered through registers: the loads of chunk c+1 are issued before chunk c
   // is multiplied and land in LDS after it.  All blocks of the grid are resident at once, so a
@@ -242,8 +304,10 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
   constexpr int kF4 = kPS / 4;                                   // float4s per staged column
   constexpr int kSt = (kDMC * kF4 + kDBlock - 1) / kDBlock;       // staging float4s per lane per chunk
   float4 pre[kSt];
+  float premax = 0.f;   // largest |q| among this lane's share of the prefetched chunk
   auto prefetch = [&](int c0) {
     const int cols = min(kDMC, N - c0);
+    premax = 0.f;
 #pragma unroll
     for (int k = 0; k < kSt; ++k) {
       const int i = threadIdx.x + k * kDBlock;
@@ -251,21 +315,42 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
       const bool live = (c < cols) && (f < T4);
       const float4 v = qrows.row4((size_t)(c0 + (live ? c : 0)), live ? f : 0);
       const float keep = live ? 1.f : 0.f;  // multiply, not select: keeps the load out of a branch
-      const float one = (ONES && c < cols && f == T4) ? 1.f : 0.f;  // the ones column, at index T of the staged row
-      pre[k] = make_float4(fmaf(v.x, keep, one), v.y * keep, v.z * keep, v.w * keep);
+      pre[k] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
+      premax = fmaxf(premax, max_abs4(pre[k]));
     }
   };
   prefetch(0);
   for (int c0 = 0; c0 < N; c0 += kDMC) {
     const int cols = min(kDMC, N - c0);
     const int cols16 = (cols + 15) & ~15;
+    prio_by_progress(c0, N);
     __syncthreads();  // every wave is done with the previous chunk
 #pragma unroll
     for (int k = 0; k < kSt; ++k) {
       const int i = threadIdx.x + k * kDBlock;
       if (i < kDMC * kF4) qs4[i] = pre[k];
     }
+    if (WITH_PQ) {
+      const float wm = wave_max(premax);
+      if (lane == 0) wmax[wave] = wm;
+    }
     __syncthreads();
+    if (WITH_PQ) {   // the chunk's payload planes, at the running scale (block-uniform arithmetic)
+      float cmax = wmax[0];
+#pragma unroll
+      for (int w = 1; w < kDWaves; ++w) cmax = fmaxf(cmax, wmax[w]);
+      const int ec = payload_scale_exp(cmax);
+      if (ec < sexp) {   // a larger entry than any before: the sums so far move to the new scale (the ones row does not)
+        const float f = pow2i(ec - sexp);
+        if (quad < T4) {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) { da[rr] *= f; db[rr] *= f; }
+        }
+        sexp = ec;
+      }
+      build_payload_planes<T, ONES>(qsw, kPS, cols, pow2i(sexp), one, pl4, threadIdx.x, kDBlock);
+      __syncthreads();
+    }
     prefetch(min(c0 + kDMC, max(N - 1, 0) / kDMC * kDMC));  // next chunk (the last trip re-reads its own)
     // two score tiles per trip: one max / vote / re-base decision for 32 columns, and the second tile's score chain
     // is independent of the first tile's exponentials.  An odd last tile is a tile of padding columns (masked).
@@ -294,26 +379,23 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
         const float mn = fmaxf(m, cx);
         const float sc = fast_exp2(m - mn);  // m at its floor on the first tile -> 0
         m = mn;
+        mo = mn - kPOff;
         lsum *= sc;
         if (WITH_PQ) {
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) { da[rr] *= sc; db[rr] *= sc; dc[rr] *= sc; dd[rr] *= sc; }
+          for (int rr = 0; rr < 4; ++rr) { da[rr] *= sc; db[rr] *= sc; }
         }
       }
       float p[8];
 #pragma unroll
-      for (int rr = 0; rr < 8; ++rr) p[rr] = fast_exp2(sv[rr] - m);
+      for (int rr = 0; rr < 8; ++rr) p[rr] = fast_exp2(sv[rr] - mo);
       if (!ONES) lsum += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
       if (WITH_PQ) {
-        // A2[i = s][k = quad] = q[column mq + rr][s = j]; B2[k = quad][j = row] = p[rr]
-        da = mfma16(qsw[(mq + 0) * kPS + j], p[0], da);
-        db = mfma16(qsw[(mq + 1) * kPS + j], p[1], db);
-        dc = mfma16(qsw[(mq + 2) * kPS + j], p[2], dc);
-        dd = mfma16(qsw[(mq + 3) * kPS + j], p[3], dd);
-        da = mfma16(qsw[(mq + 16) * kPS + j], p[4], da);
-        db = mfma16(qsw[(mq + 17) * kPS + j], p[5], db);
-        dc = mfma16(qsw[(mq + 18) * kPS + j], p[6], dc);
-        dd = mfma16(qsw[(mq + 19) * kPS + j], p[7], dd);
+        // A2[i = s][k] = the planes' (h | m) of columns m0 + 4 quad .. +3 at row s = j; B2[k][j = row] = (Ph | Pm), then (Pm | Ph)
+        const uint4 Fa = split_p(p, one), A2a = pl4[((m0 >> 4) * 4 + quad) * 16 + j];
+        da = mfma_h(A2a, Fa, da); da = mfma_h(A2a, swap_halves(Fa), da);
+        const uint4 Fb = split_p(p + 4, one), A2b = pl4[((m0 >> 4) * 4 + 4 + quad) * 16 + j];
+        db = mfma_h(A2b, Fb, db); db = mfma_h(A2b, swap_halves(Fb), db);
       }
     }
     if (c0 == 0) MSGAT_STAMP(2);
@@ -321,22 +403,21 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
 
   MSGAT_STAMP(3);
   if (ONES) {  // D2[s = T][row] sits in register T % 4 of the lanes with quad == T / 4
-    const float mine = (da[T % 4] + db[T % 4]) + (dc[T % 4] + dd[T % 4]);
+    const float mine = da[T % 4] + db[T % 4];
     lsum = __shfl(mine, j + 16 * (T / 4));
   } else {     // the row's 4 quads share m: their partial sums simply add
     lsum += __shfl_xor(lsum, 16);
     lsum += __shfl_xor(lsum, 32);
   }
-  const float lse2 = m + fast_log2(lsum);
+  const float lse2 = mo + fast_log2(lsum);   // lsum carries 2^kPOff, like the payload sums
   if (quad == 0) {
     lse2s[16 * wave + j] = lse2;
     if (valid) lse[(size_t)g * N + n] = lse2;  // log2 units: backward re-creates the exponent bit for bit
   }
   if (WITH_PQ && valid && quad < T4) {  // D2[s = 4*quad + rr][row]: this lane owns pq[n][4*quad .. +3]
-    const float inv = 1.0f / lsum;
+    const float inv = pow2i(-sexp) / lsum;   // the planes' scale leaves here; P's 2^kPOff cancels against lsum
     reinterpret_cast<float4*>(pq + ((size_t)g * N + n) * T)[quad] =
-        make_float4(((da[0] + db[0]) + (dc[0] + dd[0])) * inv, ((da[1] + db[1]) + (dc[1] + dd[1])) * inv,
-                    ((da[2] + db[2]) + (dc[2] + dd[2])) * inv, ((da[3] + db[3]) + (dc[3] + dd[3])) * inv);
+        make_float4((da[0] + db[0]) * inv, (da[1] + db[1]) * inv, (da[2] + db[2]) * inv, (da[3] + db[3]) * inv);
   }
   __syncthreads();
   MSGAT_STAMP(4);
@@ -404,12 +485,16 @@ __global__ __launch_bounds__(kDBlock) void k_scores7(
     float* __restrict__ kW, float* __restrict__ lse, float* __restrict__ pq, float* __restrict__ E,
     const int* __restrict__ cpos, float* __restrict__ Ec, int Bg, int N, int nnz, int Ca,
     const float* __restrict__ alpha, float* __restrict__ qout,
-    const float* __restrict__ apW, int apCo, float* __restrict__ apY, float* __restrict__ apZ) {
+    const float* __restrict__ apW, int apCo, float* __restrict__ apY, float* __restrict__ apZ, float one) {
   constexpr int T4 = T / 4;
   constexpr bool ONES = WITH_PQ && T < 16;
+  constexpr float kPOff = WITH_PQ ? kPOffF : 0.f;               // see k_scores
   constexpr int kOThreads = 64 * kHOwners;                      // lanes that stage the owners' chunks
   __shared__ float4 qs4[kDMC * kPS / 4];  // owners' chunk of columns [0, Ca)
   __shared__ float4 qh4[kDMC * kPS / 4];  // the helper's columns [Ca, N), staged once
+  __shared__ uint4 pl4[WITH_PQ ? kPlaneU4 : 1];   // payload planes of the owners' chunk (see build_payload_planes)
+  __shared__ uint4 ph4[WITH_PQ ? kPlaneU4 : 1];   //                of the helper's columns, built once
+  __shared__ float wmax[kDWaves];
   __shared__ float kw2s[kHRows][T];
   __shared__ float lse2s[kHRows];
   __shared__ float hmax[kHRows];          // helper partial: running max of the row over its columns
@@ -431,25 +516,64 @@ __global__ __launch_bounds__(kDBlock) void k_scores7(
   const int colsh = N - Ca;             // 1 .. kDMC (host-checked)
   const int nchunk = cdiv(Ca, kDMC);
 
+  // columns [0, Ca) go through LDS in chunks, register-prefetched by the owners' lanes (see k_scores).  The first chunk is
+  // requested before anything else: its round trip then overlaps the helper's columns, their planes and the rows' kW -- all
+  // 768 blocks start together, and as the FIRST thing after two barriers it was 9 K of a block's 90 K clocks (in-kernel stamps)
+  constexpr int kSt = (kDMC * (kPS / 4) + kOThreads - 1) / kOThreads;
+  float4 pre[kSt];
+  float premax = 0.f;
+  auto prefetch = [&](int c0) {
+    constexpr int kF4p = kPS / 4;
+    const int cols = min(kDMC, Ca - c0);
+    premax = 0.f;
+#pragma unroll
+    for (int k = 0; k < kSt; ++k) {
+      const int i = threadIdx.x + k * kOThreads;
+      const int c = i / kF4p, f = i - c * kF4p;
+      const bool live = (c < cols) && (f < T4);
+      const float4 v = qrows.row4((size_t)(c0 + (live ? c : 0)), live ? f : 0);
+      const float keep = live ? 1.f : 0.f;
+      pre[k] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
+      premax = fmaxf(premax, max_abs4(pre[k]));
+    }
+  };
+  if (owner) prefetch(0);
+
   // the helper's columns, by every lane of the block
   constexpr int kF4 = kPS / 4;
+  MSGAT_STAMP(0);
+  float hmaxabs = 0.f;
   for (int i = threadIdx.x; i < kDMC * kF4; i += kDBlock) {
     const int c = i / kF4, f = i - c * kF4;
     const bool live = (c < colsh) && (f < T4);
     const float4 v = qrows.row4((size_t)(Ca + (live ? c : 0)), live ? f : 0);
     const float keep = live ? 1.f : 0.f;
-    const float one = (ONES && c < colsh && f == T4) ? 1.f : 0.f;
-    qh4[i] = make_float4(fmaf(v.x, keep, one), v.y * keep, v.z * keep, v.w * keep);
+    const float4 w = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
+    qh4[i] = w;
+    hmaxabs = fmaxf(hmaxabs, max_abs4(w));
+  }
+  int sexp = 100, sexph = 100;   // scale exponents of the owners' planes (running) and of the helper's (fixed)
+  if (WITH_PQ) {
+    for (int i = threadIdx.x; i < kPlaneU4; i += kDBlock) { pl4[i] = make_uint4(0u, 0u, 0u, 0u); ph4[i] = make_uint4(0u, 0u, 0u, 0u); }
+    const float wm = wave_max(hmaxabs);
+    if (lane == 0) wmax[wave] = wm;
+    __syncthreads();
+    float cmax = wmax[0];
+#pragma unroll
+    for (int w = 1; w < kDWaves; ++w) cmax = fmaxf(cmax, wmax[w]);
+    sexph = payload_scale_exp(cmax);
+    build_payload_planes<T, ONES>(qhw, kPS, colsh, pow2i(sexph), one, ph4, threadIdx.x, kDBlock);
+    __syncthreads();   // (wmax is re-used by the owners' chunks)
   }
 
   float bfrag[T4];
 
-  float m = -3.0e38f;
+  float m = -3.0e38f, mo = m;   // running max; mo = m - kPOff is what the exponent subtracts
   float lsum = 0.f;
-  f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = da, dc = da, dd = da;
+  f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = da;
 
   // one trip = two score tiles of the staged columns m0 .. m0 + 31 of `buf` (k_scores' inner trip)
-  auto trip = [&](const float* buf, int m0, int cols) {
+  auto trip = [&](const float* buf, const uint4* planes, int m0, int cols) {
     f32x4 S0 = {0.f, 0.f, 0.f, 0.f}, S1 = S0;
 #pragma unroll
     for (int kk = 0; kk < T4; ++kk) S0 = mfma16(buf[(m0 + j) * kPS + 4 * kk + quad], bfrag[kk], S0);
@@ -474,46 +598,27 @@ __global__ __launch_bounds__(kDBlock) void k_scores7(
       const float mn = fmaxf(m, cx);
       const float sc = fast_exp2(m - mn);
       m = mn;
+      mo = mn - kPOff;
       lsum *= sc;
       if (WITH_PQ) {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) { da[rr] *= sc; db[rr] *= sc; dc[rr] *= sc; dd[rr] *= sc; }
+        for (int rr = 0; rr < 4; ++rr) { da[rr] *= sc; db[rr] *= sc; }
       }
     }
     float p[8];
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) p[rr] = fast_exp2(sv[rr] - m);
+    for (int rr = 0; rr < 8; ++rr) p[rr] = fast_exp2(sv[rr] - mo);
     if (!ONES) lsum += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-    if (WITH_PQ) {
-      da = mfma16(buf[(mq + 0) * kPS + j], p[0], da);
-      db = mfma16(buf[(mq + 1) * kPS + j], p[1], db);
-      dc = mfma16(buf[(mq + 2) * kPS + j], p[2], dc);
-      dd = mfma16(buf[(mq + 3) * kPS + j], p[3], dd);
-      da = mfma16(buf[(mq + 16) * kPS + j], p[4], da);
-      db = mfma16(buf[(mq + 17) * kPS + j], p[5], db);
-      dc = mfma16(buf[(mq + 18) * kPS + j], p[6], dc);
-      dd = mfma16(buf[(mq + 19) * kPS + j], p[7], dd);
+    if (WITH_PQ) {   // see k_scores
+      const uint4 Fa = split_p(p, one), A2a = planes[((m0 >> 4) * 4 + quad) * 16 + j];
+      da = mfma_h(A2a, Fa, da); da = mfma_h(A2a, swap_halves(Fa), da);
+      const uint4 Fb = split_p(p + 4, one), A2b = planes[((m0 >> 4) * 4 + 4 + quad) * 16 + j];
+      db = mfma_h(A2b, Fb, db); db = mfma_h(A2b, swap_halves(Fb), db);
     }
   };
 
   if (owner) {
-    // columns [0, Ca) in chunks, register-prefetched staging by the owners' lanes (see k_scores)
-    constexpr int kSt = (kDMC * kF4 + kOThreads - 1) / kOThreads;
-    float4 pre[kSt];
-    auto prefetch = [&](int c0) {
-      const int cols = min(kDMC, Ca - c0);
-#pragma unroll
-      for (int k = 0; k < kSt; ++k) {
-        const int i = threadIdx.x + k * kOThreads;
-        const int c = i / kF4, f = i - c * kF4;
-        const bool live = (c < cols) && (f < T4);
-        const float4 v = qrows.row4((size_t)(c0 + (live ? c : 0)), live ? f : 0);
-        const float keep = live ? 1.f : 0.f;
-        const float one = (ONES && c < cols && f == T4) ? 1.f : 0.f;
-        pre[k] = make_float4(fmaf(v.x, keep, one), v.y * keep, v.z * keep, v.w * keep);
-      }
-    };
-    prefetch(0);   // in flight while the rows' kW is computed
+    // (the first chunk was requested at the top of the kernel; it lands while the rows' kW is computed)
     {
       float qr[T];
 #pragma unroll
@@ -534,40 +639,71 @@ __global__ __launch_bounds__(kDBlock) void k_scores7(
         kw2s[16 * wave + j][s] = bfrag[kk];
       }
     }
+    MSGAT_STAMP(1);
     for (int c0 = 0; c0 < Ca; c0 += kDMC) {
       const int cols = min(kDMC, Ca - c0);
       const int cols16 = (cols + 15) & ~15;
+      prio_by_progress(c0, Ca);
       __syncthreads();
 #pragma unroll
       for (int k = 0; k < kSt; ++k) {
         const int i = threadIdx.x + k * kOThreads;
         if (i < kDMC * kF4) qs4[i] = pre[k];
       }
+      if (WITH_PQ) {
+        const float wm = wave_max(premax);
+        if (lane == 0) wmax[wave] = wm;
+      }
       __syncthreads();
+      if (WITH_PQ) {   // the chunk's payload planes at the running scale, by the owners' lanes (see k_scores)
+        float cmax = wmax[0];
+#pragma unroll
+        for (int w = 1; w < kHOwners; ++w) cmax = fmaxf(cmax, wmax[w]);
+        const int ec = payload_scale_exp(cmax);
+        if (ec < sexp) {
+          const float f = pow2i(ec - sexp);
+          if (quad < T4) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) { da[rr] *= f; db[rr] *= f; }
+          }
+          sexp = ec;
+        }
+        build_payload_planes<T, ONES>(qsw, kPS, cols, pow2i(sexp), one, pl4, threadIdx.x, kOThreads);
+        __syncthreads();
+      }
       prefetch(min(c0 + kDMC, max(Ca - 1, 0) / kDMC * kDMC));
-      for (int m0 = 0; m0 < cols16; m0 += 32) trip(qsw, m0, cols);
+      for (int m0 = 0; m0 < cols16; m0 += 32) trip(qsw, pl4, m0, cols);
+      if (c0 == 0) MSGAT_STAMP(2);
     }
+    MSGAT_STAMP(3);
   } else {
     // the helper: row group rg's last columns during the owners' chunk rg (two barriers per chunk, like them)
     const int colsh16 = (colsh + 15) & ~15;
+    constexpr int kBar = WITH_PQ ? 3 : 2;   // barriers of the owners per chunk
+    const float hf = (WITH_PQ && quad < T4) ? pow2i(-sexph) : 1.f;   // payload rows leave in true units; the ones row is unscaled
     int nbar = 0;
     for (int rg = 0; rg < kHOwners; ++rg) {
-      if (nbar < 2 * nchunk) { __syncthreads(); __syncthreads(); nbar += 2; }
+      if (nbar < kBar * nchunk) {
+#pragma unroll
+        for (int bb = 0; bb < kBar; ++bb) __syncthreads();
+        nbar += kBar;
+      }
+      prio_by_progress(rg, kHOwners);
 #pragma unroll
       for (int kk = 0; kk < T4; ++kk) bfrag[kk] = kw2s[16 * rg + j][4 * kk + quad];
-      m = -3.0e38f;
+      m = mo = -3.0e38f;
       lsum = 0.f;
-      da = db = dc = dd = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int m0 = 0; m0 < colsh16; m0 += 32) trip(qhw, m0, colsh);
+      da = db = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int m0 = 0; m0 < colsh16; m0 += 32) trip(qhw, ph4, m0, colsh);
       if (!ONES) {
         lsum += __shfl_xor(lsum, 16);
         lsum += __shfl_xor(lsum, 32);
       }
       if (quad == 0) { hmax[16 * rg + j] = m; hsum[16 * rg + j] = lsum; }
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) hpay[16 * rg + j][4 * quad + rr] = (da[rr] + db[rr]) + (dc[rr] + dd[rr]);
+      for (int rr = 0; rr < 4; ++rr) hpay[16 * rg + j][4 * quad + rr] = (da[rr] + db[rr]) * hf;
     }
-    for (; nbar < 2 * nchunk; ++nbar) __syncthreads();
+    for (; nbar < kBar * nchunk; ++nbar) __syncthreads();
   }
   __syncthreads();   // the helper's partials are in LDS
 
@@ -577,9 +713,10 @@ __global__ __launch_bounds__(kDBlock) void k_scores7(
     const float mh = hmax[row];
     const float mt = fmaxf(m, mh);
     const float so = fast_exp2(m - mt), sh = fast_exp2(mh - mt);
+    const float fo = (WITH_PQ && quad < T4) ? pow2i(-sexp) * so : so;   // the own payload sums to true units (not the ones row)
     float tot[4];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) tot[rr] = ((da[rr] + db[rr]) + (dc[rr] + dd[rr])) * so + hpay[row][4 * quad + rr] * sh;
+    for (int rr = 0; rr < 4; ++rr) tot[rr] = (da[rr] + db[rr]) * fo + hpay[row][4 * quad + rr] * sh;
     if (ONES) {
       lsum = __shfl(tot[T % 4], j + 16 * (T / 4));
     } else {
@@ -587,7 +724,7 @@ __global__ __launch_bounds__(kDBlock) void k_scores7(
       lsum += __shfl_xor(lsum, 32);
       lsum = lsum * so + hsum[row] * sh;
     }
-    const float lse2 = mt + fast_log2(lsum);
+    const float lse2 = (mt - kPOff) + fast_log2(lsum);   // both parts carry P times 2^kPOff
     if (quad == 0) {
       lse2s[row] = lse2;
       if (valid) lse[(size_t)g * N + n] = lse2;
@@ -599,13 +736,17 @@ __global__ __launch_bounds__(kDBlock) void k_scores7(
     }
   }
   __syncthreads();
+  MSGAT_STAMP(4);
 
   // edge coefficients of this block's rows (see k_scores)
   const int e0 = rowptr[min(n0, N)];
   const int e1 = rowptr[min(n0 + kHRows, N)];
-  __shared__ int tl_rp[XC > 0 ? kHRows + 1 : 1];
-  __shared__ int tl_col[XC > 0 ? kTailEdges : 1];
-  __shared__ float tl_E[XC > 0 ? kTailEdges : 1];
+  // the tail's row extents / edge list / coefficients take over the staging buffers (dead behind the barrier above): with
+  // LDS of their own the block would not fit three to a CU beside the payload planes
+  static_assert((kHRows + 4 + 2 * kTailEdges) * 4 <= (int)sizeof(float4) * 2 * (kDMC * kPS / 4), "tail arrays exceed the staging buffers");
+  int* tl_rp = reinterpret_cast<int*>(qs4);
+  int* tl_col = tl_rp + kHRows + 4;
+  float* tl_E = reinterpret_cast<float*>(tl_col + kTailEdges);
   const bool with_tail = XC > 0 && apZ != nullptr;               // kernel-uniform
   const bool tail_cached = with_tail && e1 - e0 <= kTailEdges;    // block-uniform
   if (with_tail && (int)threadIdx.x <= min(kHRows, N - n0)) tl_rp[threadIdx.x] = rowptr[n0 + threadIdx.x];
@@ -626,6 +767,7 @@ __global__ __launch_bounds__(kDBlock) void k_scores7(
     if (Ec != nullptr) Ec[(size_t)g * nnz + cpos[e]] = ev;
     if (tail_cached) { tl_col[e - e0] = (int)ce; tl_E[e - e0] = ev; }
   }
+  MSGAT_STAMP(5);
   if (with_tail) {   // see k_scores
     __syncthreads();
     const size_t NT = (size_t)N * T;
@@ -666,29 +808,30 @@ static int launch_scores_x(const msgat_graph_t& gr, const float* q, const float*
 #ifndef MSGAT_NO_SCORES7
   if (const int Ca = scores7_owner_columns(N, G)) {
     dim3 grid7(cdiv(N, kHRows), G);
-    const size_t lds7 = sizeof(float) * (2 * kDMC * kPS + kHRows * T + 3 * kHRows + kHRows * 17) +
-                        (XC > 0 ? sizeof(int) * (kHRows + 1 + 2 * kTailEdges) : 0);   // + the tail's row extents / edges
+    const size_t lds7 = sizeof(float) * (2 * kDMC * kPS + kHRows * T + 3 * kHRows + kHRows * 17 + kDWaves) +
+                        (pq != nullptr ? 2 * sizeof(uint4) * kPlaneU4 : 2 * sizeof(uint4));   // + the payload planes (the tail re-uses the staging buffers)
     const size_t pad7 = balance_pad_bytes((int)(grid7.x * grid7.y), lds7);
     if (pq != nullptr)
       hipLaunchKernelGGL((k_scores7<T, true, XC>), grid7, dim3(kDBlock), pad7, s, q, Wg, gr.rowptr, gr.col, gr.val,
-                         gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, Ca, alpha, qout, apW, apCo, apY, apZ);
+                         gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, Ca, alpha, qout, apW, apCo, apY, apZ, 1.0f);
     else
       hipLaunchKernelGGL((k_scores7<T, false, XC>), grid7, dim3(kDBlock), pad7, s, q, Wg, gr.rowptr, gr.col, gr.val,
-                         gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, Ca, alpha, qout, apW, apCo, apY, apZ);
+                         gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, Ca, alpha, qout, apW, apCo, apY, apZ, 1.0f);
     MSGAT_CHECK_LAUNCH();
     return MSGAT_OK;
   }
 #endif
   dim3 grid(cdiv(N, kDRows), G);
-  const size_t static_lds = sizeof(float) * (kDMC * kPS + kDRows * T + kDRows) +
+  const size_t static_lds = sizeof(float) * (kDMC * kPS + kDRows * T + kDRows + kDWaves) +
+                            (pq != nullptr ? sizeof(uint4) * kPlaneU4 : sizeof(uint4)) +
                             (XC > 0 ? sizeof(int) * (kDRows + 1 + 2 * kTailEdges) : 0);
   const size_t pad = balance_pad_bytes((int)(grid.x * grid.y), static_lds);
   if (pq != nullptr)
     hipLaunchKernelGGL((k_scores<T, true, XC>), grid, dim3(kDBlock), pad, s, q, Wg, gr.rowptr, gr.col, gr.val,
-                       gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, alpha, qout, apW, apCo, apY, apZ);
+                       gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, alpha, qout, apW, apCo, apY, apZ, 1.0f);
   else
     hipLaunchKernelGGL((k_scores<T, false, XC>), grid, dim3(kDBlock), pad, s, q, Wg, gr.rowptr, gr.col, gr.val,
-                       gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, alpha, qout, apW, apCo, apY, apZ);
+                       gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, alpha, qout, apW, apCo, apY, apZ, 1.0f);
   MSGAT_CHECK_LAUNCH();
   return MSGAT_OK;
 }
@@ -793,11 +936,13 @@ __global__ __launch_bounds__(kDBlock) void k_bwd_dense_col(
     const float* __restrict__ q, const float* __restrict__ kW, const float* __restrict__ lse,
     const float* __restrict__ delta, const float* __restrict__ gE, const int* __restrict__ colptr,
     const int* __restrict__ crow, const int* __restrict__ cperm, float* __restrict__ dq, int N,
-    int nnz) {
+    int nnz, float one) {
   constexpr int T4 = T / 4;
   __shared__ float4 kwr4[kDMC * T4];        // [row][kW2(T)]
-  __shared__ float4 dkr4[kDMC * kPS / 4];   // [row][delta*kW(T) | zeros]
-  __shared__ float4 lse4[kDMC / 4];         // [row] lse2 (+inf past the end)
+  __shared__ float4 dkr4[kDMC * kPS / 4];   // [row][delta*kW(T) | zeros]: fp32, the source of the payload planes
+  __shared__ float4 lse4[kDMC / 4];         // [row] lse2 - 14 (+inf past the end): P is carried times 2^14
+  __shared__ uint4 pl4[kPlaneU4];           // payload planes of the staged rows (fp16 terms of delta kW, see build_payload_planes)
+  __shared__ float wmax[kDWaves];
   const float* kwr = reinterpret_cast<const float*>(kwr4);
   const float* dkr = reinterpret_cast<const float*>(dkr4);
   float* lsew = reinterpret_cast<float*>(lse4);
@@ -814,12 +959,14 @@ __global__ __launch_bounds__(kDBlock) void k_bwd_dense_col(
 #pragma unroll
   for (int kk = 0; kk < T4; ++kk) bfrag[kk] = valid ? qg[(size_t)mcol * T + 4 * kk + quad] : 0.f;
 
-  f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = da, dc = da, dd = da;  // four independent accumulate chains
+  f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = da;  // payload accumulators (row tile a / b of a trip)
+  int sexp = 100;                              // the planes carry delta kW * 2^sexp (running, see k_scores)
+  for (int i = threadIdx.x; i < kPlaneU4; i += kDBlock) pl4[i] = make_uint4(0u, 0u, 0u, 0u);   // rows s >= T stay zero
 
   // register-prefetched staging (see k_scores): one row per lane per chunk
   static_assert(kDMC <= kDBlock, "at most one staged row per lane");
   float4 prek[T4];
-  float pred = 0.f, prel = 0.f;
+  float pred = 0.f, prel = 0.f, premax = 0.f;
   auto prefetch = [&](int r0) {
     const int rows = min(kDMC, N - r0);
     const bool live = (int)threadIdx.x < rows;  // lanes >= kDMC never stage
@@ -833,12 +980,17 @@ __global__ __launch_bounds__(kDBlock) void k_bwd_dense_col(
     }
     pred = delta[(size_t)g * N + nr] * keep;
     const float lv = lse[(size_t)g * N + nr];
-    prel = live ? lv : INFINITY;  // exp2(s - inf) = 0 for rows past the end
+    prel = live ? lv - kPOffB : INFINITY;  // exp2(s - inf) = 0 for rows past the end
+    premax = 0.f;
+#pragma unroll
+    for (int t4 = 0; t4 < T4; ++t4) premax = fmaxf(premax, max_abs4(prek[t4]));
+    premax *= fabsf(pred);
   };
   prefetch(0);
   for (int r0 = 0; r0 < N; r0 += kDMC) {
     const int rows = min(kDMC, N - r0);
     const int rows16 = (rows + 15) & ~15;
+    prio_by_progress(r0, N);
     __syncthreads();  // every wave is done with the previous chunk
     if (threadIdx.x < kDMC) {
       const int i = threadIdx.x;
@@ -850,7 +1002,25 @@ __global__ __launch_bounds__(kDBlock) void k_bwd_dense_col(
       }
       lsew[i] = prel;
     }
+    {
+      const float wm = wave_max(premax);
+      if (lane == 0) wmax[wave] = wm;
+    }
     __syncthreads();
+    {   // the chunk's payload planes at the running scale (see k_scores)
+      float cmax = wmax[0];
+#pragma unroll
+      for (int w = 1; w < kDWaves; ++w) cmax = fmaxf(cmax, wmax[w]);
+      const int ec = payload_scale_exp(cmax);
+      if (ec < sexp) {
+        const float f = pow2i(ec - sexp);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) { da[rr] *= f; db[rr] *= f; }
+        sexp = ec;
+      }
+      build_payload_planes<T, false>(dkr, kPS, rows, pow2i(sexp), one, pl4, threadIdx.x, kDBlock);
+      __syncthreads();
+    }
     prefetch(min(r0 + kDMC, max(N - 1, 0) / kDMC * kDMC));  // next chunk (the last trip re-reads its own)
     // same products in the same k order as the forward's edge pass, accumulator starting at 0: the
     // score is re-created bit for bit, so 2^(s - lse2) equals the forward's softmax value (rows that
@@ -868,27 +1038,25 @@ __global__ __launch_bounds__(kDBlock) void k_bwd_dense_col(
       const float p2 = fast_exp2(S0[2] - l4.z), p3 = fast_exp2(S0[3] - l4.w);
       const float p4 = fast_exp2(S1[0] - l5.x), p5 = fast_exp2(S1[1] - l5.y);
       const float p6 = fast_exp2(S1[2] - l5.z), p7 = fast_exp2(S1[3] - l5.w);
-      // A2[i = s][k = quad] = (delta kW)[row rq + rr][s = j]; B2[k = quad][j = column] = p[rr]
-      da = mfma16(dkr[(rq + 0) * kPS + j], p0, da);
-      db = mfma16(dkr[(rq + 1) * kPS + j], p1, db);
-      dc = mfma16(dkr[(rq + 2) * kPS + j], p2, dc);
-      dd = mfma16(dkr[(rq + 3) * kPS + j], p3, dd);
-      da = mfma16(dkr[(rq + 16) * kPS + j], p4, da);
-      db = mfma16(dkr[(rq + 17) * kPS + j], p5, db);
-      dc = mfma16(dkr[(rq + 18) * kPS + j], p6, dc);
-      dd = mfma16(dkr[(rq + 19) * kPS + j], p7, dd);
+      // A2[i = s][k] = the planes' (h | m) of rows rb + 4 quad .. +3 at s = j; B2[k][j = column] = (Ph | Pm), then (Pm | Ph)
+      const float pa[4] = {p0, p1, p2, p3}, pb[4] = {p4, p5, p6, p7};
+      const uint4 Fa = split_p(pa, one), A2a = pl4[((rb >> 4) * 4 + quad) * 16 + j];
+      da = mfma_h(A2a, Fa, da); da = mfma_h(A2a, swap_halves(Fa), da);
+      const uint4 Fb = split_p(pb, one), A2b = pl4[((rb >> 4) * 4 + 4 + quad) * 16 + j];
+      db = mfma_h(A2b, Fb, db); db = mfma_h(A2b, swap_halves(Fb), db);
     }
   }
   if (!valid || quad >= T4) return;
+  const float unscale = pow2i(-sexp - (int)kPOffB);   // the planes' scale and P's 2^14
 
   // D2[s = 4*quad + rr][column]: this lane owns dq[mcol][4*quad .. +3]; add the sparse in-edge term
   const float4 sp = in_edge_term<T>(colptr, crow, cperm, gE + (size_t)g * nnz, kWg, mcol, quad);
   float4* dst = reinterpret_cast<float4*>(dq + ((size_t)g * N + mcol) * T) + quad;
   float4 v = *dst;
-  v.x += sp.x - ((da[0] + db[0]) + (dc[0] + dd[0]));
-  v.y += sp.y - ((da[1] + db[1]) + (dc[1] + dd[1]));
-  v.z += sp.z - ((da[2] + db[2]) + (dc[2] + dd[2]));
-  v.w += sp.w - ((da[3] + db[3]) + (dc[3] + dd[3]));
+  v.x += sp.x - (da[0] + db[0]) * unscale;
+  v.y += sp.y - (da[1] + db[1]) * unscale;
+  v.z += sp.z - (da[2] + db[2]) * unscale;
+  v.w += sp.w - (da[3] + db[3]) * unscale;
   *dst = v;
 }
 
@@ -900,22 +1068,24 @@ __global__ __launch_bounds__(kDBlock) void k_bwd_dense_col7(
     const float* __restrict__ q, const float* __restrict__ kW, const float* __restrict__ lse,
     const float* __restrict__ delta, const float* __restrict__ gE, const int* __restrict__ colptr,
     const int* __restrict__ crow, const int* __restrict__ cperm, float* __restrict__ dq, int N,
-    int nnz, int Ra) {
+    int nnz, int Ra, float one) {
   constexpr int T4 = T / 4;
   constexpr int kOThreads = 64 * kHOwners;
   __shared__ float4 kwr4[kDMC * T4];        // owners' chunk: [row][kW2(T)]
   __shared__ float4 dkr4[kDMC * kPS / 4];   //                [row][delta*kW(T) | zeros]
   __shared__ float4 lse4[kDMC / 4];         //                [row] lse2 (+inf past the end)
   __shared__ float4 kwh4[kDMC * T4];        // the helper's rows [Ra, N), staged once
-  __shared__ float4 dkh4[kDMC * kPS / 4];
   __shared__ float4 lsh4[kDMC / 4];
+  __shared__ uint4 pl4[kPlaneU4];           // payload planes of the owners' chunk / of the helper's rows (see k_bwd_dense_col)
+  __shared__ uint4 ph4[kPlaneU4];
+  __shared__ float wmax[kDWaves];
   __shared__ float qfs[kHRows][T];          // q rows of the block's columns (the helper's B fragments)
   __shared__ float hpay[kHRows][17];        // helper partial: D2[s][column]
   const float* kwr = reinterpret_cast<const float*>(kwr4);
   const float* dkr = reinterpret_cast<const float*>(dkr4);
   float* lsew = reinterpret_cast<float*>(lse4);
   const float* kwh = reinterpret_cast<const float*>(kwh4);
-  const float* dkh = reinterpret_cast<const float*>(dkh4);
+  const float* dkh = dkr;   // the helper's fp32 delta kW rows pass through the owners' staging buffer: they are only the source of ph4
   float* lshw = reinterpret_cast<float*>(lsh4);
 
   const int g = blockIdx.y;
@@ -930,7 +1100,34 @@ __global__ __launch_bounds__(kDBlock) void k_bwd_dense_col7(
   const int rowsh = N - Ra;   // 1 .. kDMC
   const int nchunk = cdiv(Ra, kDMC);
 
+  // the owners' first chunk is requested before anything else (see k_scores7)
+  // rows [0, Ra) in chunks, one staged row per lane of the first two owner waves (see k_bwd_dense_col)
+  static_assert(kDMC <= kOThreads, "at most one staged row per owner lane");
+  float4 prek[T4];
+  float pred = 0.f, prel = 0.f, premax = 0.f;
+  auto prefetch = [&](int r0) {
+    const int rows = min(kDMC, Ra - r0);
+    const bool live = (int)threadIdx.x < rows;
+    const int nr = r0 + (live ? (int)threadIdx.x : 0);
+    const float keep = live ? 1.f : 0.f;
+    const float4* kr = reinterpret_cast<const float4*>(kWg + (size_t)nr * T);
+#pragma unroll
+    for (int t4 = 0; t4 < T4; ++t4) {
+      const float4 v = kr[t4];
+      prek[t4] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
+    }
+    pred = delta[(size_t)g * N + nr] * keep;
+    const float lv = lse[(size_t)g * N + nr];
+    prel = live ? lv - kPOffB : INFINITY;
+    premax = 0.f;
+#pragma unroll
+    for (int t4 = 0; t4 < T4; ++t4) premax = fmaxf(premax, max_abs4(prek[t4]));
+    premax *= fabsf(pred);
+  };
+  if (owner) prefetch(0);
+
   // the helper's rows and the block's q rows, by every lane
+  float hmaxabs = 0.f;
   if (threadIdx.x < kDMC) {
     const int i = threadIdx.x;
     const bool live = i < rowsh;
@@ -947,13 +1144,31 @@ __global__ __launch_bounds__(kDBlock) void k_bwd_dense_col7(
         v = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
         kwh4[i * T4 + t4] = make_float4(v.x * kLog2e, v.y * kLog2e, v.z * kLog2e, v.w * kLog2e);
       }
-      dkh4[i * (kPS / 4) + t4] = make_float4(v.x * pd, v.y * pd, v.z * pd, v.w * pd);
+      const float4 w = make_float4(v.x * pd, v.y * pd, v.z * pd, v.w * pd);
+      dkr4[i * (kPS / 4) + t4] = w;
+      hmaxabs = fmaxf(hmaxabs, max_abs4(w));
     }
-    lshw[i] = live ? lv : INFINITY;
+    lshw[i] = live ? lv - kPOffB : INFINITY;
+  }
+  for (int i = threadIdx.x; i < kPlaneU4; i += kDBlock) { pl4[i] = make_uint4(0u, 0u, 0u, 0u); ph4[i] = make_uint4(0u, 0u, 0u, 0u); }
+  {
+    const float wm = wave_max(hmaxabs);
+    if (lane == 0) wmax[wave] = wm;
   }
   for (int i = threadIdx.x; i < kHRows * T; i += kDBlock) {
     const int cl = i / T, t = i - cl * T;
     qfs[cl][t] = (m0c + cl < N) ? qg[(size_t)(m0c + cl) * T + t] : 0.f;
+  }
+
+  __syncthreads();
+  int sexp = 100, sexph;   // scale exponents of the owners' planes (running) and of the helper's (fixed)
+  {
+    float cmax = wmax[0];
+#pragma unroll
+    for (int w = 1; w < kDWaves; ++w) cmax = fmaxf(cmax, wmax[w]);
+    sexph = payload_scale_exp(cmax);
+    build_payload_planes<T, false>(dkh, kPS, rowsh, pow2i(sexph), one, ph4, threadIdx.x, kDBlock);
+    __syncthreads();   // (wmax is re-used by the owners' chunks)
   }
 
   float bfrag[T4];
@@ -961,10 +1176,10 @@ __global__ __launch_bounds__(kDBlock) void k_bwd_dense_col7(
 #pragma unroll
     for (int kk = 0; kk < T4; ++kk) bfrag[kk] = valid ? qg[(size_t)mcol * T + 4 * kk + quad] : 0.f;
   }
-  f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = da, dc = da, dd = da;
+  f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = da;
 
   // one trip = two row tiles rb .. rb + 31 of the staged rows (k_bwd_dense_col's inner trip)
-  auto trip = [&](const float* kw, const float* dk, const float4* l4s, int rb) {
+  auto trip = [&](const float* kw, const uint4* planes, const float4* l4s, int rb) {
     f32x4 S0 = {0.f, 0.f, 0.f, 0.f}, S1 = S0;
 #pragma unroll
     for (int kk = 0; kk < T4; ++kk) S0 = mfma16(kw[(rb + j) * T + 4 * kk + quad], bfrag[kk], S0);
@@ -976,40 +1191,19 @@ __global__ __launch_bounds__(kDBlock) void k_bwd_dense_col7(
     const float p2 = fast_exp2(S0[2] - l4.z), p3 = fast_exp2(S0[3] - l4.w);
     const float p4 = fast_exp2(S1[0] - l5.x), p5 = fast_exp2(S1[1] - l5.y);
     const float p6 = fast_exp2(S1[2] - l5.z), p7 = fast_exp2(S1[3] - l5.w);
-    da = mfma16(dk[(rq + 0) * kPS + j], p0, da);
-    db = mfma16(dk[(rq + 1) * kPS + j], p1, db);
-    dc = mfma16(dk[(rq + 2) * kPS + j], p2, dc);
-    dd = mfma16(dk[(rq + 3) * kPS + j], p3, dd);
-    da = mfma16(dk[(rq + 16) * kPS + j], p4, da);
-    db = mfma16(dk[(rq + 17) * kPS + j], p5, db);
-    dc = mfma16(dk[(rq + 18) * kPS + j], p6, dc);
-    dd = mfma16(dk[(rq + 19) * kPS + j], p7, dd);
+    const float pa[4] = {p0, p1, p2, p3}, pb[4] = {p4, p5, p6, p7};   // see k_bwd_dense_col
+    const uint4 Fa = split_p(pa, one), A2a = planes[((rb >> 4) * 4 + quad) * 16 + j];
+    da = mfma_h(A2a, Fa, da); da = mfma_h(A2a, swap_halves(Fa), da);
+    const uint4 Fb = split_p(pb, one), A2b = planes[((rb >> 4) * 4 + 4 + quad) * 16 + j];
+    db = mfma_h(A2b, Fb, db); db = mfma_h(A2b, swap_halves(Fb), db);
   };
 
   if (owner) {
-    // rows [0, Ra) in chunks, one staged row per lane of the first two owner waves (see k_bwd_dense_col)
-    static_assert(kDMC <= kOThreads, "at most one staged row per owner lane");
-    float4 prek[T4];
-    float pred = 0.f, prel = 0.f;
-    auto prefetch = [&](int r0) {
-      const int rows = min(kDMC, Ra - r0);
-      const bool live = (int)threadIdx.x < rows;
-      const int nr = r0 + (live ? (int)threadIdx.x : 0);
-      const float keep = live ? 1.f : 0.f;
-      const float4* kr = reinterpret_cast<const float4*>(kWg + (size_t)nr * T);
-#pragma unroll
-      for (int t4 = 0; t4 < T4; ++t4) {
-        const float4 v = kr[t4];
-        prek[t4] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
-      }
-      pred = delta[(size_t)g * N + nr] * keep;
-      const float lv = lse[(size_t)g * N + nr];
-      prel = live ? lv : INFINITY;
-    };
-    prefetch(0);
+    // (the first chunk was requested at the top of the kernel)
     for (int r0 = 0; r0 < Ra; r0 += kDMC) {
       const int rows = min(kDMC, Ra - r0);
       const int rows16 = (rows + 15) & ~15;
+      prio_by_progress(r0, Ra);
       __syncthreads();
       if (threadIdx.x < kDMC) {
         const int i = threadIdx.x;
@@ -1021,23 +1215,43 @@ __global__ __launch_bounds__(kDBlock) void k_bwd_dense_col7(
         }
         lsew[i] = prel;
       }
+      {
+        const float wm = wave_max(premax);
+        if (lane == 0) wmax[wave] = wm;
+      }
       __syncthreads();
+      {   // the chunk's payload planes at the running scale, by the owners' lanes
+        float cmax = wmax[0];
+#pragma unroll
+        for (int w = 1; w < kHOwners; ++w) cmax = fmaxf(cmax, wmax[w]);
+        const int ec = payload_scale_exp(cmax);
+        if (ec < sexp) {
+          const float f = pow2i(ec - sexp);
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) { da[rr] *= f; db[rr] *= f; }
+          sexp = ec;
+        }
+        build_payload_planes<T, false>(dkr, kPS, rows, pow2i(sexp), one, pl4, threadIdx.x, kOThreads);
+        __syncthreads();
+      }
       prefetch(min(r0 + kDMC, max(Ra - 1, 0) / kDMC * kDMC));
-      for (int rb = 0; rb < rows16; rb += 32) trip(kwr, dkr, lse4, rb);
+      for (int rb = 0; rb < rows16; rb += 32) trip(kwr, pl4, lse4, rb);
     }
   } else {
     const int rowsh16 = (rowsh + 15) & ~15;
+    const float hf = pow2i(-sexph - (int)kPOffB);   // to true units
     int nbar = 0;
     for (int cg = 0; cg < kHOwners; ++cg) {
-      if (nbar < 2 * nchunk) { __syncthreads(); __syncthreads(); nbar += 2; }
+      if (nbar < 3 * nchunk) { __syncthreads(); __syncthreads(); __syncthreads(); nbar += 3; }   // the owners' three barriers per chunk
+      prio_by_progress(cg, kHOwners);
 #pragma unroll
       for (int kk = 0; kk < T4; ++kk) bfrag[kk] = qfs[16 * cg + j][4 * kk + quad];
-      da = db = dc = dd = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int rb = 0; rb < rowsh16; rb += 32) trip(kwh, dkh, lsh4, rb);
+      da = db = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int rb = 0; rb < rowsh16; rb += 32) trip(kwh, ph4, lsh4, rb);
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) hpay[16 * cg + j][4 * quad + rr] = (da[rr] + db[rr]) + (dc[rr] + dd[rr]);
+      for (int rr = 0; rr < 4; ++rr) hpay[16 * cg + j][4 * quad + rr] = (da[rr] + db[rr]) * hf;
     }
-    for (; nbar < 2 * nchunk; ++nbar) __syncthreads();
+    for (; nbar < 3 * nchunk; ++nbar) __syncthreads();
   }
   __syncthreads();   // the helper's partials are in LDS
   if (!valid || quad >= T4) return;
@@ -1046,10 +1260,11 @@ __global__ __launch_bounds__(kDBlock) void k_bwd_dense_col7(
   const float4 sp = in_edge_term<T>(colptr, crow, cperm, gE + (size_t)g * nnz, kWg, mcol, quad);
   float4* dst = reinterpret_cast<float4*>(dq + ((size_t)g * N + mcol) * T) + quad;
   float4 v = *dst;
-  v.x += sp.x - (((da[0] + db[0]) + (dc[0] + dd[0])) + hpay[cl][4 * quad + 0]);
-  v.y += sp.y - (((da[1] + db[1]) + (dc[1] + dd[1])) + hpay[cl][4 * quad + 1]);
-  v.z += sp.z - (((da[2] + db[2]) + (dc[2] + dd[2])) + hpay[cl][4 * quad + 2]);
-  v.w += sp.w - (((da[3] + db[3]) + (dc[3] + dd[3])) + hpay[cl][4 * quad + 3]);
+  const float unscale = pow2i(-sexp - (int)kPOffB);   // the own sums to true units (the helper's are already)
+  v.x += sp.x - ((da[0] + db[0]) * unscale + hpay[cl][4 * quad + 0]);
+  v.y += sp.y - ((da[1] + db[1]) * unscale + hpay[cl][4 * quad + 1]);
+  v.z += sp.z - ((da[2] + db[2]) * unscale + hpay[cl][4 * quad + 2]);
+  v.w += sp.w - ((da[3] + db[3]) * unscale + hpay[cl][4 * quad + 3]);
   *dst = v;
 }
 
@@ -1063,11 +1278,12 @@ int launch_bwd_dense_col(const msgat_graph_t& gr, const float* q, const float* k
 #ifndef MSGAT_NO_SCORES7
   if (const int Ra = scores7_owner_columns(N, G)) {   // the same split, over rows
     dim3 grid7(cdiv(N, kHRows), G);
-    const size_t lds7 = sizeof(float) * (2 * (kDMC * T + kDMC * kPS + kDMC) + kHRows * T + kHRows * 17);
+    const size_t lds7 = sizeof(float) * (2 * (kDMC * T + kDMC) + kDMC * kPS + kHRows * T + kHRows * 17 + kDWaves) +
+                        2 * sizeof(uint4) * kPlaneU4;
     const size_t pad7 = balance_pad_bytes((int)(grid7.x * grid7.y), lds7);
 #define MSGAT_DCOL7(TT)                                                                                    \
   hipLaunchKernelGGL(k_bwd_dense_col7<TT>, grid7, dim3(kDBlock), pad7, s, q, kW, lse, delta, gE, gr.colptr, \
-                     gr.crow, gr.cperm, dq, N, gr.nnz, Ra)
+                     gr.crow, gr.cperm, dq, N, gr.nnz, Ra, 1.0f)
     switch (T) {
       case 4: MSGAT_DCOL7(4); break;
       case 8: MSGAT_DCOL7(8); break;
@@ -1081,11 +1297,11 @@ int launch_bwd_dense_col(const msgat_graph_t& gr, const float* q, const float* k
   }
 #endif
   dim3 grid(cdiv(N, kDRows), G);
-  const size_t static_lds = sizeof(float) * (kDMC * T + kDMC * kPS + kDMC);
+  const size_t static_lds = sizeof(float) * (kDMC * T + kDMC * kPS + kDMC + kDWaves) + sizeof(uint4) * kPlaneU4;
   const size_t pad = balance_pad_bytes((int)(grid.x * grid.y), static_lds);
 #define MSGAT_DCOL(TT)                                                                                \
   hipLaunchKernelGGL(k_bwd_dense_col<TT>, grid, dim3(kDBlock), pad, s, q, kW, lse, delta, gE, gr.colptr, \
-                     gr.crow, gr.cperm, dq, N, gr.nnz)
+                     gr.crow, gr.cperm, dq, N, gr.nnz, 1.0f)
   switch (T) {
     case 4: MSGAT_DCOL(4); break;
     case 8: MSGAT_DCOL(8); break;

@@ -563,7 +563,10 @@ def test_randomised_shape_sweep():
         R, Bg = int(rng.choice([1, 2, 3])), int(rng.choice([1, 2, 3]))
         E = int(min(N * (N - 1) // 2, rng.choice([0, 1, N // 2, N, 3 * N, 8 * N])))
         prob = random_problem(R, Bg, C, Co, N, T, E, seed=1000 + it)
-        assert_close(run_ours(*prob), oracle_f64(*prob), what=f"T{T} N{N} C{C} Co{Co} R{R} Bg{Bg} E{E}")
+        # (a single node has softmax == 1 and dWg == 0 exactly: held to the bar on the O(1) input scale, as in
+        # test_against_numpy_oracle -- the fp16 payload product returns pq = q to 1e-7, not to the bit)
+        assert_close(run_ours(*prob), oracle_f64(*prob), what=f"T{T} N{N} C{C} Co{Co} R{R} Bg{Bg} E{E}",
+                     floor=1.0 if N == 1 else 0.0)
 
 
 @pytest.mark.parametrize("R,Bg,Cu,N,T,E", [

@@ -35,8 +35,11 @@ int main(int argc, char** argv) {   // scores_stamps [G N nnz]  (default: the PE
   hipDeviceSynchronize();
   std::vector<unsigned long long> st(8 * 4096);
   hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(msgat::g_stamps), st.size() * 8);
-  const int nb = std::min(4096, G * ((N + msgat::kDRows - 1) / msgat::kDRows));
-  const char* names[] = {"prologue (row fragment, kW)", "first chunk (stage + tiles)", "remaining chunks", "merge + stores", "edge pass"};
+  const bool seven = (N == 883 || (argc > 4 && atoi(argv[4]) == 7));   // the 7 + 1 wave form stamps its own phases
+  const int nb = std::min(4096, G * ((N + (seven ? msgat::kHRows : msgat::kDRows) - 1) / (seven ? msgat::kHRows : msgat::kDRows)));
+  const char* names8[] = {"prologue (row fragment, kW)", "first chunk (stage + tiles)", "remaining chunks", "merge + stores", "edge pass"};
+  const char* names7[] = {"helper columns staged + planes, rows' kW", "first chunk (stage, planes, tiles)", "remaining chunks", "wait for helper + fold + stores", "edge pass"};
+  const char** names = seven ? names7 : names8;
   for (int ph = 0; ph < 5; ++ph) {
     std::vector<double> d;
     for (int b = 0; b < nb; ++b) d.push_back((double)(st[b * 8 + ph + 1] - st[b * 8 + ph]));
