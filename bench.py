@@ -490,8 +490,10 @@ def time_dense_kernels(hp, reps=20):
                          f"{MFMA_BF16_PEAK_TFLOPS:.0f} TFLOP/s dense bf16: the passes are bound by instruction issue (4 v_exp, 8 split "
                          "and ~10 other vector instructions per tile beside 5 MFMAs), not by the pipe",
                 "kernels": out}
-    return {"bound": "mfma", "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "dtype": "f32 (v_mfma_f32_16x16x4_f32)",
-            "matrix": "fp32 (v_mfma_f32_16x16x4_f32): below N = 1536 the split form's operand images cost what it gains",
+    return {"bound": "mfma", "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "dtype": "f32; scores on v_mfma_f32_16x16x4_f32 (exact), payload product on two-term fp16 operands, fp32 accumulate",
+            "matrix": "fp32 scores (3 x v_mfma_f32_16x16x4_f32 per tile) + fp16 split x4 payload (2 x v_mfma_f32_16x16x32_f16): below "
+                      "N = 1536 the operand images of the all-split form cost what it gains (profiles/r06/dense_split_lab.txt)",
             "kernels": out}
 
 
