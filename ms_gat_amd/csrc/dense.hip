@@ -575,23 +575,10 @@ __global__ __launch_bounds__(kDBlock) void k_scores7(
   // one trip = two score tiles of the staged columns m0 .. m0 + 31 of `buf` (k_scores' inner trip)
   auto trip = [&](const float* buf, const uint4* planes, int m0, int cols) {
     f32x4 S0 = {0.f, 0.f, 0.f, 0.f}, S1 = S0;
-#ifdef MSGAT_SLAB   // timing model (wrong results): the score product as three bf16 MFMAs on fragments read from LDS planes
-    {
-      typedef __bf16 bf16x8l __attribute__((ext_vector_type(8)));
-      const uint4 fa0 = planes[((m0 >> 4) * 4 + quad) * 16 + j], fa1 = planes[((m0 >> 4) * 4 + ((quad + 1) & 3)) * 16 + j];
-      const uint4 fb0 = planes[((m0 >> 4) * 4 + 4 + quad) * 16 + j], fb1 = planes[((m0 >> 4) * 4 + 4 + ((quad + 1) & 3)) * 16 + j];
-      const uint4 d0 = make_uint4(__float_as_uint(bfrag[0]), __float_as_uint(bfrag[1]), __float_as_uint(bfrag[2]), 0x3c003c00u);
-#define MSGAT_BF(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8l, a_), __builtin_bit_cast(bf16x8l, b_), c_, 0, 0, 0)
-      S0 = MSGAT_BF(fa0, d0, S0); S0 = MSGAT_BF(fa0, d0, S0); S0 = MSGAT_BF(fa1, d0, S0);
-      S1 = MSGAT_BF(fb0, d0, S1); S1 = MSGAT_BF(fb0, d0, S1); S1 = MSGAT_BF(fb1, d0, S1);
-#undef MSGAT_BF
-    }
-#else
 #pragma unroll
     for (int kk = 0; kk < T4; ++kk) S0 = mfma16(buf[(m0 + j) * kPS + 4 * kk + quad], bfrag[kk], S0);
 #pragma unroll
     for (int kk = 0; kk < T4; ++kk) S1 = mfma16(buf[(m0 + 16 + j) * kPS + 4 * kk + quad], bfrag[kk], S1);
-#endif
     const int mq = m0 + 4 * quad;
     float sv[8];
     if (m0 + 32 > cols) {
