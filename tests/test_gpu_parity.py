@@ -633,6 +633,21 @@ def test_dense_passes_with_a_helper_wave_at_every_timestep_count(T, N, Bg, x_sca
             assert rel_err(got[k], f64[k]) < bar, (k, rel_err(got[k], f64[k]), bar)
 
 
+@pytest.mark.parametrize("N,Bg", [(100, 2), (883, 4), (1600, 2)])
+@pytest.mark.parametrize("cq,cg", [(1e-6, 1e-8), (1e3, 1e5), (3e7, 1e-3)])
+def test_payload_magnitudes_far_from_one(N, Bg, cq, cg):
+    """The payload product of the dense passes runs on fp16 operands behind a power-of-two scale that follows the data
+    (csrc/halfsplit.hpp).  Signals of magnitude `cq` with Wg scaled by 1 / cq^2 (the scores, and with them the attention, stay
+    what they are) and cotangents of magnitude `cg`: every output and gradient against float64 at the usual bar -- fp16 on its own
+    would overflow at 7e4 and lose everything below 6e-8.  N = 100: 8-wave forms; 883: the 7 + 1 wave forms; 1600: the
+    split-operand forms with their per-group image scale."""
+    x, adj, Wg, alpha, W, dz = random_problem(2, Bg, 5, 24, N, 12, N, seed=4000 + N)
+    prob = ((x * cq).astype(np.float32), adj, (Wg / (cq * cq)).astype(np.float32), alpha, W, (dz * cg).astype(np.float32))
+    got, want = run_ours(*prob), oracle_f64(*prob)
+    assert all(np.isfinite(v).all() for v in got.values())
+    assert_close(got, want, what=f"payload magnitudes N{N} q~{cq:g} dz~{cg:g}")
+
+
 def test_double_backward_is_refused_at_the_library_node():
     """Every backward of ms_gat_amd.ops launches kernels on raw pointers and is marked `once_differentiable`:
     `create_graph=True` yields gradients whose own backward fails with PyTorch's message, not silent constants."""
