@@ -9,16 +9,16 @@
 //             E[e]  = 2^(kW2[row_e].q[col_e] - lse[row_e]) * adj_e (edges only)
 //   backward  dq[m] -= sum_n softmax(S)[n,m] delta[n] kW[n]        (the dense column term)
 //
-// These kernels read [G,N,T] and are bound by fp32 issue, not HBM.  BOTH matrix products of a
-// 16x16 tile run on the matrix core as exact-fp32 v_mfma_f32_16x16x4_f32 (bf16 is not an option:
-// the scores feed an exp and the parity bar is 1e-4):
-//   1. scores   S = own . streamed^T      K = T     -> T/4 MFMAs (3 at T = 12)
-//   2. payload  acc += P . payload        K = 16    -> 4 MFMAs, the accumulator of (1), after the
-//      exp, IS the B operand of (2) with no data movement (its k index is just permuted, and the A
-//      operand is read from LDS in the matching order)
-// and the VALU is left with 4 exp + ~25 bookkeeping instructions per tile.  An all-VALU version of
-// these loops issued ~32 instructions per (row, column) pair and ran at ~75 us; a version with (1)
-// on MFMA and (2) on the VALU was paced by LDS broadcast traffic (in-kernel stamps).
+// These kernels read [G,N,T] and are bound by instruction issue, not HBM.  Both matrix products of a 16x16 tile run on the
+// matrix cores:
+//   1. scores   S = own . streamed^T      K = T     -> T/4 exact-fp32 v_mfma_f32_16x16x4_f32 (3 at T = 12): a k-ordered fmaf
+//      chain, bit-compatible with the VALU chain of the edge pass and with the backward's re-creation of the tile
+//   2. payload  acc += P . payload        K = 16    -> since round 6 two v_mfma_f32_16x16x32_f16 on two-term fp16 operands
+//      (halfsplit.hpp; rounds 1-5: four fp32 MFMAs, 128 of a tile's ~320 clocks).  The accumulator of (1), after the exp, is in
+//      the B layout of (2) already; it is split per tile on the VALU (8 instructions), the payload matrix once per staged chunk
+// and the VALU is left with 4 exp + 8 split + ~15 bookkeeping instructions per tile.  An all-VALU version of these loops issued
+// ~32 instructions per (row, column) pair and ran at ~75 us; a version with (1) on MFMA and (2) on the VALU was paced by LDS
+// broadcast traffic (in-kernel stamps).  From 1536 nodes both products run on split bf16 / fp16 operands (dense_bf16.hip).
 //
 // 16x16x4 layouts: A[i][k]: lane (i = lane & 15, k = lane >> 4); B[k][j]: lane (j = lane & 15,
 // k = lane >> 4); D[4*quad + r][j] in register r of lane (j = lane & 15, quad = lane >> 4).
