@@ -232,7 +232,11 @@ static size_t balance_pad_bytes(int nblocks, size_t static_lds) {
 // Wave w owns rows n0 + 16w .. +15 (B operand of the score product: their kW2) and streams all
 // columns.  Score tile D[i = column][j = row]: lane (row j, quad) holds its row against columns
 // m0 + 4*quad + r.  Payload tile D2[i = timestep s][j = row] += q[m][s] P[row][m].
-template <int T, bool WITH_PQ, int XC = 0>
+// F16P: the payload product on the fp16 matrix core (halfsplit.hpp); false: on four exact-fp32 MFMAs per tile as in rounds 1-5 --
+// kept for grids that leave CUs empty (PEMSD4's single relation: 192 blocks, two waves per SIMD), where the matrix pipe is idle
+// most of the time anyway and the conversion of the payload planes with its third barrier per chunk is pure latency
+// (0.2168 -> 0.2205 ms per hot-path step with the fp16 form there, same box).
+template <int T, bool WITH_PQ, int XC = 0, bool F16P = true>
 __global__ __launch_bounds__(kDBlock) void k_scores(
     const float* __restrict__ q, const float* __restrict__ Wg, const int* __restrict__ rowptr,
     const int* __restrict__ col, const float* __restrict__ val, const int* __restrict__ erow,
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
     float one) {   // 1.0f, opaque to the compiler (split2_f16)
   constexpr int T4 = T / 4;
   __shared__ float4 qs4[kDMC * kPS / 4];  // staged columns: [column][q(T) | zeros]
-  __shared__ uint4 pl4[WITH_PQ ? kPlaneU4 : 1];   // their payload planes (fp16 terms, see build_payload_planes)
+  __shared__ uint4 pl4[WITH_PQ && F16P ? kPlaneU4 : 1];   // their payload planes (fp16 terms, see build_payload_planes)
   __shared__ float wmax[kDWaves];
   __shared__ float kw2s[kDRows][T];       // the block's rows, log2-scaled, for the edge pass
   __shared__ float lse2s[kDRows];
@@ -288,13 +292,14 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
   // column m carries a 1 behind its T values of q, so D2[s = T][row] accumulates sum_m p[row][m] on the matrix core
   // and three v_add per tile leave the VALU stream (which the fp32 MFMAs share an issue port with)
   constexpr bool ONES = WITH_PQ && T < 16;
-  constexpr float kPOff = WITH_PQ ? kPOffF : 0.f;   // P = 2^(S - m) is carried times 2^kPOff through the fp16 payload product
+  constexpr bool HP = WITH_PQ && F16P;              // the fp16 payload path
+  constexpr float kPOff = HP ? kPOffF : 0.f;        // P = 2^(S - m) is carried times 2^kPOff through the fp16 payload product
   float m = -3.0e38f;  // running max of the row, identical in its 4 quads; finite floor, not -inf
   float mo = m;        // m - kPOff: what the exponent subtracts
   float lsum = 0.f;    // this quad's share of sum_m 2^(S - mo) (unused with ONES)
-  f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = da;  // payload accumulators (tile a / tile b of a trip)
+  f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = da, dc = da, dd = da;  // payload accumulators (fp16 path: tile a / tile b of a trip)
   int sexp = 100;      // the payload planes carry q * 2^sexp (block-uniform; follows the largest |q| staged so far)
-  if (WITH_PQ)
+  if (HP)
     for (int i = threadIdx.x; i < kPlaneU4; i += kDBlock) pl4[i] = make_uint4(0u, 0u, 0u, 0u);   // rows past the ones row stay zero
 
   // Staging is double-buffered through registers: the loads of chunk c+1 are issued before chunk c
@@ -315,8 +320,9 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
       const bool live = (c < cols) && (f < T4);
       const float4 v = qrows.row4((size_t)(c0 + (live ? c : 0)), live ? f : 0);
       const float keep = live ? 1.f : 0.f;  // multiply, not select: keeps the load out of a branch
-      pre[k] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
-      premax = fmaxf(premax, max_abs4(pre[k]));
+      const float onec = (!F16P && ONES && c < cols && f == T4) ? 1.f : 0.f;  // fp32 payload: the ones column, at index T of the staged row
+      pre[k] = make_float4(fmaf(v.x, keep, onec), v.y * keep, v.z * keep, v.w * keep);
+      if (HP) premax = fmaxf(premax, max_abs4(pre[k]));
     }
   };
   prefetch(0);
@@ -330,12 +336,12 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
       const int i = threadIdx.x + k * kDBlock;
       if (i < kDMC * kF4) qs4[i] = pre[k];
     }
-    if (WITH_PQ) {
+    if (HP) {
       const float wm = wave_max(premax);
       if (lane == 0) wmax[wave] = wm;
     }
     __syncthreads();
-    if (WITH_PQ) {   // the chunk's payload planes, at the running scale (block-uniform arithmetic)
+    if (HP) {   // the chunk's payload planes, at the running scale (block-uniform arithmetic)
       float cmax = wmax[0];
 #pragma unroll
       for (int w = 1; w < kDWaves; ++w) cmax = fmaxf(cmax, wmax[w]);
@@ -383,19 +389,29 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
         lsum *= sc;
         if (WITH_PQ) {
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) { da[rr] *= sc; db[rr] *= sc; }
+          for (int rr = 0; rr < 4; ++rr) { da[rr] *= sc; db[rr] *= sc; dc[rr] *= sc; dd[rr] *= sc; }
         }
       }
       float p[8];
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) p[rr] = fast_exp2(sv[rr] - mo);
       if (!ONES) lsum += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-      if (WITH_PQ) {
+      if (HP) {
         // A2[i = s][k] = the planes' (h | m) of columns m0 + 4 quad .. +3 at row s = j; B2[k][j = row] = (Ph | Pm), then (Pm | Ph)
         const uint4 Fa = split_p(p, one), A2a = pl4[((m0 >> 4) * 4 + quad) * 16 + j];
         da = mfma_h(A2a, Fa, da); da = mfma_h(A2a, swap_halves(Fa), da);
         const uint4 Fb = split_p(p + 4, one), A2b = pl4[((m0 >> 4) * 4 + 4 + quad) * 16 + j];
         db = mfma_h(A2b, Fb, db); db = mfma_h(A2b, swap_halves(Fb), db);
+      } else if (WITH_PQ) {
+        // A2[i = s][k = quad] = q[column mq + rr][s = j]; B2[k = quad][j = row] = p[rr]
+        da = mfma16(qsw[(mq + 0) * kPS + j], p[0], da);
+        db = mfma16(qsw[(mq + 1) * kPS + j], p[1], db);
+        dc = mfma16(qsw[(mq + 2) * kPS + j], p[2], dc);
+        dd = mfma16(qsw[(mq + 3) * kPS + j], p[3], dd);
+        da = mfma16(qsw[(mq + 16) * kPS + j], p[4], da);
+        db = mfma16(qsw[(mq + 17) * kPS + j], p[5], db);
+        dc = mfma16(qsw[(mq + 18) * kPS + j], p[6], dc);
+        dd = mfma16(qsw[(mq + 19) * kPS + j], p[7], dd);
       }
     }
     if (c0 == 0) MSGAT_STAMP(2);
@@ -403,7 +419,7 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
 
   MSGAT_STAMP(3);
   if (ONES) {  // D2[s = T][row] sits in register T % 4 of the lanes with quad == T / 4
-    const float mine = da[T % 4] + db[T % 4];
+    const float mine = (da[T % 4] + db[T % 4]) + (dc[T % 4] + dd[T % 4]);
     lsum = __shfl(mine, j + 16 * (T / 4));
   } else {     // the row's 4 quads share m: their partial sums simply add
     lsum += __shfl_xor(lsum, 16);
@@ -415,9 +431,10 @@ __global__ __launch_bounds__(kDBlock) void k_scores(
     if (valid) lse[(size_t)g * N + n] = lse2;  // log2 units: backward re-creates the exponent bit for bit
   }
   if (WITH_PQ && valid && quad < T4) {  // D2[s = 4*quad + rr][row]: this lane owns pq[n][4*quad .. +3]
-    const float inv = pow2i(-sexp) / lsum;   // the planes' scale leaves here; P's 2^kPOff cancels against lsum
+    const float inv = (HP ? pow2i(-sexp) : 1.0f) / lsum;   // the planes' scale leaves here; P's 2^kPOff cancels against lsum
     reinterpret_cast<float4*>(pq + ((size_t)g * N + n) * T)[quad] =
-        make_float4((da[0] + db[0]) * inv, (da[1] + db[1]) * inv, (da[2] + db[2]) * inv, (da[3] + db[3]) * inv);
+        make_float4(((da[0] + db[0]) + (dc[0] + dd[0])) * inv, ((da[1] + db[1]) + (dc[1] + dd[1])) * inv,
+                    ((da[2] + db[2]) + (dc[2] + dd[2])) * inv, ((da[3] + db[3]) + (dc[3] + dd[3])) * inv);
   }
   __syncthreads();
   MSGAT_STAMP(4);
@@ -826,7 +843,10 @@ static int launch_scores_x(const msgat_graph_t& gr, const float* q, const float*
                             (pq != nullptr ? sizeof(uint4) * kPlaneU4 : sizeof(uint4)) +
                             (XC > 0 ? sizeof(int) * (kDRows + 1 + 2 * kTailEdges) : 0);
   const size_t pad = balance_pad_bytes((int)(grid.x * grid.y), static_lds);
-  if (pq != nullptr)
+  if (pq != nullptr && (int)(grid.x * grid.y) <= device_cu_count())   // a grid that leaves CUs empty: the fp32 payload product
+    hipLaunchKernelGGL((k_scores<T, true, XC, false>), grid, dim3(kDBlock), pad, s, q, Wg, gr.rowptr, gr.col, gr.val,
+                       gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, alpha, qout, apW, apCo, apY, apZ, 1.0f);
+  else if (pq != nullptr)
     hipLaunchKernelGGL((k_scores<T, true, XC>), grid, dim3(kDBlock), pad, s, q, Wg, gr.rowptr, gr.col, gr.val,
                        gr.erow, kW, lse, pq, E, gr.cpos, Ec, Bg, N, gr.nnz, alpha, qout, apW, apCo, apY, apZ, 1.0f);
   else
@@ -931,7 +951,7 @@ __device__ __forceinline__ float4 in_edge_term(const int* __restrict__ colptr, c
 // lane (column j, quad) holds rows rb + 4*quad + r.  Payload tile D2[i = s][j = column] +=
 // (delta kW)[row][s] P[row][column].
 //   dq[m] += sum_{e into m} g_e kW[row_e]  -  sum_n 2^(kW2[n].q[m] - lse2[n]) delta[n] kW[n]
-template <int T>
+template <int T, bool F16P = true>   // F16P: see k_scores
 __global__ __launch_bounds__(kDBlock) void k_bwd_dense_col(
     const float* __restrict__ q, const float* __restrict__ kW, const float* __restrict__ lse,
     const float* __restrict__ delta, const float* __restrict__ gE, const int* __restrict__ colptr,
@@ -941,7 +961,7 @@ __global__ __launch_bounds__(kDBlock) void k_bwd_dense_col(
   __shared__ float4 kwr4[kDMC * T4];        // [row][kW2(T)]
   __shared__ float4 dkr4[kDMC * kPS / 4];   // [row][delta*kW(T) | zeros]: fp32, the source of the payload planes
   __shared__ float4 lse4[kDMC / 4];         // [row] lse2 - 14 (+inf past the end): P is carried times 2^14
-  __shared__ uint4 pl4[kPlaneU4];           // payload planes of the staged rows (fp16 terms of delta kW, see build_payload_planes)
+  __shared__ uint4 pl4[F16P ? kPlaneU4 : 1];   // payload planes of the staged rows (fp16 terms of delta kW, see build_payload_planes)
   __shared__ float wmax[kDWaves];
   const float* kwr = reinterpret_cast<const float*>(kwr4);
   const float* dkr = reinterpret_cast<const float*>(dkr4);
@@ -959,9 +979,11 @@ __global__ __launch_bounds__(kDBlock) void k_bwd_dense_col(
 #pragma unroll
   for (int kk = 0; kk < T4; ++kk) bfrag[kk] = valid ? qg[(size_t)mcol * T + 4 * kk + quad] : 0.f;
 
-  f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = da;  // payload accumulators (row tile a / b of a trip)
+  f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = da, dc = da, dd = da;  // payload accumulators (fp16 path: row tile a / b of a trip)
   int sexp = 100;                              // the planes carry delta kW * 2^sexp (running, see k_scores)
-  for (int i = threadIdx.x; i < kPlaneU4; i += kDBlock) pl4[i] = make_uint4(0u, 0u, 0u, 0u);   // rows s >= T stay zero
+  constexpr float kPOff = F16P ? kPOffB : 0.f;
+  if (F16P)
+    for (int i = threadIdx.x; i < kPlaneU4; i += kDBlock) pl4[i] = make_uint4(0u, 0u, 0u, 0u);   // rows s >= T stay zero
 
   // register-prefetched staging (see k_scores): one row per lane per chunk
   static_assert(kDMC <= kDBlock, "at most one staged row per lane");
@@ -980,11 +1002,13 @@ __global__ __launch_bounds__(kDBlock) void k_bwd_dense_col(
     }
     pred = delta[(size_t)g * N + nr] * keep;
     const float lv = lse[(size_t)g * N + nr];
-    prel = live ? lv - kPOffB : INFINITY;  // exp2(s - inf) = 0 for rows past the end
+    prel = live ? lv - kPOff : INFINITY;  // exp2(s - inf) = 0 for rows past the end
     premax = 0.f;
+    if (F16P) {
 #pragma unroll
-    for (int t4 = 0; t4 < T4; ++t4) premax = fmaxf(premax, max_abs4(prek[t4]));
-    premax *= fabsf(pred);
+      for (int t4 = 0; t4 < T4; ++t4) premax = fmaxf(premax, max_abs4(prek[t4]));
+      premax *= fabsf(pred);
+    }
   };
   prefetch(0);
   for (int r0 = 0; r0 < N; r0 += kDMC) {
@@ -1002,12 +1026,12 @@ __global__ __launch_bounds__(kDBlock) void k_bwd_dense_col(
       }
       lsew[i] = prel;
     }
-    {
+    if (F16P) {
       const float wm = wave_max(premax);
       if (lane == 0) wmax[wave] = wm;
     }
     __syncthreads();
-    {   // the chunk's payload planes at the running scale (see k_scores)
+    if (F16P) {   // the chunk's payload planes at the running scale (see k_scores)
       float cmax = wmax[0];
 #pragma unroll
       for (int w = 1; w < kDWaves; ++w) cmax = fmaxf(cmax, wmax[w]);
@@ -1039,24 +1063,35 @@ __global__ __launch_bounds__(kDBlock) void k_bwd_dense_col(
       const float p4 = fast_exp2(S1[0] - l5.x), p5 = fast_exp2(S1[1] - l5.y);
       const float p6 = fast_exp2(S1[2] - l5.z), p7 = fast_exp2(S1[3] - l5.w);
       // A2[i = s][k] = the planes' (h | m) of rows rb + 4 quad .. +3 at s = j; B2[k][j = column] = (Ph | Pm), then (Pm | Ph)
-      const float pa[4] = {p0, p1, p2, p3}, pb[4] = {p4, p5, p6, p7};
-      const uint4 Fa = split_p(pa, one), A2a = pl4[((rb >> 4) * 4 + quad) * 16 + j];
-      da = mfma_h(A2a, Fa, da); da = mfma_h(A2a, swap_halves(Fa), da);
-      const uint4 Fb = split_p(pb, one), A2b = pl4[((rb >> 4) * 4 + 4 + quad) * 16 + j];
-      db = mfma_h(A2b, Fb, db); db = mfma_h(A2b, swap_halves(Fb), db);
+      if (F16P) {
+        const float pa[4] = {p0, p1, p2, p3}, pb[4] = {p4, p5, p6, p7};
+        const uint4 Fa = split_p(pa, one), A2a = pl4[((rb >> 4) * 4 + quad) * 16 + j];
+        da = mfma_h(A2a, Fa, da); da = mfma_h(A2a, swap_halves(Fa), da);
+        const uint4 Fb = split_p(pb, one), A2b = pl4[((rb >> 4) * 4 + 4 + quad) * 16 + j];
+        db = mfma_h(A2b, Fb, db); db = mfma_h(A2b, swap_halves(Fb), db);
+      } else {   // A2[i = s][k = quad] = (delta kW)[row rq + rr][s = j]; B2[k = quad][j = column] = p[rr]
+        da = mfma16(dkr[(rq + 0) * kPS + j], p0, da);
+        db = mfma16(dkr[(rq + 1) * kPS + j], p1, db);
+        dc = mfma16(dkr[(rq + 2) * kPS + j], p2, dc);
+        dd = mfma16(dkr[(rq + 3) * kPS + j], p3, dd);
+        da = mfma16(dkr[(rq + 16) * kPS + j], p4, da);
+        db = mfma16(dkr[(rq + 17) * kPS + j], p5, db);
+        dc = mfma16(dkr[(rq + 18) * kPS + j], p6, dc);
+        dd = mfma16(dkr[(rq + 19) * kPS + j], p7, dd);
+      }
     }
   }
   if (!valid || quad >= T4) return;
-  const float unscale = pow2i(-sexp - (int)kPOffB);   // the planes' scale and P's 2^14
+  const float unscale = F16P ? pow2i(-sexp - (int)kPOffB) : 1.f;   // the planes' scale and P's 2^14
 
   // D2[s = 4*quad + rr][column]: this lane owns dq[mcol][4*quad .. +3]; add the sparse in-edge term
   const float4 sp = in_edge_term<T>(colptr, crow, cperm, gE + (size_t)g * nnz, kWg, mcol, quad);
   float4* dst = reinterpret_cast<float4*>(dq + ((size_t)g * N + mcol) * T) + quad;
   float4 v = *dst;
-  v.x += sp.x - (da[0] + db[0]) * unscale;
-  v.y += sp.y - (da[1] + db[1]) * unscale;
-  v.z += sp.z - (da[2] + db[2]) * unscale;
-  v.w += sp.w - (da[3] + db[3]) * unscale;
+  v.x += sp.x - ((da[0] + db[0]) + (dc[0] + dd[0])) * unscale;
+  v.y += sp.y - ((da[1] + db[1]) + (dc[1] + dd[1])) * unscale;
+  v.z += sp.z - ((da[2] + db[2]) + (dc[2] + dd[2])) * unscale;
+  v.w += sp.w - ((da[3] + db[3]) + (dc[3] + dd[3])) * unscale;
   *dst = v;
 }
 
@@ -1299,9 +1334,14 @@ int launch_bwd_dense_col(const msgat_graph_t& gr, const float* q, const float* k
   dim3 grid(cdiv(N, kDRows), G);
   const size_t static_lds = sizeof(float) * (kDMC * T + kDMC * kPS + kDMC + kDWaves) + sizeof(uint4) * kPlaneU4;
   const size_t pad = balance_pad_bytes((int)(grid.x * grid.y), static_lds);
-#define MSGAT_DCOL(TT)                                                                                \
-  hipLaunchKernelGGL(k_bwd_dense_col<TT>, grid, dim3(kDBlock), pad, s, q, kW, lse, delta, gE, gr.colptr, \
-                     gr.crow, gr.cperm, dq, N, gr.nnz, 1.0f)
+  const bool f16p = (int)(grid.x * grid.y) > device_cu_count();   // see k_scores: F16P
+#define MSGAT_DCOL(TT)                                                                                                       \
+  if (f16p)                                                                                                                  \
+    hipLaunchKernelGGL((k_bwd_dense_col<TT, true>), grid, dim3(kDBlock), pad, s, q, kW, lse, delta, gE, gr.colptr, gr.crow, \
+                       gr.cperm, dq, N, gr.nnz, 1.0f);                                                                       \
+  else                                                                                                                       \
+    hipLaunchKernelGGL((k_bwd_dense_col<TT, false>), grid, dim3(kDBlock), pad, s, q, kW, lse, delta, gE, gr.colptr, gr.crow, \
+                       gr.cperm, dq, N, gr.nnz, 1.0f)
   switch (T) {
     case 4: MSGAT_DCOL(4); break;
     case 8: MSGAT_DCOL(8); break;

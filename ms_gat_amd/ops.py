@@ -1229,7 +1229,11 @@ class _AttentionCoreFunction(torch.autograd.Function):
         Ec = _new(u, G, max(graph.nnz, 1)) if need_bwd else None     # E in CSC order, for backward's transposed pass
         z = torch.empty_like(u)
         stream = _stream_handle(dev)
-        ndense = int(L.msgat_dense_scratch_bytes(C.byref(shape)))   # operand images of the score pass (large graphs only)
+        # operand images of the score pass (large graphs only; the size depends on the dimensions alone: asked once per shape)
+        sizes = graph.__dict__.setdefault("_dense_scratch_bytes", {})
+        ndense = sizes.get((R, G, N, T))
+        if ndense is None:
+            ndense = sizes[(R, G, N, T)] = int(L.msgat_dense_scratch_bytes(C.byref(shape)))
         dense_t = torch.empty(ndense, device=dev, dtype=torch.uint8) if ndense else None
         _lib.check(L.msgat_stage_scores(C.byref(shape), C.byref(gstruct), _ptr(q), _ptr(Wg), _ptr(kW), _ptr(lse), _ptr(pq),
                                         _ptr(E), _ptr(Ec), _ptr(dense_t), stream), "msgat_stage_scores")
@@ -1554,7 +1558,22 @@ def _guard(fn, is_forward: bool):
 #     instead of silently returning gradients that are constants of the outer graph.
 from torch.autograd.function import once_differentiable  # noqa: E402
 
+
+def _once(fn):
+    """`once_differentiable`, entered only when it has something to do: in an ordinary backward grad mode is off already and
+    the decorator's `no_grad` context is ~2 us of host time per call for nothing (28 calls per training step)."""
+    import functools
+    guarded = once_differentiable(fn)
+
+    @functools.wraps(fn)
+    def backward(ctx, *args):
+        if torch.is_grad_enabled():      # backward(create_graph=True): hand the gradients over behind an error node
+            return guarded(ctx, *args)
+        return fn(ctx, *args)
+    return backward
+
+
 for _name, _cls in list(globals().items()):
     if isinstance(_cls, type) and issubclass(_cls, torch.autograd.Function) and _cls is not torch.autograd.Function:
         _cls.forward = staticmethod(_guard(_cls.forward, True))
-        _cls.backward = staticmethod(once_differentiable(_guard(_cls.backward, False)))
+        _cls.backward = staticmethod(_once(_guard(_cls.backward, False)))
