@@ -633,14 +633,15 @@ def test_dense_passes_with_a_helper_wave_at_every_timestep_count(T, N, Bg, x_sca
             assert rel_err(got[k], f64[k]) < bar, (k, rel_err(got[k], f64[k]), bar)
 
 
-@pytest.mark.parametrize("N,Bg", [(100, 2), (883, 4), (1600, 2)])
+@pytest.mark.parametrize("N,Bg", [(100, 2), (300, 48), (883, 4), (1600, 2)])
 @pytest.mark.parametrize("cq,cg", [(1e-6, 1e-8), (1e3, 1e5), (3e7, 1e-3)])
 def test_payload_magnitudes_far_from_one(N, Bg, cq, cg):
     """The payload product of the dense passes runs on fp16 operands behind a power-of-two scale that follows the data
     (csrc/halfsplit.hpp).  Signals of magnitude `cq` with Wg scaled by 1 / cq^2 (the scores, and with them the attention, stay
     what they are) and cotangents of magnitude `cg`: every output and gradient against float64 at the usual bar -- fp16 on its own
-    would overflow at 7e4 and lose everything below 6e-8.  N = 100: 8-wave forms; 883: the 7 + 1 wave forms; 1600: the
-    split-operand forms with their per-group image scale."""
+    would overflow at 7e4 and lose everything below 6e-8.  N = 300 in 96 groups: the 8-wave forms (288 blocks: more than the
+    CUs); 883: the 7 + 1 wave forms; 1600: the split-operand forms with their per-group image scale; N = 100 in 4 groups: a grid
+    that leaves CUs empty keeps the fp32 payload product (dense.hip, F16P = false) and has to pass the same bar."""
     x, adj, Wg, alpha, W, dz = random_problem(2, Bg, 5, 24, N, 12, N, seed=4000 + N)
     prob = ((x * cq).astype(np.float32), adj, (Wg / (cq * cq)).astype(np.float32), alpha, W, (dz * cg).astype(np.float32))
     got, want = run_ours(*prob), oracle_f64(*prob)
