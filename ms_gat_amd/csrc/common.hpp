@@ -389,7 +389,7 @@ int launch_head_dW(const float* dout, const float* x, float* dWc, float* part, i
 // LayerNorm over the last axis of [rows, T] (layernorm.hip)
 size_t layernorm_partial_floats(long long rows, int T, int R);
 int launch_reduce_split(const float* part, int R, int J, int Wd, float* dst0, int n0, float* dst1, int n1,
-                        hipStream_t s);
+                        hipStream_t s, ReduceJobs* defer = nullptr);
 int launch_layernorm_fwd(const float* x, const float* w, const float* b, float* y, long long rows, int T,
                          float eps, int R, hipStream_t s,
                          const float* pool_w = nullptr, float* pool_part = nullptr, float* pooled = nullptr, int N = 1);

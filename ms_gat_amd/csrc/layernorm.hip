@@ -280,10 +280,11 @@ int launch_layernorm_bwd(const float* x, const float* w, const float* dy, const 
     default: return MSGAT_ERR_UNSUPPORTED;
   }
   MSGAT_CHECK_LAUNCH();
-  if (int st = launch_reduce_split(part, R, nb, 2 * T, dw, T, db, T, s)) return st;
+  ReduceJobs jobs{};   // both sums in one launch
+  if (int st = launch_reduce_split(part, R, nb, 2 * T, dw, T, db, T, s, &jobs)) return st;
   if (pool_w != nullptr && dpw_rows != nullptr && dpw != nullptr)   // dpool_w [R,N]: the column sums of a relation's [rows / N, N] terms
-    return launch_reduce_groups(dpw_rows, R, (int)(rows / N), N, dpw, s);
-  return MSGAT_OK;
+    if (int st = launch_reduce_groups_defer(dpw_rows, R, (int)(rows / N), N, dpw, s, &jobs)) return st;
+  return launch_reduce_jobs(jobs, s);
 }
 
 }  // namespace msgat

@@ -112,8 +112,8 @@ int launch_reduce_rows(const float* part, int J, int Wd, float* dst0, int n0, fl
 }
 
 int launch_reduce_split(const float* part, int R, int J, int Wd, float* dst0, int n0, float* dst1, int n1,
-                        hipStream_t s) {
-  return launch_reduce_partials(part, R, J, Wd, dst0, n0, dst1, n1, s);
+                        hipStream_t s, ReduceJobs* defer) {
+  return launch_reduce_partials(part, R, J, Wd, dst0, n0, dst1, n1, s, defer);
 }
 
 int launch_reduce_lastcol(const float* part, int R, int J, int rows, int rw, float* dst, hipStream_t s, ReduceJobs* defer) {

@@ -217,9 +217,10 @@ int launch_chanatt_bwd(const float* dMc, const float* att, const float* pooled, 
   }
 #undef MSGAT_CA_BWD
   MSGAT_CHECK_LAUNCH();
-  int st = launch_reduce_groups(pWc, R, G / R, T * T, dWc, s);
-  if (st) return st;
-  return launch_reduce_groups(pconv, R, G / R, cb * C, dconv, s);
+  ReduceJobs jobs{};   // both sums in one launch
+  if (int st = launch_reduce_groups_defer(pWc, R, G / R, T * T, dWc, s, &jobs)) return st;
+  if (int st = launch_reduce_groups_defer(pconv, R, G / R, cb * C, dconv, s, &jobs)) return st;
+  return launch_reduce_jobs(jobs, s);
 }
 
 // ---- temporal attention -> taps of the first causal convolution ---------------------------------------------------
@@ -450,9 +451,10 @@ int launch_tempatt_bwd(const float* dtaps, const float* att, const float* lr, co
     default: return MSGAT_ERR_UNSUPPORTED;
   }
   MSGAT_CHECK_LAUNCH();
-  int st = launch_reduce_groups(p1, R, G / R, K * N, dWt1, s);
-  if (st) return st;
-  return launch_reduce_groups(p2, R, G / R, K * N, dWt2, s);
+  ReduceJobs jobs{};   // both sums in one launch
+  if (int st = launch_reduce_groups_defer(p1, R, G / R, K * N, dWt1, s, &jobs)) return st;
+  if (int st = launch_reduce_groups_defer(p2, R, G / R, K * N, dWt2, s, &jobs)) return st;
+  return launch_reduce_jobs(jobs, s);
 }
 
 }  // namespace msgat
