@@ -391,7 +391,11 @@ template <int MG, int kMaxK>   // kMaxK: k-steps the registers hold (8: Cr <= 32
 __global__ __launch_bounds__(kBlock, 2) void k_causal_conv(
     const float* __restrict__ in, int in_gstride, const float* __restrict__ taps, int m_in_major,
     const float* __restrict__ bias, int bias_rstride, float* __restrict__ out, int Bg, int P4, int Cr, int Co,
-    int tshift, int T, int tiles, int per_block) {
+    int tshift, int T, int tiles, int per_block
+#ifdef MSGAT_LAB
+    , int lab   // MSGAT_LAB_CC: 1 = no lane shuffles (shifted operand = plain), 2 = only the plain half's MFMAs, 4 = no stores
+#endif
+    ) {
   extern __shared__ float lds[];
   const int Ci = 2 * Cr;                      // virtual channels [shifted | plain]
   const int K4r = Cr >> 2;                    // k-steps over the REAL channels (Cr % 4 == 0, host-checked)
@@ -473,13 +477,23 @@ __global__ __launch_bounds__(kBlock, 2) void k_causal_conv(
     for (int k = 0; k < kMaxK; ++k) {
       if (k < K4r) {                            // kernel-uniform; MFMAs, shuffles and LDS reads only
         const float4 pl = own[k];
+#ifdef MSGAT_LAB
+        const float4 sh = (lab & 1) ? pl : shifted(pl);
+#else
         const float4 sh = shifted(pl);
+#endif
 #pragma unroll
         for (int mg = 0; mg < MG; ++mg) {
           const float a0 = wrow[mg * 16 * Kpad + 4 * k];
           const float a1 = wrow[mg * 16 * Kpad + Cr + 4 * k];
+#ifdef MSGAT_LAB
+          if (!(lab & 2)) {
+#endif
           acc[mg][0] = mfma16(a0, sh.x, acc[mg][0]); acc[mg][1] = mfma16(a0, sh.y, acc[mg][1]);
           acc[mg][2] = mfma16(a0, sh.z, acc[mg][2]); acc[mg][3] = mfma16(a0, sh.w, acc[mg][3]);
+#ifdef MSGAT_LAB
+          }
+#endif
           acc[mg][0] = mfma16(a1, pl.x, acc[mg][0]); acc[mg][1] = mfma16(a1, pl.y, acc[mg][1]);
           acc[mg][2] = mfma16(a1, pl.z, acc[mg][2]); acc[mg][3] = mfma16(a1, pl.w, acc[mg][3]);
         }
@@ -494,6 +508,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_causal_conv(
         const int co = mg * 16 + 4 * kq + reg;
         const float bb = bl[co];
         const float4 v = make_float4(acc[mg][0][reg] + bb, acc[mg][1][reg] + bb, acc[mg][2][reg] + bb, acc[mg][3][reg] + bb);
+#ifdef MSGAT_LAB
+        if ((lab & 4) && v.x != 12345.678f) continue;
+#endif
         if (co < Co && pvalid) store_global(out + ((size_t)g * Co + co) * (4 * (size_t)P4) + 4 * (size_t)p4, v);
       }
     if constexpr (kPrefetch) {
@@ -538,12 +555,17 @@ int launch_project_taps(const float* in, int in_gstride, const float* taps, int 
 #endif
     const dim3 grid1(cdiv(tiles, per_block), G);
     const int gs = in_gstride > Cr ? in_gstride : Cr;
+#ifdef MSGAT_LAB
+#define MSGAT_CC_LAB , lab_env("MSGAT_LAB_CC", 0)
+#else
+#define MSGAT_CC_LAB
+#endif
 #define MSGAT_CC(mg, kk)                                                                                               \
   {                                                                                                                   \
     static LdsGrant granted;                                                                                          \
     if (int st_ = grant_dynamic_lds(&k_causal_conv<mg, kk>, lds, granted)) return st_;                                 \
     hipLaunchKernelGGL((k_causal_conv<mg, kk>), grid1, dim3(kBlock), lds, s, in, gs, taps, m_in_major, bias,           \
-                       bias_rstride, out, Bg, P4, Cr, Co, tshift, T, tiles, per_block);                               \
+                       bias_rstride, out, Bg, P4, Cr, Co, tshift, T, tiles, per_block MSGAT_CC_LAB);                  \
   }
 #define MSGAT_CC2(mg) case mg: if (Cr <= 32) MSGAT_CC(mg, 8) else MSGAT_CC(mg, 16) break;
     switch (MG) { MSGAT_CC2(1) MSGAT_CC2(2) MSGAT_CC2(3) MSGAT_CC2(4) }

@@ -131,6 +131,14 @@ def main():
     Wm = rnd(R, Cm, Cc) * 0.1
     reg("mix_fwd98    x(72)->98", 4 * G * P * (Cc + Cm),
         lambda: _lib.check(L.msgat_stage_mix(sp, Cc, Cm, ptr(rot(xs)), ptr(Wm), 0, None, None, ptr(rot(ys)), st()), "m"))
+    # lab (round-5 review, item 5): the 72 -> 98 mixing as TWO passes over x with half of the output rows each -- the time
+    # of a two-z-block form whose second reader finds NOTHING in a cache (x is 293 MB): an upper bound for such a form
+    for Ch in (48, 50):
+        yh = [rnd(G, Ch, N, T) for _ in range(min(a.sets, 2))]
+        Wh = rnd(R, Ch, Cc) * 0.1
+        reg(f"mix_fwd{Ch}    x(72)->{Ch}", 4 * G * P * (Cc + Ch),
+            lambda yh=yh, Wh=Wh, Ch=Ch: _lib.check(L.msgat_stage_mix(sp, Cc, Ch, ptr(rot(xs)), ptr(Wh), 0, None, None,
+                                                                      ptr(rot(yh)), st()), "m"))
     reg("mix_bwd98    d98->dx(72)", 4 * G * P * (Cc + Cm),
         lambda: _lib.check(L.msgat_stage_mix(sp, Cm, Cc, ptr(rot(ys)), ptr(Wm), 1, None, None, ptr(rot(oxs)), st()), "m"))
     # the same passes as the model issues them (stacked.py / model.MEAM): channel axes assembled from several tensors
