@@ -73,8 +73,48 @@ __global__ __launch_bounds__(kRedBlock) void k_reduce_partials(ReduceJobs jobs) 
   }
 }
 
+// Few partials of many columns (the per-sample matrix gradient of the merged channel mixing: 2 partials of 98 x 73 sums for each
+// of 96 groups): a lane per column.  k_reduce_partials gives such a job 16 waves per 64 columns of which J work -- 10 656 blocks
+// of 1024 lanes, 25 us; here 2 700 blocks of 256.  Same order of additions (p0 + p1 + ... from wave 0 upwards), same bits.
+constexpr int kFewPartials = 16;   // = kRedWaves: up to here k_reduce_partials gives every partial its own wave (S = 1)
+__global__ __launch_bounds__(256) void k_reduce_few(ReduceJobs jobs) {
+  const ReduceJob& jb = jobs.job[blockIdx.z];
+  const int r = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int Wd = jb.Wd, J = jb.J;
+  if (r >= jb.R || i >= Wd) return;
+  const float* p = jb.part + (size_t)r * J * Wd + i;
+  float a[kFewPartials];
+#pragma unroll
+  for (int j = 0; j < kFewPartials; ++j) a[j] = j < J ? p[(size_t)j * Wd] : 0.f;
+  float v = 0.f;
+#pragma unroll
+  for (int j = 0; j < kFewPartials; ++j) v += a[j];
+  if (jb.rw > 0) {
+    const int row = i / jb.rw, c = i - row * jb.rw;
+    if (c < jb.rw - 1) jb.dst0[(size_t)r * jb.n0 + row * (jb.rw - 1) + c] = v;
+    else jb.dst1[(size_t)r * jb.n1 + row] = v;
+  } else if (i < jb.n0) {
+    if (jb.dst0 != nullptr) jb.dst0[(size_t)r * jb.n0 + i] = v;
+  } else if (jb.dst1 != nullptr && i - jb.n0 < jb.n1) {
+    jb.dst1[(size_t)r * jb.n1 + (i - jb.n0)] = v;
+  }
+}
+
 int launch_reduce_jobs(const ReduceJobs& jobs, hipStream_t s) {
   if (jobs.n <= 0) return MSGAT_OK;
+  bool few = true;
+  int fx = 1, fy = 1;
+  for (int k = 0; k < jobs.n; ++k) {
+    few = few && jobs.job[k].J <= kFewPartials && jobs.job[k].Wd >= kWave;   // Wd >= 64: one sub-slice per wave over there
+    fx = max(fx, cdiv(jobs.job[k].Wd, 256));
+    fy = max(fy, jobs.job[k].R);
+  }
+  if (few) {
+    hipLaunchKernelGGL(k_reduce_few, dim3(fx, fy, jobs.n), dim3(256), 0, s, jobs);
+    MSGAT_CHECK_LAUNCH();
+    return MSGAT_OK;
+  }
   int bx = 1, by = 1;
   for (int k = 0; k < jobs.n; ++k) {
     bx = max(bx, cdiv(jobs.job[k].Wd, red_cols(jobs.job[k].Wd)));
