@@ -7,7 +7,8 @@ import torch
 import bench
 dev = torch.device("cuda:0")
 sync = lambda: torch.cuda.synchronize(dev)
-ts = bench.TrainStep(dict(bench.CFG4, R=3), dev)
+R = int(os.environ.get("LAB_R", "3"))
+ts = bench.TrainStep(dict(bench.CFG4, R=R), dev)
 for rep in range(2):
     w3, p3 = bench.time_train_step(ts, 20, 5, sync)
-    print("CCPB", os.environ.get("MSGAT_LAB_CCPB", "-"), "training step R=3 wall / median ms:", round(w3 / 20 * 1e3, 3), round(statistics.median(p3), 3), flush=True)
+    print("CCPB", os.environ.get("MSGAT_LAB_CCPB", "-"), f"training step R={R} wall / median ms:", round(w3 / 20 * 1e3, 3), round(statistics.median(p3), 3), flush=True)
