@@ -633,6 +633,16 @@ def test_dense_passes_with_a_helper_wave_at_every_timestep_count(T, N, Bg, x_sca
             assert rel_err(got[k], f64[k]) < bar, (k, rel_err(got[k], f64[k]), bar)
 
 
+@pytest.mark.parametrize("T", [4, 8, 16])
+def test_eight_wave_dense_passes_on_the_fp16_payload_at_every_timestep_count(T):
+    """The 8-wave forms of the dense passes choose their payload arithmetic by the grid (dense.hip, F16P): fp32 when the blocks
+    leave CUs empty -- every other small case of this file -- and the fp16 two-term product from 257 blocks up.  96 groups of
+    300 nodes are 288 blocks: the fp16 form at the timestep counts the T = 12 cases do not reach."""
+    prob = random_problem(2, 48, 5, 24, 300, T, 300, seed=700 + T)
+    got, want = run_ours(*prob), _dense_oracle_gpu(*prob)
+    assert_close(got, want, what=f"8-wave dense passes, fp16 payload, T={T}")
+
+
 @pytest.mark.parametrize("N,Bg", [(100, 2), (300, 48), (883, 4), (1600, 2)])
 @pytest.mark.parametrize("cq,cg", [(1e-6, 1e-8), (1e3, 1e5), (3e7, 1e-3)])
 def test_payload_magnitudes_far_from_one(N, Bg, cq, cg):
