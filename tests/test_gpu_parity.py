@@ -633,14 +633,15 @@ def test_dense_passes_with_a_helper_wave_at_every_timestep_count(T, N, Bg, x_sca
             assert rel_err(got[k], f64[k]) < bar, (k, rel_err(got[k], f64[k]), bar)
 
 
-@pytest.mark.parametrize("T", [4, 8, 16])
-def test_eight_wave_dense_passes_on_the_fp16_payload_at_every_timestep_count(T):
+@pytest.mark.parametrize("T,C", [(4, 5), (8, 5), (16, 5), (12, 3), (12, 1)])
+def test_eight_wave_dense_passes_on_the_fp16_payload_at_every_timestep_count(T, C):
     """The 8-wave forms of the dense passes choose their payload arithmetic by the grid (dense.hip, F16P): fp32 when the blocks
     leave CUs empty -- every other small case of this file -- and the fp16 two-term product from 257 blocks up.  96 groups of
-    300 nodes are 288 blocks: the fp16 form at the timestep counts the T = 12 cases do not reach."""
-    prob = random_problem(2, 48, 5, 24, 300, T, 300, seed=700 + T)
+    300 nodes are 288 blocks: the fp16 form at the timestep counts the T = 12 cases do not reach, and (C = 1, 3) in the score
+    kernels that finish the layer for their own rows."""
+    prob = random_problem(2, 48, C, 24, 300, T, 300, seed=700 + T + C)
     got, want = run_ours(*prob), _dense_oracle_gpu(*prob)
-    assert_close(got, want, what=f"8-wave dense passes, fp16 payload, T={T}")
+    assert_close(got, want, what=f"8-wave dense passes, fp16 payload, T={T} C={C}")
 
 
 @pytest.mark.parametrize("N,Bg", [(100, 2), (300, 48), (883, 4), (1600, 2)])
