@@ -4,7 +4,8 @@
     (cd build/ab/r05 && python tools/ab_step.py)  # another round's tree (source + its built .so), on the SAME box
 
 Every round keeps the previous round's tree under build/ab/<round>/ (`git archive` of the round's last commit + the library
-built from it; not tracked, shipped by gpurun) and commits the pair of lines as profiles/<round>/ab_*.txt."""
+built from it; not tracked) and commits the pair of lines as profiles/<round>/ab_*.txt.  `.gpurunignore` lists build/ab/ and
+build/lab/ so that an ordinary lease stays small: take those two lines out for an A/B or lab call."""
 import os
 import statistics
 import sys
